@@ -1,0 +1,428 @@
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE (read-only /root/reference).
+
+TEST INFRASTRUCTURE; build-container only (``python -m oracle.make_golden``).
+Every case stores the seeded inputs and the outputs of the reference's own
+functions.  While generating, the oracle restatements in ``oracle/`` are checked
+against the reference outputs (the "pin"); ``tests/test_oracle_golden.py`` repeats
+that check from the committed files on every run, with no reference present.
+
+Reference entry points exercised (file:line):
+  utils/general.py:887 non_max_suppression_ssod, :994 non_max_suppression
+  models/assigner/yolo_anchor_assigner.py:319 build_targets, :640 build_uc_targets_aug
+  utils/metrics.py:207 bbox_iou(CIoU)
+  models/loss/loss.py:93 ComputeLoss, :376 TargetLoss, :398 DomainLoss
+  models/loss/ssod/ssod_loss.py:26 ComputeStudentMatchLoss
+  utils/self_supervised_utils.py:194 FairPseudoLabel.create_pseudo_label_online_with_gt
+  models/detector/yolo_ssod.py:44 Model (train + eval forward, backward)
+  utils/torch_utils.py:308 ModelEMA, :381 CosineEMA ; torch.optim.SGD as trainer.py:215
+"""
+import copy
+import os
+import sys
+
+import numpy as np
+import torch
+
+from . import assigner as o_asg
+from . import detect as o_det
+from . import losses as o_loss
+from . import nms as o_nms
+from . import optim as o_opt
+from . import pseudo_label as o_pl
+from . import ref_loader
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+SSOD_YAML = "configs/ssod/coco-standard/yolov5l_coco_ssod_10_percent.yaml"
+TINY = ["Model.width_multiple", 0.125, "Model.depth_multiple", 0.33]
+
+
+def save(name, **arrs):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrs.items()})
+    print(f"  wrote {name}.npz ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def synth_pred(rng, B, A, nc, obj_pow=4, cls_pow=4, dup=False):
+    """Decoded-prediction-like tensor (B,A,5+nc): xywh px, obj, cls."""
+    p = np.zeros((B, A, 5 + nc), np.float32)
+    p[..., 0:2] = rng.uniform(0, 640, (B, A, 2))
+    p[..., 2:4] = rng.uniform(4, 220, (B, A, 2))
+    p[..., 4] = rng.uniform(0, 1, (B, A)) ** obj_pow
+    p[..., 5:] = rng.uniform(0, 1, (B, A, nc)) ** cls_pow
+    if dup:  # exact score ties + identical boxes exercise the stable-sort rule
+        p[:, 1::7] = p[:, 0:-1:7][:, : p[:, 1::7].shape[1]]
+    return p
+
+
+def case_nms():
+    from utils.general import non_max_suppression, non_max_suppression_ssod
+    rng = np.random.default_rng(11)
+    cases = {
+        "a": (synth_pred(rng, 2, 900, 20), 0.1, 0.65),
+        "b": (synth_pred(rng, 3, 700, 8, obj_pow=1, cls_pow=1, dup=True), 0.1, 0.65),
+        "c": (synth_pred(rng, 2, 300, 5, obj_pow=8), 0.25, 0.45),
+        "empty": (synth_pred(rng, 2, 64, 4) * np.float32(0.05), 0.1, 0.65),
+    }
+    # cluster boxes so that suppression actually happens
+    for k in ("a", "b"):
+        p = cases[k][0]
+        centers = rng.uniform(100, 540, (p.shape[0], 12, 2)).astype(np.float32)
+        idx = rng.integers(0, 12, p.shape[:2])
+        p[..., 0:2] = np.take_along_axis(centers, idx[..., None].repeat(2, 2), 1) + \
+            rng.normal(0, 6, p.shape[:2] + (2,)).astype(np.float32)
+        p[..., 2:4] = 80 + rng.normal(0, 8, p.shape[:2] + (2,)).astype(np.float32)
+    out = {}
+    for k, (pred, ct, it) in cases.items():
+        ref = non_max_suppression_ssod(torch.from_numpy(pred.copy()), ct, it)
+        mine, keeps = o_nms.non_max_suppression_ssod(pred, ct, it)
+        for r, m in zip(ref, mine):
+            r = r.numpy().reshape(-1, 8) if r.shape[-1] == 8 else np.zeros((0, 8), np.float32)
+            assert np.array_equal(r, m), f"nms_ssod pin failed ({k})"
+        out[f"{k}_pred"] = pred
+        out[f"{k}_thr"] = np.array([ct, it], np.float64)
+        out[f"{k}_counts"] = np.array([m.shape[0] for m in mine], np.int64)
+        out[f"{k}_dets"] = np.concatenate(mine, 0)
+        out[f"{k}_keep"] = np.concatenate(keeps, 0)
+        # val-path NMS (multi_label) on the same tensors  (row f-1)
+        refv = non_max_suppression(torch.from_numpy(pred.copy()), ct, it, multi_label=True)
+        minev = o_nms.non_max_suppression(pred, ct, it, multi_label=True)
+        for r, m in zip(refv, minev):
+            assert np.array_equal(r.numpy().reshape(-1, 6), m), f"nms(val) pin failed ({k})"
+        out[f"{k}_val_counts"] = np.array([m.shape[0] for m in minev], np.int64)
+        out[f"{k}_val_dets"] = np.concatenate(minev, 0)
+    save("nms", **out)
+
+
+def synth_targets(rng, B, n_per=(1, 9), with_edge=True):
+    rows = []
+    for b in range(B):
+        n = int(rng.integers(*n_per))
+        xy = rng.uniform(0.02, 0.98, (n, 2))
+        wh = np.exp(rng.uniform(np.log(0.02), np.log(0.7), (n, 2)))
+        cls = rng.integers(0, 80, (n, 1))
+        rows.append(np.concatenate((np.full((n, 1), b), cls, xy, wh), 1))
+    t = np.concatenate(rows, 0).astype(np.float32)
+    if with_edge:  # cells on the image border / exact half-cell positions
+        t[0, 2:4] = [0.999, 0.0005]
+        t[-1, 2:4] = [0.5, 0.5]
+    return t
+
+
+def build_tiny_model(nc=80, seed=0):
+    cfg = ref_loader.get_cfg(SSOD_YAML, TINY + ["Dataset.nc", nc])
+    cfg.freeze()
+    from models.detector.yolo_ssod import Model
+    torch.manual_seed(seed)
+    model = Model(cfg)
+    # default init leaves BN weight=1,bias=0 and running stats trivial: perturb so that the
+    # eval path (running stats) and affine terms are exercised
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.copy_(1 + 0.2 * torch.randn(m.weight.shape, generator=g))
+                m.bias.copy_(0.1 * torch.randn(m.bias.shape, generator=g))
+                m.running_mean.copy_(0.1 * torch.randn(m.bias.shape, generator=g))
+                m.running_var.copy_(1 + 0.3 * torch.rand(m.bias.shape, generator=g))
+    return cfg, model
+
+
+def case_assigner_and_losses():
+    cfg, model = build_tiny_model()
+    from models.loss.loss import ComputeLoss, DomainLoss, TargetLoss
+    from models.loss.ssod.ssod_loss import ComputeStudentMatchLoss
+    from utils.metrics import bbox_iou
+    det = model.head
+    anchors = det.anchors.clone()
+    rng = np.random.default_rng(5)
+    B = 3
+    shapes = [(16, 16), (8, 8), (4, 4)]        # a 128x128 image
+    targets = synth_targets(rng, B)
+    p = [torch.from_numpy(rng.normal(0, 1.5, (B, 3, ny, nx, 85)).astype(np.float32)) for ny, nx in shapes]
+
+    # --- build_targets / build_uc_targets_aug ---------------------------------
+    closs = ComputeLoss(model, cfg)
+    ref = closs.assigner(p, torch.from_numpy(targets))
+    mine = o_asg.build_targets(shapes, anchors.numpy(), targets, cfg.Loss.anchor_t)
+    out = dict(targets=targets, anchors=anchors.numpy(), shapes=np.array(shapes),
+               anchor_t=np.float64(cfg.Loss.anchor_t))
+    for i in range(3):
+        tcls, tbox, ind, anch = ref[0][i], ref[1][i], ref[2][i], ref[3][i]
+        m = mine[i]
+        assert np.array_equal(tcls.numpy(), m["tcls"]) and np.array_equal(tbox.numpy(), m["tbox"])
+        assert all(np.array_equal(ind[k].numpy(), m[n]) for k, n in enumerate(("b", "a", "gj", "gi")))
+        assert np.array_equal(anch.numpy(), m["anch"])
+        for k, v in m.items():
+            out[f"bt{i}_{k}"] = v
+    t7 = np.concatenate((targets, rng.uniform(0.1, 1, (targets.shape[0], 1)).astype(np.float32)), 1)
+    refu = closs.assigner(p, torch.from_numpy(t7), with_pseudo_score=True)
+    mineu = o_asg.build_targets(shapes, anchors.numpy(), t7, cfg.Loss.anchor_t, with_score=True)
+    for i in range(3):
+        assert np.array_equal(refu[4][i].numpy(), mineu[i]["tscore"])
+        assert np.array_equal(refu[2][i][3].numpy(), mineu[i]["gi"])
+        out[f"uc{i}_tscore"] = mineu[i]["tscore"]
+        out[f"uc{i}_gi"] = mineu[i]["gi"]
+    out["targets7"] = t7
+    save("assigner", **out)
+
+    # --- CIoU ------------------------------------------------------------------
+    n = 257
+    pb = np.abs(rng.normal(1.0, 0.8, (n, 4))).astype(np.float32) + 0.01
+    tb = np.abs(rng.normal(1.0, 0.8, (n, 4))).astype(np.float32) + 0.01
+    pbt = torch.from_numpy(pb).requires_grad_(True)
+    iou = bbox_iou(pbt.T, torch.from_numpy(tb), x1y1x2y2=False, CIoU=True)
+    (1 - iou).mean().backward()
+    pbt2 = torch.from_numpy(pb).requires_grad_(True)
+    iou2 = o_loss.ciou_xywh(pbt2, torch.from_numpy(tb))
+    (1 - iou2).mean().backward()
+    assert torch.equal(iou, iou2) and torch.equal(pbt.grad, pbt2.grad), "ciou pin failed"
+    save("ciou", pbox=pb, tbox=tb, iou=iou.detach().numpy(), grad=pbt.grad.numpy())
+
+    # --- ComputeLoss -------------------------------------------------------------
+    out = dict(targets=targets, anchors=anchors.numpy())
+    pr = [x.clone().requires_grad_(True) for x in p]
+    loss, items = closs(pr, torch.from_numpy(targets))
+    loss.backward()
+    kw = dict(nc=80, box_w=closs.box_w, obj_w=closs.obj_w, cls_w=closs.cls_w, anchor_t=closs.anchor_t)
+    po = [x.clone().requires_grad_(True) for x in p]
+    loss2, items2 = o_loss.compute_loss(po, torch.from_numpy(targets), anchors, **kw)
+    loss2.backward()
+    assert torch.allclose(loss, loss2, rtol=1e-6, atol=1e-7), (loss, loss2)
+    for a, b in zip(pr, po):
+        assert torch.allclose(a.grad, b.grad, rtol=1e-5, atol=1e-8)
+    for i in range(3):
+        out[f"p{i}"] = p[i].numpy()
+        out[f"grad{i}"] = pr[i].grad.numpy()
+    out["loss"] = loss.detach().numpy()
+    out["items"] = np.array([items[k].item() for k in ("box", "obj", "cls")], np.float32)
+    out["weights"] = np.array([closs.box_w, closs.obj_w, closs.cls_w, closs.anchor_t], np.float64)
+    # empty-target case (loss.py:149 n == 0 branch)
+    l0, _ = closs([x.clone() for x in p], torch.zeros((0, 6)))
+    l0o, _ = o_loss.compute_loss([x.clone() for x in p], torch.zeros((0, 6)), anchors, **kw)
+    assert torch.allclose(l0, l0o, rtol=1e-6)
+    out["loss_empty"] = l0.detach().numpy()
+    save("compute_loss", **out)
+
+    # --- ComputeStudentMatchLoss -------------------------------------------------
+    sloss = ComputeStudentMatchLoss(model, cfg)
+    nt = 40
+    t9 = np.zeros((nt, 9), np.float64)
+    t9[:, 0] = rng.integers(0, B, nt)
+    t9[:, 0].sort()
+    t9[:, 1] = rng.integers(0, 80, nt)
+    t9[:, 2:4] = rng.uniform(0.05, 0.95, (nt, 2))
+    t9[:, 4:6] = np.exp(rng.uniform(np.log(0.03), np.log(0.6), (nt, 2)))
+    t9[:, 7] = rng.uniform(0.1, 1, nt) ** 0.3          # obj conf
+    t9[:, 8] = rng.uniform(0.1, 1, nt) ** 0.3          # cls conf
+    t9[:, 6] = t9[:, 7] * t9[:, 8]
+    t9[::5, 7] = 0.995                                  # force the uc_obj branch
+    t9[1::5, 8] = 0.999
+    t9[3, 6] = 0.6                                      # exactly on the high threshold
+    t9[4, 6] = 0.1                                      # exactly on the low threshold
+    t9[5, 6] = 0.05                                     # below low: dropped
+    out = dict(targets9=t9, anchors=anchors.numpy())
+    for tag, flags in (("default", {}), ("cls", dict(pseudo_label_with_cls=True)),
+                       ("ignore", dict(ignore_obj=True))):
+        s = copy.copy(sloss)
+        for k, v in flags.items():
+            setattr(s, k, v)
+        pr = [x.clone().requires_grad_(True) for x in p]
+        loss, items = s(pr, torch.from_numpy(t9))
+        loss.backward()
+        po = [x.clone().requires_grad_(True) for x in p]
+        loss2, _ = o_loss.compute_student_match_loss(
+            po, torch.from_numpy(t9), anchors, nc=80, box_w=s.box_w, obj_w=s.obj_w, cls_w=s.cls_w,
+            anchor_t=s.anchor_t, thr_low=s.ignore_thres_low, thr_high=s.ignore_thres_high,
+            ignore_obj=s.ignore_obj, with_obj=s.pseudo_label_with_obj,
+            with_bbox=s.pseudo_label_with_bbox, with_cls=s.pseudo_label_with_cls)
+        loss2.backward()
+        assert torch.allclose(loss, loss2, rtol=1e-6, atol=1e-7), (tag, loss, loss2)
+        for a, b in zip(pr, po):
+            assert torch.allclose(a.grad, b.grad, rtol=1e-5, atol=1e-8), tag
+        out[f"{tag}_loss"] = loss.detach().numpy()
+        out[f"{tag}_items"] = np.array([float(items[k]) for k in ("ss_box", "ss_obj", "ss_cls")], np.float32)
+        for i in range(3):
+            out[f"{tag}_grad{i}"] = pr[i].grad.numpy()
+    rel, unc, uo, ucl = sloss.select_targets(torch.from_numpy(t9))
+    mr = o_loss.select_targets(t9, sloss.ignore_thres_low, sloss.ignore_thres_high)
+    for a, b in zip((rel, unc, uo, ucl), mr):
+        assert np.array_equal(a.numpy().reshape(-1, 7), b)
+    out["sel_counts"] = np.array([x.shape[0] for x in mr], np.int64)
+    out["weights"] = np.array([sloss.box_w, sloss.obj_w, sloss.cls_w, sloss.anchor_t], np.float64)
+    save("student_match_loss", **out)
+
+    # --- Domain / Target loss --------------------------------------------------
+    feats = [torch.from_numpy(rng.normal(0, 1, (2, 2, s, s)).astype(np.float32)) for s in (8, 4, 2)]
+    fr = [f.clone().requires_grad_(True) for f in feats]
+    d = DomainLoss()(fr); t = TargetLoss()(fr); (d + 2 * t).backward()
+    fo = [f.clone().requires_grad_(True) for f in feats]
+    d2 = o_loss.domain_loss(fo, 0); t2 = o_loss.domain_loss(fo, 1); (d2 + 2 * t2).backward()
+    assert torch.allclose(d, d2, rtol=1e-6) and torch.allclose(t, t2, rtol=1e-6)
+    for a, b in zip(fr, fo):
+        assert torch.allclose(a.grad, b.grad, rtol=1e-5, atol=1e-8)
+    save("domain_loss", f0=feats[0].numpy(), f1=feats[1].numpy(), f2=feats[2].numpy(),
+         d=d.detach().numpy(), t=t.detach().numpy(),
+         g0=fr[0].grad.numpy(), g1=fr[1].grad.numpy(), g2=fr[2].grad.numpy())
+    return cfg, model
+
+
+def case_pseudo_label(cfg):
+    from utils.self_supervised_utils import FairPseudoLabel
+    rng = np.random.default_rng(21)
+    B, A, nc = 3, 500, 80
+    W = H = 640
+    pred = synth_pred(rng, B, A, nc, obj_pow=2, cls_pow=6)
+    pred[..., 5:] = 0
+    hot = rng.integers(0, nc, (B, A))
+    np.put_along_axis(pred[..., 5:], hot[..., None], rng.uniform(0.3, 1, (B, A, 1)).astype(np.float32), 2)
+    M_s = np.zeros((B, 13), np.float64)
+    for i in range(B):
+        s = [1.0, 0.8, 1.25][i]
+        M = np.array([[s, 0.02 * i, 30.0 * i - 20], [-0.03 * i, s, 12.0 * i], [0, 0, 1]], np.float64)
+        M_s[i] = [i, *M.reshape(-1), s, i % 2, (i + 1) % 2]
+    imgs = torch.zeros(B, 3, H, W)
+    fpl = FairPseudoLabel(cfg)
+    ref_t, ref_invalid = fpl.create_pseudo_label_online_with_gt(
+        torch.from_numpy(pred.copy()), imgs, torch.from_numpy(M_s), imgs.clone())
+    dets, _ = o_nms.non_max_suppression_ssod(pred, cfg.SSOD.nms_conf_thres, cfg.SSOD.nms_iou_thres)
+    mine_t, mine_invalid = o_pl.create_pseudo_label(dets, M_s, W, H)
+    assert ref_invalid == mine_invalid and ref_t.dtype == torch.float64
+    assert np.array_equal(ref_t.numpy(), mine_t), "pseudo-label pin failed"
+    # no-detection case
+    ref_e, inv_e = fpl.create_pseudo_label_online_with_gt(
+        torch.from_numpy(pred * np.float32(0.01)), imgs, torch.from_numpy(M_s), imgs.clone())
+    assert inv_e is True and len(ref_e) == 0
+    save("pseudo_label", pred=pred, M_s=M_s, targets=mine_t, hw=np.array([H, W]),
+         thr=np.array([cfg.SSOD.nms_conf_thres, cfg.SSOD.nms_iou_thres]))
+
+
+def state_arrays(model):
+    return {k.replace(".", "__"): v.detach().numpy() for k, v in model.state_dict().items()}
+
+
+def case_model(cfg, model):
+    """Tiny-width SSOD model (yolo_ssod.py:44): eval + train forward, loss backward."""
+    from models.loss.loss import ComputeLoss
+    rng = np.random.default_rng(33)
+    B, S = 2, 64
+    x = rng.uniform(0, 1, (B, 3, S, S)).astype(np.float32)
+    targets = synth_targets(rng, B, n_per=(2, 5), with_edge=False)
+    sd = state_arrays(model)
+    out = {f"w__{k}": v for k, v in sd.items()}
+    out["x"] = x
+    out["targets"] = targets
+    out["stride"] = model.stride.numpy()
+    out["anchors"] = model.head.anchors.numpy()
+    # eval forward (teacher path, ssod_trainer.py:599)
+    m = copy.deepcopy(model).eval()
+    with torch.no_grad():
+        (z, xs), feats = m(torch.from_numpy(x))
+    zo = o_det.decode([t.clone() for t in xs], m.head.anchors, m.head.stride)
+    assert torch.allclose(z, zo, rtol=1e-6, atol=1e-6), "decode pin failed"
+    out["eval_z"] = z.numpy()
+    for i in range(3):
+        out[f"eval_x{i}"] = xs[i].numpy()
+        out[f"eval_feat{i}"] = feats[i].numpy()
+    # train forward + ComputeLoss backward (student path, ssod_trainer.py:626-628)
+    m = copy.deepcopy(model).train()
+    closs = ComputeLoss(m, cfg)
+    pred, feats = m(torch.from_numpy(x))
+    loss, items = closs(pred, torch.from_numpy(targets))
+    loss.backward()
+    out["train_loss"] = loss.detach().numpy()
+    out["train_items"] = np.array([items[k].item() for k in ("box", "obj", "cls")], np.float32)
+    for i in range(3):
+        out[f"train_p{i}"] = pred[i].detach().numpy()
+        out[f"train_feat{i}"] = feats[i].detach().numpy()
+    for k, p in m.named_parameters():
+        out["g__" + k.replace(".", "__")] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy()
+    for k, b in m.named_buffers():
+        if "running" in k:
+            out["b__" + k.replace(".", "__")] = b.numpy()
+    save("model_tiny", **out)
+
+
+def case_optim(model):
+    from utils.torch_utils import CosineEMA, ModelEMA
+    m = copy.deepcopy(model).train()
+    # param groups exactly as trainer/trainer.py:199-223
+    g0, g1, g2 = [], [], []
+    for v in m.modules():
+        if hasattr(v, "bias") and isinstance(v.bias, torch.nn.Parameter):
+            g2.append(v.bias)
+        if isinstance(v, torch.nn.BatchNorm2d):
+            g0.append(v.weight)
+        elif hasattr(v, "weight") and isinstance(v.weight, torch.nn.Parameter):
+            g1.append(v.weight)
+    opt = torch.optim.SGD(g0, lr=0.01, momentum=0.937, nesterov=True)
+    opt.add_param_group({"params": g1, "weight_decay": 5e-4})
+    opt.add_param_group({"params": g2})
+    ema = ModelEMA(m)
+    semi = CosineEMA(ema.ema, decay_start=0.999, decay_end=0.9999, total_epoch=300)
+    gen = torch.Generator().manual_seed(9)
+    p0 = {k: v.detach().clone() for k, v in m.named_parameters()}
+    grads = []
+    for step in range(2):
+        gs = {}
+        for k, p in m.named_parameters():
+            p.grad = 0.01 * torch.randn(p.shape, generator=gen)
+            gs[k] = p.grad.clone()
+        grads.append(gs)
+        opt.step()
+        ema.update(m)
+        semi.update(ema.ema)
+    # oracle restatement
+    pw = {k: v.numpy().copy() for k, v in p0.items()}
+    wd = {id(p): 5e-4 for p in g1}
+    buf = {}
+    ema_o = {k: v.detach().numpy().copy() for k, v in model.state_dict().items()}
+    semi_o = copy.deepcopy(ema_o)
+    name_of = {id(p): k for k, p in m.named_parameters()}
+    for step in range(2):
+        for k, p in m.named_parameters():
+            pw[k], buf[k] = o_opt.sgd_nesterov(pw[k], grads[step][k].numpy(), buf.get(k), 0.01, 0.937,
+                                              wd.get(id(p), 0.0), step == 0)
+        d = o_opt.ema_decay_ramp(step + 1)
+        for k in ema_o:
+            if ema_o[k].dtype.kind == "f":
+                cur = pw[k] if k in pw else m.state_dict()[k].numpy()
+                ema_o[k] = o_opt.ema_update(ema_o[k], cur, d)
+                semi_o[k] = o_opt.ema_update(semi_o[k], ema_o[k], 0.999)
+    for k, p in m.named_parameters():
+        assert np.allclose(p.detach().numpy(), pw[k], rtol=1e-6, atol=1e-8), k
+    esd, ssd = ema.ema.state_dict(), semi.ema.state_dict()
+    for k in ema_o:
+        if ema_o[k].dtype.kind == "f":
+            assert np.allclose(esd[k].numpy(), ema_o[k], rtol=1e-6, atol=1e-8), k
+            assert np.allclose(ssd[k].numpy(), semi_o[k], rtol=1e-6, atol=1e-8), k
+    keys = ["backbone.stage1.conv.weight", "backbone.stage1.bn.weight", "head.m.0.bias",
+            "neck.C1.cv3.conv.weight"]
+    out = {}
+    for k in keys:
+        kk = k.replace(".", "__")
+        out["p0__" + kk] = p0[k].numpy()
+        out["g0__" + kk] = grads[0][k].numpy()
+        out["g1__" + kk] = grads[1][k].numpy()
+        out["p2__" + kk] = dict(m.named_parameters())[k].detach().numpy()
+        out["ema2__" + kk] = esd[k].numpy()
+        out["semi2__" + kk] = ssd[k].numpy()
+    out["groups"] = np.array([len(g0), len(g1), len(g2)])
+    save("optim", **out)
+
+
+def main():
+    if not ref_loader.available():
+        sys.exit("reference tree not present; golden vectors can only be generated in the build container")
+    ref_loader.load()
+    torch.set_num_threads(4)
+    print("nms ..."); case_nms()
+    print("assigner / losses ..."); cfg, model = case_assigner_and_losses()
+    print("pseudo label ..."); case_pseudo_label(cfg)
+    print("model ..."); case_model(cfg, model)
+    print("optimizer / EMA ..."); case_optim(model)
+    print("done")
+
+
+if __name__ == "__main__":
+    main()

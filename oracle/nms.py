@@ -1,0 +1,146 @@
+"""TEST INFRASTRUCTURE -- CPU restatement of the pseudo-label filter.
+
+Restates, in numpy fp32:
+  * ``torchvision.ops.nms``  (third party, requirements.txt:12 torchvision>=0.8.1;
+    call site utils/general.py:976).  PARITY UNPINNED: torchvision is not
+    installed and the reference holds no golden output for it.  Published
+    kernel semantics (torchvision/csrc/ops/cpu/nms_kernel.cpp): boxes sorted by
+    score, *stable*, descending; box j is dropped iff a kept higher-ranked box i
+    has inter/(area_i+area_j-inter) > thr (strict), area=(x2-x1)*(y2-y1),
+    inter=max(0,xx2-xx1)*max(0,yy2-yy1), all fp32; returns int64 indices into
+    the input in descending-score order.
+  * ``non_max_suppression_ssod``  utils/general.py:887-992
+  * ``non_max_suppression``       utils/general.py:994-1100  (val.py path, row f-1)
+  * ``xywh2xyxy`` / ``xyxy2xywh`` utils/general.py:630-637 / 549-556
+"""
+import numpy as np
+
+MAX_WH = 7680.0  # utils/general.py:907
+MAX_NMS = 30000  # utils/general.py:908
+F32 = np.float32
+
+
+def xywh2xyxy(x):
+    y = np.copy(x)
+    y[:, 0] = x[:, 0] - x[:, 2] / 2
+    y[:, 1] = x[:, 1] - x[:, 3] / 2
+    y[:, 2] = x[:, 0] + x[:, 2] / 2
+    y[:, 3] = x[:, 1] + x[:, 3] / 2
+    return y
+
+
+def xyxy2xywh(x):
+    y = np.copy(x)
+    y[:, 0] = (x[:, 0] + x[:, 2]) / 2
+    y[:, 1] = (x[:, 1] + x[:, 3]) / 2
+    y[:, 2] = x[:, 2] - x[:, 0]
+    y[:, 3] = x[:, 3] - x[:, 1]
+    return y
+
+
+def nms(boxes, scores, iou_thres):
+    """Greedy NMS, fp32, returns int64 keep indices (descending score)."""
+    boxes = np.ascontiguousarray(boxes, dtype=F32)
+    scores = np.ascontiguousarray(scores, dtype=F32)
+    n = boxes.shape[0]
+    if n == 0:
+        return np.zeros((0,), np.int64)
+    order = np.argsort(-scores, kind="stable")
+    x1, y1, x2, y2 = (boxes[order, k] for k in range(4))
+    areas = (x2 - x1) * (y2 - y1)
+    thr = F32(iou_thres)
+    suppressed = np.zeros(n, bool)
+    keep = []
+    with np.errstate(invalid="ignore", divide="ignore"):
+        for i in range(n):
+            if suppressed[i]:
+                continue
+            keep.append(order[i])
+            if i + 1 == n:
+                break
+            xx1 = np.maximum(x1[i], x1[i + 1:])
+            yy1 = np.maximum(y1[i], y1[i + 1:])
+            xx2 = np.minimum(x2[i], x2[i + 1:])
+            yy2 = np.minimum(y2[i], y2[i + 1:])
+            w = np.maximum(F32(0), xx2 - xx1)
+            h = np.maximum(F32(0), yy2 - yy1)
+            inter = w * h
+            ovr = inter / (areas[i] + areas[i + 1:] - inter)
+            suppressed[i + 1:] |= ovr > thr
+    return np.asarray(keep, np.int64)
+
+
+def nms_torch(boxes, scores, iou_threshold):
+    """torch-tensor wrapper used as the ``torchvision.ops.nms`` stub."""
+    import torch
+
+    k = nms(boxes.detach().cpu().numpy(), scores.detach().cpu().numpy(), float(iou_threshold))
+    return torch.from_numpy(k).to(boxes.device)
+
+
+def non_max_suppression_ssod(prediction, conf_thres=0.25, iou_thres=0.45, agnostic=False,
+                             max_det=300):
+    """utils/general.py:887-992, multi_label=False, classes=None, labels=().
+
+    prediction (B, A, 5+nc) fp32 -> list of B arrays (n_i, 8)
+    [x1,y1,x2,y2, conf, cls, obj_conf, cls_conf]; also returns the pre-NMS
+    candidate rows and the keep indices so tests can check indices bit-exactly.
+    """
+    prediction = np.asarray(prediction, dtype=F32)
+    nc = prediction.shape[2] - 5
+    ct = F32(conf_thres)
+    out, keeps = [], []
+    for x in prediction:
+        x = x[x[:, 4] > ct].copy()                       # :921 obj filter
+        if not x.shape[0]:
+            out.append(np.zeros((0, 8), F32)); keeps.append(np.zeros((0,), np.int64)); continue
+        cls_score = x[:, 5:5 + nc].max(1, keepdims=True)  # :937
+        x[:, 5:5 + nc] *= x[:, 4:5]                       # :938
+        box = xywh2xyxy(x[:, :4])                         # :943
+        j = x[:, 5:5 + nc].argmax(1)[:, None]             # :952 (first max index)
+        conf = np.take_along_axis(x[:, 5:5 + nc], j, 1)
+        obj = x[:, 4:5]
+        x = np.concatenate((box, conf, j.astype(F32), obj, cls_score), 1)[conf.reshape(-1) > ct]
+        n = x.shape[0]
+        if not n:
+            out.append(np.zeros((0, 8), F32)); keeps.append(np.zeros((0,), np.int64)); continue
+        if n > MAX_NMS:                                   # :969
+            x = x[np.argsort(-x[:, 4], kind="stable")[:MAX_NMS]]
+        c = x[:, 5:6] * F32(0 if agnostic else MAX_WH)    # :972
+        boxes, scores = x[:, :4] + c, x[:, 4]
+        i = nms(boxes, scores, iou_thres)[:max_det]       # :976-978
+        out.append(x[i]); keeps.append(i)
+    return out, keeps
+
+
+def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, agnostic=False,
+                        multi_label=False, max_det=300):
+    """utils/general.py:994-1100 (val.py:335 uses multi_label=True)."""
+    prediction = np.asarray(prediction, dtype=F32)
+    nc = prediction.shape[2] - 5
+    ct = F32(conf_thres)
+    multi_label = multi_label and nc > 1
+    out = []
+    for x in prediction:
+        xc = (x[:, 4] > ct) & (x[:, 5:].max(1) > ct)      # :1002
+        x = x[xc].copy()
+        if not x.shape[0]:
+            out.append(np.zeros((0, 6), F32)); continue
+        x[:, 5:] *= x[:, 4:5]
+        box = xywh2xyxy(x[:, :4])
+        if multi_label:
+            i, j = np.nonzero(x[:, 5:] > ct)
+            x = np.concatenate((box[i], x[i, j + 5, None], j[:, None].astype(F32)), 1)
+        else:
+            j = x[:, 5:].argmax(1)[:, None]
+            conf = np.take_along_axis(x[:, 5:], j, 1)
+            x = np.concatenate((box, conf, j.astype(F32)), 1)[conf.reshape(-1) > ct]
+        n = x.shape[0]
+        if not n:
+            out.append(np.zeros((0, 6), F32)); continue
+        if n > MAX_NMS:
+            x = x[np.argsort(-x[:, 4], kind="stable")[:MAX_NMS]]
+        c = x[:, 5:6] * F32(0 if agnostic else MAX_WH)
+        i = nms(x[:, :4] + c, x[:, 4], iou_thres)[:max_det]
+        out.append(x[i])
+    return out
