@@ -1,0 +1,86 @@
+"""ctypes binding of libet_hip.so (C ABI: include/et_hip.h).
+
+The HIP library is the product: if it is missing (not built) or a tensor is not on a GPU, every
+entry point raises -- there is no CPU fallback.  ``tests/`` may substitute the SIMT-emulator build
+of the *same kernel sources* (tests/simt_emu) through ``_use_library_for_tests`` to exercise the
+kernels and the host glue on CPU before a GPU run; nothing in the package does that by itself.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libet_hip.so")
+
+ET_F32, ET_BF16 = 0, 1
+
+P = c_void_p
+# name -> (restype, argtypes); kept in the order of include/et_hip.h
+SIGNATURES = {
+    "et_build_arch": (c_char_p, []),
+    "et_abi_version": (c_int, []),
+    "et_nms_ssod_workspace_bytes": (c_int, [c_int, c_int, ctypes.POINTER(c_size_t)]),
+    "et_nms_ssod": (c_int, [P, c_int, c_int, c_int, c_float, c_float, c_int, c_int, P, P, P, P, P, c_size_t, P]),
+}
+
+_dll = None
+_emulated = False
+
+
+class EtHipError(RuntimeError):
+    pass
+
+
+def _declare(dll):
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(dll, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    return dll
+
+
+def load(path=None):
+    """Load (once) and return the HIP library.  Raises if it has not been built."""
+    global _dll
+    if _dll is None:
+        path = path or LIB_PATH
+        if not os.path.exists(path):
+            raise EtHipError(
+                f"{path} not found: build the gfx950 kernels first "
+                f"(python -m efficientteacher_amd.csrc.build).  There is no CPU fallback.")
+        _dll = _declare(ctypes.CDLL(path))
+    return _dll
+
+
+def _use_library_for_tests(path, emulated):
+    """TEST HOOK: point the binding at another build of the same C ABI (the SIMT emulator)."""
+    global _dll, _emulated
+    _dll = _declare(ctypes.CDLL(path)) if path else None
+    _emulated = bool(emulated) if path else False
+
+
+def is_emulated():
+    return _emulated
+
+
+def check(rc, what):
+    if rc != 0:
+        raise EtHipError(f"{what} failed with code {rc}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (or NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda and not _emulated:
+        raise EtHipError("efficientteacher_amd kernels need CUDA/HIP tensors (got a CPU tensor); "
+                         "there is no CPU fallback")
+    return t.data_ptr()
+
+
+def stream(t=None):
+    if _emulated:
+        return None
+    return torch.cuda.current_stream(t.device if t is not None else None).cuda_stream

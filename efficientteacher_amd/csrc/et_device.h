@@ -1,0 +1,58 @@
+// Shared device helpers for the gfx950 kernels (wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define ET_WAVE 64
+
+#define ET_CHECK_LAUNCH()                                    \
+    do {                                                     \
+        hipError_t e__ = hipGetLastError();                  \
+        if (e__ != hipSuccess) return -100 - (int)e__;       \
+    } while (0)
+
+static inline int et_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// ---- bf16 <-> f32 (round-to-nearest-even), storage type is uint16_t -------------------------
+__device__ __forceinline__ float et_bf2f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ uint16_t et_f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // quiet NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t et_pack_bf2(float lo, float hi) {
+    return (uint32_t)et_f2bf(lo) | ((uint32_t)et_f2bf(hi) << 16);
+}
+
+// element-type traits: T = float (parity mode) or uint16_t holding bf16 (performance mode)
+template <typename T> struct et_elem;
+template <> struct et_elem<float> {
+    static constexpr int VEC = 4;  // elements per 16-byte vector
+    __device__ static __forceinline__ float ld(float v) { return v; }
+    __device__ static __forceinline__ float st(float v) { return v; }
+};
+template <> struct et_elem<uint16_t> {
+    static constexpr int VEC = 8;
+    __device__ static __forceinline__ float ld(uint16_t v) { return et_bf2f(v); }
+    __device__ static __forceinline__ uint16_t st(float v) { return et_f2bf(v); }
+};
+
+// ---- wave / block reductions ------------------------------------------------------------------
+__device__ __forceinline__ float et_wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+__device__ __forceinline__ double et_wave_sum_d(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+__device__ __forceinline__ int et_wave_sum_i(int v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
+__device__ __forceinline__ float et_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
