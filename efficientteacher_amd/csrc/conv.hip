@@ -1,0 +1,647 @@
+// Implicit-GEMM convolution on the gfx950 matrix cores: forward, dgrad and wgrad of the
+// conv in `Conv` (reference models/backbone/common.py:471-481; shapes: SURVEY.md appendix A), the
+// Detect output convs (models/head/yolov5_head.py:30) and the netD 1x1 convs (yolo_ssod.py:224-238).
+//
+// Layout: activations NHWC (channels contiguous), weights [Cout][KH][KW][Cin] -- so the GEMM K axis
+// (tap, ci) is contiguous for BOTH MFMA operands and every global access is a 16-byte vector.
+//
+//   gather-GEMM (fwd, dgrad):  D[pixel, cout] = sum_{tap, ci} X[gather(pixel, tap), ci] * W[cout, tap, ci]
+//       A rows = output-lattice pixels, B rows = output channels.  dgrad is the same kernel run on dY
+//       with the transposed weight and a tap table of (dy,dx) input offsets; stride-2 dgrad is split
+//       into its 4 output-parity classes so that no MFMA work is spent on structurally-zero taps.
+//   wgrad:  dW[cout, (tap,ci)] = sum_pixel dY[pixel, cout] * X[gather(pixel,tap), ci]; K = pixels, so
+//       both operands are transposed on the fly: each lane loads VEC pixel-rows of VEC channels
+//       (16 B each, coalesced along channels), transposes the VECxVEC block in registers and writes
+//       K(pixel)-contiguous 16-byte rows to LDS.  Split-K over pixels, fp32 atomicAdd into the grad.
+//
+// Tile: 256 threads = 4 waves, BM x BN block tile (128x128 / 128x64), each wave a 64x64 or 64x32
+// sub-tile of 32x32 MFMAs (v_mfma_f32_32x32x16_bf16; parity mode: exact-f32 v_mfma_f32_32x32x2_f32).
+// LDS rows hold BKV 16-byte K-vectors, XOR-swizzled so that the ds_read_b128 fragment reads of a
+// lane group hit 16 distinct (bank-half, slot) pairs; double buffered, one barrier per K-chunk,
+// next chunk's global loads are issued before the MFMAs of the current one.
+#include "et_device.h"
+#include "../../include/et_hip.h"
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;   // 16-byte register vector (SSA, no struct)
+__device__ __forceinline__ u32x4 mk4(unsigned a, unsigned b, unsigned c, unsigned d) { u32x4 v = {a, b, c, d}; return v; }
+
+#define CONV_MAX_TAPS 36
+
+struct FastDiv {
+    uint32_t magic, shift, d;
+};
+static FastDiv make_fastdiv(uint32_t d) {
+    FastDiv f;
+    f.d = d;
+    uint32_t s = 0;
+    while ((1ull << s) < d) ++s;
+    f.shift = s;
+    f.magic = (uint32_t)((((1ull << 32) * ((1ull << s) - d)) / d) + 1);
+    return f;
+}
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) {
+    return (__umulhi(n, f.magic) + n) >> f.shift;   // exact for n < 2^31
+}
+
+struct GatherGeom {
+    int N, IH, IW, Cin, ldx;     // gathered tensor (NHWC), channels per tap, pixel stride (elements)
+    int QH, QW, M;               // output lattice and its size N*QH*QW
+    int OH, OW, Cout, ldy;       // written tensor, pixel stride
+    int isy, isx;                // gathered coord = q*is + d[tap]
+    int osy, osx, ooy, oox;      // written coord  = q*os + oo
+    int T, TT;                   // taps in this launch / taps per weight row (row = TT*Cin)
+    int CV, KV;                  // Cin/VEC, T*CV
+    FastDiv dQW, dQH, dCV;
+    signed char dy[CONV_MAX_TAPS], dx[CONV_MAX_TAPS];
+    unsigned char wt[CONV_MAX_TAPS];
+};
+
+enum { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2 };
+
+struct Epilogue {
+    const float* bias;      // [Cout] or null
+    int act;
+    const void* res;        // residual (same dtype, added after act) or null
+    int ldr;
+    float* stats;           // partial BN statistics [gridDim.x][2][Cout] or null
+    int accumulate;         // out += result
+};
+
+template <int BKV> __device__ __forceinline__ int lds_swz(int r) {
+    if constexpr (BKV == 8) return ((r >> 1) & 7) ^ ((r >> 4) & 3);
+    else return (r >> 2) & 3;
+}
+
+// ---- one K-chunk of MFMAs from LDS --------------------------------------------------------------
+template <typename T, int BM, int BN, int WM, int WN, int BKV>
+__device__ __forceinline__ void mma_chunk(const u32x4* __restrict__ sm, f32x16 (&acc)[BM / WM / 32][BN / WN / 32],
+                                          int wm, int wn, int lane) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    const int l31 = lane & 31, g = lane >> 5;
+#pragma unroll
+    for (int kk = 0; kk < BKV / 2; ++kk) {
+        u32x4 af[TM], bf[TN];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            const int r = wm * (BM / WM) + tm * 32 + l31;
+            af[tm] = sm[r * BKV + ((kk * 2 + g) ^ lds_swz<BKV>(r))];
+        }
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int r = wn * (BN / WN) + tn * 32 + l31;
+            bf[tn] = sm[(BM + r) * BKV + ((kk * 2 + g) ^ lds_swz<BKV>(r))];
+        }
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                if constexpr (sizeof(T) == 2) {
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        __builtin_bit_cast(bf16x8, af[tm]), __builtin_bit_cast(bf16x8, bf[tn]), acc[tm][tn], 0, 0, 0);
+                } else {
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(af[tm].x), __uint_as_float(bf[tn].x), acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(af[tm].y), __uint_as_float(bf[tn].y), acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(af[tm].z), __uint_as_float(bf[tn].z), acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(af[tm].w), __uint_as_float(bf[tn].w), acc[tm][tn], 0, 0, 0);
+                }
+            }
+    }
+}
+
+// ---- forward / dgrad gather-GEMM ----------------------------------------------------------------
+template <typename T, int BM, int BN, int WM, int WN, int BKV, bool UTAP>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const T* __restrict__ X, const T* __restrict__ W,
+                                                        T* __restrict__ Y, GatherGeom g, Epilogue ep) {
+    constexpr int VEC = et_elem<T>::VEC;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int RPT = 256 / BKV;                 // rows covered by one pass of the 256 loader threads
+    constexpr int RA = BM / RPT, RB = BN / RPT;    // 16-byte vectors per thread per chunk
+    __shared__ __attribute__((aligned(16))) u32x4 lds[2][(BM + BN) * BKV];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int lvec = tid % BKV, lrow = tid / BKV;
+
+    // loader state: A rows are lattice pixels, B rows are output channels
+    int a_off[RA], a_iy[RA], a_ix[RA];
+    bool a_ok[RA];
+#pragma unroll
+    for (int j = 0; j < RA; ++j) {
+        const int p = m0 + lrow + j * RPT;
+        a_ok[j] = p < g.M;
+        const uint32_t pp = a_ok[j] ? p : 0;
+        const uint32_t t1 = fdiv(pp, g.dQW), qx = pp - t1 * g.QW;
+        const uint32_t n = fdiv(t1, g.dQH), qy = t1 - n * g.QH;
+        a_iy[j] = qy * g.isy;
+        a_ix[j] = qx * g.isx;
+        a_off[j] = ((n * g.IH + a_iy[j]) * g.IW + a_ix[j]) * g.ldx;
+    }
+    int b_off[RB];
+    bool b_ok[RB];
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+        const int co = n0 + lrow + j * RPT;
+        b_ok[j] = co < g.Cout;
+        b_off[j] = (b_ok[j] ? co : 0) * g.TT * g.Cin;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+    const int nchunks = (g.KV + BKV - 1) / BKV;
+    u32x4 ra[RA], rb[RB];
+    int tap_u = 0, cv_u = 0;   // UTAP: chunk-uniform tap / channel-vector cursor
+
+    auto gload = [&](int chunk) {
+        int tap, cv;
+        bool kok = true;
+        if constexpr (UTAP) {
+            tap = tap_u; cv = cv_u + lvec;
+        } else {
+            const uint32_t kv = chunk * BKV + lvec;
+            kok = kv < (uint32_t)g.KV;
+            const uint32_t kk = kok ? kv : 0;
+            tap = fdiv(kk, g.dCV); cv = kk - tap * g.CV;
+        }
+        const int dy = g.dy[tap], dx = g.dx[tap];
+        const int doff = (dy * g.IW + dx) * g.ldx + cv * VEC;
+        const int woff = (int)g.wt[tap] * g.Cin + cv * VEC;
+        const u32x4 zero = mk4(0, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < RA; ++j) {
+            const bool ok = kok && a_ok[j] && (unsigned)(a_iy[j] + dy) < (unsigned)g.IH &&
+                            (unsigned)(a_ix[j] + dx) < (unsigned)g.IW;
+            ra[j] = ok ? *(const u32x4*)(X + (a_off[j] + doff)) : zero;
+        }
+#pragma unroll
+        for (int j = 0; j < RB; ++j) rb[j] = (kok && b_ok[j]) ? *(const u32x4*)(W + (b_off[j] + woff)) : zero;
+        if constexpr (UTAP) {
+            cv_u += BKV;
+            if (cv_u >= g.CV) { cv_u = 0; ++tap_u; }
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < RA; ++j) {
+            const int r = lrow + j * RPT;
+            lds[buf][r * BKV + (lvec ^ lds_swz<BKV>(r))] = ra[j];
+        }
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+            const int r = lrow + j * RPT;
+            lds[buf][(BM + r) * BKV + (lvec ^ lds_swz<BKV>(r))] = rb[j];
+        }
+    };
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const bool more = c + 1 < nchunks;
+        if (more) gload(c + 1);
+        mma_chunk<T, BM, BN, WM, WN, BKV>(lds[c & 1], acc, wm, wn, lane);
+        if (more) lstore((c + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias / activation / residual / store / BN partial statistics ------------------
+    const int l31 = lane & 31, hi = lane >> 5;
+    float ssum[TN], ssq[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) { ssum[tn] = 0.f; ssq[tn] = 0.f; }
+    const bool ident = (g.osy == 1 && g.osx == 1 && g.ooy == 0 && g.oox == 0 && g.QH == g.OH && g.QW == g.OW);
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int p = m0 + wm * (BM / WM) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const bool pok = p < g.M;
+            long long obase;
+            if (ident) {
+                obase = (long long)p * g.ldy;
+            } else {
+                const uint32_t pp = pok ? p : 0;
+                const uint32_t t1 = fdiv(pp, g.dQW), qx = pp - t1 * g.QW;
+                const uint32_t n = fdiv(t1, g.dQH), qy = t1 - n * g.QH;
+                obase = (((long long)n * g.OH + (qy * g.osy + g.ooy)) * g.OW + (qx * g.osx + g.oox)) * g.ldy;
+            }
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const int co = n0 + wn * (BN / WN) + tn * 32 + l31;
+                float v = acc[tm][tn][r];
+                ssum[tn] += v;
+                ssq[tn] += v * v;
+                if (pok && co < g.Cout) {
+                    if (ep.bias) v += ep.bias[co];
+                    if (ep.act == ACT_SILU) v = v / (1.0f + expf(-v));
+                    else if (ep.act == ACT_RELU) v = fmaxf(v, 0.f);
+                    if (ep.res) {
+                        const long long rbase = ident ? (long long)p * ep.ldr : (obase / g.ldy) * ep.ldr;
+                        v += et_elem<T>::ld(((const T*)ep.res)[rbase + co]);
+                    }
+                    if (ep.accumulate) v += et_elem<T>::ld(Y[obase + co]);
+                    Y[obase + co] = et_elem<T>::st(v);
+                }
+            }
+        }
+    }
+    if (ep.stats) {
+        // rows beyond M were zero-filled, so they add nothing.  Reduce lane halves, then the WM waves
+        // that share these channels (through LDS), then one plain store per channel per block.
+        float* red = (float*)lds;                  // [WM][BN][2], stage buffers are free now
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const float s = ssum[tn] + __shfl_xor(ssum[tn], 32);
+            const float q = ssq[tn] + __shfl_xor(ssq[tn], 32);
+            if (hi == 0) {
+                const int c = wn * (BN / WN) + tn * 32 + l31;
+                red[(wm * BN + c) * 2 + 0] = s;
+                red[(wm * BN + c) * 2 + 1] = q;
+            }
+        }
+        __syncthreads();
+        if (tid < BN) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) { s += red[(w * BN + tid) * 2]; q += red[(w * BN + tid) * 2 + 1]; }
+            const int co = n0 + tid;
+            if (co < g.Cout) {
+                ep.stats[((size_t)blockIdx.x * 2 + 0) * g.Cout + co] = s;
+                ep.stats[((size_t)blockIdx.x * 2 + 1) * g.Cout + co] = q;
+            }
+        }
+    }
+}
+
+// ---- wgrad ----------------------------------------------------------------------------------------
+struct WgradGeom {
+    int N, IH, IW, Cin, ldx;     // X (gathered operand)
+    int QH, QW, P;               // dY lattice (== dY tensor), P = N*QH*QW
+    int Cout, ldy;               // dY channels / pixel stride
+    int isy, isx;
+    int T, NC;                   // taps, NC = T*Cin columns of dW
+    int Pper;                    // pixels per split-K slice (multiple of the K-chunk)
+    FastDiv dQW, dQH, dCin;
+    signed char dy[CONV_MAX_TAPS], dx[CONV_MAX_TAPS];
+};
+
+template <typename T> struct Transposer;
+template <> struct Transposer<uint16_t> {   // 8x8 block of 16-bit elements
+    __device__ static __forceinline__ void run(const u32x4 (&in)[8], u32x4 (&out)[8]) {
+        const uint32_t* s[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s[i] = (const uint32_t*)&in[i];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            uint32_t w[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t lo = s[2 * j][c >> 1], hi = s[2 * j + 1][c >> 1];
+                w[j] = (c & 1) ? ((lo >> 16) | (hi & 0xffff0000u)) : ((lo & 0xffffu) | (hi << 16));
+            }
+            out[c] = mk4(w[0], w[1], w[2], w[3]);
+        }
+    }
+};
+template <> struct Transposer<float> {      // 4x4 block of 32-bit elements
+    __device__ static __forceinline__ void run(const u32x4 (&in)[4], u32x4 (&out)[4]) {
+        out[0] = mk4(in[0].x, in[1].x, in[2].x, in[3].x);
+        out[1] = mk4(in[0].y, in[1].y, in[2].y, in[3].y);
+        out[2] = mk4(in[0].z, in[1].z, in[2].z, in[3].z);
+        out[3] = mk4(in[0].w, in[1].w, in[2].w, in[3].w);
+    }
+};
+
+template <typename T, int BM, int BN>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const T* __restrict__ X, const T* __restrict__ DY,
+                                                         float* __restrict__ DW, WgradGeom g) {
+    constexpr int VEC = et_elem<T>::VEC, BKV = 8, WM = 2, WN = 2;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int GA = BM / VEC, GB = BN / VEC;        // channel groups per tile
+    constexpr int NBLK = (GA + GB) * BKV;              // VECxVEC transposition blocks per chunk
+    constexpr int ITER = (NBLK + 255) / 256;
+    constexpr int BKP = BKV * VEC;                     // pixels per K-chunk
+    __shared__ __attribute__((aligned(16))) u32x4 lds[2][(BM + BN) * BKV];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+    const int pk_begin = blockIdx.z * g.Pper;
+    const int pk_end = min(g.P, pk_begin + g.Pper);
+
+    // per-thread block descriptors (fixed over the K loop)
+    bool isA[ITER], live[ITER], chan_ok[ITER];
+    int grp[ITER], kvv[ITER], coff[ITER], tdy[ITER], tdx[ITER];
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const int blk = tid + it * 256;
+        live[it] = blk < NBLK;
+        isA[it] = blk < GA * BKV;
+        const int b2 = isA[it] ? blk : blk - GA * BKV;
+        const int G = isA[it] ? GA : GB;
+        grp[it] = b2 % G;
+        kvv[it] = b2 / G;
+        tdy[it] = tdx[it] = 0;
+        if (isA[it]) {
+            const int co = m0 + grp[it] * VEC;
+            chan_ok[it] = co < g.Cout;      // Cout % VEC == 0 is required by the host wrapper
+            coff[it] = co;
+        } else {
+            const int col = n0 + grp[it] * VEC;
+            chan_ok[it] = col < g.NC;
+            const uint32_t cc = chan_ok[it] ? col : 0;
+            const uint32_t tap = fdiv(cc, g.dCin);
+            coff[it] = cc - tap * g.Cin;
+            tdy[it] = g.dy[tap];
+            tdx[it] = g.dx[tap];
+        }
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+    u32x4 stage[ITER][VEC];
+    auto gload = [&](int pk0) {
+        const u32x4 zero = mk4(0, 0, 0, 0);
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            if (!live[it]) continue;
+            const int p0 = pk0 + kvv[it] * VEC;
+            u32x4 in[VEC];
+            if (isA[it]) {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    const int p = p0 + i;
+                    in[i] = (chan_ok[it] && p < pk_end) ? *(const u32x4*)(DY + ((long long)p * g.ldy + coff[it])) : zero;
+                }
+            } else {
+                const uint32_t pp = min(p0, g.P - 1);
+                const uint32_t t1 = fdiv(pp, g.dQW);
+                int qx = pp - t1 * g.QW;
+                const uint32_t n_ = fdiv(t1, g.dQH);
+                int qy = t1 - n_ * g.QH;
+                int n = n_;
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    const int p = p0 + i;
+                    const int iy = qy * g.isy + tdy[it], ix = qx * g.isx + tdx[it];
+                    const bool ok = chan_ok[it] && p < pk_end && (unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW;
+                    in[i] = ok ? *(const u32x4*)(X + ((((long long)n * g.IH + iy) * g.IW + ix) * g.ldx + coff[it])) : zero;
+                    if (++qx == g.QW) { qx = 0; if (++qy == g.QH) { qy = 0; ++n; } }
+                }
+            }
+            Transposer<T>::run(in, stage[it]);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            if (!live[it]) continue;
+            const int rbase = (isA[it] ? 0 : BM) + grp[it] * VEC;
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) {
+                const int rl = grp[it] * VEC + c;          // row inside its operand tile
+                lds[buf][(rbase + c) * BKV + (kvv[it] ^ lds_swz<BKV>(rl))] = stage[it][c];
+            }
+        }
+    };
+
+    const int nchunks = (pk_end - pk_begin + BKP - 1) / BKP;
+    if (nchunks > 0) {
+        gload(pk_begin);
+        lstore(0);
+    }
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const bool more = c + 1 < nchunks;
+        if (more) gload(pk_begin + (c + 1) * BKP);
+        mma_chunk<T, BM, BN, WM, WN, BKV>(lds[c & 1], acc, wm, wn, lane);
+        if (more) lstore((c + 1) & 1);
+        __syncthreads();
+    }
+    if (nchunks <= 0) return;
+    const int l31 = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = m0 + wm * (BM / WM) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const int col = n0 + wn * (BN / WN) + tn * 32 + l31;
+                if (co < g.Cout && col < g.NC) atomicAdd(DW + ((size_t)co * g.NC + col), acc[tm][tn][r]);
+            }
+        }
+}
+
+// ---- small helpers ---------------------------------------------------------------------------------
+// W [Cout][TT][Cin] -> WT [Cin][TT][Cout]  (operand of dgrad)
+template <typename T>
+__global__ __launch_bounds__(256) void weight_transpose_kernel(const T* __restrict__ w, T* __restrict__ wt, int Cout,
+                                                               int TT, int Cin, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;   // index into wt
+    if (i >= n) return;
+    const int co = i % Cout;
+    const int t = (i / Cout) % TT;
+    const int ci = i / ((long long)Cout * TT);
+    wt[i] = w[((long long)co * TT + t) * Cin + ci];
+}
+
+// column sums of a [P][C] (pixel stride ld) tensor into fp32 out[C] (atomicAdd): bias gradients
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int P, int C, int ld, int rows_per_block,
+                                                     float* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int p0 = blockIdx.y * rows_per_block, p1 = min(P, p0 + rows_per_block);
+    float s = 0.f;
+    for (int p = p0; p < p1; ++p) s += et_elem<T>::ld(x[(long long)p * ld + c]);
+    atomicAdd(out + c, s);
+}
+
+// ---- host side -------------------------------------------------------------------------------------
+static int fill_common(GatherGeom& g, int N, int IH, int IW, int Cin, int ldx, int QH, int QW, int OH, int OW,
+                       int Cout, int ldy, int vec) {
+    if (Cin % vec) return -2;
+    g.N = N; g.IH = IH; g.IW = IW; g.Cin = Cin; g.ldx = ldx;
+    g.QH = QH; g.QW = QW; g.M = N * QH * QW;
+    g.OH = OH; g.OW = OW; g.Cout = Cout; g.ldy = ldy;
+    g.CV = Cin / vec; g.KV = g.T * g.CV;
+    g.dQW = make_fastdiv(QW); g.dQH = make_fastdiv(QH); g.dCV = make_fastdiv(g.CV);
+    if ((long long)N * IH * IW * ldx >= (1ll << 31) || (long long)Cout * g.TT * Cin >= (1ll << 31)) return -2;
+    return 0;
+}
+
+template <typename T>
+static int launch_gemm(const void* X, const void* W, void* Y, const GatherGeom& g, const Epilogue& ep, hipStream_t s) {
+    if (g.M <= 0) return 0;
+    const bool wide = g.Cout > 64;
+    const int bn = wide ? 128 : 64;
+    const dim3 grid((g.M + 127) / 128, (g.Cout + bn - 1) / bn), block(256);
+    const T* x = (const T*)X; const T* w = (const T*)W; T* y = (T*)Y;
+#define ET_LAUNCH(BN_, WM_, WN_, BKV_, UT_) \
+    hipLaunchKernelGGL((conv_gemm_kernel<T, 128, BN_, WM_, WN_, BKV_, UT_>), grid, block, 0, s, x, w, y, g, ep)
+    if (g.CV % 8 == 0) {
+        if (wide) ET_LAUNCH(128, 2, 2, 8, true); else ET_LAUNCH(64, 2, 2, 8, true);
+    } else if (g.CV % 4 == 0) {
+        if (wide) ET_LAUNCH(128, 2, 2, 4, true); else ET_LAUNCH(64, 2, 2, 4, true);
+    } else {
+        if (wide) ET_LAUNCH(128, 2, 2, 4, false); else ET_LAUNCH(64, 2, 2, 4, false);
+    }
+#undef ET_LAUNCH
+    return 0;
+}
+
+extern "C" int et_conv2d_stats_rows(int N, int OH, int OW) { return (N * OH * OW + 127) / 128; }
+
+extern "C" int et_conv2d_fwd(const void* x, const void* w, void* y, int dtype, int N, int IH, int IW, int Cin,
+                             int ldx, int Cout, int KH, int KW, int stride, int pad, int ldy, const float* bias,
+                             int act, const void* residual, int ldr, float* stats_partial, et_stream_t stream) {
+    if (!x || !w || !y) return -1;
+    if (KH * KW > CONV_MAX_TAPS || stride < 1 || N <= 0 || Cout <= 0) return -2;
+    GatherGeom g;
+    const int OH = (IH + 2 * pad - KH) / stride + 1, OW = (IW + 2 * pad - KW) / stride + 1;
+    g.T = g.TT = KH * KW;
+    for (int ky = 0; ky < KH; ++ky)
+        for (int kx = 0; kx < KW; ++kx) {
+            const int t = ky * KW + kx;
+            g.dy[t] = (signed char)(ky - pad); g.dx[t] = (signed char)(kx - pad); g.wt[t] = (unsigned char)t;
+        }
+    g.isy = g.isx = stride; g.osy = g.osx = 1; g.ooy = g.oox = 0;
+    const int vec = dtype == ET_F32 ? 4 : 8;
+    int rc = fill_common(g, N, IH, IW, Cin, ldx, OH, OW, OH, OW, Cout, ldy, vec);
+    if (rc) return rc;
+    Epilogue ep{bias, act, residual, ldr, stats_partial, 0};
+    if (dtype == ET_F32) rc = launch_gemm<float>(x, w, y, g, ep, (hipStream_t)stream);
+    else if (dtype == ET_BF16) rc = launch_gemm<uint16_t>(x, w, y, g, ep, (hipStream_t)stream);
+    else return -2;
+    if (rc) return rc;
+    ET_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int et_conv2d_dgrad(const void* dy, const void* wT, void* dx, int dtype, int N, int IH, int IW, int Cin,
+                               int ldx, int Cout, int KH, int KW, int stride, int pad, int ldy, int accumulate,
+                               et_stream_t stream) {
+    // dx[n,iy,ix,ci] = sum_{ky,kx,co} dy[n,(iy+pad-ky)/s,(ix+pad-kx)/s,co] * wT[ci,ky,kx,co]
+    if (!dy || !wT || !dx) return -1;
+    if (KH * KW > CONV_MAX_TAPS || stride < 1 || stride > 2 || N <= 0) return -2;
+    const int OH = (IH + 2 * pad - KH) / stride + 1, OW = (IW + 2 * pad - KW) / stride + 1;
+    const int vec = dtype == ET_F32 ? 4 : 8;
+    for (int py = 0; py < stride; ++py)
+        for (int px = 0; px < stride; ++px) {
+            GatherGeom g;
+            g.TT = KH * KW;
+            int t = 0;
+            for (int ky = 0; ky < KH; ++ky) {
+                if ((py + pad - ky) % stride) continue;
+                for (int kx = 0; kx < KW; ++kx) {
+                    if ((px + pad - kx) % stride) continue;
+                    // floor division is exact here (remainder checked above, also for negatives)
+                    g.dy[t] = (signed char)((py + pad - ky) / stride);
+                    g.dx[t] = (signed char)((px + pad - kx) / stride);
+                    g.wt[t] = (unsigned char)(ky * KW + kx);
+                    ++t;
+                }
+            }
+            g.T = t;
+            g.isy = g.isx = 1; g.osy = g.osx = stride; g.ooy = py; g.oox = px;
+            const int QH = (IH - py + stride - 1) / stride, QW = (IW - px + stride - 1) / stride;
+            // the "gathered" tensor of dgrad is dy (OH x OW x Cout), the written one is dx (IH x IW x Cin)
+            int rc = fill_common(g, N, OH, OW, Cout, ldy, QH, QW, IH, IW, Cin, ldx, vec);
+            if (rc) return rc;
+            Epilogue ep{nullptr, ACT_NONE, nullptr, 0, nullptr, accumulate};
+            if (t == 0) return -2;   // would need a zero fill; does not occur for k>=stride
+            if (dtype == ET_F32) rc = launch_gemm<float>(dy, wT, dx, g, ep, (hipStream_t)stream);
+            else if (dtype == ET_BF16) rc = launch_gemm<uint16_t>(dy, wT, dx, g, ep, (hipStream_t)stream);
+            else return -2;
+            if (rc) return rc;
+        }
+    ET_CHECK_LAUNCH();
+    return 0;
+}
+
+template <typename T>
+static void launch_wgrad(const void* x, const void* dy, float* dw, WgradGeom& g, hipStream_t s) {
+    constexpr int VEC = et_elem<T>::VEC;
+    constexpr int BKP = 8 * VEC;
+    const bool wideN = g.NC > 64;
+    const int bn = wideN ? 128 : 64;
+    const int tiles = ((g.NC + bn - 1) / bn) * ((g.Cout + 127) / 128);
+    // split K so that ~4 waves of blocks cover the chip, each slice >= 8 chunks
+    int sk = (1024 + tiles - 1) / tiles;
+    const int max_sk = max(1, g.P / (BKP * 8));
+    sk = max(1, min(sk, max_sk));
+    int per = (g.P + sk - 1) / sk;
+    per = ((per + BKP - 1) / BKP) * BKP;
+    sk = (g.P + per - 1) / per;
+    g.Pper = per;
+    const dim3 grid((g.NC + bn - 1) / bn, (g.Cout + 127) / 128, sk), block(256);
+    if (wideN) hipLaunchKernelGGL((conv_wgrad_kernel<T, 128, 128>), grid, block, 0, s, (const T*)x, (const T*)dy, dw, g);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<T, 128, 64>), grid, block, 0, s, (const T*)x, (const T*)dy, dw, g);
+}
+
+extern "C" int et_conv2d_wgrad(const void* x, const void* dy, float* dw, int dtype, int N, int IH, int IW, int Cin,
+                               int ldx, int Cout, int KH, int KW, int stride, int pad, int ldy, et_stream_t stream) {
+    // dw[co,ky,kx,ci] += sum_{n,oy,ox} dy[n,oy,ox,co] * x[n,oy*s+ky-pad,ox*s+kx-pad,ci]   (fp32, atomic)
+    if (!x || !dy || !dw) return -1;
+    if (KH * KW > CONV_MAX_TAPS || stride < 1 || N <= 0) return -2;
+    const int vec = dtype == ET_F32 ? 4 : 8;
+    if (Cin % vec || Cout % vec) return -2;
+    WgradGeom g;
+    const int OH = (IH + 2 * pad - KH) / stride + 1, OW = (IW + 2 * pad - KW) / stride + 1;
+    g.N = N; g.IH = IH; g.IW = IW; g.Cin = Cin; g.ldx = ldx;
+    g.QH = OH; g.QW = OW; g.P = N * OH * OW; g.Cout = Cout; g.ldy = ldy;
+    g.isy = g.isx = stride; g.T = KH * KW; g.NC = g.T * Cin;
+    g.dQW = make_fastdiv(OW); g.dQH = make_fastdiv(OH); g.dCin = make_fastdiv(Cin);
+    for (int ky = 0; ky < KH; ++ky)
+        for (int kx = 0; kx < KW; ++kx) {
+            g.dy[ky * KW + kx] = (signed char)(ky - pad);
+            g.dx[ky * KW + kx] = (signed char)(kx - pad);
+        }
+    if (g.P <= 0) return 0;
+    if (dtype == ET_F32) launch_wgrad<float>(x, dy, dw, g, (hipStream_t)stream);
+    else if (dtype == ET_BF16) launch_wgrad<uint16_t>(x, dy, dw, g, (hipStream_t)stream);
+    else return -2;
+    ET_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int et_weight_transpose(const void* w, void* wT, int dtype, int Cout, int taps, int Cin, et_stream_t stream) {
+    if (!w || !wT) return -1;
+    const long long n = (long long)Cout * taps * Cin;
+    if (n <= 0) return -2;
+    const dim3 grid(et_cdiv(n, 256)), block(256);
+    if (dtype == ET_F32)
+        hipLaunchKernelGGL((weight_transpose_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)w, (float*)wT, Cout, taps, Cin, n);
+    else if (dtype == ET_BF16)
+        hipLaunchKernelGGL((weight_transpose_kernel<uint16_t>), grid, block, 0, (hipStream_t)stream, (const uint16_t*)w, (uint16_t*)wT, Cout, taps, Cin, n);
+    else return -2;
+    ET_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int et_colsum(const void* x, int dtype, int P, int C, int ld, float* out, et_stream_t stream) {
+    if (!x || !out) return -1;
+    if (P <= 0 || C <= 0) return -2;
+    const int rpb = 256;
+    const dim3 grid((C + 255) / 256, (P + rpb - 1) / rpb), block(256);
+    if (dtype == ET_F32) hipLaunchKernelGGL((colsum_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)x, P, C, ld, rpb, out);
+    else if (dtype == ET_BF16) hipLaunchKernelGGL((colsum_kernel<uint16_t>), grid, block, 0, (hipStream_t)stream, (const uint16_t*)x, P, C, ld, rpb, out);
+    else return -2;
+    ET_CHECK_LAUNCH();
+    return 0;
+}

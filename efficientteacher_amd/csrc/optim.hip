@@ -1,0 +1,81 @@
+// Per-step state updates over FLAT fp32 arenas (all parameters / buffers of a model live in one
+// contiguous allocation, see efficientteacher_amd/flat_state.py): one HBM-bound launch replaces the
+// reference's python loop over 619 state tensors.
+//   EMA  : utils/torch_utils.py:330-338 (ModelEMA), :366-375 (SemiSupModelEMA), :406-416 (CosineEMA)
+//          v *= d ; v += (1-d) * m      (three separately rounded fp32 ops, as the reference)
+//   SGD  : torch.optim.SGD(momentum, nesterov=True) as built at trainer/trainer.py:215-223, plus the
+//          GradScaler-style 1/scale (trainer/trainer.py:399-400) and an optional bf16 shadow copy of
+//          the updated weights for the MFMA kernels, all in the same pass.
+// Compiled with -ffp-contract=off.
+#include "et_device.h"
+#include "../../include/et_hip.h"
+
+__global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ v, const float* __restrict__ m, long long n,
+                                                  float d, float omd) {
+    const long long i4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i4 + 3 < n) {
+        float4 a = *(float4*)(v + i4);
+        const float4 b = *(const float4*)(m + i4);
+        a.x = a.x * d; a.x = a.x + omd * b.x;
+        a.y = a.y * d; a.y = a.y + omd * b.y;
+        a.z = a.z * d; a.z = a.z + omd * b.z;
+        a.w = a.w * d; a.w = a.w + omd * b.w;
+        *(float4*)(v + i4) = a;
+    } else {
+        for (long long i = i4; i < n; ++i) { float a = v[i] * d; v[i] = a + omd * m[i]; }
+    }
+}
+
+extern "C" int et_ema_update(float* ema, const float* model, int64_t n, float d, float one_minus_d,
+                             et_stream_t stream) {
+    if (!ema || !model) return -1;
+    if (n < 0 || (((uintptr_t)ema | (uintptr_t)model) & 15)) return -2;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(ema_kernel, dim3(et_cdiv(n, 1024)), dim3(256), 0, (hipStream_t)stream, ema, model,
+                       (long long)n, d, one_minus_d);
+    ET_CHECK_LAUNCH();
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                  float* __restrict__ buf, uint16_t* __restrict__ shadow,
+                                                  long long n, float lr, float mu, float wd, int first,
+                                                  float inv_scale) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float gi = g[i] * inv_scale;
+    const float pi = p[i];
+    if (wd != 0.0f) gi = gi + wd * pi;
+    float b = first ? gi : (buf[i] * mu + gi);
+    buf[i] = b;
+    gi = gi + mu * b;
+    const float o = pi - lr * gi;
+    p[i] = o;
+    if (shadow) shadow[i] = et_f2bf(o);
+}
+
+extern "C" int et_sgd_nesterov(float* p, const float* grad, float* momentum_buf, void* bf16_shadow, int64_t n,
+                               float lr, float momentum, float weight_decay, int first_step, float inv_scale,
+                               et_stream_t stream) {
+    if (!p || !grad || !momentum_buf) return -1;
+    if (n < 0) return -2;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(sgd_kernel, dim3(et_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, p, grad, momentum_buf,
+                       (uint16_t*)bf16_shadow, (long long)n, lr, momentum, weight_decay, first_step, inv_scale);
+    ET_CHECK_LAUNCH();
+    return 0;
+}
+
+// fp32 -> bf16 cast of a flat arena (initial shadow copy of the weights)
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ s, uint16_t* __restrict__ d, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) d[i] = et_f2bf(s[i]);
+}
+extern "C" int et_cast_f32_to_bf16(const float* src, void* dst, int64_t n, et_stream_t stream) {
+    if (!src || !dst) return -1;
+    if (n <= 0) return n == 0 ? 0 : -2;
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(et_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, src,
+                       (uint16_t*)dst, (long long)n);
+    ET_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,99 @@
+"""Thin tensor-level wrappers over the C ABI (include/et_hip.h).
+
+Activations are NHWC tensors (N, H, W, C) -- possibly channel-slices of a wider buffer, i.e. the
+last dim has stride 1 and the pixel stride is ``x.stride(2)``.  Weights are (Cout, KH, KW, Cin).
+No arithmetic happens here: every function validates shapes, allocates outputs and launches.
+"""
+import torch
+
+from . import _lib
+from ._lib import ET_BF16, ET_F32
+
+ACT_NONE, ACT_SILU, ACT_RELU = 0, 1, 2
+
+
+def et_dtype(t):
+    if t.dtype == torch.float32:
+        return ET_F32
+    if t.dtype == torch.bfloat16:
+        return ET_BF16
+    raise TypeError(f"unsupported dtype {t.dtype} (float32 = parity mode, bfloat16 = performance mode)")
+
+
+def _nhwc(x):
+    """(N,H,W,C) with unit channel stride and dense N,H,W over a pixel stride -> pixel stride."""
+    assert x.dim() == 4 and x.stride(3) == 1, "NHWC tensor with contiguous channels expected"
+    ld = x.stride(2)
+    assert x.stride(1) == ld * x.shape[2] and x.stride(0) == ld * x.shape[2] * x.shape[1], \
+        "pixels must be dense over the pixel stride"
+    return ld
+
+
+def conv_out_hw(ih, iw, k, s, p):
+    return (ih + 2 * p - k) // s + 1, (iw + 2 * p - k) // s + 1
+
+
+def conv2d_fwd(x, w, stride, pad, *, bias=None, act=ACT_NONE, residual=None, out=None, want_stats=False):
+    """y = act(conv(x, w) + bias) + residual ; optional BN partial statistics (rows, 2, Cout)."""
+    N, IH, IW, Cin = x.shape
+    Cout, KH, KW, Cin2 = w.shape
+    assert Cin == Cin2 and w.is_contiguous() and w.dtype == x.dtype
+    OH, OW = conv_out_hw(IH, IW, KH, stride, pad)
+    lib = _lib.load()
+    if out is None:
+        out = torch.empty((N, OH, OW, Cout), dtype=x.dtype, device=x.device)
+    assert out.shape == (N, OH, OW, Cout)
+    stats = None
+    if want_stats:
+        rows = lib.et_conv2d_stats_rows(N, OH, OW)
+        stats = torch.empty((rows, 2, Cout), dtype=torch.float32, device=x.device)
+    ldr = _nhwc(residual) if residual is not None else 0
+    _lib.check(lib.et_conv2d_fwd(_lib.ptr(x), _lib.ptr(w), _lib.ptr(out), et_dtype(x), N, IH, IW, Cin, _nhwc(x),
+                                 Cout, KH, KW, stride, pad, _nhwc(out), _lib.ptr(bias), act,
+                                 _lib.ptr(residual), ldr, _lib.ptr(stats), _lib.stream(x)), "et_conv2d_fwd")
+    return (out, stats) if want_stats else out
+
+
+def weight_transpose(w):
+    """(Cout, KH, KW, Cin) -> (Cin, KH, KW, Cout), the dgrad operand."""
+    Cout, KH, KW, Cin = w.shape
+    wt = torch.empty((Cin, KH, KW, Cout), dtype=w.dtype, device=w.device)
+    _lib.check(_lib.load().et_weight_transpose(_lib.ptr(w), _lib.ptr(wt), et_dtype(w), Cout, KH * KW, Cin,
+                                               _lib.stream(w)), "et_weight_transpose")
+    return wt
+
+
+def conv2d_dgrad(dy, wT, in_hw, stride, pad, *, out=None, accumulate=False):
+    """dx (N, IH, IW, Cin) from dy (N, OH, OW, Cout) and wT (Cin, KH, KW, Cout)."""
+    N, OH, OW, Cout = dy.shape
+    Cin, KH, KW, Cout2 = wT.shape
+    assert Cout == Cout2 and wT.dtype == dy.dtype
+    IH, IW = in_hw
+    assert conv_out_hw(IH, IW, KH, stride, pad) == (OH, OW)
+    if out is None:
+        assert not accumulate
+        out = torch.empty((N, IH, IW, Cin), dtype=dy.dtype, device=dy.device)
+    _lib.check(_lib.load().et_conv2d_dgrad(_lib.ptr(dy), _lib.ptr(wT), _lib.ptr(out), et_dtype(dy), N, IH, IW, Cin,
+                                           _nhwc(out), Cout, KH, KW, stride, pad, _nhwc(dy), int(accumulate),
+                                           _lib.stream(dy)), "et_conv2d_dgrad")
+    return out
+
+
+def conv2d_wgrad(x, dy, dw, ksize, stride, pad):
+    """dw (Cout, KH, KW, Cin) fp32 += wgrad(x, dy)   (accumulates: dw is the gradient arena slice)."""
+    N, IH, IW, Cin = x.shape
+    _, OH, OW, Cout = dy.shape
+    assert dw.dtype == torch.float32 and dw.is_contiguous() and dw.shape == (Cout, ksize, ksize, Cin)
+    assert x.dtype == dy.dtype
+    _lib.check(_lib.load().et_conv2d_wgrad(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), et_dtype(x), N, IH, IW, Cin,
+                                           _nhwc(x), Cout, ksize, ksize, stride, pad, _nhwc(dy), _lib.stream(x)),
+               "et_conv2d_wgrad")
+    return dw
+
+
+def colsum(x2d_like, out):
+    """out[c] += sum over pixels of an NHWC tensor."""
+    N, H, W, C = x2d_like.shape
+    _lib.check(_lib.load().et_colsum(_lib.ptr(x2d_like), et_dtype(x2d_like), N * H * W, C, _nhwc(x2d_like),
+                                     _lib.ptr(out), _lib.stream(out)), "et_colsum")
+    return out

@@ -46,6 +46,56 @@ int et_nms_ssod(const float* pred, int B, int A, int no, float conf_thres, float
                 int agnostic, int max_det, float* dets, int* counts, int64_t* keep,
                 int* n_candidates, void* workspace, size_t ws_bytes, et_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Detect head inference decode.  Replaces models/head/yolov5_head.py:68-78 (+ _make_grid_old
+ * :127-136) for one level: reads the head conv output through element strides
+ * raw[b*sb + a*sa + y*sy + x*sx + c] (so the NHWC GEMM output is consumed in place) and writes
+ * z[b, a_offset + (a*ny + y)*nx + x, c] of z (B, A_total, no) fp32.
+ *   anchor_px (na, 2) fp32 = anchors[level] * stride (the reference's anchor_grid values).        */
+int et_detect_decode(const void* raw, int dtype, int B, int na, int ny, int nx, int no,
+                     int64_t sb, int64_t sa, int64_t sy, int64_t sx, const float* anchor_px,
+                     float stride, float* z, int64_t A_total, int64_t a_offset, et_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Flat-arena state updates (one launch instead of the reference's per-tensor python loops).
+ * EMA: utils/torch_utils.py:330-338 / :366-375 / :406-416   v = v*d ; v += (1-d)*m   (fp32)
+ * SGD: torch.optim.SGD(momentum, nesterov=True) built at trainer/trainer.py:215-223, with the
+ *      GradScaler 1/scale (trainer.py:399-400) folded in and an optional bf16 shadow copy of the
+ *      updated values (bf16_shadow may be NULL).  Pointers must be 16-byte aligned for EMA.      */
+int et_ema_update(float* ema, const float* model, int64_t n, float d, float one_minus_d, et_stream_t stream);
+int et_sgd_nesterov(float* p, const float* grad, float* momentum_buf, void* bf16_shadow, int64_t n,
+                    float lr, float momentum, float weight_decay, int first_step, float inv_scale,
+                    et_stream_t stream);
+int et_cast_f32_to_bf16(const float* src, void* dst, int64_t n, et_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Convolution (the conv inside `Conv`, models/backbone/common.py:471-481; Detect.m,
+ * models/head/yolov5_head.py:30; netD, models/detector/yolo_ssod.py:224-238) as implicit GEMM on
+ * MFMA.  x (N, IH, IW, Cin) NHWC with pixel stride ldx (elements, so channel slices of a wider
+ * buffer can be read in place); w (Cout, KH, KW, Cin); y (N, OH, OW, *) with pixel stride ldy.
+ * Requirements: Cin % 8 == 0 (pad the 3-channel stem input to 8), 16-byte aligned pointers and
+ * strides, KH*KW <= 36, tensors < 2^31 elements.  dgrad/wgrad additionally need Cout % 8 == 0.
+ *   fwd epilogue: v = acc (+ bias[co]); act (0 none, 1 SiLU, 2 ReLU); (+ residual[pix*ldr + co]).
+ *   stats_partial, if not NULL: (et_conv2d_stats_rows(N,OH,OW), 2, Cout) fp32 partial per-channel
+ *   sum / sum-of-squares of the raw accumulators (BatchNorm batch statistics, reduced later by
+ *   et_bn_finalize) -- every row is fully overwritten.
+ *   dgrad: dx = conv_transpose(dy, w) with wT = (Cin, KH, KW, Cout) from et_weight_transpose;
+ *          stride 2 is executed as 4 parity-class launches; accumulate != 0 adds into dx.
+ *   wgrad: dw (Cout, KH, KW, Cin) fp32 += ... (split-K over pixels, atomicAdd: zero or reuse the
+ *          gradient arena as the accumulator).                                                    */
+int et_conv2d_stats_rows(int N, int OH, int OW);
+int et_conv2d_fwd(const void* x, const void* w, void* y, int dtype, int N, int IH, int IW, int Cin,
+                  int ldx, int Cout, int KH, int KW, int stride, int pad, int ldy, const float* bias,
+                  int act, const void* residual, int ldr, float* stats_partial, et_stream_t stream);
+int et_conv2d_dgrad(const void* dy, const void* wT, void* dx, int dtype, int N, int IH, int IW, int Cin,
+                    int ldx, int Cout, int KH, int KW, int stride, int pad, int ldy, int accumulate,
+                    et_stream_t stream);
+int et_conv2d_wgrad(const void* x, const void* dy, float* dw, int dtype, int N, int IH, int IW, int Cin,
+                    int ldx, int Cout, int KH, int KW, int stride, int pad, int ldy, et_stream_t stream);
+int et_weight_transpose(const void* w, void* wT, int dtype, int Cout, int taps, int Cin, et_stream_t stream);
+/* out[c] += sum_p x[p*ld + c]  (bias gradient of the Detect convs) */
+int et_colsum(const void* x, int dtype, int P, int C, int ld, float* out, et_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -223,6 +223,7 @@ static inline unsigned __float_as_uint(float f) { unsigned i; memcpy(&i, &f, 4);
 static inline float __int_as_float(int i) { float f; memcpy(&f, &i, 4); return f; }
 static inline float __uint_as_float(unsigned i) { float f; memcpy(&f, &i, 4); return f; }
 static inline double __longlong_as_double(long long i) { double f; memcpy(&f, &i, 8); return f; }
+static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 using std::max;
 using std::min;
 

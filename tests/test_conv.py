@@ -1,0 +1,117 @@
+"""Implicit-GEMM conv kernels (fwd / dgrad / wgrad) vs a plain PyTorch fp32 reference of the same op.
+
+fp32 (parity mode, exact-f32 MFMA): tolerance 2e-5 relative to the output scale.
+bf16 (performance mode): inputs are rounded to bf16 first, the reference runs in fp32 on those rounded
+values, tolerance 2e-2 (bf16 output rounding + accumulation order).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+CASES = [
+    # N, H, W, Cin, Cout, k, s, p
+    (2, 12, 12, 32, 64, 1, 1, 0),
+    (1, 9, 11, 64, 40, 3, 1, 1),      # ragged M, Cout guard, BKV=8
+    (2, 12, 12, 16, 128, 3, 2, 1),    # stride 2, BKV=4 (fp32) / non-uniform tap (bf16: CV=2)
+    (1, 16, 16, 8, 32, 6, 2, 2),      # the stem: Cin padded to 8, 36 taps
+    (1, 6, 6, 128, 136, 1, 1, 0),     # wide N tile with a ragged second tile
+]
+
+
+def _mk(hip, shape, dtype, seed):
+    g = torch.Generator().manual_seed(seed)
+    t = torch.randn(shape, generator=g)
+    return t.to(dtype).to(hip.device)
+
+
+def _ref_conv(x, w, s, p):
+    # x (N,H,W,C), w (Cout,KH,KW,Cin) -> NHWC fp32
+    y = F.conv2d(x.float().cpu().permute(0, 3, 1, 2), w.float().cpu().permute(0, 3, 1, 2), stride=s, padding=p)
+    return y.permute(0, 2, 3, 1).contiguous()
+
+
+def _tol(dtype):
+    return 2e-5 if dtype == torch.float32 else 2e-2
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", CASES)
+def test_conv_fwd(hip, case, dtype):
+    from efficientteacher_amd import ops
+    N, H, W, Cin, Cout, k, s, p = case
+    x = _mk(hip, (N, H, W, Cin), dtype, 1)
+    w = _mk(hip, (Cout, k, k, Cin), dtype, 2) * (1.0 / (k * k * Cin) ** 0.5)
+    w = w.to(dtype)
+    y, stats = ops.conv2d_fwd(x, w, s, p, want_stats=True)
+    ref = _ref_conv(x, w, s, p)
+    err = (y.float().cpu() - ref).abs().max().item()
+    assert err <= _tol(dtype) * max(1.0, ref.abs().max().item()), err
+    # BN partial statistics: sum / sum of squares over pixels of the raw accumulators
+    st = stats.sum(0).cpu()
+    flat = ref.reshape(-1, Cout)
+    assert torch.allclose(st[0], flat.sum(0), rtol=1e-3, atol=_tol(dtype) * flat.shape[0] ** 0.5 * 4)
+    assert torch.allclose(st[1], (flat ** 2).sum(0), rtol=2e-2 if dtype != torch.float32 else 1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_fwd_epilogue_and_slices(hip, dtype):
+    """bias + SiLU + residual, reading a channel slice and writing into a slice of a wider buffer."""
+    from efficientteacher_amd import ops
+    N, H, W, Cin, Cout = 2, 8, 8, 32, 24
+    xb = _mk(hip, (N, H, W, 64), dtype, 3)
+    x = xb[..., 16:48]
+    w = (_mk(hip, (Cout, 3, 3, Cin), dtype, 4) * 0.08).to(dtype)
+    bias = _mk(hip, (Cout,), torch.float32, 5)
+    res = _mk(hip, (N, H, W, Cout), dtype, 6)
+    outb = torch.zeros((N, H, W, 40), dtype=dtype, device=hip.device)
+    out = outb[..., 8:32]
+    ops.conv2d_fwd(x, w, 1, 1, bias=bias, act=ops.ACT_SILU, residual=res, out=out)
+    ref = _ref_conv(x, w, 1, 1) + bias.cpu()
+    ref = F.silu(ref) + res.float().cpu()
+    err = (out.float().cpu() - ref).abs().max().item()
+    assert err <= _tol(dtype) * 8, err
+    assert (outb[..., :8] == 0).all() and (outb[..., 32:] == 0).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", [c for c in CASES if c[3] % 8 == 0 and c[4] % 8 == 0 and c[5] != 6])
+def test_conv_dgrad(hip, case, dtype):
+    from efficientteacher_amd import ops
+    N, H, W, Cin, Cout, k, s, p = case
+    OH, OW = ops.conv_out_hw(H, W, k, s, p)
+    dy = _mk(hip, (N, OH, OW, Cout), dtype, 7)
+    w = (_mk(hip, (Cout, k, k, Cin), dtype, 8) * (1.0 / (k * k * Cout) ** 0.5)).to(dtype)
+    wT = ops.weight_transpose(w)
+    assert torch.equal(wT.cpu(), w.cpu().permute(3, 1, 2, 0).contiguous())
+    dx = ops.conv2d_dgrad(dy, wT, (H, W), s, p)
+    xr = torch.zeros((N, Cin, H, W), requires_grad=True)
+    yr = F.conv2d(xr, w.float().cpu().permute(0, 3, 1, 2), stride=s, padding=p)
+    yr.backward(dy.float().cpu().permute(0, 3, 1, 2))
+    ref = xr.grad.permute(0, 2, 3, 1)
+    err = (dx.float().cpu() - ref).abs().max().item()
+    assert err <= _tol(dtype) * max(1.0, ref.abs().max().item()), err
+    # accumulate form
+    dx2 = dx.clone()
+    ops.conv2d_dgrad(dy, wT, (H, W), s, p, out=dx2, accumulate=True)
+    assert torch.allclose(dx2.float().cpu(), 2 * dx.float().cpu(), rtol=2e-2, atol=1e-2 if dtype != torch.float32 else 1e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", [c for c in CASES if c[4] % 8 == 0])
+def test_conv_wgrad(hip, case, dtype):
+    from efficientteacher_amd import ops
+    N, H, W, Cin, Cout, k, s, p = case
+    OH, OW = ops.conv_out_hw(H, W, k, s, p)
+    x = _mk(hip, (N, H, W, Cin), dtype, 9)
+    dy = _mk(hip, (N, OH, OW, Cout), dtype, 10)
+    dw = torch.zeros((Cout, k, k, Cin), dtype=torch.float32, device=hip.device)
+    ops.conv2d_wgrad(x, dy, dw, k, s, p)
+    wr = torch.zeros((Cout, Cin, k, k), requires_grad=True)
+    yr = F.conv2d(x.float().cpu().permute(0, 3, 1, 2), wr, stride=s, padding=p)
+    yr.backward(dy.float().cpu().permute(0, 3, 1, 2))
+    ref = wr.grad.permute(0, 2, 3, 1)
+    err = (dw.cpu() - ref).abs().max().item()
+    assert err <= 1e-4 * max(1.0, ref.abs().max().item()), err
+    ops.conv2d_wgrad(x, dy, dw, k, s, p)          # accumulates
+    assert torch.allclose(dw.cpu(), 2 * ref, rtol=1e-4, atol=1e-3)
