@@ -1,0 +1,350 @@
+// BatchNorm2d (train-mode batch statistics, eps 1e-3 / momentum 0.03 as set by
+// utils/torch_utils.py:162-169) + SiLU (+ Bottleneck residual, models/backbone/common.py:544) of the
+// reference's `Conv` block (common.py:471-481), forward and backward, on NHWC tensors.
+//
+// The conv epilogue already produced per-block partial sums of y and y^2 (et_conv2d_fwd
+// stats_partial), so the forward is:  bn_finalize (tiny, per channel, fp64 combine) -> one HBM-bound
+// elementwise pass  z = silu(y*scale + shift) (+ residual), 16 bytes per lane, every thread pinned to
+// one channel vector so scale/shift live in registers.  Backward is the classic two passes:
+// reduce (sum du, sum du*xhat) -> finalize -> apply.
+#include "et_device.h"
+#include "../../include/et_hip.h"
+
+enum { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2 };
+
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+    static constexpr int N = 4;
+    __device__ static __forceinline__ void load(const float* p, float (&v)[4]) {
+        const float4 t = *(const float4*)p; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+    __device__ static __forceinline__ void store(float* p, const float (&v)[4]) {
+        *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
+    }
+};
+template <> struct Vec16<uint16_t> {
+    static constexpr int N = 8;
+    __device__ static __forceinline__ void load(const uint16_t* p, float (&v)[8]) {
+        const uint4 t = *(const uint4*)p;
+        const unsigned w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+    }
+    __device__ static __forceinline__ void store(uint16_t* p, const float (&v)[8]) {
+        *(uint4*)p = make_uint4(et_pack_bf2(v[0], v[1]), et_pack_bf2(v[2], v[3]), et_pack_bf2(v[4], v[5]), et_pack_bf2(v[6], v[7]));
+    }
+};
+
+// ---- forward ------------------------------------------------------------------------------------------
+// stats_partial (rows, 2, C) -> scale/shift (+ saved mean / invstd, running statistics update)
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int rows, int C, double count,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float eps, float momentum, float* __restrict__ rmean,
+                                                          float* __restrict__ rvar, float* __restrict__ scale,
+                                                          float* __restrict__ shift, float* __restrict__ smean,
+                                                          float* __restrict__ sinvstd) {
+    __shared__ double red[2][8][32];
+    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double s = 0.0, q = 0.0;
+    if (c < C)
+        for (int r = rg; r < rows; r += 8) {
+            s += (double)part[((size_t)r * 2 + 0) * C + c];
+            q += (double)part[((size_t)r * 2 + 1) * C + c];
+        }
+    red[0][rg][cl] = s; red[1][rg][cl] = q;
+    __syncthreads();
+    if (rg == 0 && c < C) {
+        for (int k = 1; k < 8; ++k) { s += red[0][k][cl]; q += red[1][k][cl]; }
+        const double mean = s / count;
+        double var = q / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float sc = gamma[c] * invstd;
+        scale[c] = sc;
+        shift[c] = beta[c] - (float)mean * sc;
+        if (smean) { smean[c] = (float)mean; sinvstd[c] = invstd; }
+        if (rmean) {
+            const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+            rmean[c] = (1.0f - momentum) * rmean[c] + momentum * (float)mean;
+            rvar[c] = (1.0f - momentum) * rvar[c] + momentum * (float)unb;
+        }
+    }
+}
+
+// eval-mode affine from running statistics (teacher path): scale = g/sqrt(rv+eps), shift = b - rm*scale
+__global__ __launch_bounds__(256) void bn_eval_affine_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             const float* __restrict__ rmean, const float* __restrict__ rvar,
+                                                             float eps, float* __restrict__ scale, float* __restrict__ shift) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float sc = gamma[c] / sqrtf(rvar[c] + eps);
+    scale[c] = sc;
+    shift[c] = beta[c] - rmean[c] * sc;
+}
+
+__device__ __forceinline__ float act_fwd(float u, int act) {
+    if (act == ACT_SILU) return u / (1.0f + expf(-u));
+    if (act == ACT_RELU) return fmaxf(u, 0.f);
+    return u;
+}
+__device__ __forceinline__ float act_grad(float u, int act) {
+    if (act == ACT_SILU) { const float s = 1.0f / (1.0f + expf(-u)); return s * (1.0f + u * (1.0f - s)); }
+    if (act == ACT_RELU) return u > 0.f ? 1.f : 0.f;
+    return 1.f;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y, int ldy, T* __restrict__ z, int ldz,
+                                                         const T* __restrict__ res, int ldr, int P, int CV,
+                                                         const float* __restrict__ scale, const float* __restrict__ shift, int act) {
+    constexpr int N = Vec16<T>::N;
+    const long long gt = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int cv = (int)(gt % CV);
+    long long p = gt / CV;
+    const long long pstep = ((long long)gridDim.x * 256) / CV;   // grid is sized so that CV | gridDim.x*256
+    float sc[N], sh[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) { sc[i] = scale[cv * N + i]; sh[i] = shift[cv * N + i]; }
+    for (; p < P; p += pstep) {
+        float v[N];
+        Vec16<T>::load(y + p * ldy + cv * N, v);
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = act_fwd(v[i] * sc[i] + sh[i], act);
+        if (res) {
+            float r[N];
+            Vec16<T>::load(res + p * ldr + cv * N, r);
+#pragma unroll
+            for (int i = 0; i < N; ++i) v[i] += r[i];
+        }
+        Vec16<T>::store(z + p * ldz + cv * N, v);
+    }
+}
+
+// ---- backward -----------------------------------------------------------------------------------------
+// pass 1: per-block partial sums of du and du*xhat, du = dz * act'(y*scale+shift), xhat = (y-mean)*invstd
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const T* __restrict__ dz, int lddz, const T* __restrict__ y, int ldy,
+                                                                int P, int CV, const float* __restrict__ scale,
+                                                                const float* __restrict__ shift, const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd, int act,
+                                                                float* __restrict__ part) {
+    constexpr int N = Vec16<T>::N;
+    __shared__ float acc[2][2048];
+    const int C = CV * N;
+    for (int i = threadIdx.x; i < C; i += 256) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
+    __syncthreads();
+    const long long gt = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int cv = (int)(gt % CV);
+    long long p = gt / CV;
+    const long long pstep = ((long long)gridDim.x * 256) / CV;
+    float sc[N], sh[N], mu[N], is[N], s1[N], s2[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        sc[i] = scale[cv * N + i]; sh[i] = shift[cv * N + i]; mu[i] = mean[cv * N + i]; is[i] = invstd[cv * N + i];
+        s1[i] = 0.f; s2[i] = 0.f;
+    }
+    for (; p < P; p += pstep) {
+        float g[N], v[N];
+        Vec16<T>::load(dz + p * lddz + cv * N, g);
+        Vec16<T>::load(y + p * ldy + cv * N, v);
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const float du = g[i] * act_grad(v[i] * sc[i] + sh[i], act);
+            s1[i] += du;
+            s2[i] += du * ((v[i] - mu[i]) * is[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) { atomicAdd(&acc[0][cv * N + i], s1[i]); atomicAdd(&acc[1][cv * N + i], s2[i]); }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C; i += 256) {
+        part[((size_t)blockIdx.x * 2 + 0) * C + i] = acc[0][i];
+        part[((size_t)blockIdx.x * 2 + 1) * C + i] = acc[1][i];
+    }
+}
+
+// finalize: dbeta += s1, dgamma += s2, coefficients of pass 2
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int rows, int C, float count,
+                                                              const float* __restrict__ gamma, const float* __restrict__ invstd,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                              float* __restrict__ k0, float* __restrict__ k1, float* __restrict__ k2) {
+    __shared__ double red[2][8][32];
+    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double s = 0.0, q = 0.0;
+    if (c < C)
+        for (int r = rg; r < rows; r += 8) {
+            s += (double)part[((size_t)r * 2 + 0) * C + c];
+            q += (double)part[((size_t)r * 2 + 1) * C + c];
+        }
+    red[0][rg][cl] = s; red[1][rg][cl] = q;
+    __syncthreads();
+    if (rg == 0 && c < C) {
+        for (int k = 1; k < 8; ++k) { s += red[0][k][cl]; q += red[1][k][cl]; }
+        if (dbeta) dbeta[c] += (float)s;
+        if (dgamma) dgamma[c] += (float)q;
+        k0[c] = gamma[c] * invstd[c];
+        k1[c] = (float)(s / count);
+        k2[c] = (float)(q / count);
+    }
+}
+
+// pass 2: dy = k0 * (du - k1 - xhat*k2)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restrict__ dz, int lddz, const T* __restrict__ y, int ldy,
+                                                               T* __restrict__ dy, int lddy, int P, int CV,
+                                                               const float* __restrict__ scale, const float* __restrict__ shift,
+                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                               const float* __restrict__ k0, const float* __restrict__ k1,
+                                                               const float* __restrict__ k2, int act) {
+    constexpr int N = Vec16<T>::N;
+    const long long gt = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int cv = (int)(gt % CV);
+    long long p = gt / CV;
+    const long long pstep = ((long long)gridDim.x * 256) / CV;
+    float sc[N], sh[N], mu[N], is[N], a0[N], a1[N], a2[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const int c = cv * N + i;
+        sc[i] = scale[c]; sh[i] = shift[c]; mu[i] = mean[c]; is[i] = invstd[c]; a0[i] = k0[c]; a1[i] = k1[c]; a2[i] = k2[c];
+    }
+    for (; p < P; p += pstep) {
+        float g[N], v[N];
+        Vec16<T>::load(dz + p * lddz + cv * N, g);
+        Vec16<T>::load(y + p * ldy + cv * N, v);
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const float du = g[i] * act_grad(v[i] * sc[i] + sh[i], act);
+            g[i] = a0[i] * (du - a1[i] - ((v[i] - mu[i]) * is[i]) * a2[i]);
+        }
+        Vec16<T>::store(dy + p * lddy + cv * N, g);
+    }
+}
+
+// plain activation backward (netD ReLU between its two 1x1 convs, yolo_ssod.py:231-238): dy = dz * act'(y)
+template <typename T>
+__global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ dz, int lddz, const T* __restrict__ y, int ldy,
+                                                      T* __restrict__ dy, int lddy, int P, int CV, int act) {
+    constexpr int N = Vec16<T>::N;
+    const long long gt = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int cv = (int)(gt % CV);
+    long long p = gt / CV;
+    const long long pstep = ((long long)gridDim.x * 256) / CV;
+    for (; p < P; p += pstep) {
+        float g[N], v[N];
+        Vec16<T>::load(dz + p * lddz + cv * N, g);
+        Vec16<T>::load(y + p * ldy + cv * N, v);
+#pragma unroll
+        for (int i = 0; i < N; ++i) g[i] *= act_grad(v[i], act);
+        Vec16<T>::store(dy + p * lddy + cv * N, g);
+    }
+}
+
+// ---- host ------------------------------------------------------------------------------------------------
+// number of 256-thread blocks such that CV divides blocks*256 and the grid is ~4 waves of the chip
+static int ew_blocks(long long P, int CV) {
+    int a = CV, b = 256;
+    while (b) { const int t = a % b; a = b; b = t; }
+    const int unit = CV / a;                                   // blocks must be a multiple of this
+    const long long need = (P * CV + 255) / 256;
+    long long blocks = need < 2048 ? need : 2048;
+    blocks = ((blocks + unit - 1) / unit) * unit;
+    return (int)blocks;
+}
+
+extern "C" int et_bn_reduce_rows(int P, int C, int dtype) {
+    const int vec = dtype == ET_F32 ? 4 : 8;
+    return ew_blocks(P, C / vec);
+}
+
+extern "C" int et_bn_finalize(const float* stats_partial, int rows, int C, double count, const float* gamma,
+                              const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                              float* scale, float* shift, float* save_mean, float* save_invstd, et_stream_t stream) {
+    if (!stats_partial || !gamma || !beta || !scale || !shift) return -1;
+    if (rows <= 0 || C <= 0 || count <= 0) return -2;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, stats_partial, rows, C, count,
+                       gamma, beta, eps, momentum, running_mean, running_var, scale, shift, save_mean, save_invstd);
+    ET_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int et_bn_eval_affine(int C, const float* gamma, const float* beta, const float* running_mean,
+                                 const float* running_var, float eps, float* scale, float* shift, et_stream_t stream) {
+    if (!gamma || !beta || !running_mean || !running_var || !scale || !shift) return -1;
+    hipLaunchKernelGGL(bn_eval_affine_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, C, gamma, beta,
+                       running_mean, running_var, eps, scale, shift);
+    ET_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int et_bn_act_fwd(const void* y, int ldy, void* z, int ldz, const void* residual, int ldr, int dtype, int P,
+                             int C, const float* scale, const float* shift, int act, et_stream_t stream) {
+    if (!y || !z || !scale || !shift) return -1;
+    const int vec = dtype == ET_F32 ? 4 : 8;
+    if (P <= 0 || C <= 0 || C % vec || ldy % vec || ldz % vec || (residual && ldr % vec)) return -2;
+    const int CV = C / vec;
+    const dim3 grid(ew_blocks(P, CV));
+    if (dtype == ET_F32)
+        hipLaunchKernelGGL((bn_act_fwd_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)y, ldy, (float*)z, ldz,
+                           (const float*)residual, ldr, P, CV, scale, shift, act);
+    else if (dtype == ET_BF16)
+        hipLaunchKernelGGL((bn_act_fwd_kernel<uint16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)y, ldy, (uint16_t*)z, ldz,
+                           (const uint16_t*)residual, ldr, P, CV, scale, shift, act);
+    else return -2;
+    ET_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int et_bn_act_bwd(const void* dz, int lddz, const void* y, int ldy, void* dy, int lddy, int dtype, int P, int C,
+                             const float* gamma, const float* scale, const float* shift, const float* save_mean,
+                             const float* save_invstd, int act, float* dgamma, float* dbeta, float* workspace,
+                             size_t ws_floats, et_stream_t stream) {
+    // workspace: rows*2*C partial sums + 3*C coefficients (fp32)
+    if (!dz || !y || !dy || !gamma || !scale || !shift || !save_mean || !save_invstd || !workspace) return -1;
+    const int vec = dtype == ET_F32 ? 4 : 8;
+    if (P <= 0 || C <= 0 || C > 2048 || C % vec || lddz % vec || ldy % vec || lddy % vec) return -2;
+    const int CV = C / vec;
+    const int rows = ew_blocks(P, CV);
+    if (ws_floats < (size_t)rows * 2 * C + 3 * (size_t)C) return -3;
+    float* part = workspace;
+    float* k0 = workspace + (size_t)rows * 2 * C;
+    float* k1 = k0 + C;
+    float* k2 = k1 + C;
+    const dim3 grid(rows);
+    if (dtype == ET_F32)
+        hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)dz, lddz,
+                           (const float*)y, ldy, P, CV, scale, shift, save_mean, save_invstd, act, part);
+    else if (dtype == ET_BF16)
+        hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<uint16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)dz, lddz,
+                           (const uint16_t*)y, ldy, P, CV, scale, shift, save_mean, save_invstd, act, part);
+    else return -2;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, part, rows, C, (float)P, gamma,
+                       save_invstd, dgamma, dbeta, k0, k1, k2);
+    if (dtype == ET_F32)
+        hipLaunchKernelGGL((bn_act_bwd_apply_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)dz, lddz,
+                           (const float*)y, ldy, (float*)dy, lddy, P, CV, scale, shift, save_mean, save_invstd, k0, k1, k2, act);
+    else
+        hipLaunchKernelGGL((bn_act_bwd_apply_kernel<uint16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)dz, lddz,
+                           (const uint16_t*)y, ldy, (uint16_t*)dy, lddy, P, CV, scale, shift, save_mean, save_invstd, k0, k1, k2, act);
+    ET_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int et_act_bwd(const void* dz, int lddz, const void* y, int ldy, void* dy, int lddy, int dtype, int P, int C,
+                          int act, et_stream_t stream) {
+    if (!dz || !y || !dy) return -1;
+    const int vec = dtype == ET_F32 ? 4 : 8;
+    if (P <= 0 || C <= 0 || C % vec || lddz % vec || ldy % vec || lddy % vec) return -2;
+    const int CV = C / vec;
+    const dim3 grid(ew_blocks(P, CV));
+    if (dtype == ET_F32)
+        hipLaunchKernelGGL((act_bwd_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)dz, lddz, (const float*)y, ldy,
+                           (float*)dy, lddy, P, CV, act);
+    else if (dtype == ET_BF16)
+        hipLaunchKernelGGL((act_bwd_kernel<uint16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)dz, lddz, (const uint16_t*)y, ldy,
+                           (uint16_t*)dy, lddy, P, CV, act);
+    else return -2;
+    ET_CHECK_LAUNCH();
+    return 0;
+}

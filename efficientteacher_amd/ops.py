@@ -97,3 +97,112 @@ def colsum(x2d_like, out):
     _lib.check(_lib.load().et_colsum(_lib.ptr(x2d_like), et_dtype(x2d_like), N * H * W, C, _nhwc(x2d_like),
                                      _lib.ptr(out), _lib.stream(out)), "et_colsum")
     return out
+
+
+# ---- BatchNorm + activation -----------------------------------------------------------------------
+def bn_finalize(stats, count, gamma, beta, eps, momentum, running_mean=None, running_var=None):
+    rows, _, C = stats.shape
+    dev = stats.device
+    scale, shift, mean, invstd = (torch.empty(C, dtype=torch.float32, device=dev) for _ in range(4))
+    _lib.check(_lib.load().et_bn_finalize(_lib.ptr(stats), rows, C, float(count), _lib.ptr(gamma), _lib.ptr(beta),
+                                          eps, momentum, _lib.ptr(running_mean), _lib.ptr(running_var),
+                                          _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(mean), _lib.ptr(invstd),
+                                          _lib.stream(stats)), "et_bn_finalize")
+    return scale, shift, mean, invstd
+
+
+def bn_eval_affine(gamma, beta, running_mean, running_var, eps):
+    C = gamma.numel()
+    scale = torch.empty(C, dtype=torch.float32, device=gamma.device)
+    shift = torch.empty_like(scale)
+    _lib.check(_lib.load().et_bn_eval_affine(C, _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(running_mean),
+                                             _lib.ptr(running_var), eps, _lib.ptr(scale), _lib.ptr(shift),
+                                             _lib.stream(gamma)), "et_bn_eval_affine")
+    return scale, shift
+
+
+def bn_act_fwd(y, scale, shift, act, residual=None, out=None):
+    N, H, W, C = y.shape
+    if out is None:
+        out = torch.empty((N, H, W, C), dtype=y.dtype, device=y.device)
+    ldr = _nhwc(residual) if residual is not None else 0
+    _lib.check(_lib.load().et_bn_act_fwd(_lib.ptr(y), _nhwc(y), _lib.ptr(out), _nhwc(out), _lib.ptr(residual), ldr,
+                                         et_dtype(y), N * H * W, C, _lib.ptr(scale), _lib.ptr(shift), act,
+                                         _lib.stream(y)), "et_bn_act_fwd")
+    return out
+
+
+def bn_act_bwd(dz, y, gamma, scale, shift, mean, invstd, act, dgamma, dbeta, out=None):
+    N, H, W, C = y.shape
+    lib = _lib.load()
+    if out is None:
+        out = torch.empty((N, H, W, C), dtype=y.dtype, device=y.device)
+    rows = lib.et_bn_reduce_rows(N * H * W, C, et_dtype(y))
+    nws = rows * 2 * C + 3 * C
+    ws = torch.empty(nws, dtype=torch.float32, device=y.device)
+    _lib.check(lib.et_bn_act_bwd(_lib.ptr(dz), _nhwc(dz), _lib.ptr(y), _nhwc(y), _lib.ptr(out), _nhwc(out),
+                                 et_dtype(y), N * H * W, C, _lib.ptr(gamma), _lib.ptr(scale), _lib.ptr(shift),
+                                 _lib.ptr(mean), _lib.ptr(invstd), act, _lib.ptr(dgamma), _lib.ptr(dbeta),
+                                 _lib.ptr(ws), nws, _lib.stream(y)), "et_bn_act_bwd")
+    return out
+
+
+def act_bwd(dz, y, act, out=None):
+    N, H, W, C = y.shape
+    if out is None:
+        out = torch.empty((N, H, W, C), dtype=y.dtype, device=y.device)
+    _lib.check(_lib.load().et_act_bwd(_lib.ptr(dz), _nhwc(dz), _lib.ptr(y), _nhwc(y), _lib.ptr(out), _nhwc(out),
+                                      et_dtype(y), N * H * W, C, act, _lib.stream(y)), "et_act_bwd")
+    return out
+
+
+# ---- spatial ----------------------------------------------------------------------------------------
+def pack_input(x_nchw, dtype):
+    """(B,3,H,W) fp32 NCHW -> (B,H,W,8) NHWC of `dtype`, channels zero padded."""
+    x = x_nchw.contiguous()
+    if x.dtype != torch.float32:
+        x = x.float()
+    B, C, H, W = x.shape
+    y = torch.empty((B, H, W, 8), dtype=dtype, device=x.device)
+    _lib.check(_lib.load().et_pack_input(_lib.ptr(x), _lib.ptr(y), et_dtype(y), B, C, H, W, _lib.stream(x)),
+               "et_pack_input")
+    return y
+
+
+def maxpool5_fwd(x, out=None):
+    N, H, W, C = x.shape
+    if out is None:
+        out = torch.empty((N, H, W, C), dtype=x.dtype, device=x.device)
+    idx = torch.empty((N, H, W, C), dtype=torch.uint8, device=x.device)
+    _lib.check(_lib.load().et_maxpool5_fwd(_lib.ptr(x), _nhwc(x), _lib.ptr(out), _nhwc(out), _lib.ptr(idx),
+                                           et_dtype(x), N, H, W, C, _lib.stream(x)), "et_maxpool5_fwd")
+    return out, idx
+
+
+def maxpool5_bwd(dy, idx, base=None, out=None):
+    N, H, W, C = dy.shape
+    if out is None:
+        out = torch.empty((N, H, W, C), dtype=dy.dtype, device=dy.device)
+    ldb = _nhwc(base) if base is not None else 0
+    _lib.check(_lib.load().et_maxpool5_bwd(_lib.ptr(dy), _nhwc(dy), _lib.ptr(idx), _lib.ptr(base), ldb, _lib.ptr(out),
+                                           _nhwc(out), et_dtype(dy), N, H, W, C, _lib.stream(dy)), "et_maxpool5_bwd")
+    return out
+
+
+def upsample2x_fwd(x, out=None):
+    N, H, W, C = x.shape
+    if out is None:
+        out = torch.empty((N, 2 * H, 2 * W, C), dtype=x.dtype, device=x.device)
+    _lib.check(_lib.load().et_upsample2x_fwd(_lib.ptr(x), _nhwc(x), _lib.ptr(out), _nhwc(out), et_dtype(x), N, H, W, C,
+                                             _lib.stream(x)), "et_upsample2x_fwd")
+    return out
+
+
+def upsample2x_bwd(dy, out=None):
+    N, H2, W2, C = dy.shape
+    H, W = H2 // 2, W2 // 2
+    if out is None:
+        out = torch.empty((N, H, W, C), dtype=dy.dtype, device=dy.device)
+    _lib.check(_lib.load().et_upsample2x_bwd(_lib.ptr(dy), _nhwc(dy), _lib.ptr(out), _nhwc(out), et_dtype(dy), N, H, W, C,
+                                             _lib.stream(dy)), "et_upsample2x_bwd")
+    return out

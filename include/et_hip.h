@@ -96,6 +96,49 @@ int et_weight_transpose(const void* w, void* wT, int dtype, int Cout, int taps, 
 /* out[c] += sum_p x[p*ld + c]  (bias gradient of the Detect convs) */
 int et_colsum(const void* x, int dtype, int P, int C, int ld, float* out, et_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * BatchNorm2d + activation (+ residual) of the reference `Conv` block
+ * (models/backbone/common.py:471-481, Bottleneck add :544; eps / momentum from
+ * utils/torch_utils.py:162-169), NHWC, elementwise 16 B per lane.
+ *   et_bn_finalize: (rows,2,C) partial sums from et_conv2d_fwd -> scale = g*invstd,
+ *       shift = b - mean*scale, saved mean / invstd for backward, running stats update
+ *       (running_* may be NULL; unbiased variance as torch).
+ *   et_bn_eval_affine: eval-mode (teacher) scale/shift from the running statistics.
+ *   et_bn_act_fwd: z = act(y*scale + shift) (+ residual).
+ *   et_bn_act_bwd: dy = dBN/dSiLU(dz) in two passes; dgamma/dbeta (fp32) are ACCUMULATED.
+ *       workspace: >= et_bn_reduce_rows(P,C,dtype)*2*C + 3*C floats.  C <= 2048.
+ *   et_act_bwd: dy = dz * act'(y)   (netD ReLU, models/detector/yolo_ssod.py:231-238).          */
+int et_bn_reduce_rows(int P, int C, int dtype);
+int et_bn_finalize(const float* stats_partial, int rows, int C, double count, const float* gamma,
+                   const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                   float* scale, float* shift, float* save_mean, float* save_invstd, et_stream_t stream);
+int et_bn_eval_affine(int C, const float* gamma, const float* beta, const float* running_mean,
+                      const float* running_var, float eps, float* scale, float* shift, et_stream_t stream);
+int et_bn_act_fwd(const void* y, int ldy, void* z, int ldz, const void* residual, int ldr, int dtype, int P,
+                  int C, const float* scale, const float* shift, int act, et_stream_t stream);
+int et_bn_act_bwd(const void* dz, int lddz, const void* y, int ldy, void* dy, int lddy, int dtype, int P, int C,
+                  const float* gamma, const float* scale, const float* shift, const float* save_mean,
+                  const float* save_invstd, int act, float* dgamma, float* dbeta, float* workspace,
+                  size_t ws_floats, et_stream_t stream);
+int et_act_bwd(const void* dz, int lddz, const void* y, int ldy, void* dy, int lddy, int dtype, int P, int C,
+               int act, et_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Spatial data movement on NHWC tensors.
+ *   et_pack_input: (B,C<=8,H,W) fp32 NCHW image -> (B,H,W,8) NHWC, zero padded channels (feeds the
+ *       stem conv, models/backbone/yolov5_backbone.py:56).
+ *   et_maxpool5_*: nn.MaxPool2d(5,1,2) of SPPF (models/backbone/common.py:702-708); argmax is
+ *       (B,H,W,C) uint8 window codes ky*5+kx (first maximum in scan order, torch's tie rule);
+ *       bwd: dx = base + gather(dy) (base may be NULL).
+ *   et_upsample2x_*: nn.Upsample(scale_factor=2, 'nearest') (models/neck/yolov5_neck.py:60,64).   */
+int et_pack_input(const float* x_nchw, void* y_nhwc8, int dtype, int B, int C, int H, int W, et_stream_t stream);
+int et_maxpool5_fwd(const void* x, int ldx, void* y, int ldy, uint8_t* argmax, int dtype, int B, int H, int W, int C,
+                    et_stream_t stream);
+int et_maxpool5_bwd(const void* dy, int lddy, const uint8_t* argmax, const void* base, int ldb, void* dx, int lddx,
+                    int dtype, int B, int H, int W, int C, et_stream_t stream);
+int et_upsample2x_fwd(const void* x, int ldx, void* y, int ldy, int dtype, int B, int H, int W, int C, et_stream_t stream);
+int et_upsample2x_bwd(const void* dy, int lddy, void* dx, int lddx, int dtype, int B, int H, int W, int C, et_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
