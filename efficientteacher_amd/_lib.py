@@ -29,7 +29,7 @@ SIGNATURES = {
     "et_sgd_nesterov": (c_int, [P, P, P, P, c_int64, c_float, c_float, c_float, c_int, c_float, P]),
     "et_cast_f32_to_bf16": (c_int, [P, P, c_int64, P]),
     "et_conv2d_stats_rows": (c_int, [c_int, c_int, c_int]),
-    "et_conv2d_fwd": (c_int, [P, P, P, c_int] + [c_int] * 11 + [P, c_int, P, c_int, P, P]),
+    "et_conv2d_fwd": (c_int, [P, P, P, c_int] + [c_int] * 11 + [P, P, c_int, P, c_int, P, P]),
     "et_conv2d_dgrad": (c_int, [P, P, P, c_int] + [c_int] * 11 + [c_int, P]),
     "et_conv2d_wgrad": (c_int, [P, P, P, c_int] + [c_int] * 11 + [P]),
     "et_weight_transpose": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
@@ -46,7 +46,26 @@ SIGNATURES = {
     "et_maxpool5_bwd": (c_int, [P, c_int, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "et_upsample2x_fwd": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "et_upsample2x_bwd": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "et_pseudo_label_transform": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P, P]),
+    "et_yolo_loss": (c_int, [P, P]),
+    "et_select_targets": (c_int, [P, P, c_int, P, P, c_int, c_int, P, P]),
+    "et_scale_cast": (c_int, [P, P, c_int, c_int64, c_float, P, P]),
 }
+
+
+
+class LossLevel(ctypes.Structure):
+    _fields_ = [("p", P), ("dp", P), ("tobj_ws", P), ("sb", c_int64), ("sa", c_int64), ("sy", c_int64),
+                ("sx", c_int64), ("ny", c_int), ("nx", c_int), ("anchors", c_float * 6), ("balance", c_float)]
+
+
+class LossDesc(ctypes.Structure):
+    _fields_ = [("dtype", c_int), ("B", c_int), ("na", c_int), ("nc", c_int), ("NT", c_int), ("nl", c_int),
+                ("anchor_t", c_float), ("gr", c_float), ("cp", c_float), ("cn", c_float), ("cls_pw", c_float),
+                ("obj_pw", c_float), ("box_w", c_float), ("obj_w", c_float), ("cls_w", c_float),
+                ("pass_mask", c_int), ("ignore_obj", c_int), ("targets", P), ("acc_ws", P), ("out", P),
+                ("level", LossLevel * 4)]
+
 
 _dll = None
 _emulated = False

@@ -1,0 +1,168 @@
+"""torch.autograd glue: one Function per fused block of the YOLOv5 graph.  Each forward/backward is a
+short sequence of kernel launches (efficientteacher_amd/ops.py); parameter gradients are accumulated
+by the kernels straight into the flat gradient arena (FlatState.grads), so backward returns ``None``
+for them and autograd only carries activation gradients.
+"""
+import torch
+from torch.autograd import Function
+
+from . import ops
+
+ACT_CODE = {"silu": ops.ACT_SILU, "relu": ops.ACT_RELU, "none": ops.ACT_NONE}
+
+
+class ConvBnActFn(Function):
+    """z = act(BN_train(conv(x, w))) (+ residual)   -- reference Conv.forward (common.py:480-481) in
+    train mode, plus the Bottleneck shortcut (common.py:544)."""
+
+    @staticmethod
+    def forward(ctx, x, residual, wparam, cs, bs, act, nbt):
+        # wparam (the nn.Parameter) only ties the op into the autograd graph; its gradient is written
+        # by the wgrad kernel directly into the flat arena, so backward returns None for it.
+        ctx.w_needs_grad = wparam.requires_grad
+        y, stats = ops.conv2d_fwd(x, cs.w_lp, cs.stride, cs.pad, want_stats=True)
+        N, OH, OW, _ = y.shape
+        scale, shift, mean, invstd = ops.bn_finalize(stats, N * OH * OW, bs.gamma, bs.beta, bs.eps, bs.momentum,
+                                                     bs.rmean, bs.rvar)
+        if nbt is not None:
+            nbt.add_(1)
+        z = ops.bn_act_fwd(y, scale, shift, act, residual=residual)
+        ctx.cs, ctx.bs, ctx.act = cs, bs, act
+        ctx.has_res = residual is not None
+        ctx.x_needs_grad = x.requires_grad
+        ctx.save_for_backward(x, y, scale, shift, mean, invstd)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, y, scale, shift, mean, invstd = ctx.saved_tensors
+        cs, bs = ctx.cs, ctx.bs
+        dz = _dense_or_slice(dz)
+        dy = ops.bn_act_bwd(dz, y, bs.gamma, scale, shift, mean, invstd, ctx.act, bs.ggamma, bs.gbeta)
+        if ctx.w_needs_grad:
+            ops.conv2d_wgrad(x, dy, cs.gw, cs.k, cs.stride, cs.pad)
+        dx = None
+        if ctx.x_needs_grad:
+            wT = ops.weight_transpose(cs.w_lp)
+            dx = ops.conv2d_dgrad(dy, wT, (x.shape[1], x.shape[2]), cs.stride, cs.pad)
+        return dx, (dz if ctx.has_res else None), None, None, None, None, None
+
+
+class ConvBiasFn(Function):
+    """y = act(conv(x, w) + bias): the Detect output convs (yolov5_head.py:30,55) and netD
+    (yolo_ssod.py:224-238).  With ``head=(na, no)`` the result is returned as the (B, na, ny, nx, no)
+    logits view of the NHWC GEMM output (yolov5_head.py:66 without the permute/contiguous copy)."""
+
+    @staticmethod
+    def forward(ctx, x, wparam, cs, act, head):
+        ctx.w_needs_grad = wparam.requires_grad
+        y = ops.conv2d_fwd(x, cs.w_lp, cs.stride, cs.pad, bias=cs.bias, act=act)
+        ctx.cs, ctx.act, ctx.head = cs, act, head
+        ctx.x_needs_grad = x.requires_grad
+        ctx.save_for_backward(x, y)
+        if head is None:
+            return y
+        return head_view(y, *head)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y = ctx.saved_tensors
+        cs = ctx.cs
+        if ctx.head is not None:
+            dy = head_grad_to_nhwc(dy, y.shape, *ctx.head)
+        dy = _dense_or_slice(dy)
+        if ctx.act != ops.ACT_NONE:
+            dy = ops.act_bwd(dy, y, ctx.act)
+        if ctx.w_needs_grad:
+            ops.conv2d_wgrad(x, dy, cs.gw, cs.k, cs.stride, cs.pad)
+            if cs.gbias is not None:
+                ops.colsum(dy, cs.gbias)
+        dx = None
+        if ctx.x_needs_grad:
+            wT = ops.weight_transpose(cs.w_lp)
+            dx = ops.conv2d_dgrad(dy, wT, (x.shape[1], x.shape[2]), cs.stride, cs.pad)
+        return dx, None, None, None, None
+
+
+def head_view(y, na, no):
+    B, ny, nx, CP = y.shape
+    return y.as_strided((B, na, ny, nx, no), (ny * nx * CP, no, nx * CP, CP, 1), y.storage_offset())
+
+
+def head_grad_to_nhwc(g, yshape, na, no):
+    """(B, na, ny, nx, no) gradient -> (B, ny, nx, CP).  The fused loss returns its gradient already in
+    that memory layout (zero-copy); anything else is scattered into a zeroed buffer."""
+    B, ny, nx, CP = yshape
+    want = (ny * nx * CP, no, nx * CP, CP, 1)
+    need = (g.storage_offset() + B * ny * nx * CP) * g.element_size()
+    if tuple(g.stride()) == want and g.untyped_storage().nbytes() >= need:
+        return g.as_strided((B, ny, nx, CP), (ny * nx * CP, nx * CP, CP, 1), g.storage_offset())
+    buf = torch.zeros((B, ny, nx, CP), dtype=g.dtype, device=g.device)
+    buf.as_strided((B, na, ny, nx, no), want).copy_(g)
+    return buf
+
+
+class SppfPoolFn(Function):
+    """cat([x, m(x), m(m(x)), m(m(m(x)))], C)   -- SPPF.forward (common.py:702-708), m = MaxPool2d(5,1,2)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        N, H, W, C = x.shape
+        cat = torch.empty((N, H, W, 4 * C), dtype=x.dtype, device=x.device)
+        cat[..., :C].copy_(x)
+        idx = []
+        for i in range(3):
+            _, ix = ops.maxpool5_fwd(cat[..., i * C:(i + 1) * C], out=cat[..., (i + 1) * C:(i + 2) * C])
+            idx.append(ix)
+        ctx.save_for_backward(*idx)
+        ctx.C = C
+        return cat
+
+    @staticmethod
+    def backward(ctx, dcat):
+        i1, i2, i3 = ctx.saved_tensors
+        C = ctx.C
+        dcat = _dense_or_slice(dcat)
+        d2 = ops.maxpool5_bwd(dcat[..., 3 * C:], i3, base=dcat[..., 2 * C:3 * C])
+        d1 = ops.maxpool5_bwd(d2, i2, base=dcat[..., C:2 * C])
+        return ops.maxpool5_bwd(d1, i1, base=dcat[..., :C])
+
+
+class UpsampleCatFn(Function):
+    """cat([upsample2x(a), b], C)   -- nn.Upsample + Concat in the neck (yolov5_neck.py:92-93, 97-98):
+    the upsampled rows are written straight into the concat buffer."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        N, H, W, Ca = a.shape
+        Cb = b.shape[3]
+        cat = torch.empty((N, 2 * H, 2 * W, Ca + Cb), dtype=a.dtype, device=a.device)
+        ops.upsample2x_fwd(a, out=cat[..., :Ca])
+        cat[..., Ca:].copy_(b)
+        ctx.Ca = Ca
+        return cat
+
+    @staticmethod
+    def backward(ctx, dcat):
+        dcat = _dense_or_slice(dcat)
+        return ops.upsample2x_bwd(dcat[..., :ctx.Ca]), dcat[..., ctx.Ca:]
+
+
+class GradReverseFn(Function):  # reference models/detector/yolo_ssod.py:158-171
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        raise NotImplementedError("domain-adaptation backward (SSOD.with_da_loss) is not built yet")
+
+
+def _dense_or_slice(g):
+    """Kernels need unit channel stride and pixels dense over one pixel stride; autograd may hand over
+    expanded / broadcast gradients (e.g. zeros) -- materialise those."""
+    if g.dim() == 4 and g.stride(3) == 1:
+        ld = g.stride(2)
+        if ld >= g.shape[3] and g.stride(1) == ld * g.shape[2] and g.stride(0) == ld * g.shape[2] * g.shape[1]:
+            return g
+    return g.contiguous()

@@ -61,6 +61,7 @@ struct GatherGeom {
 enum { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2 };
 
 struct Epilogue {
+    const float* scale;     // [Cout] or null: v = acc*scale (folded eval-mode BatchNorm)
     const float* bias;      // [Cout] or null
     int act;
     const void* res;        // residual (same dtype, added after act) or null
@@ -240,6 +241,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const T* __restrict__ X,
                 ssum[tn] += v;
                 ssq[tn] += v * v;
                 if (pok && co < g.Cout) {
+                    if (ep.scale) v *= ep.scale[co];
                     if (ep.bias) v += ep.bias[co];
                     if (ep.act == ACT_SILU) v = v / (1.0f + expf(-v));
                     else if (ep.act == ACT_RELU) v = fmaxf(v, 0.f);
@@ -508,8 +510,9 @@ static int launch_gemm(const void* X, const void* W, void* Y, const GatherGeom& 
 extern "C" int et_conv2d_stats_rows(int N, int OH, int OW) { return (N * OH * OW + 127) / 128; }
 
 extern "C" int et_conv2d_fwd(const void* x, const void* w, void* y, int dtype, int N, int IH, int IW, int Cin,
-                             int ldx, int Cout, int KH, int KW, int stride, int pad, int ldy, const float* bias,
-                             int act, const void* residual, int ldr, float* stats_partial, et_stream_t stream) {
+                             int ldx, int Cout, int KH, int KW, int stride, int pad, int ldy, const float* scale,
+                             const float* bias, int act, const void* residual, int ldr, float* stats_partial,
+                             et_stream_t stream) {
     if (!x || !w || !y) return -1;
     if (KH * KW > CONV_MAX_TAPS || stride < 1 || N <= 0 || Cout <= 0) return -2;
     GatherGeom g;
@@ -524,7 +527,7 @@ extern "C" int et_conv2d_fwd(const void* x, const void* w, void* y, int dtype, i
     const int vec = dtype == ET_F32 ? 4 : 8;
     int rc = fill_common(g, N, IH, IW, Cin, ldx, OH, OW, OH, OW, Cout, ldy, vec);
     if (rc) return rc;
-    Epilogue ep{bias, act, residual, ldr, stats_partial, 0};
+    Epilogue ep{scale, bias, act, residual, ldr, stats_partial, 0};
     if (dtype == ET_F32) rc = launch_gemm<float>(x, w, y, g, ep, (hipStream_t)stream);
     else if (dtype == ET_BF16) rc = launch_gemm<uint16_t>(x, w, y, g, ep, (hipStream_t)stream);
     else return -2;
@@ -563,7 +566,7 @@ extern "C" int et_conv2d_dgrad(const void* dy, const void* wT, void* dx, int dty
             // the "gathered" tensor of dgrad is dy (OH x OW x Cout), the written one is dx (IH x IW x Cin)
             int rc = fill_common(g, N, OH, OW, Cout, ldy, QH, QW, IH, IW, Cin, ldx, vec);
             if (rc) return rc;
-            Epilogue ep{nullptr, ACT_NONE, nullptr, 0, nullptr, accumulate};
+            Epilogue ep{nullptr, nullptr, ACT_NONE, nullptr, 0, nullptr, accumulate};
             if (t == 0) return -2;   // would need a zero fill; does not occur for k>=stride
             if (dtype == ET_F32) rc = launch_gemm<float>(dy, wT, dx, g, ep, (hipStream_t)stream);
             else if (dtype == ET_BF16) rc = launch_gemm<uint16_t>(dy, wT, dx, g, ep, (hipStream_t)stream);

@@ -1,0 +1,150 @@
+"""Building blocks of the YOLOv5 graph (host-side mirror of reference models/backbone/common.py:
+Conv :471, Bottleneck :534, C3 :566, SPPF :682, Concat :790, get_activation :28, autopad :50).
+
+Same class names, constructor signatures, sub-module names (=> identical state_dict keys and
+identical construction order => identical default initialisation for a given seed).  ``forward``
+consumes / produces NHWC activations (N, H, W, C) and runs the gfx950 kernels: the ``nn.Conv2d`` /
+``nn.BatchNorm2d`` children are parameter containers only, their own forward is never called.
+"""
+import torch
+import torch.nn as nn
+
+from ... import ops
+from ...autograd import ConvBnActFn, SppfPoolFn
+
+
+def get_activation(act=True):
+    act_name = None
+    if isinstance(act, str):
+        if act == "silu":
+            m = nn.SiLU()
+        elif act == "relu":
+            m = nn.ReLU(inplace=True)
+            act_name = 'relu'
+        elif act == "hard_swish":
+            m = nn.Hardswish(inplace=True)
+            act_name = 'hard_swish'
+        elif act == "lrelu":
+            m = nn.LeakyReLU(0.1, inplace=True)
+            act_name = 'leaky_relu'
+        else:
+            raise AttributeError("Unsupported act type: {}".format(act))
+    else:
+        m = nn.SiLU() if act is True else (act if isinstance(act, nn.Module) else nn.Identity())
+    return m, act_name
+
+
+def autopad(k, p=None):  # kernel, padding
+    if p is None:
+        p = k // 2 if isinstance(k, int) else [x // 2 for x in k]
+    return p
+
+
+def _act_code(m):
+    if isinstance(m, nn.SiLU):
+        return ops.ACT_SILU
+    if isinstance(m, nn.ReLU):
+        return ops.ACT_RELU
+    if isinstance(m, nn.Identity):
+        return ops.ACT_NONE
+    raise NotImplementedError(f"activation {type(m).__name__} has no gfx950 kernel yet (SiLU / ReLU / Identity only)")
+
+
+class Conv(nn.Module):
+    # Standard convolution: act(bn(conv(x)))
+    def __init__(self, c1, c2, k=1, s=1, p=None, g=1, act=True):  # ch_in, ch_out, kernel, stride, padding, groups
+        super().__init__()
+        self.conv = nn.Conv2d(c1, c2, k, s, autopad(k, p), groups=g, bias=False)
+        self.bn = nn.BatchNorm2d(c2)
+        self.act, self.act_name = get_activation(act=act)
+
+    def forward(self, x, residual=None):
+        cs = getattr(self.conv, "_et_slot", None)
+        if cs is None:
+            raise RuntimeError("model state is not on the device arenas yet: move the Model to a GPU "
+                               "(model.to('cuda')) before calling it -- there is no CPU path")
+        bs = self.bn._et_slot
+        act = _act_code(self.act)
+        if self.bn.training:
+            return ConvBnActFn.apply(x, residual, self.conv.weight, cs, bs, act, self.bn.num_batches_tracked)
+        # eval (EMA teacher): BatchNorm is an affine of the running statistics, folded into the conv epilogue
+        flat = self._et_flat()
+        o = bs.aff_off
+        return ops.conv2d_fwd(x, cs.w_lp, cs.stride, cs.pad, scale=flat.eval_scale[o:o + bs.c],
+                              bias=flat.eval_shift[o:o + bs.c], act=act, residual=residual)
+
+    def forward_fuse(self, x):
+        return self.forward(x)
+
+    def _et_flat(self):
+        return self.conv._et_flat_ref()
+
+
+class Bottleneck(nn.Module):
+    # Standard bottleneck
+    def __init__(self, c1, c2, shortcut=True, g=1, k=(1, 3), e=0.5, act=True):
+        super().__init__()
+        c_ = int(c2 * e)  # hidden channels
+        self.cv1 = Conv(c1, c_, k[0], 1, act=act)
+        self.cv2 = Conv(c_, c2, k[1], 1, g=g, act=act)
+        self.add = shortcut and c1 == c2
+
+    def forward(self, x):
+        return self.cv2(self.cv1(x), residual=x if self.add else None)
+
+
+class C3(nn.Module):
+    # CSP Bottleneck with 3 convolutions
+    def __init__(self, c1, c2, n=1, shortcut=True, g=1, e=0.5, act=True):
+        super().__init__()
+        c_ = int(c2 * e)  # hidden channels
+        if act == 'relu_silu':
+            act, last_act = 'relu', 'silu'
+        elif act == 'silu':
+            act, last_act = 'silu', 'silu'
+        elif act == 'relu_lrelu':
+            act, last_act = 'relu', 'lrelu'
+        elif act == 'relu_hswish':
+            act, last_act = 'relu', 'hard_swish'
+        else:
+            last_act = act
+        self.cv1 = Conv(c1, c_, 1, 1, act=act)
+        self.cv2 = Conv(c1, c_, 1, 1, act=act)
+        self.cv3 = Conv(2 * c_, c2, 1, act=last_act)
+        self.m = nn.Sequential(*[Bottleneck(c_, c_, shortcut, g, e=1.0, act=act) for _ in range(n)])
+
+    def forward(self, x):
+        return self.cv3(torch.cat((self.m(self.cv1(x)), self.cv2(x)), dim=3))
+
+
+class SPPF(nn.Module):
+    # Spatial Pyramid Pooling - Fast (SPPF) layer
+    def __init__(self, c1, c2, k=5, act=True):
+        super().__init__()
+        if k != 5:
+            raise NotImplementedError("the SPPF pooling kernel is specialised for k=5 (every shipped config)")
+        c_ = c1 // 2
+        if act == 'relu_silu':
+            act, last_act = 'relu', 'silu'
+        elif act == 'relu_lrelu':
+            act, last_act = 'relu', 'lrelu'
+        elif act == 'relu_hswish':
+            act, last_act = 'relu', 'hard_swish'
+        else:
+            last_act = act
+        self.cv1 = Conv(c1, c_, 1, 1, act=act)
+        self.cv2 = Conv(c_ * 4, c2, 1, 1, act=last_act)
+        self.m = nn.MaxPool2d(kernel_size=k, stride=1, padding=k // 2)
+
+    def forward(self, x):
+        return self.cv2(SppfPoolFn.apply(self.cv1(x)))
+
+
+class Concat(nn.Module):
+    # Concatenate a list of tensors along the channel dimension (NHWC: dim 3 <-> reference dim 1)
+    def __init__(self, dimension=1):
+        super().__init__()
+        self.d = dimension
+
+    def forward(self, x):
+        return torch.cat(x, 3 if self.d == 1 else self.d)

@@ -1,0 +1,8 @@
+from .yolov5_head import Detect
+
+
+def build_head(cfg):
+    # reference models/head/__init__.py:12
+    if cfg.Model.Head.name == 'YoloV5':
+        return Detect(cfg)
+    raise NotImplementedError(f"head {cfg.Model.Head.name}: only the YoloV5 hot path is built")

@@ -1,0 +1,9 @@
+from .loss import ComputeLoss  # noqa: F401
+from .ssod.ssod_loss import ComputeStudentMatchLoss  # noqa: F401
+
+
+def build_ssod_loss(model, cfg):
+    # reference models/loss/__init__.py: build_ssod_loss dispatches on cfg.SSOD.loss_type
+    if cfg.SSOD.loss_type == 'ComputeStudentMatchLoss':
+        return ComputeStudentMatchLoss(model, cfg)
+    raise NotImplementedError(cfg.SSOD.loss_type)

@@ -1,0 +1,90 @@
+"""Host-side mirror of the reference's ``models/loss/loss.py`` for the SSOD hot path.
+
+``ComputeLoss(model, cfg)(p, targets) -> (loss*bs [1], dict(box, obj, cls, loss))`` with the
+reference's constructor logic (models/loss/loss.py:95-136); the arithmetic (anchor assignment,
+CIoU, BCE, scatter, reductions AND their gradients) runs in ``et_yolo_loss`` (csrc/loss.hip).
+"""
+import torch
+
+from ... import ops
+from ...utils.torch_utils import is_parallel
+
+
+def smooth_BCE(eps=0.1):  # reference models/loss/loss.py:26
+    return 1.0 - 0.5 * eps, 0.5 * eps
+
+
+class YoloLossFn(torch.autograd.Function):
+    """out (8,) = [lbox*w, lobj*w, lcls*w, loss*bs, n_pos pass0..3]; d out[3] / d p from the fused kernel."""
+
+    @staticmethod
+    def forward(ctx, table, hp, anchors_host, balance, *p):
+        out, dps = ops.yolo_loss(list(p), table, anchors_host, balance, **hp)
+        ctx.dps = dps
+        ctx.meta = [(pi.shape, pi.stride(), pi.dtype) for pi in p]
+        ctx.bs = p[0].shape[0]
+        ctx.mark_non_differentiable()
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        g3 = gout[3:4].contiguous().float()
+        grads = []
+        for dp, (shape, stride, dtype) in zip(ctx.dps, ctx.meta):
+            g = ops.scale_cast(dp, dtype, scale=float(ctx.bs), dev_scale=g3)
+            grads.append(g.as_strided(shape, stride))
+        return (None, None, None, None, *grads)
+
+
+def _head_of(model):
+    return model.module.head if is_parallel(model) else model.head
+
+
+class ComputeLoss:
+    # Compute losses (reference models/loss/loss.py:93)
+    def __init__(self, model, cfg):
+        self.sort_obj_iou = False
+        if cfg.Loss.fl_gamma > 0:
+            raise NotImplementedError("focal loss (Loss.fl_gamma > 0) is outside the hot path")
+        if cfg.Loss.autobalance:
+            raise NotImplementedError("Loss.autobalance needs a host sync per level; off in every shipped config")
+        if cfg.Loss.assigner_type == 'SimOTA':
+            raise NotImplementedError("SimOTA assignment is SURVEY.md 8(f-4), not built yet")
+        self.cls_pw, self.obj_pw = float(cfg.Loss.cls_pw), float(cfg.Loss.obj_pw)
+        self.cp, self.cn = smooth_BCE(eps=cfg.Loss.label_smoothing)
+        det = _head_of(model)
+        self.balance = {3: [4.0, 1.0, 0.4]}.get(det.nl, [4.0, 1.0, 0.25, 0.06, .02])
+        self.ssi = 0
+        self.gr, self.autobalance = 1.0, False
+        nl = det.nl
+        nc = 1 if cfg.single_cls else cfg.Dataset.nc
+        self.box_w = cfg.Loss.box * 3.0 / nl
+        self.obj_w = cfg.Loss.obj
+        self.cls_w = cfg.Loss.cls * nc / 80. * 3. / nl
+        self.anchor_t = cfg.Loss.anchor_t
+        self.single_targets = cfg.Loss.single_targets
+        for k in 'na', 'nc', 'nl', 'num_keypoints', 'anchors':
+            setattr(self, k, getattr(det, k))
+        if self.num_keypoints > 0:
+            raise NotImplementedError("keypoint losses are outside the hot path")
+        self.ota = False
+        self._anchors_host = [[[float(v) for v in a] for a in lvl] for lvl in det.anchors.detach().cpu().tolist()]
+
+    def _hp(self):
+        return dict(nc=self.nc, anchor_t=float(self.anchor_t), gr=float(self.gr), cp=float(self.cp), cn=float(self.cn),
+                    cls_pw=self.cls_pw, obj_pw=self.obj_pw, box_w=float(self.box_w), obj_w=float(self.obj_w),
+                    cls_w=float(self.cls_w))
+
+    def default_loss(self, p, targets):
+        dev = p[0].device
+        t = targets[:, :6].to(device=dev, dtype=torch.float32)
+        n = t.shape[0]
+        table = torch.cat((t, torch.zeros((n, 1), device=dev), torch.ones((n, 1), device=dev)), 1)
+        out = YoloLossFn.apply(table, self._hp(), self._anchors_host, self.balance, *p)
+        loss = out[3:4]
+        det = out.detach()
+        loss_dict = dict(box=det[0:1], obj=det[1:2], cls=det[2:3], loss=det[3:4])
+        return loss, loss_dict
+
+    def __call__(self, p, targets):
+        return self.default_loss(p, targets)

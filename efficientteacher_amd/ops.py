@@ -33,8 +33,8 @@ def conv_out_hw(ih, iw, k, s, p):
     return (ih + 2 * p - k) // s + 1, (iw + 2 * p - k) // s + 1
 
 
-def conv2d_fwd(x, w, stride, pad, *, bias=None, act=ACT_NONE, residual=None, out=None, want_stats=False):
-    """y = act(conv(x, w) + bias) + residual ; optional BN partial statistics (rows, 2, Cout)."""
+def conv2d_fwd(x, w, stride, pad, *, scale=None, bias=None, act=ACT_NONE, residual=None, out=None, want_stats=False):
+    """y = act(conv(x, w) * scale + bias) + residual ; optional BN partial statistics (rows, 2, Cout)."""
     N, IH, IW, Cin = x.shape
     Cout, KH, KW, Cin2 = w.shape
     assert Cin == Cin2 and w.is_contiguous() and w.dtype == x.dtype
@@ -49,7 +49,7 @@ def conv2d_fwd(x, w, stride, pad, *, bias=None, act=ACT_NONE, residual=None, out
         stats = torch.empty((rows, 2, Cout), dtype=torch.float32, device=x.device)
     ldr = _nhwc(residual) if residual is not None else 0
     _lib.check(lib.et_conv2d_fwd(_lib.ptr(x), _lib.ptr(w), _lib.ptr(out), et_dtype(x), N, IH, IW, Cin, _nhwc(x),
-                                 Cout, KH, KW, stride, pad, _nhwc(out), _lib.ptr(bias), act,
+                                 Cout, KH, KW, stride, pad, _nhwc(out), _lib.ptr(scale), _lib.ptr(bias), act,
                                  _lib.ptr(residual), ldr, _lib.ptr(stats), _lib.stream(x)), "et_conv2d_fwd")
     return (out, stats) if want_stats else out
 
@@ -206,3 +206,119 @@ def upsample2x_bwd(dy, out=None):
     _lib.check(_lib.load().et_upsample2x_bwd(_lib.ptr(dy), _nhwc(dy), _lib.ptr(out), _nhwc(out), et_dtype(dy), N, H, W, C,
                                              _lib.stream(dy)), "et_upsample2x_bwd")
     return out
+
+
+# ---- pseudo labels / losses ---------------------------------------------------------------------------
+def pseudo_label_transform(dets, counts, M_s, width, height):
+    """dets (B,max_det,8) fp32, counts (B) int32, M_s (B,13) fp64 -> targets9 (B*max_det,9) fp64, valid uint8."""
+    B, max_det, _ = dets.shape
+    dev = dets.device
+    M_s = M_s.to(device=dev, dtype=torch.float64).contiguous()
+    t9 = torch.empty((B * max_det, 9), dtype=torch.float64, device=dev)
+    valid = torch.empty((B * max_det,), dtype=torch.uint8, device=dev)
+    _lib.check(_lib.load().et_pseudo_label_transform(_lib.ptr(dets), _lib.ptr(counts), _lib.ptr(M_s), B, max_det,
+                                                     int(width), int(height), _lib.ptr(t9), _lib.ptr(valid),
+                                                     _lib.stream(dets)), "et_pseudo_label_transform")
+    return t9, valid
+
+
+def select_targets(targets9, valid, thr_low, thr_high, nc, with_obj):
+    """(N,9) fp64 pseudo labels (+ optional valid mask) -> (N,8) fp32 target table for et_yolo_loss."""
+    N = targets9.shape[0]
+    dev = targets9.device
+    t9 = targets9.to(torch.float64).contiguous()
+    lo = torch.as_tensor(thr_low, dtype=torch.float64).to(dev)
+    hi = torch.as_tensor(thr_high, dtype=torch.float64).to(dev)
+    table = torch.empty((N, 8), dtype=torch.float32, device=dev)
+    _lib.check(_lib.load().et_select_targets(_lib.ptr(t9), _lib.ptr(valid), N, _lib.ptr(lo), _lib.ptr(hi), nc,
+                                             int(bool(with_obj)), _lib.ptr(table), _lib.stream(t9)),
+               "et_select_targets")
+    return table
+
+
+def _flat_span(p):
+    """Elements of storage spanned by a strided 5-d logits view, rounded up to whole pixels."""
+    span = sum((s - 1) * st for s, st in zip(p.shape, p.stride())) + 1
+    sx = p.stride(3)
+    return ((span + sx - 1) // sx) * sx if sx > 0 else span
+
+
+def yolo_loss(p, table, anchors_host, balance, *, nc, anchor_t, gr, cp, cn, cls_pw, obj_pw, box_w, obj_w, cls_w,
+              pass_mask=1, ignore_obj=False):
+    """Fused assignment + loss + gradient.  p: list of (B,na,ny,nx,no) logits views (channel stride 1).
+    Returns out (8,) fp32 [lbox, lobj, lcls, loss*bs, npos0..3] and the flat fp32 gradient buffers."""
+    lib = _lib.load()
+    dev = p[0].device
+    B, na = p[0].shape[0], p[0].shape[1]
+    d = _lib.LossDesc()
+    d.dtype = et_dtype(p[0]); d.B = B; d.na = na; d.nc = nc; d.NT = int(table.shape[0]); d.nl = len(p)
+    d.anchor_t = anchor_t; d.gr = gr; d.cp = cp; d.cn = cn; d.cls_pw = cls_pw; d.obj_pw = obj_pw
+    d.box_w = box_w; d.obj_w = obj_w; d.cls_w = cls_w
+    d.pass_mask = pass_mask; d.ignore_obj = int(bool(ignore_obj))
+    table = table.contiguous()
+    acc = torch.empty(64, dtype=torch.float32, device=dev)
+    out = torch.empty(8, dtype=torch.float32, device=dev)
+    d.targets = _lib.ptr(table) if table.numel() else _lib.ptr(acc)
+    d.acc_ws = _lib.ptr(acc); d.out = _lib.ptr(out)
+    keep, dps = [table, acc], []
+    for i, pi in enumerate(p):
+        assert pi.dim() == 5 and pi.stride(4) == 1 and pi.shape[4] == nc + 5 and pi.dtype == p[0].dtype
+        _, _, ny, nx, _ = pi.shape
+        dp = torch.zeros(_flat_span(pi), dtype=torch.float32, device=dev)
+        tobj = torch.empty(B * na * ny * nx, dtype=torch.int64, device=dev)
+        L = d.level[i]
+        L.p = _lib.ptr(pi); L.dp = _lib.ptr(dp); L.tobj_ws = _lib.ptr(tobj)
+        L.sb, L.sa, L.sy, L.sx = pi.stride(0), pi.stride(1), pi.stride(2), pi.stride(3)
+        L.ny, L.nx = ny, nx
+        for a in range(na):
+            L.anchors[2 * a] = float(anchors_host[i][a][0]); L.anchors[2 * a + 1] = float(anchors_host[i][a][1])
+        L.balance = float(balance[i])
+        dps.append(dp); keep.append(tobj)
+    import ctypes
+    _lib.check(lib.et_yolo_loss(ctypes.byref(d), _lib.stream(p[0])), "et_yolo_loss")
+    return out, dps
+
+
+def scale_cast(src_flat, dtype, scale=1.0, dev_scale=None):
+    dst = torch.empty(src_flat.shape, dtype=dtype, device=src_flat.device)
+    _lib.check(_lib.load().et_scale_cast(_lib.ptr(src_flat), _lib.ptr(dst), et_dtype(dst), src_flat.numel(), float(scale),
+                                         _lib.ptr(dev_scale), _lib.stream(src_flat)), "et_scale_cast")
+    return dst
+
+
+# ---- flat-arena state updates ------------------------------------------------------------------------
+def cast_f32_to_bf16(src, dst):
+    assert src.dtype == torch.float32 and dst.dtype == torch.bfloat16 and src.numel() == dst.numel()
+    _lib.check(_lib.load().et_cast_f32_to_bf16(_lib.ptr(src), _lib.ptr(dst), src.numel(), _lib.stream(src)),
+               "et_cast_f32_to_bf16")
+    return dst
+
+
+def bn_eval_affine_into(gamma, beta, running_mean, running_var, eps, scale, shift):
+    C = gamma.numel()
+    _lib.check(_lib.load().et_bn_eval_affine(C, _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(running_mean),
+                                             _lib.ptr(running_var), eps, _lib.ptr(scale), _lib.ptr(shift),
+                                             _lib.stream(gamma)), "et_bn_eval_affine")
+
+
+def ema_update(ema_flat, model_flat, d):
+    """v = v*d ; v += (1-d)*m over a flat fp32 arena (utils/torch_utils.py:335-338)."""
+    assert ema_flat.numel() == model_flat.numel() and ema_flat.dtype == torch.float32
+    _lib.check(_lib.load().et_ema_update(_lib.ptr(ema_flat), _lib.ptr(model_flat), ema_flat.numel(), float(d),
+                                         float(1. - d), _lib.stream(ema_flat)), "et_ema_update")
+
+
+def sgd_nesterov(p, g, buf, shadow, lr, momentum, weight_decay, first_step, inv_scale=1.0):
+    _lib.check(_lib.load().et_sgd_nesterov(_lib.ptr(p), _lib.ptr(g), _lib.ptr(buf), _lib.ptr(shadow), p.numel(),
+                                           float(lr), float(momentum), float(weight_decay), int(bool(first_step)),
+                                           float(inv_scale), _lib.stream(p)), "et_sgd_nesterov")
+
+
+def detect_decode(raw5, anchor_px, stride, z, a_offset):
+    """raw5: (B,na,ny,nx,no) logits view; writes z[:, a_offset : a_offset+na*ny*nx, :] (fp32)."""
+    B, na, ny, nx, no = raw5.shape
+    assert raw5.stride(4) == 1 and z.is_contiguous() and z.dtype == torch.float32
+    _lib.check(_lib.load().et_detect_decode(_lib.ptr(raw5), et_dtype(raw5), B, na, ny, nx, no, raw5.stride(0),
+                                            raw5.stride(1), raw5.stride(2), raw5.stride(3), _lib.ptr(anchor_px),
+                                            float(stride), _lib.ptr(z), z.shape[1], a_offset, _lib.stream(z)),
+               "et_detect_decode")

@@ -1,0 +1,109 @@
+"""Host-side mirror of the reference's ``utils/torch_utils.py`` for the hot path: the three EMA
+classes (ModelEMA :308, SemiSupModelEMA :344, CosineEMA :381) with their exact decay schedules, and
+small helpers.  The per-tensor python loop of the reference's ``update`` is one flat-arena kernel
+launch per arena here (et_ema_update, csrc/optim.hip)."""
+import math
+from copy import deepcopy
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+
+def is_parallel(model):
+    # Returns True if model is of type DP or DDP (or this package's flat data-parallel wrapper)
+    from ..parallel import FlatDataParallel
+    return type(model) in (nn.parallel.DataParallel, nn.parallel.DistributedDataParallel, FlatDataParallel)
+
+
+def de_parallel(model):
+    return model.module if is_parallel(model) else model
+
+
+def copy_attr(a, b, include=(), exclude=()):
+    # Copy attributes from b to a, options to only include [...] and to exclude [...]
+    for k, v in b.__dict__.items():
+        if (len(include) and k not in include) or k.startswith('_') or k in exclude:
+            continue
+        else:
+            setattr(a, k, v)
+
+
+def initialize_weights(model):
+    # reference utils/torch_utils.py:162-172
+    for m in model.modules():
+        t = type(m)
+        if t is nn.BatchNorm2d:
+            m.eps = 1e-3
+            m.momentum = 0.03
+        elif t in [nn.Hardswish, nn.LeakyReLU, nn.ReLU, nn.ReLU6]:
+            m.inplace = True
+
+
+def _flat_ema_update(ema_model, model, d):
+    """v = v*d + (1-d)*m for every floating state tensor (parameters AND buffers)."""
+    src = de_parallel(model)
+    fe, fm = ema_model.flat_state(), src.flat_state()
+    ops.ema_update(fe.params, fm.params, d)
+    ops.ema_update(fe.buffers, fm.buffers, d)
+    fe.mark_weights_changed()
+
+
+class _EMABase:
+    def _make(self, model):
+        self.ema = deepcopy(de_parallel(model)).eval()  # FP32 EMA
+        for p in self.ema.parameters():
+            p.requires_grad_(False)
+
+    def update_attr(self, model, include=(), exclude=('process_group', 'reducer')):
+        copy_attr(self.ema, model, include, exclude)
+
+
+class ModelEMA(_EMABase):
+    """decay ramp d = decay * (1 - exp(-updates / 2000))  (reference :324)."""
+
+    def __init__(self, model, decay=0.9999, updates=0):
+        self._make(model)
+        self.updates = updates
+        self.decay = lambda x: decay * (1 - math.exp(-x / 2000))
+
+    def update(self, model):
+        with torch.no_grad():
+            self.updates += 1
+            _flat_ema_update(self.ema, model, self.decay(self.updates))
+
+
+class SemiSupModelEMA(_EMABase):
+    """constant decay (reference :358)."""
+
+    def __init__(self, model, decay=0.99, updates=0):
+        self._make(model)
+        self.updates = updates
+        self.decay = decay
+
+    def update(self, model):
+        with torch.no_grad():
+            self.updates += 1
+            _flat_ema_update(self.ema, model, self.decay)
+
+
+class CosineEMA(_EMABase):
+    """decay_start -> decay_end on a cosine over the epochs (reference :391-419)."""
+
+    def __init__(self, model, decay_start=0.99, decay_end=0.9999, total_epoch=0):
+        self._make(model)
+        self.total_epoch = total_epoch
+        self.decay_start = decay_start
+        self.decay_end = decay_end
+        self.decay = decay_start
+        self.updates = 0
+
+    def update(self, model):
+        with torch.no_grad():
+            _flat_ema_update(self.ema, model, self.decay)
+
+    def update_decay(self, cur_epoch):
+        self.decay = self.decay_end - (self.decay_end - self.decay_start) * \
+            (np.cos(np.pi * cur_epoch / self.total_epoch) + 1) / 2

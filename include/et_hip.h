@@ -75,7 +75,8 @@ int et_cast_f32_to_bf16(const float* src, void* dst, int64_t n, et_stream_t stre
  * buffer can be read in place); w (Cout, KH, KW, Cin); y (N, OH, OW, *) with pixel stride ldy.
  * Requirements: Cin % 8 == 0 (pad the 3-channel stem input to 8), 16-byte aligned pointers and
  * strides, KH*KW <= 36, tensors < 2^31 elements.  dgrad/wgrad additionally need Cout % 8 == 0.
- *   fwd epilogue: v = acc (+ bias[co]); act (0 none, 1 SiLU, 2 ReLU); (+ residual[pix*ldr + co]).
+ *   fwd epilogue: v = acc (* scale[co]) (+ bias[co]); act (0 none, 1 SiLU, 2 ReLU); (+ residual[pix*ldr + co]);
+ *   scale/bias = the eval-mode BatchNorm affine of the EMA teacher (et_bn_eval_affine), or the head bias.
  *   stats_partial, if not NULL: (et_conv2d_stats_rows(N,OH,OW), 2, Cout) fp32 partial per-channel
  *   sum / sum-of-squares of the raw accumulators (BatchNorm batch statistics, reduced later by
  *   et_bn_finalize) -- every row is fully overwritten.
@@ -85,8 +86,9 @@ int et_cast_f32_to_bf16(const float* src, void* dst, int64_t n, et_stream_t stre
  *          gradient arena as the accumulator).                                                    */
 int et_conv2d_stats_rows(int N, int OH, int OW);
 int et_conv2d_fwd(const void* x, const void* w, void* y, int dtype, int N, int IH, int IW, int Cin,
-                  int ldx, int Cout, int KH, int KW, int stride, int pad, int ldy, const float* bias,
-                  int act, const void* residual, int ldr, float* stats_partial, et_stream_t stream);
+                  int ldx, int Cout, int KH, int KW, int stride, int pad, int ldy, const float* scale,
+                  const float* bias, int act, const void* residual, int ldr, float* stats_partial,
+                  et_stream_t stream);
 int et_conv2d_dgrad(const void* dy, const void* wT, void* dx, int dtype, int N, int IH, int IW, int Cin,
                     int ldx, int Cout, int KH, int KW, int stride, int pad, int ldy, int accumulate,
                     et_stream_t stream);
@@ -138,6 +140,58 @@ int et_maxpool5_bwd(const void* dy, int lddy, const uint8_t* argmax, const void*
                     int dtype, int B, int H, int W, int C, et_stream_t stream);
 int et_upsample2x_fwd(const void* x, int ldx, void* y, int ldy, int dtype, int B, int H, int W, int C, et_stream_t stream);
 int et_upsample2x_bwd(const void* dy, int lddy, void* dx, int lddx, int dtype, int B, int H, int W, int C, et_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Online pseudo labels.  Replaces FairPseudoLabel.create_pseudo_label_online_with_gt
+ * (utils/self_supervised_utils.py:194-245) after the NMS: per detection xyxy->xywh (fp32),
+ * then in fp64 the affine warp by M_s (B,13) [img, M00..M22, s, ud, lr], clip, box_candidates
+ * filter, normalise, flips.  targets9 (B*max_det, 9) fp64 rows
+ * [img, cls, x, y, w, h, conf, obj_conf, cls_conf] stay PADDED, valid (B*max_det) uint8 marks
+ * the surviving rows (the reference's row order == ascending padded index).                    */
+int et_pseudo_label_transform(const float* dets, const int* counts, const double* M_s, int B, int max_det,
+                              int width, int height, double* targets9, uint8_t* valid, et_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Detection losses with fused anchor assignment, forward + gradient.  Replaces
+ * YOLOAnchorAssigner.build_targets / build_uc_targets_aug
+ * (models/assigner/yolo_anchor_assigner.py:319-372, 640-696), bbox_iou CIoU (utils/metrics.py:207),
+ * ComputeLoss.default_loss (models/loss/loss.py:138-208) and
+ * ComputeStudentMatchLoss.default_loss (models/loss/ssod/ssod_loss.py:194-288).
+ *   targets table (NT, 8) fp32 rows [img, cls, x, y, w, h, score, flags]; flags bit p = row takes part
+ *   in pass p: 0 reliable / labelled (box + cls + tobj = CIoU), 1 uncertain (tobj = score, or -1
+ *   "ignore" if ignore_obj), 2 uncertain with obj_conf >= .99 (extra box term), 3 uncertain with
+ *   cls_conf >= .99 (extra cls term).  Supervised loss: every row has flags = 1.
+ *   level[l].p: logits viewed as [b*sb + a*sa + y*sy + x*sx + c]; level[l].dp: fp32 gradient buffer
+ *   with the same strides, ZEROED by the caller, receives d(lbox*box_w + lobj*obj_w + lcls*cls_w)/dp
+ *   (without the reference's final *bs); tobj_ws: B*na*ny*nx uint64 scratch; acc_ws: 64 floats.
+ *   out (8 floats, device): [lbox*box_w, lobj*obj_w, lcls*cls_w, (sum)*B, n_pos pass0..3].
+ * et_select_targets builds the table from (N,9) fp64 pseudo labels
+ * (ComputeStudentMatchLoss.select_targets, ssod_loss.py:130-192; thresholds per class, fp64).
+ * et_scale_cast: dst = (T)(src * scale * (dev_scale ? *dev_scale : 1)): hands dp to the head's
+ * dgrad/wgrad with the autograd upstream factor (a device scalar) folded in, no host sync.      */
+typedef struct {
+    const void* p;
+    float* dp;
+    void* tobj_ws;
+    int64_t sb, sa, sy, sx;
+    int ny, nx;
+    float anchors[6];
+    float balance;
+} et_loss_level;
+typedef struct {
+    int dtype, B, na, nc, NT, nl;
+    float anchor_t, gr, cp, cn, cls_pw, obj_pw, box_w, obj_w, cls_w;
+    int pass_mask, ignore_obj;
+    const float* targets;
+    float* acc_ws;
+    float* out;
+    et_loss_level level[4];
+} et_loss_desc;
+int et_yolo_loss(const et_loss_desc* desc /*host*/, et_stream_t stream);
+int et_select_targets(const double* targets9, const uint8_t* valid, int N, const double* thr_low,
+                      const double* thr_high, int nc, int with_obj, float* table, et_stream_t stream);
+int et_scale_cast(const float* src, void* dst, int dtype, int64_t n, float scale,
+                  const float* dev_scale /*device scalar or NULL*/, et_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,110 @@
+"""Tiny-width SSOD detector (width 0.125, depth 0.33, 64x64 input) vs the reference's own outputs
+(tests/golden/model_tiny.npz, produced by oracle/make_golden.py from models/detector/yolo_ssod.py):
+state_dict key compatibility, eval forward (decode), train forward, ComputeLoss, full backward.
+fp32 parity mode: 1e-4 on losses / outputs (BASELINE north_star tolerance), gradients 2e-3 relative.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests.conftest import golden
+
+YAML = "efficientteacher_amd/configs/ssod/coco-standard/yolov5l_coco_ssod_10_percent.yaml"
+
+
+def build(hip, dtype=torch.float32):
+    import os
+    from efficientteacher_amd.configs import get_cfg
+    from efficientteacher_amd.models.detector.yolo_ssod import Model
+    from tests.conftest import ROOT
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(ROOT, YAML))
+    cfg.merge_from_list(["Model.width_multiple", 0.125, "Model.depth_multiple", 0.33])
+    cfg.freeze()
+    g = golden("model_tiny")
+    model = Model(cfg)
+    sd = {k[3:].replace("__", "."): torch.from_numpy(g[k]) for k in g.files if k.startswith("w__")}
+    missing, unexpected = model.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    model = model.to(hip.device)
+    model.set_compute_dtype(dtype)
+    return cfg, model, g
+
+
+def test_state_dict_keys_and_init_match_reference(hip):
+    """Same module names / construction order => same keys AND the same default init for seed 0."""
+    import os
+    from efficientteacher_amd.configs import get_cfg
+    from efficientteacher_amd.models.detector.yolo_ssod import Model
+    from tests.conftest import ROOT
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(ROOT, YAML))
+    cfg.merge_from_list(["Model.width_multiple", 0.125, "Model.depth_multiple", 0.33])
+    g = golden("model_tiny")
+    torch.manual_seed(0)
+    m = Model(cfg)
+    keys = {k[3:].replace("__", ".") for k in g.files if k.startswith("w__")}
+    assert set(m.state_dict().keys()) == keys
+    # conv weights are untouched by make_golden's BN perturbation: default init must be identical
+    w = m.state_dict()["backbone.stage2_2.m.0.cv2.conv.weight"].numpy()
+    assert np.array_equal(w, g["w__backbone__stage2_2__m__0__cv2__conv__weight"])
+    assert np.allclose(m.head.anchors.numpy(), g["anchors"]) and np.allclose(m.stride.numpy(), g["stride"])
+    assert np.array_equal(m.state_dict()["head.m.0.bias"].numpy(), g["w__head__m__0__bias"])
+
+
+def test_eval_forward(hip):
+    cfg, model, g = build(hip)
+    model.eval()
+    with torch.no_grad():
+        (z, xs), feats = model(hip.t(g["x"]))
+    assert z.shape == g["eval_z"].shape
+    err = np.abs(z.cpu().numpy() - g["eval_z"]).max()
+    assert err <= 1e-4 * max(1.0, np.abs(g["eval_z"]).max()), err
+    for i in range(3):
+        assert np.abs(xs[i].cpu().numpy() - g[f"eval_x{i}"]).max() <= 1e-4
+        assert feats[i].shape == g[f"eval_feat{i}"].shape
+        assert np.abs(feats[i].cpu().numpy() - g[f"eval_feat{i}"]).max() <= 1e-4
+
+
+def test_train_forward_loss_backward(hip):
+    from efficientteacher_amd.models.loss import ComputeLoss
+    cfg, model, g = build(hip)
+    model.train()
+    closs = ComputeLoss(model, cfg)
+    pred, feats = model(hip.t(g["x"]))
+    for i in range(3):
+        assert tuple(pred[i].shape) == g[f"train_p{i}"].shape
+        assert np.abs(pred[i].detach().cpu().numpy() - g[f"train_p{i}"]).max() <= 2e-4
+    loss, items = closs(pred, hip.t(g["targets"]))
+    assert abs(loss.item() - float(g["train_loss"][0])) <= 1e-4 * max(1.0, abs(float(g["train_loss"][0])))
+    got = np.array([items[k].item() for k in ("box", "obj", "cls")])
+    assert np.allclose(got, g["train_items"], rtol=1e-4, atol=1e-5)
+    model.zero_grad()
+    loss.backward()
+    # running statistics updated exactly like torch's BatchNorm (momentum 0.03, unbiased variance)
+    sd = model.state_dict()
+    for k in g.files:
+        if k.startswith("b__"):
+            name = k[3:].replace("__", ".")
+            assert np.allclose(sd[name].cpu().numpy(), g[k], rtol=1e-4, atol=1e-5), name
+    worst = 0.0
+    for name, p in model.named_parameters():
+        ref = g["g__" + name.replace(".", "__")]
+        if name.startswith("det_"):
+            continue        # netD: zero-weighted DA loss -> no gradient (documented in yolo_ssod.py)
+        got = p.grad.detach().cpu().numpy()
+        scale = max(np.abs(ref).max(), 1e-6)
+        err = np.abs(got - ref).max() / scale
+        worst = max(worst, err)
+        assert err <= 2e-3, (name, err)
+    print("worst relative grad error", worst)
+
+
+def test_bf16_mode_close_to_fp32(hip):
+    """Performance mode (bf16 storage, fp32 accumulate) stays close to the fp32 golden outputs."""
+    cfg, model, g = build(hip, torch.bfloat16)
+    model.eval()
+    with torch.no_grad():
+        (z, xs), _ = model(hip.t(g["x"]))
+    rel = np.abs(z.cpu().numpy() - g["eval_z"]).max() / np.abs(g["eval_z"]).max()
+    assert rel <= 3e-2, rel
