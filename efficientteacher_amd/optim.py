@@ -1,0 +1,46 @@
+"""SGD(momentum, nesterov) over the flat parameter arena: three launches (one per optimizer group of
+reference trainer/trainer.py:199-217: [biases | weights with decay | BN weights]) instead of one
+kernel chain per tensor.  It is a ``torch.optim.Optimizer`` so the reference's schedulers
+(LambdaLR / MultiStepLR, trainer.py:242, ssod_trainer.py:90) and its warm-up code, which edits
+``optimizer.param_groups[j]['lr' | 'momentum']`` (trainer.py:391-395), work unchanged.
+The bf16 shadow copy of the conv weights is refreshed by the same kernel.
+"""
+import torch
+
+from . import ops
+
+
+class FlatSGD(torch.optim.Optimizer):
+    def __init__(self, model, lr, momentum=0.937, nesterov=True, weight_decay=0.0):
+        if not nesterov:
+            raise NotImplementedError("the reference always builds SGD(nesterov=True) (trainer.py:215)")
+        self.flat = model.flat_state()
+        g_bnw, g_w, g_b = [], [], []
+        import torch.nn as nn
+        for v in model.modules():   # same walk as the reference => same groups
+            if hasattr(v, 'bias') and isinstance(v.bias, nn.Parameter):
+                g_b.append(v.bias)
+            if isinstance(v, nn.BatchNorm2d):
+                g_bnw.append(v.weight)
+            elif hasattr(v, 'weight') and isinstance(v.weight, nn.Parameter):
+                g_w.append(v.weight)
+        groups = [dict(params=g_b), dict(params=g_w, weight_decay=weight_decay), dict(params=g_bnw)]
+        super().__init__(groups, dict(lr=lr, momentum=momentum, nesterov=True, weight_decay=0.0))
+        for g, r in zip(self.param_groups, self.flat.group_ranges()):
+            g['range'] = r
+            g.setdefault('initial_lr', lr)
+        self.momentum_buf = torch.zeros_like(self.flat.params)
+        self.first = True
+
+    @torch.no_grad()
+    def step(self, closure=None, inv_scale=1.0):
+        f = self.flat
+        for g in self.param_groups:
+            o, n = g['range']
+            shadow = f.shadow if (f.shadow is not None and (o, n) == tuple(f.w_range)) else None
+            ops.sgd_nesterov(f.params[o:o + n], f.grads[o:o + n], self.momentum_buf[o:o + n], shadow,
+                             g['lr'], g['momentum'], g['weight_decay'], self.first, inv_scale)
+        self.first = False
+
+    def zero_grad(self, set_to_none=False):
+        self.flat.zero_grad()

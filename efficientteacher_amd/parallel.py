@@ -41,12 +41,15 @@ class FlatDataParallel(nn.Module):
         if self.world <= 1:
             return
         g = self.module.flat_state().grads
+        avg = dist.get_backend(self.pg) == "nccl"        # RCCL averages in the collective itself
         works = []
         for o in range(0, g.numel(), self.chunk):
-            works.append(dist.all_reduce(g[o:o + self.chunk], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+            works.append(dist.all_reduce(g[o:o + self.chunk], op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM,
+                                         group=self.pg, async_op=True))
         for w in works:
             w.wait()
-        g.mul_(1.0 / self.world)
+        if not avg:                                       # gloo (CPU tests) has no AVG
+            g.mul_(1.0 / self.world)
 
     def flat_state(self):
         return self.module.flat_state()

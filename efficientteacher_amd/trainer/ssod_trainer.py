@@ -1,0 +1,118 @@
+"""Efficient-Teacher SSOD trainer core (host-side mirror of reference trainer/ssod_trainer.py:
+build_model :96, update_optimizer :458-488, split_predict_and_feature :568, train_instance :587-680).
+
+One ``train_instance`` = EMA-teacher inference on the weak view -> NMS + pseudo-label transform ->
+student forward on cat(labelled, unlabelled strong view) -> ComputeLoss + ComputeStudentMatchLoss ->
+backward -> (every ``accumulate`` iterations) SGD step, ModelEMA update, semi-EMA update.
+Everything between the two image batches arriving and the optimizer step is device-resident and
+stream-ordered: no ``.cpu()``, no per-detection python loops, no deepcopy of the image batches.
+"""
+import numpy as np
+import torch
+
+from ..models.loss import ComputeLoss, build_ssod_loss
+from ..parallel import FlatDataParallel
+from ..utils.self_supervised_utils import FairPseudoLabel
+from ..utils.torch_utils import CosineEMA, ModelEMA, SemiSupModelEMA
+from .trainer import Trainer
+
+
+class SSODTrainer(Trainer):
+    MODEL_MODULE = "efficientteacher_amd.models.detector.yolo_ssod"
+
+    def __init__(self, cfg, device, callbacks=None, LOCAL_RANK=-1, RANK=-1, WORLD_SIZE=1, nb=1000):
+        self.cfg = cfg
+        self.set_env(cfg, device, LOCAL_RANK, RANK, WORLD_SIZE, callbacks, nb)
+        self.build_model(cfg, device)
+        self.build_optimizer(cfg)
+        if cfg.SSOD.pseudo_label_type == 'FairPseudoLabel':
+            self.pseudo_label_creator = FairPseudoLabel(cfg)
+        else:
+            raise NotImplementedError("LabelMatch thresholds are SURVEY.md 8(f-4), not built yet")
+        self.build_ddp_model(cfg, device)
+
+    def set_env(self, cfg, device, LOCAL_RANK, RANK, WORLD_SIZE, callbacks, nb=1000):
+        super().set_env(cfg, device, LOCAL_RANK, RANK, WORLD_SIZE, callbacks, nb)
+        self.epoch_adaptor = cfg.SSOD.epoch_adaptor
+        self.da_loss_weights = cfg.SSOD.da_loss_weights
+        self.cosine_ema = cfg.SSOD.cosine_ema
+        self.fixed_accumulate = cfg.SSOD.fixed_accumulate
+        self.extra_teacher_models = []
+        if cfg.SSOD.with_da_loss:
+            raise NotImplementedError("SSOD.with_da_loss (domain-adaptation gradient) is not built yet")
+
+    def build_model(self, cfg, device):
+        super().build_model(cfg, device)            # student + ModelEMA (the teacher is self.ema.ema)
+        if cfg.hyp.burn_epochs > 0:
+            self.semi_ema = None
+        elif self.cosine_ema:
+            self.semi_ema = CosineEMA(self.ema.ema, decay_start=cfg.SSOD.ema_rate, total_epoch=self.epochs)
+        else:
+            self.semi_ema = SemiSupModelEMA(self.ema.ema, cfg.SSOD.ema_rate)
+
+    def build_ddp_model(self, cfg, device):
+        super().build_ddp_model(cfg, device)
+        self.compute_un_sup_loss = build_ssod_loss(self.model, cfg)
+
+    def update_optimizer(self, loss, ni):
+        loss.backward()
+        if isinstance(self.model, FlatDataParallel):
+            self.model.reduce_gradients()
+        self.accumulate = 1 if self.fixed_accumulate else max(round(64 / self.batch_size), 1)
+        self._warmup(ni, 1 if self.fixed_accumulate else 64 / self.batch_size)
+        if ni - self.last_opt_step >= self.accumulate:
+            self.optimizer.step()
+            self.optimizer.zero_grad()
+            self.ema.update(self.model)
+            if self.semi_ema:
+                self.semi_ema.update(self.ema.ema)
+            self.last_opt_step = ni
+
+    @staticmethod
+    def split_predict_and_feature(total_pred, total_feature, n_img):
+        sup_feature = [f[:n_img] for f in total_feature]
+        un_sup_feature = [f[n_img:] for f in total_feature]
+        sup_pred = [p[:n_img] for p in total_pred]
+        un_sup_pred = [p[n_img:] for p in total_pred]
+        return sup_pred, sup_feature, un_sup_pred, un_sup_feature
+
+    def train_instance(self, imgs, targets, paths, unlabeled_imgs, unlabeled_imgs_ori, unlabeled_gt, unlabeled_M, ni,
+                       pbar=None, callbacks=None):
+        n_img = imgs.shape[0]
+        height, width = unlabeled_imgs.shape[2], unlabeled_imgs.shape[3]
+        # 1 teacher forward (ssod_trainer.py:595-599): EMA model, eval mode, no grad
+        with torch.no_grad():
+            (teacher_pred, _), _ = self.ema.ema(unlabeled_imgs_ori, augment=False)
+        # 2 pseudo labels (:618), device resident
+        t9, valid = self.pseudo_label_creator.create_pseudo_label_padded(teacher_pred, unlabeled_M, width, height)
+        has_targets = valid.any().float()            # == not invalid_target_shape, as a device flag
+        # 3 student forward on the concatenated batch (:623-627)
+        total_imgs = torch.cat([imgs, unlabeled_imgs], 0)
+        total_pred, total_feature = self.model(total_imgs)
+        sup_pred, sup_feature, un_sup_pred, un_sup_feature = self.split_predict_and_feature(total_pred, total_feature, n_img)
+        # 4 losses (:628-649); the zero-weighted domain losses (:631-636) contribute nothing
+        sup_loss, sup_loss_items = self.compute_loss(sup_pred, targets.to(self.device))
+        if self.RANK != -1:
+            sup_loss = sup_loss * self.WORLD_SIZE
+        un_sup_loss, un_sup_loss_items = self.compute_un_sup_loss(un_sup_pred, t9, valid)
+        un_sup_loss = un_sup_loss * has_targets       # reference: zeros(1) when no pseudo label survived (:640-643)
+        if self.RANK != -1:
+            un_sup_loss = un_sup_loss * self.WORLD_SIZE
+        loss = sup_loss + un_sup_loss * self.cfg.SSOD.teacher_loss_weight
+        # 5 backward / optimizer / EMAs (:651)
+        self.update_optimizer(loss, ni)
+        return dict(sup_loss_items, **un_sup_loss_items)
+
+    def train_with_unlabeled(self, labeled_batches, unlabeled_batches, start_ni=0):
+        """ssod_trainer.py:682-697 for iterables of the reference's batch tuples
+        (imgs, targets, paths, shapes) and (imgs, targets, paths, shapes, imgs_ori, M_s)."""
+        self.optimizer.zero_grad()
+        labeled = iter(labeled_batches)
+        out = None
+        for i, (t_imgs, t_gt, t_paths, _, t_imgs_ori, t_M) in enumerate(unlabeled_batches):
+            imgs, targets, paths, _ = next(labeled)
+            imgs = imgs.to(self.device, non_blocking=True).float() / 255.0
+            t_imgs = t_imgs.to(self.device, non_blocking=True).float() / 255.0
+            t_imgs_ori = t_imgs_ori.to(self.device, non_blocking=True).float() / 255.0
+            out = self.train_instance(imgs, targets, paths, t_imgs, t_imgs_ori, t_gt, t_M, start_ni + i)
+        return out

@@ -1,0 +1,127 @@
+"""Supervised trainer core (host-side mirror of reference trainer/trainer.py: build_model :125,
+build_optimizer :193, build_ddp_model :308, update_optimizer :381, the train_in_epoch body :406-443).
+
+Only the per-iteration hot path is mirrored: data loading, validation, checkpoints and loggers are the
+reference's own host code (out of scope) and plug in around ``train_step``.
+Mixed precision: the reference autocasts to fp16 and scales the loss (trainer.py:248,348); here the
+performance mode is bf16 storage with fp32 accumulation and fp32 master weights, which needs no loss
+scaling -- ``self.scaler`` is therefore a fixed scale of 1.
+"""
+import logging
+
+import numpy as np
+import torch
+from torch.optim import lr_scheduler
+
+from ..models.loss import ComputeLoss
+from ..optim import FlatSGD
+from ..parallel import FlatDataParallel
+from ..utils.torch_utils import ModelEMA, de_parallel
+
+LOGGER = logging.getLogger(__name__)
+
+
+class Trainer:
+    MODEL_MODULE = "efficientteacher_amd.models.detector.yolo"
+
+    def __init__(self, cfg, device, callbacks=None, LOCAL_RANK=-1, RANK=-1, WORLD_SIZE=1, nb=1000):
+        self.cfg = cfg
+        self.set_env(cfg, device, LOCAL_RANK, RANK, WORLD_SIZE, callbacks, nb)
+        self.build_model(cfg, device)
+        self.build_optimizer(cfg)
+        self.build_ddp_model(cfg, device)
+
+    # ---- reference trainer.py:253-306 (the parts the step needs) ------------------------------------------
+    def set_env(self, cfg, device, LOCAL_RANK, RANK, WORLD_SIZE, callbacks, nb=1000):
+        self.device = torch.device(device)
+        self.cuda = self.device.type != 'cpu'
+        self.LOCAL_RANK, self.RANK, self.WORLD_SIZE = LOCAL_RANK, RANK, WORLD_SIZE
+        self.callbacks = callbacks
+        self.epochs = cfg.epochs
+        self.epoch = 0
+        self.start_epoch = 0
+        self.batch_size = cfg.Dataset.batch_size
+        self.imgsz = cfg.Dataset.img_size
+        self.norm_scale = cfg.Dataset.norm_scale if 'norm_scale' in cfg.Dataset else 255.0
+        self.warmup_epochs = cfg.hyp.warmup_epochs
+        self.warmup_momentum = cfg.hyp.warmup_momentum
+        self.warmup_bias_lr = cfg.hyp.warmup_bias_lr
+        self.momentum = cfg.hyp.momentum
+        self.nb = nb                                   # batches per epoch (set by whoever owns the loader)
+        self.last_opt_step = -1
+        self.amp_dtype = torch.bfloat16 if self.cuda else torch.float32
+        self.model_type = 'yolov5'
+        self.sync_bn = False
+        if cfg.sync_bn:
+            raise NotImplementedError("SyncBatchNorm is off in every shipped config (SURVEY.md 2a)")
+
+    def _model_class(self):
+        import importlib
+        return importlib.import_module(self.MODEL_MODULE).Model
+
+    def build_model(self, cfg, device):
+        if cfg.weights:
+            raise NotImplementedError("checkpoint interchange is SURVEY.md 8(f-3), not built yet")
+        self.model = self._model_class()(cfg).to(device)
+        self.model.set_compute_dtype(self.amp_dtype)
+        for _, v in self.model.named_parameters():
+            v.requires_grad = True
+        self.ema = ModelEMA(self.model)
+
+    def build_optimizer(self, cfg):
+        nbs = 64  # nominal batch size
+        self.accumulate = max(round(nbs / self.batch_size), 1)
+        weight_decay = cfg.hyp.weight_decay * self.batch_size * self.accumulate / nbs
+        if cfg.adam:
+            raise NotImplementedError("AdamW is outside the hot path (every SSOD recipe uses SGD)")
+        self.optimizer = FlatSGD(self.model, lr=cfg.hyp.lr0, momentum=cfg.hyp.momentum, nesterov=True,
+                                 weight_decay=weight_decay)
+        if cfg.linear_lr:
+            self.lf = lambda x: (1 - x / (self.epochs - 1)) * (1.0 - cfg.hyp.lrf) + cfg.hyp.lrf
+        else:
+            import math
+            self.lf = lambda x: ((1 - math.cos(x * math.pi / self.epochs)) / 2) * (cfg.hyp.lrf - 1) + 1
+        self.scheduler = lr_scheduler.LambdaLR(self.optimizer, lr_lambda=self.lf)
+        self.scheduler.last_epoch = self.epoch - 1
+        # warm-up length (trainer.py:372-376)
+        self.nw = max(round(self.warmup_epochs * self.nb), 1000)
+        self.nw = min(self.nw, (self.epochs - self.start_epoch) / 2 * self.nb)
+
+    def build_ddp_model(self, cfg, device):
+        if self.cuda and self.RANK != -1:
+            self.model = FlatDataParallel(self.model)
+        self.compute_loss = ComputeLoss(self.model, cfg)
+
+    # ---- the step ------------------------------------------------------------------------------------------
+    def _warmup(self, ni, accumulate_target):
+        if ni <= self.nw:
+            xi = [0, self.nw]
+            self.accumulate = max(1, np.interp(ni, xi, [1, accumulate_target]).round())
+            for j, x in enumerate(self.optimizer.param_groups):
+                # (sic) group 2 = BN weights gets warmup_bias_lr, exactly as the reference (trainer.py:393)
+                x['lr'] = np.interp(ni, xi, [self.warmup_bias_lr if j == 2 else 0.0, x['initial_lr'] * self.lf(self.epoch)])
+                if 'momentum' in x:
+                    x['momentum'] = np.interp(ni, xi, [self.warmup_momentum, self.momentum])
+
+    def update_optimizer(self, loss, ni):
+        loss.backward()
+        if isinstance(self.model, FlatDataParallel):
+            self.model.reduce_gradients()
+        self.accumulate = max(round(64 / self.batch_size), 1)
+        self._warmup(ni, 64 / self.batch_size)
+        if ni - self.last_opt_step >= self.accumulate:
+            self.optimizer.step()
+            self.optimizer.zero_grad()
+            if self.ema:
+                self.ema.update(self.model)
+            self.last_opt_step = ni
+
+    def train_step(self, imgs, targets, ni):
+        """Body of train_in_epoch (trainer.py:411-430) for one batch: imgs uint8/float NCHW, targets (n,6)."""
+        imgs = imgs.to(self.device, non_blocking=True).float() / self.norm_scale
+        pred = self.model(imgs)
+        loss, loss_items = self.compute_loss(pred, targets.to(self.device))
+        if self.RANK != -1:
+            loss = loss * self.WORLD_SIZE      # gradient averaged between devices in DDP mode
+        self.update_optimizer(loss, ni)
+        return loss_items

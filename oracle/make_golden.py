@@ -411,6 +411,119 @@ def case_optim(model):
     save("optim", **out)
 
 
+def case_ssod_step(cfg, model):
+    """One real ``SSODTrainer.train_instance`` (trainer/ssod_trainer.py:587-680) + ``update_optimizer``
+    (:458-488) of the reference, CPU fp32, on the tiny model.  The trainer object is created without
+    running its data/logging set-up (``object.__new__``) and given exactly the attributes the two
+    methods read; RANK=1 / WORLD_SIZE=1 skips the rank-0 logging block, not the arithmetic."""
+    import copy as _copy
+    from torch.cuda import amp
+    from models.loss.loss import ComputeLoss, DomainLoss, TargetLoss
+    from models.loss.ssod.ssod_loss import ComputeStudentMatchLoss
+    from trainer.ssod_trainer import SSODTrainer
+    from utils.self_supervised_utils import FairPseudoLabel
+    from utils.torch_utils import CosineEMA, ModelEMA
+    # The reference's ``tobj[b,a,gj,gi] = v`` scatter (ssod_loss.py:231,248) has duplicate indices; torch's
+    # CPU index_put_ is only sequential (= last writer wins, the rule this repo implements) when it does
+    # not split the rows across threads, so the reference step is run single-threaded here.
+    torch.set_num_threads(1)
+    rng = np.random.default_rng(77)
+    m = _copy.deepcopy(model).train()
+    with torch.no_grad():                      # make the (random) teacher emit detections above 0.1
+        for mi in m.head.m:
+            b = mi.bias.view(m.head.na, -1)
+            b[:, 4] += 6.0
+            b[:, 5:] += 3.5
+            b[:, 5 + 7] += 2.0
+    B, S = 2, 64
+    imgs = rng.uniform(0, 1, (B, 3, S, S)).astype(np.float32)
+    u_ori = rng.uniform(0, 1, (B, 3, S, S)).astype(np.float32)
+    u_str = np.clip(u_ori + rng.normal(0, 0.05, u_ori.shape), 0, 1).astype(np.float32)
+    targets = synth_targets(rng, B, n_per=(2, 5), with_edge=False)
+    M_s = np.zeros((B, 13), np.float64)
+    M_s[0] = [0, 1, 0, 0, 0, 1, 0, 0, 0, 1, 1.0, 0, 0]
+    M_s[1] = [1, 0.9, 0, 3.0, 0, 0.9, 2.0, 0, 0, 1, 0.9, 0, 1]
+    t = object.__new__(SSODTrainer)
+    t.cfg = cfg; t.model = m; t.model_type = 'yolov5'; t.cuda = False; t.device = torch.device('cpu')
+    t.RANK = 1; t.WORLD_SIZE = 1; t.extra_teacher_models = []
+    t.epochs = cfg.epochs; t.epoch = 0; t.batch_size = cfg.Dataset.batch_size
+    t.ema = ModelEMA(m)
+    t.semi_ema = CosineEMA(t.ema.ema, decay_start=cfg.SSOD.ema_rate, total_epoch=t.epochs)
+    t.pseudo_label_creator = FairPseudoLabel(cfg)
+    t.compute_loss = ComputeLoss(m, cfg)
+    t.compute_un_sup_loss = ComputeStudentMatchLoss(m, cfg)
+    t.domain_loss = DomainLoss(); t.target_loss = TargetLoss()
+    t.da_loss_weights = cfg.SSOD.da_loss_weights
+    t.fixed_accumulate = cfg.SSOD.fixed_accumulate
+    t.scaler = amp.GradScaler(enabled=False)
+    # optimizer exactly as trainer/trainer.py:193-243
+    t.accumulate = max(round(64 / t.batch_size), 1)
+    wd = cfg.hyp.weight_decay * t.batch_size * t.accumulate / 64
+    g_bnw, g_w, g_b = [], [], []
+    for v in m.modules():
+        if hasattr(v, 'bias') and isinstance(v.bias, torch.nn.Parameter):
+            g_b.append(v.bias)
+        if isinstance(v, torch.nn.BatchNorm2d):
+            g_bnw.append(v.weight)
+        elif hasattr(v, 'weight') and isinstance(v.weight, torch.nn.Parameter):
+            g_w.append(v.weight)
+    t.optimizer = torch.optim.SGD(g_b, lr=cfg.hyp.lr0, momentum=cfg.hyp.momentum, nesterov=True)
+    t.optimizer.add_param_group({'params': g_w, 'weight_decay': wd})
+    t.optimizer.add_param_group({'params': g_bnw})
+    t.lf = lambda x: (1 - x / (t.epochs - 1)) * (1.0 - cfg.hyp.lrf) + cfg.hyp.lrf
+    t.scheduler = torch.optim.lr_scheduler.LambdaLR(t.optimizer, lr_lambda=t.lf)
+    nb = 1000
+    t.nw = min(max(round(cfg.hyp.warmup_epochs * nb), 1000), (t.epochs - 0) / 2 * nb)
+    t.warmup_bias_lr = cfg.hyp.warmup_bias_lr; t.warmup_momentum = cfg.hyp.warmup_momentum
+    t.momentum = cfg.hyp.momentum
+    t.last_opt_step = -1
+    ni = 500
+    t.optimizer.zero_grad()
+    captured = {}
+    orig = t.compute_un_sup_loss.__call__
+
+    class Spy:
+        def __init__(self, inner):
+            self.inner = inner
+            self.ignore_thres_low, self.ignore_thres_high = inner.ignore_thres_low, inner.ignore_thres_high
+
+        def __call__(self, p, tg):
+            captured['targets9'] = tg.detach().clone().numpy()
+            loss, items = self.inner(p, tg)
+            captured['un_items'] = np.array([float(items[k]) for k in ('ss_box', 'ss_obj', 'ss_cls')], np.float32)
+            captured['un_loss'] = loss.detach().numpy().copy()
+            return loss, items
+
+    t.compute_un_sup_loss = Spy(t.compute_un_sup_loss)
+    closs = t.compute_loss
+
+    def spy_sup(p, tg):
+        loss, items = closs(p, tg)
+        captured['sup_items'] = np.array([items[k].item() for k in ('box', 'obj', 'cls')], np.float32)
+        captured['sup_loss'] = loss.detach().numpy().copy()
+        return loss, items
+
+    t.compute_loss = spy_sup
+    t.train_instance(torch.from_numpy(imgs), torch.from_numpy(targets), None, torch.from_numpy(u_str),
+                     torch.from_numpy(u_ori), None, torch.from_numpy(M_s), ni, None, None)
+    assert 'targets9' in captured and captured['targets9'].shape[0] > 0, "no pseudo labels: bump the biases"
+    print("   pseudo labels:", captured['targets9'].shape[0], "sup", captured['sup_loss'], "unsup", captured['un_loss'])
+    out = dict(imgs=imgs, u_ori=u_ori, u_str=u_str, targets=targets, M_s=M_s, ni=np.int64(ni), nb=np.int64(nb),
+               **captured)
+    keys = ["backbone.stage1.conv.weight", "backbone.stage1.bn.weight", "backbone.stage3_2.m.0.cv2.conv.weight",
+            "neck.C2.cv3.bn.bias", "head.m.1.weight", "head.m.2.bias", "backbone.sppf.cv2.bn.running_var",
+            "det_8.conv1.weight"]
+    sd, esd, ssd = m.state_dict(), t.ema.ema.state_dict(), t.semi_ema.ema.state_dict()
+    sd0 = model.state_dict()
+    for k in keys:
+        kk = k.replace(".", "__")
+        out["m__" + kk] = sd[k].numpy(); out["e__" + kk] = esd[k].numpy(); out["s__" + kk] = ssd[k].numpy()
+        out["d__" + kk] = (sd[k] - sd0[k]).numpy() if k in sd0 and "head" not in k else np.zeros(1)
+    out["lrs"] = np.array([g['lr'] for g in t.optimizer.param_groups])
+    out["moms"] = np.array([g['momentum'] for g in t.optimizer.param_groups])
+    save("ssod_step", **out)
+
+
 def main():
     if not ref_loader.available():
         sys.exit("reference tree not present; golden vectors can only be generated in the build container")
@@ -421,6 +534,7 @@ def main():
     print("pseudo label ..."); case_pseudo_label(cfg)
     print("model ..."); case_model(cfg, model)
     print("optimizer / EMA ..."); case_optim(model)
+    print("ssod step (reference SSODTrainer.train_instance) ..."); case_ssod_step(cfg, model)
     print("done")
 
 

@@ -1,0 +1,56 @@
+"""FlatSGD + the three EMA classes vs the reference's torch.optim.SGD / ModelEMA / CosineEMA
+(tests/golden/optim.npz: two optimizer steps with stored gradients on the tiny model)."""
+import numpy as np
+import torch
+
+from tests.conftest import golden
+from tests.test_model import build
+
+KEYS = ["backbone.stage1.conv.weight", "backbone.stage1.bn.weight", "head.m.0.bias", "neck.C1.cv3.conv.weight"]
+
+
+def test_sgd_and_ema_two_steps(hip):
+    from efficientteacher_amd.optim import FlatSGD
+    from efficientteacher_amd.utils.torch_utils import CosineEMA, ModelEMA
+    cfg, model, _ = build(hip, torch.bfloat16)
+    g = golden("optim")
+    model.train()
+    params = dict(model.named_parameters())
+    for k in KEYS:
+        assert np.array_equal(params[k].detach().cpu().numpy(), g["p0__" + k.replace(".", "__")])
+    opt = FlatSGD(model, lr=0.01, momentum=0.937, nesterov=True, weight_decay=5e-4)
+    assert [len(x["params"]) for x in opt.param_groups] == [int(g["groups"][2]), int(g["groups"][1]), int(g["groups"][0])]
+    ema = ModelEMA(model)
+    semi = CosineEMA(ema.ema, decay_start=0.999, decay_end=0.9999, total_epoch=300)
+    for step in range(2):
+        opt.zero_grad()
+        for k in KEYS:
+            params[k].grad.copy_(hip.t(g[f"g{step}__" + k.replace(".", "__")]))
+        opt.step()
+        ema.update(model)
+        semi.update(ema.ema)
+    esd, ssd = ema.ema.state_dict(), semi.ema.state_dict()
+    for k in KEYS:
+        kk = k.replace(".", "__")
+        assert np.allclose(params[k].detach().cpu().numpy(), g["p2__" + kk], rtol=1e-6, atol=1e-8), k
+        assert np.allclose(esd[k].cpu().numpy(), g["ema2__" + kk], rtol=1e-6, atol=1e-8), k
+        assert np.allclose(ssd[k].cpu().numpy(), g["semi2__" + kk], rtol=1e-6, atol=1e-8), k
+    # the bf16 shadow the MFMA kernels read follows the fp32 master
+    f = model.flat_state()
+    o, n = f.w_range
+    assert torch.equal(f.shadow.float().cpu(), f.params[o:o + n].to(torch.bfloat16).float().cpu())
+    assert ema.updates == 2 and abs(ema.decay(2) - 0.9999 * (1 - np.exp(-2 / 2000))) < 1e-12
+
+
+def test_ema_teacher_is_independent_copy(hip):
+    from efficientteacher_amd.utils.torch_utils import ModelEMA
+    cfg, model, g = build(hip)
+    ema = ModelEMA(model)
+    assert not ema.ema.training and all(not p.requires_grad for p in ema.ema.parameters())
+    a, b = model.flat_state().params, ema.ema.flat_state().params
+    assert a.data_ptr() != b.data_ptr() and torch.equal(a.cpu(), b.cpu())
+    model.flat_state().params.add_(1.0)
+    assert not torch.equal(a.cpu(), b.cpu())
+    with torch.no_grad():
+        (z, _), _ = ema.ema(hip.t(g["x"]))
+    assert np.abs(z.cpu().numpy() - g["eval_z"]).max() <= 1e-4 * np.abs(g["eval_z"]).max()
