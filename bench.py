@@ -1,0 +1,220 @@
+"""bench.py -- SSOD images/sec of one Efficient-Teacher training step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Metric (BASELINE.json): SSOD images/sec (teacher + student step), YOLOv5l, 640 px.
+One step = SSODTrainer.train_instance on one batch of synthetic input already resident in HBM:
+EMA-teacher inference on the unlabeled weak view -> NMS + pseudo-label transform -> student forward on
+cat(labeled, unlabeled) -> ComputeLoss + ComputeStudentMatchLoss -> backward (+ RCCL gradient
+all-reduce for N > 1) -> SGD step + ModelEMA + semi-EMA update (optimizer every step:
+SSOD.fixed_accumulate).  Per-GPU work is fixed: 32 labeled + 32 unlabeled images per rank (config 3 of
+BASELINE.json at N = 1; weak scaling).  value = N * 64 * K / max-over-ranks time.
+
+Extra objects on the JSON line:
+  roofline     : the dominant kernel (bf16 MFMA implicit-GEMM conv), algorithmic FLOPs per launch
+                 divided by its HIP-event-measured average launch duration inside the timed region.
+  cpu_baseline : the plain-torch CPU port of the same step (oracle/model.py + oracle losses/NMS) timed
+                 on the host cores, rank 0 at N = 1 only, on a bounded sample.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+YAML = os.path.join(ROOT, "efficientteacher_amd", "configs", "ssod", "coco-standard",
+                    "yolov5l_coco_ssod_10_percent.yaml")
+F_IMG = 111.52e9          # conv FLOPs / image forward, YOLOv5l SSOD model
+PEAK_BF16 = 2.5e15        # dense bf16 MFMA peak, MI355X_MICROARCH.md
+
+
+def synth_targets(rng, B):
+    rows = []
+    for b in range(B):
+        n = int(rng.integers(1, 17))
+        xy = rng.uniform(0.1, 0.9, (n, 2))
+        wh = np.exp(rng.uniform(np.log(0.02), np.log(0.6), (n, 2)))
+        wh = np.minimum(wh, 2 * np.minimum(xy, 1 - xy))
+        rows.append(np.concatenate((np.full((n, 1), b), rng.integers(0, 80, (n, 1)), xy, wh), 1))
+    return torch.from_numpy(np.concatenate(rows, 0).astype(np.float32))
+
+
+def make_batch(rng, Bl, Bu, S, device):
+    g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+    imgs = torch.randint(0, 256, (Bl, 3, S, S), generator=g, dtype=torch.uint8)
+    u_ori = torch.randint(0, 256, (Bu, 3, S, S), generator=g, dtype=torch.uint8)
+    M_s = torch.zeros(Bu, 13, dtype=torch.float64)
+    for i in range(Bu):          # fixed affine: scale 0.8, translate 0.1*S, lr flip on odd images
+        s = 0.8
+        M_s[i] = torch.tensor([i, s, 0, 0.1 * S, 0, s, 0.1 * S, 0, 0, 1, s, 0, i % 2], dtype=torch.float64)
+    f = lambda t: (t.to(device).float() / 255.0)
+    return f(imgs), synth_targets(rng, Bl).to(device), f(u_ori), f(u_ori), M_s.to(device)
+
+
+def build_trainer(device, rank, world, local_rank, per_rank):
+    from efficientteacher_amd.configs import get_cfg
+    from efficientteacher_amd.trainer import SSODTrainer
+    cfg = get_cfg()
+    cfg.merge_from_file(YAML)
+    cfg.merge_from_list(["Dataset.batch_size", per_rank * world, "SSOD.fixed_accumulate", True])
+    cfg.freeze()
+    torch.manual_seed(0)
+    return cfg, SSODTrainer(cfg, device, None, local_rank if world > 1 else -1, rank if world > 1 else -1, world, nb=1000)
+
+
+def cpu_baseline(cfg, seconds=25.0):
+    """Plain-torch CPU port of the same step on a bounded sample (1 labeled + 1 unlabeled image)."""
+    import copy
+    from oracle import losses as o_loss, model as o_model, nms as o_nms, optim as o_opt, pseudo_label as o_pl
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    rng = np.random.default_rng(0)
+    S, Bl, Bu = 640, 1, 1
+    torch.manual_seed(0)
+    student = o_model.Model.from_cfg(cfg).train()
+    teacher = copy.deepcopy(student).eval()
+    imgs, targets, u_str, u_ori, M_s = make_batch(rng, Bl, Bu, S, "cpu")
+    synth = torch.rand(Bu, 25200, 81) ** torch.cat((torch.full((1,), 16.0), torch.full((80,), 4.0)))
+    opt = torch.optim.SGD(student.parameters(), lr=0.01, momentum=0.937, nesterov=True)
+    kw = dict(nc=80, box_w=0.05, obj_w=0.7, cls_w=0.3)
+
+    def step():
+        with torch.no_grad():
+            (tp, _), _ = teacher(u_ori)
+            tp[..., 4:] = synth
+        dets, _ = o_nms.non_max_suppression_ssod(tp.numpy(), 0.1, 0.65)
+        t9, invalid = o_pl.create_pseudo_label(dets, M_s.numpy(), S, S)
+        pred, _ = student(torch.cat([imgs, u_str], 0))
+        sup = [p[:Bl] for p in pred]; uns = [p[Bl:] for p in pred]
+        loss, _ = o_loss.compute_loss(sup, targets, student.head.anchors, **kw)
+        if not invalid:
+            lu, _ = o_loss.compute_student_match_loss(uns, torch.from_numpy(t9[:60]), student.head.anchors, **kw)
+            loss = loss + 3.0 * lu
+        opt.zero_grad(); loss.backward(); opt.step()
+        with torch.no_grad():
+            for v, m in zip(teacher.state_dict().values(), student.state_dict().values()):
+                if v.dtype.is_floating_point:
+                    v.mul_(0.9999).add_(m, alpha=1e-4)
+
+    step()
+    t0, n = time.time(), 0
+    while n < 1 or (time.time() - t0 < seconds and n < 8):
+        step(); n += 1
+    dt = (time.time() - t0) / n
+    return dict(value=(Bl + Bu) / dt, unit="images/s", cores=cores, kind="port",
+                sample=f"YOLOv5l SSOD step, {Bl} labeled + {Bu} unlabeled 640x640, {n} steps, plain-torch fp32 CPU port "
+                       f"(pseudo-label loss on the first 60 labels)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--per-rank", type=int, default=32, help="labeled (= unlabeled) images per rank")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    from efficientteacher_amd import ops
+    cfg, tr = build_trainer(device, rank, world, local_rank, a.per_rank)
+    rng = np.random.default_rng(1234 + rank)
+    S = cfg.Dataset.img_size
+    Bl = Bu = a.per_rank
+    imgs, targets, u_str, u_ori, M_s = make_batch(rng, Bl, Bu, S, device)
+    g = torch.Generator(device="cpu").manual_seed(99 + rank)
+    pw = torch.cat((torch.full((1,), 16.0), torch.full((80,), 4.0)))
+    synth = (torch.rand(Bu, 25200, 81, generator=g) ** pw).to(device)
+
+    def hook(tp):           # a random-init teacher scores nothing above 0.1: SURVEY.md 8(d) synthetic scores
+        tp[..., 4:] = synth
+        return tp
+    tr.teacher_pred_hook = hook
+
+    ni = 2000               # past the warm-up ramp's first iterations, inside warm-up like early training
+
+    def step(i):
+        return tr.train_instance(imgs, targets, None, u_str, u_ori, None, M_s, ni + i)
+
+    for i in range(a.warmup):
+        step(i)
+    timer = ops.KernelTimer()
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    sync()
+    ops.TIMER = timer
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        items = step(a.warmup + i)
+    sync()
+    dt = time.perf_counter() - t0
+    ops.TIMER = None
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss_ok = all(math.isfinite(float(v)) for v in items.values())
+
+    if rank == 0:
+        agg = timer.summary()
+        dom = max((k for k in agg if k.startswith("conv_gemm")), key=lambda k: agg[k]["ms"])
+        d = agg[dom]
+        per_launch_flops = d["flops"] / d["launches"]
+        per_launch_s = d["ms"] * 1e-3 / d["launches"]
+        conv_ms = sum(v["ms"] for v in agg.values()) / a.steps
+        conv_fl = sum(v["flops"] for v in agg.values()) / a.steps
+        roof = dict(bound="mfma", kernel=dom, achieved=per_launch_flops / per_launch_s / 1e12, peak=PEAK_BF16 / 1e12,
+                    unit="TFLOP/s", frac=per_launch_flops / per_launch_s / PEAK_BF16, traffic=None,
+                    launches_per_step=d["launches"] / a.steps, avg_launch_us=per_launch_s * 1e6,
+                    algorithmic_gflop_per_launch=per_launch_flops / 1e9,
+                    all_conv_kernels=dict(ms_per_step=conv_ms, tflops=conv_fl / (conv_ms * 1e-3) / 1e12,
+                                          algorithmic_tflop_per_step=conv_fl / 1e12))
+        step_flop = F_IMG * Bu + 3 * F_IMG * (Bl + Bu)
+        out = {
+            "metric": "SSOD images/sec (teacher+student step) YOLOv5l 640px",
+            "value": world * (Bl + Bu) * a.steps / dt, "unit": "images/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic (random-init YOLOv5l; teacher obj/cls scores "
+            "replaced by U^16 / U^4 so that NMS and the pseudo-label loss do representative work)",
+            "config": {"workload": "YOLOv5l Efficient-Teacher SSOD, 32 labeled + 32 unlabeled 640px per GPU "
+                                   "(BASELINE configs[2])", "global_batch": world * (Bl + Bu), "img_size": S,
+                       "parallelism": f"dp{world}", "optimizer_every_step": True,
+                       "algorithmic_tflop_per_step_per_gpu": step_flop / 1e12,
+                       "step_tflops_per_gpu": step_flop / (dt / a.steps) / 1e12,
+                       "frac_of_bf16_mfma_peak": step_flop / (dt / a.steps) / PEAK_BF16, "loss_finite": loss_ok},
+            "roofline": roof,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(cfg)
+            except Exception as e:   # never lose the GPU number to the baseline leg
+                out["cpu_baseline"] = dict(value=None, unit="images/s", cores=os.cpu_count(), kind="port",
+                                           sample=f"failed: {type(e).__name__}: {e}")
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -12,6 +12,39 @@ from ._lib import ET_BF16, ET_F32
 ACT_NONE, ACT_SILU, ACT_RELU = 0, 1, 2
 
 
+class KernelTimer:
+    """Optional HIP-event timing of the MFMA conv launches on the launching stream (bench.py's roofline
+    leg).  ``ops.TIMER = KernelTimer()`` switches it on; nothing is recorded otherwise."""
+
+    def __init__(self):
+        self.rows = []          # (tag, flops, launches, start_event, end_event)
+
+    def span(self, tag, flops, launches=1):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.rows.append((tag, flops, launches, a, b))
+        return a, b
+
+    def summary(self):
+        agg = {}
+        for tag, fl, n, a, b in self.rows:
+            ms = a.elapsed_time(b)
+            t = agg.setdefault(tag, dict(ms=0.0, flops=0.0, launches=0))
+            t["ms"] += ms; t["flops"] += fl; t["launches"] += n
+        return agg
+
+
+TIMER = None
+
+
+def _gemm_tag(kind, x_dtype, cout, cin_padded):
+    vec = 4 if x_dtype == torch.float32 else 8
+    cv = cin_padded // vec
+    bkv = 8 if cv % 8 == 0 else 4
+    ut = "true" if cv % 4 == 0 else "false"
+    t = "float" if x_dtype == torch.float32 else "unsigned short"
+    return f"conv_gemm_kernel<{t}, 128, {128 if cout > 64 else 64}, 2, 2, {bkv}, {ut}>"
+
+
 def et_dtype(t):
     if t.dtype == torch.float32:
         return ET_F32
@@ -48,9 +81,14 @@ def conv2d_fwd(x, w, stride, pad, *, scale=None, bias=None, act=ACT_NONE, residu
         rows = lib.et_conv2d_stats_rows(N, OH, OW)
         stats = torch.empty((rows, 2, Cout), dtype=torch.float32, device=x.device)
     ldr = _nhwc(residual) if residual is not None else 0
+    ev = TIMER.span(_gemm_tag("fwd", x.dtype, Cout, Cin), 2.0 * N * OH * OW * Cout * Cin * KH * KW) if TIMER else None
+    if ev:
+        ev[0].record()
     _lib.check(lib.et_conv2d_fwd(_lib.ptr(x), _lib.ptr(w), _lib.ptr(out), et_dtype(x), N, IH, IW, Cin, _nhwc(x),
                                  Cout, KH, KW, stride, pad, _nhwc(out), _lib.ptr(scale), _lib.ptr(bias), act,
                                  _lib.ptr(residual), ldr, _lib.ptr(stats), _lib.stream(x)), "et_conv2d_fwd")
+    if ev:
+        ev[1].record()
     return (out, stats) if want_stats else out
 
 
@@ -73,9 +111,15 @@ def conv2d_dgrad(dy, wT, in_hw, stride, pad, *, out=None, accumulate=False):
     if out is None:
         assert not accumulate
         out = torch.empty((N, IH, IW, Cin), dtype=dy.dtype, device=dy.device)
+    ev = TIMER.span(_gemm_tag("dgrad", dy.dtype, Cin, Cout), 2.0 * N * OH * OW * Cout * Cin * KH * KW,
+                    stride * stride) if TIMER else None
+    if ev:
+        ev[0].record()
     _lib.check(_lib.load().et_conv2d_dgrad(_lib.ptr(dy), _lib.ptr(wT), _lib.ptr(out), et_dtype(dy), N, IH, IW, Cin,
                                            _nhwc(out), Cout, KH, KW, stride, pad, _nhwc(dy), int(accumulate),
                                            _lib.stream(dy)), "et_conv2d_dgrad")
+    if ev:
+        ev[1].record()
     return out
 
 
@@ -85,9 +129,14 @@ def conv2d_wgrad(x, dy, dw, ksize, stride, pad):
     _, OH, OW, Cout = dy.shape
     assert dw.dtype == torch.float32 and dw.is_contiguous() and dw.shape == (Cout, ksize, ksize, Cin)
     assert x.dtype == dy.dtype
+    ev = TIMER.span("conv_wgrad_kernel", 2.0 * N * OH * OW * Cout * Cin * ksize * ksize) if TIMER else None
+    if ev:
+        ev[0].record()
     _lib.check(_lib.load().et_conv2d_wgrad(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), et_dtype(x), N, IH, IW, Cin,
                                            _nhwc(x), Cout, ksize, ksize, stride, pad, _nhwc(dy), _lib.stream(x)),
                "et_conv2d_wgrad")
+    if ev:
+        ev[1].record()
     return dw
 
 

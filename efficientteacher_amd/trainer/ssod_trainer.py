@@ -38,6 +38,7 @@ class SSODTrainer(Trainer):
         self.cosine_ema = cfg.SSOD.cosine_ema
         self.fixed_accumulate = cfg.SSOD.fixed_accumulate
         self.extra_teacher_models = []
+        self.teacher_pred_hook = None      # optional callable(teacher_pred) -> teacher_pred (bench: synthetic scores)
         if cfg.SSOD.with_da_loss:
             raise NotImplementedError("SSOD.with_da_loss (domain-adaptation gradient) is not built yet")
 
@@ -83,6 +84,8 @@ class SSODTrainer(Trainer):
         # 1 teacher forward (ssod_trainer.py:595-599): EMA model, eval mode, no grad
         with torch.no_grad():
             (teacher_pred, _), _ = self.ema.ema(unlabeled_imgs_ori, augment=False)
+            if self.teacher_pred_hook is not None:
+                teacher_pred = self.teacher_pred_hook(teacher_pred)
         # 2 pseudo labels (:618), device resident
         t9, valid = self.pseudo_label_creator.create_pseudo_label_padded(teacher_pred, unlabeled_M, width, height)
         has_targets = valid.any().float()            # == not invalid_target_shape, as a device flag

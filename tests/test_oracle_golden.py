@@ -1,0 +1,91 @@
+"""CPU tier: the oracle restatements (oracle/*.py) re-checked against the committed golden vectors that
+oracle/make_golden.py produced by running the reference itself.  No reference tree, no GPU needed."""
+import numpy as np
+import torch
+
+from oracle import assigner as o_asg
+from oracle import losses as o_loss
+from oracle import model as o_model
+from oracle import nms as o_nms
+from oracle import pseudo_label as o_pl
+from tests.conftest import golden
+
+
+def test_nms_oracle_vs_golden():
+    g = golden("nms")
+    for case in ("a", "b", "c", "empty"):
+        ct, it = g[f"{case}_thr"]
+        dets, keeps = o_nms.non_max_suppression_ssod(g[f"{case}_pred"], ct, it)
+        assert np.array_equal(np.concatenate(dets, 0), g[f"{case}_dets"])
+        assert np.array_equal(np.concatenate(keeps, 0), g[f"{case}_keep"])
+        v = o_nms.non_max_suppression(g[f"{case}_pred"], ct, it, multi_label=True)
+        assert np.array_equal(np.concatenate(v, 0), g[f"{case}_val_dets"])
+
+
+def test_assigner_oracle_vs_golden():
+    g = golden("assigner")
+    shapes = [tuple(s) for s in g["shapes"]]
+    res = o_asg.build_targets(shapes, g["anchors"], g["targets"], float(g["anchor_t"]))
+    for i, r in enumerate(res):
+        for k, v in r.items():
+            assert np.array_equal(v, g[f"bt{i}_{k}"]), (i, k)
+    resu = o_asg.build_targets(shapes, g["anchors"], g["targets7"], float(g["anchor_t"]), with_score=True)
+    for i, r in enumerate(resu):
+        assert np.array_equal(r["tscore"], g[f"uc{i}_tscore"]) and np.array_equal(r["gi"], g[f"uc{i}_gi"])
+    # empty input (yolo_anchor_assigner.py:356-358)
+    e = o_asg.build_targets(shapes, g["anchors"], np.zeros((0, 6), np.float32))
+    assert all(r["b"].shape == (0,) and r["tbox"].shape == (0, 4) for r in e)
+
+
+def test_ciou_and_losses_oracle_vs_golden():
+    g = golden("ciou")
+    pb = torch.from_numpy(g["pbox"]).requires_grad_(True)
+    iou = o_loss.ciou_xywh(pb, torch.from_numpy(g["tbox"]))
+    (1 - iou).mean().backward()
+    assert np.array_equal(iou.detach().numpy(), g["iou"]) and np.array_equal(pb.grad.numpy(), g["grad"])
+    g = golden("compute_loss")
+    w = g["weights"]
+    p = [torch.from_numpy(g[f"p{i}"]).requires_grad_(True) for i in range(3)]
+    loss, items = o_loss.compute_loss(p, torch.from_numpy(g["targets"]), torch.from_numpy(g["anchors"]), nc=80,
+                                      box_w=w[0], obj_w=w[1], cls_w=w[2], anchor_t=w[3])
+    loss.backward()
+    assert np.allclose(loss.detach().numpy(), g["loss"], rtol=1e-6)
+    for i in range(3):
+        assert np.allclose(p[i].grad.numpy(), g[f"grad{i}"], rtol=1e-5, atol=1e-8)
+    gs = golden("student_match_loss")
+    w = gs["weights"]
+    for tag, kw in (("default", {}), ("cls", dict(with_cls=True)), ("ignore", dict(ignore_obj=True))):
+        p = [torch.from_numpy(g[f"p{i}"]).requires_grad_(True) for i in range(3)]
+        loss, _ = o_loss.compute_student_match_loss(p, torch.from_numpy(gs["targets9"]), torch.from_numpy(gs["anchors"]),
+                                                    nc=80, box_w=w[0], obj_w=w[1], cls_w=w[2], anchor_t=w[3], **kw)
+        assert np.allclose(loss.detach().numpy(), gs[f"{tag}_loss"], rtol=1e-6), tag
+    gd = golden("domain_loss")
+    f = [torch.from_numpy(gd[f"f{i}"]) for i in range(3)]
+    assert np.allclose(o_loss.domain_loss(f, 0).numpy(), gd["d"], rtol=1e-6)
+    assert np.allclose(o_loss.domain_loss(f, 1).numpy(), gd["t"], rtol=1e-6)
+
+
+def test_pseudo_label_oracle_vs_golden():
+    g = golden("pseudo_label")
+    dets, _ = o_nms.non_max_suppression_ssod(g["pred"], g["thr"][0], g["thr"][1])
+    t, invalid = o_pl.create_pseudo_label(dets, g["M_s"], int(g["hw"][1]), int(g["hw"][0]))
+    assert not invalid and np.array_equal(t, g["targets"])
+    t0, inv0 = o_pl.create_pseudo_label([np.zeros((0, 8), np.float32)] * 3, g["M_s"], 640, 640)
+    assert inv0 and t0.shape == (0, 9)
+
+
+def test_model_oracle_vs_golden():
+    g = golden("model_tiny")
+    m = o_model.Model(0.125, 0.33, 80)
+    sd = {k[3:].replace("__", "."): torch.from_numpy(g[k]) for k in g.files if k.startswith("w__")}
+    missing, unexpected = m.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    m.eval()
+    with torch.no_grad():
+        (z, xs), feats = m(torch.from_numpy(g["x"]))
+    assert np.allclose(z.numpy(), g["eval_z"], rtol=1e-5, atol=1e-5)
+    m.train()
+    pred, _ = m(torch.from_numpy(g["x"]))
+    loss, _ = o_loss.compute_loss(pred, torch.from_numpy(g["targets"]), m.head.anchors, nc=80, box_w=0.05, obj_w=0.7,
+                                  cls_w=0.3)
+    assert np.allclose(loss.detach().numpy(), g["train_loss"], rtol=1e-5)
