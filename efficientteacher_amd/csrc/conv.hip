@@ -119,7 +119,12 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const T* __restrict__ X,
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int RPT = 256 / BKV;                 // rows covered by one pass of the 256 loader threads
     constexpr int RA = BM / RPT, RB = BN / RPT;    // 16-byte vectors per thread per chunk
-    __shared__ __attribute__((aligned(16))) u32x4 lds[2][(BM + BN) * BKV];
+    constexpr int STAGE_VEC = (BM + BN) * BKV;                       // one K-chunk of A and B
+    constexpr int EPI_VEC = ((BM / WM) * (BN + 4) * 4 + 15) / 16;     // fp32 staging of half a block tile
+    constexpr int LDS_VEC = 2 * STAGE_VEC > EPI_VEC ? 2 * STAGE_VEC : EPI_VEC;
+    __shared__ __attribute__((aligned(16))) u32x4 lds_raw[LDS_VEC];
+    u32x4* const lds0 = lds_raw;
+    u32x4* const lds1 = lds_raw + STAGE_VEC;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -193,12 +198,12 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const T* __restrict__ X,
 #pragma unroll
         for (int j = 0; j < RA; ++j) {
             const int r = lrow + j * RPT;
-            lds[buf][r * BKV + (lvec ^ lds_swz<BKV>(r))] = ra[j];
+            (buf ? lds1 : lds0)[r * BKV + (lvec ^ lds_swz<BKV>(r))] = ra[j];
         }
 #pragma unroll
         for (int j = 0; j < RB; ++j) {
             const int r = lrow + j * RPT;
-            lds[buf][(BM + r) * BKV + (lvec ^ lds_swz<BKV>(r))] = rb[j];
+            (buf ? lds1 : lds0)[(BM + r) * BKV + (lvec ^ lds_swz<BKV>(r))] = rb[j];
         }
     };
 
@@ -208,57 +213,122 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const T* __restrict__ X,
     for (int c = 0; c < nchunks; ++c) {
         const bool more = c + 1 < nchunks;
         if (more) gload(c + 1);
-        mma_chunk<T, BM, BN, WM, WN, BKV>(lds[c & 1], acc, wm, wn, lane);
+        mma_chunk<T, BM, BN, WM, WN, BKV>((c & 1) ? lds1 : lds0, acc, wm, wn, lane);
         if (more) lstore((c + 1) & 1);
         __syncthreads();
     }
 
-    // ---- epilogue: bias / activation / residual / store / BN partial statistics ------------------
+    // ---- epilogue ----------------------------------------------------------------------------------
+    // scale/bias/activation in registers (a lane owns ONE output channel per 32x32 tile), BN partial
+    // statistics from the raw accumulators, then the tile goes through LDS (fp32, one 64-row half of the
+    // block tile at a time) so that the global stores are 16-byte vectors along the channel axis
+    // (256 B contiguous per pixel) instead of 2-byte scatters; residual / accumulate are vector loads.
     const int l31 = lane & 31, hi = lane >> 5;
     float ssum[TN], ssq[TN];
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) { ssum[tn] = 0.f; ssq[tn] = 0.f; }
     const bool ident = (g.osy == 1 && g.osx == 1 && g.ooy == 0 && g.oox == 0 && g.QH == g.OH && g.QW == g.OW);
+    constexpr int HROWS = BM / WM;                 // rows staged per pass (64)
+    constexpr int SLD = BN + 4;                    // fp32 row stride in LDS (pad keeps 16-byte alignment)
+    constexpr int CVN = BN / 8;                    // 8-channel groups per row
+    constexpr int PER_T = HROWS * CVN / 256;       // groups per thread per pass
+    float* stg = (float*)lds_raw;
+    float csc[TN], cbi[TN];
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
+    for (int tn = 0; tn < TN; ++tn) {
+        const int co = n0 + wn * (BN / WN) + tn * 32 + l31;
+        const bool cok = co < g.Cout;
+        csc[tn] = (ep.scale && cok) ? ep.scale[co] : 1.0f;
+        cbi[tn] = (ep.bias && cok) ? ep.bias[co] : 0.0f;
+    }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int p = m0 + wm * (BM / WM) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            const bool pok = p < g.M;
-            long long obase;
-            if (ident) {
-                obase = (long long)p * g.ldy;
-            } else {
-                const uint32_t pp = pok ? p : 0;
-                const uint32_t t1 = fdiv(pp, g.dQW), qx = pp - t1 * g.QW;
-                const uint32_t n = fdiv(t1, g.dQH), qy = t1 - n * g.QH;
-                obase = (((long long)n * g.OH + (qy * g.osy + g.ooy)) * g.OW + (qx * g.osx + g.oox)) * g.ldy;
-            }
+    for (int w = 0; w < WM; ++w) {
+        if (wm == w) {
 #pragma unroll
-            for (int tn = 0; tn < TN; ++tn) {
-                const int co = n0 + wn * (BN / WN) + tn * 32 + l31;
-                float v = acc[tm][tn][r];
-                ssum[tn] += v;
-                ssq[tn] += v * v;
-                if (pok && co < g.Cout) {
-                    if (ep.scale) v *= ep.scale[co];
-                    if (ep.bias) v += ep.bias[co];
-                    if (ep.act == ACT_SILU) v = v / (1.0f + expf(-v));
-                    else if (ep.act == ACT_RELU) v = fmaxf(v, 0.f);
-                    if (ep.res) {
-                        const long long rbase = ident ? (long long)p * ep.ldr : (obase / g.ldy) * ep.ldr;
-                        v += et_elem<T>::ld(((const T*)ep.res)[rbase + co]);
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) {
+                        float v = acc[tm][tn][r];
+                        ssum[tn] += v;
+                        ssq[tn] += v * v;
+                        v = v * csc[tn] + cbi[tn];
+                        if (ep.act == ACT_SILU) v = v / (1.0f + expf(-v));
+                        else if (ep.act == ACT_RELU) v = fmaxf(v, 0.f);
+                        stg[row * SLD + wn * (BN / WN) + tn * 32 + l31] = v;
                     }
-                    if (ep.accumulate) v += et_elem<T>::ld(Y[obase + co]);
-                    Y[obase + co] = et_elem<T>::st(v);
+                }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < PER_T; ++it) {
+            const int gidx = tid + it * 256;
+            const int row = gidx / CVN, cv = gidx % CVN;
+            const int p = m0 + w * HROWS + row;
+            const int co = n0 + cv * 8;
+            if (p < g.M && co < g.Cout) {
+                long long pix;
+                if (ident) {
+                    pix = p;
+                } else {
+                    const uint32_t t1 = fdiv((uint32_t)p, g.dQW), qx = p - t1 * g.QW;
+                    const uint32_t n = fdiv(t1, g.dQH), qy = t1 - n * g.QH;
+                    pix = ((long long)n * g.OH + (qy * g.osy + g.ooy)) * g.OW + (qx * g.osx + g.oox);
+                }
+                float v[8];
+                const float4 a = *(const float4*)(stg + row * SLD + cv * 8);
+                const float4 b = *(const float4*)(stg + row * SLD + cv * 8 + 4);
+                v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+                T* yp = Y + pix * g.ldy + co;
+                if (co + 8 <= g.Cout) {
+                    if constexpr (sizeof(T) == 2) {
+                        if (ep.res) {
+                            const u32x4 rr = *(const u32x4*)((const T*)ep.res + pix * ep.ldr + co);
+                            v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
+                            v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
+                            v[4] += __uint_as_float(rr.z << 16); v[5] += __uint_as_float(rr.z & 0xffff0000u);
+                            v[6] += __uint_as_float(rr.w << 16); v[7] += __uint_as_float(rr.w & 0xffff0000u);
+                        }
+                        if (ep.accumulate) {
+                            const u32x4 rr = *(const u32x4*)yp;
+                            v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
+                            v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
+                            v[4] += __uint_as_float(rr.z << 16); v[5] += __uint_as_float(rr.z & 0xffff0000u);
+                            v[6] += __uint_as_float(rr.w << 16); v[7] += __uint_as_float(rr.w & 0xffff0000u);
+                        }
+                        *(u32x4*)yp = mk4(et_pack_bf2(v[0], v[1]), et_pack_bf2(v[2], v[3]), et_pack_bf2(v[4], v[5]),
+                                          et_pack_bf2(v[6], v[7]));
+                    } else {
+                        if (ep.res) {
+                            const float* rp = (const float*)ep.res + pix * ep.ldr + co;
+                            const float4 r0 = *(const float4*)rp, r1 = *(const float4*)(rp + 4);
+                            v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+                        }
+                        if (ep.accumulate) {
+                            const float4 r0 = *(const float4*)yp, r1 = *(const float4*)((const float*)yp + 4);
+                            v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+                        }
+                        *(float4*)yp = make_float4(v[0], v[1], v[2], v[3]);
+                        *(float4*)((float*)yp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                    }
+                } else {
+                    for (int e = 0; e < 8 && co + e < g.Cout; ++e) {
+                        float x = v[e];
+                        if (ep.res) x += et_elem<T>::ld(((const T*)ep.res)[pix * ep.ldr + co + e]);
+                        if (ep.accumulate) x += et_elem<T>::ld(yp[e]);
+                        yp[e] = et_elem<T>::st(x);
+                    }
                 }
             }
         }
+        __syncthreads();
     }
     if (ep.stats) {
         // rows beyond M were zero-filled, so they add nothing.  Reduce lane halves, then the WM waves
         // that share these channels (through LDS), then one plain store per channel per block.
-        float* red = (float*)lds;                  // [WM][BN][2], stage buffers are free now
+        float* red = (float*)lds_raw;              // [WM][BN][2], the staging area is free now
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
             const float s = ssum[tn] + __shfl_xor(ssum[tn], 32);

@@ -36,19 +36,18 @@ template <> struct Vec16<uint16_t> {
 };
 
 // ---- forward ------------------------------------------------------------------------------------------
-// stats_partial (rows, 2, C) -> scale/shift (+ saved mean / invstd, running statistics update)
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int rows, int C, double count,
-                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                          float eps, float momentum, float* __restrict__ rmean,
-                                                          float* __restrict__ rvar, float* __restrict__ scale,
-                                                          float* __restrict__ shift, float* __restrict__ smean,
-                                                          float* __restrict__ sinvstd) {
+// (rows, 2, C) fp32 partial sums -> ws[2][C] fp64 totals.  grid (C/32, RB): each block reduces a slice of
+// the rows for 32 channels (256 threads = 32 channels x 8 row groups) and issues 64 fp64 atomics, so
+// the reduction is spread over the chip instead of a handful of workgroups walking 10^4 rows.
+__global__ __launch_bounds__(256) void rows_reduce_kernel(const float* __restrict__ part, int rows, int C, int rows_per_block,
+                                                          double* __restrict__ ws) {
     __shared__ double red[2][8][32];
     const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
     double s = 0.0, q = 0.0;
     if (c < C)
-        for (int r = rg; r < rows; r += 8) {
+        for (int r = r0 + rg; r < r1; r += 8) {
             s += (double)part[((size_t)r * 2 + 0) * C + c];
             q += (double)part[((size_t)r * 2 + 1) * C + c];
         }
@@ -56,19 +55,40 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     __syncthreads();
     if (rg == 0 && c < C) {
         for (int k = 1; k < 8; ++k) { s += red[0][k][cl]; q += red[1][k][cl]; }
-        const double mean = s / count;
-        double var = q / count - mean * mean;
-        if (var < 0.0) var = 0.0;
-        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-        const float sc = gamma[c] * invstd;
-        scale[c] = sc;
-        shift[c] = beta[c] - (float)mean * sc;
-        if (smean) { smean[c] = (float)mean; sinvstd[c] = invstd; }
-        if (rmean) {
-            const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
-            rmean[c] = (1.0f - momentum) * rmean[c] + momentum * (float)mean;
-            rvar[c] = (1.0f - momentum) * rvar[c] + momentum * (float)unb;
-        }
+        atomicAdd(ws + c, s);
+        atomicAdd(ws + C + c, q);
+    }
+}
+
+static void launch_rows_reduce(const float* part, int rows, int C, double* ws, hipStream_t s) {
+    (void)hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, s);
+    int rb = rows / 64;
+    rb = rb < 1 ? 1 : (rb > 64 ? 64 : rb);
+    const int per = (rows + rb - 1) / rb;
+    hipLaunchKernelGGL(rows_reduce_kernel, dim3((C + 31) / 32, (rows + per - 1) / per), dim3(256), 0, s, part, rows, C, per, ws);
+}
+
+// ws[2][C] totals -> scale/shift (+ saved mean / invstd, running statistics update)
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ ws, int C, double count,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float eps, float momentum, float* __restrict__ rmean,
+                                                          float* __restrict__ rvar, float* __restrict__ scale,
+                                                          float* __restrict__ shift, float* __restrict__ smean,
+                                                          float* __restrict__ sinvstd) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const double mean = ws[c] / count;
+    double var = ws[C + c] / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gamma[c] * invstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - (float)mean * sc;
+    if (smean) { smean[c] = (float)mean; sinvstd[c] = invstd; }
+    if (rmean) {
+        const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+        rmean[c] = (1.0f - momentum) * rmean[c] + momentum * (float)mean;
+        rvar[c] = (1.0f - momentum) * rvar[c] + momentum * (float)unb;
     }
 }
 
@@ -164,30 +184,19 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const T* __restr
     }
 }
 
-// finalize: dbeta += s1, dgamma += s2, coefficients of pass 2
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int rows, int C, float count,
+// finalize: dbeta += s1, dgamma += s2, coefficients of pass 2 (ws = fp64 totals from rows_reduce_kernel)
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ ws, int C, float count,
                                                               const float* __restrict__ gamma, const float* __restrict__ invstd,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                               float* __restrict__ k0, float* __restrict__ k1, float* __restrict__ k2) {
-    __shared__ double red[2][8][32];
-    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
-    double s = 0.0, q = 0.0;
-    if (c < C)
-        for (int r = rg; r < rows; r += 8) {
-            s += (double)part[((size_t)r * 2 + 0) * C + c];
-            q += (double)part[((size_t)r * 2 + 1) * C + c];
-        }
-    red[0][rg][cl] = s; red[1][rg][cl] = q;
-    __syncthreads();
-    if (rg == 0 && c < C) {
-        for (int k = 1; k < 8; ++k) { s += red[0][k][cl]; q += red[1][k][cl]; }
-        if (dbeta) dbeta[c] += (float)s;
-        if (dgamma) dgamma[c] += (float)q;
-        k0[c] = gamma[c] * invstd[c];
-        k1[c] = (float)(s / count);
-        k2[c] = (float)(q / count);
-    }
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const double s = ws[c], q = ws[C + c];
+    if (dbeta) dbeta[c] += (float)s;
+    if (dgamma) dgamma[c] += (float)q;
+    k0[c] = gamma[c] * invstd[c];
+    k1[c] = (float)(s / count);
+    k2[c] = (float)(q / count);
 }
 
 // pass 2: dy = k0 * (du - k1 - xhat*k2)
@@ -260,10 +269,12 @@ extern "C" int et_bn_reduce_rows(int P, int C, int dtype) {
 
 extern "C" int et_bn_finalize(const float* stats_partial, int rows, int C, double count, const float* gamma,
                               const float* beta, float eps, float momentum, float* running_mean, float* running_var,
-                              float* scale, float* shift, float* save_mean, float* save_invstd, et_stream_t stream) {
-    if (!stats_partial || !gamma || !beta || !scale || !shift) return -1;
+                              float* scale, float* shift, float* save_mean, float* save_invstd, double* ws,
+                              et_stream_t stream) {
+    if (!stats_partial || !gamma || !beta || !scale || !shift || !ws) return -1;
     if (rows <= 0 || C <= 0 || count <= 0) return -2;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, stats_partial, rows, C, count,
+    launch_rows_reduce(stats_partial, rows, C, ws, (hipStream_t)stream);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, C, count,
                        gamma, beta, eps, momentum, running_mean, running_var, scale, shift, save_mean, save_invstd);
     ET_CHECK_LAUNCH();
     return 0;
@@ -300,15 +311,16 @@ extern "C" int et_bn_act_bwd(const void* dz, int lddz, const void* y, int ldy, v
                              const float* gamma, const float* scale, const float* shift, const float* save_mean,
                              const float* save_invstd, int act, float* dgamma, float* dbeta, float* workspace,
                              size_t ws_floats, et_stream_t stream) {
-    // workspace: rows*2*C partial sums + 3*C coefficients (fp32)
+    // workspace (fp32 units): 4*C (= 2*C fp64 totals) + rows*2*C partial sums + 3*C coefficients
     if (!dz || !y || !dy || !gamma || !scale || !shift || !save_mean || !save_invstd || !workspace) return -1;
     const int vec = dtype == ET_F32 ? 4 : 8;
     if (P <= 0 || C <= 0 || C > 2048 || C % vec || lddz % vec || ldy % vec || lddy % vec) return -2;
     const int CV = C / vec;
     const int rows = ew_blocks(P, CV);
-    if (ws_floats < (size_t)rows * 2 * C + 3 * (size_t)C) return -3;
-    float* part = workspace;
-    float* k0 = workspace + (size_t)rows * 2 * C;
+    if (ws_floats < (size_t)rows * 2 * C + 7 * (size_t)C || (((uintptr_t)workspace) & 7)) return -3;
+    double* tot = (double*)workspace;
+    float* part = workspace + 4 * (size_t)C;
+    float* k0 = part + (size_t)rows * 2 * C;
     float* k1 = k0 + C;
     float* k2 = k1 + C;
     const dim3 grid(rows);
@@ -319,7 +331,8 @@ extern "C" int et_bn_act_bwd(const void* dz, int lddz, const void* y, int ldy, v
         hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<uint16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)dz, lddz,
                            (const uint16_t*)y, ldy, P, CV, scale, shift, save_mean, save_invstd, act, part);
     else return -2;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, part, rows, C, (float)P, gamma,
+    launch_rows_reduce(part, rows, C, tot, (hipStream_t)stream);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, tot, C, (float)P, gamma,
                        save_invstd, dgamma, dbeta, k0, k1, k2);
     if (dtype == ET_F32)
         hipLaunchKernelGGL((bn_act_bwd_apply_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)dz, lddz,

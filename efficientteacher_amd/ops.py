@@ -152,11 +152,13 @@ def colsum(x2d_like, out):
 def bn_finalize(stats, count, gamma, beta, eps, momentum, running_mean=None, running_var=None):
     rows, _, C = stats.shape
     dev = stats.device
-    scale, shift, mean, invstd = (torch.empty(C, dtype=torch.float32, device=dev) for _ in range(4))
+    aff = torch.empty((4, C), dtype=torch.float32, device=dev)
+    scale, shift, mean, invstd = aff[0], aff[1], aff[2], aff[3]
+    ws = torch.empty(2 * C, dtype=torch.float64, device=dev)
     _lib.check(_lib.load().et_bn_finalize(_lib.ptr(stats), rows, C, float(count), _lib.ptr(gamma), _lib.ptr(beta),
                                           eps, momentum, _lib.ptr(running_mean), _lib.ptr(running_var),
                                           _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(mean), _lib.ptr(invstd),
-                                          _lib.stream(stats)), "et_bn_finalize")
+                                          _lib.ptr(ws), _lib.stream(stats)), "et_bn_finalize")
     return scale, shift, mean, invstd
 
 
@@ -187,7 +189,7 @@ def bn_act_bwd(dz, y, gamma, scale, shift, mean, invstd, act, dgamma, dbeta, out
     if out is None:
         out = torch.empty((N, H, W, C), dtype=y.dtype, device=y.device)
     rows = lib.et_bn_reduce_rows(N * H * W, C, et_dtype(y))
-    nws = rows * 2 * C + 3 * C
+    nws = rows * 2 * C + 7 * C
     ws = torch.empty(nws, dtype=torch.float32, device=y.device)
     _lib.check(lib.et_bn_act_bwd(_lib.ptr(dz), _nhwc(dz), _lib.ptr(y), _nhwc(y), _lib.ptr(out), _nhwc(out),
                                  et_dtype(y), N * H * W, C, _lib.ptr(gamma), _lib.ptr(scale), _lib.ptr(shift),
