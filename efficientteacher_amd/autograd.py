@@ -10,6 +10,10 @@ from . import ops
 
 ACT_CODE = {"silu": ops.ACT_SILU, "relu": ops.ACT_RELU, "none": ops.ACT_NONE}
 
+# set by parallel.FlatDataParallel: callable(ConvSlot) invoked right after a layer's wgrad has been
+# launched, so that the gradient all-reduce of finished arena chunks overlaps the rest of backward
+GRAD_READY_HOOK = None
+
 
 class ConvBnActFn(Function):
     """z = act(BN_train(conv(x, w))) (+ residual)   -- reference Conv.forward (common.py:480-481) in
@@ -41,6 +45,8 @@ class ConvBnActFn(Function):
         dy = ops.bn_act_bwd(dz, y, bs.gamma, scale, shift, mean, invstd, ctx.act, bs.ggamma, bs.gbeta)
         if ctx.w_needs_grad:
             ops.conv2d_wgrad(x, dy, cs.gw, cs.k, cs.stride, cs.pad)
+            if GRAD_READY_HOOK is not None:
+                GRAD_READY_HOOK(cs)
         dx = None
         if ctx.x_needs_grad:
             wT = ops.weight_transpose(cs.w_lp)
@@ -77,6 +83,8 @@ class ConvBiasFn(Function):
             ops.conv2d_wgrad(x, dy, cs.gw, cs.k, cs.stride, cs.pad)
             if cs.gbias is not None:
                 ops.colsum(dy, cs.gbias)
+            if GRAD_READY_HOOK is not None:
+                GRAD_READY_HOOK(cs)
         dx = None
         if ctx.x_needs_grad:
             wT = ops.weight_transpose(cs.w_lp)

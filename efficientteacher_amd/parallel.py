@@ -17,18 +17,74 @@ import torch.nn as nn
 
 
 class FlatDataParallel(nn.Module):
-    def __init__(self, module, process_group=None, chunk_mb=64, broadcast_buffers=True):
+    def __init__(self, module, process_group=None, chunk_mb=48, broadcast_buffers=True, overlap=True):
         super().__init__()
         self.module = module
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.chunk = int(chunk_mb * (1 << 20) // 4)
         self.broadcast_buffers = broadcast_buffers
+        self.overlap = overlap
+        self._works = []
+        self._launched = set()
         if self.world > 1:
             f = module.flat_state()
             dist.broadcast(f.params, 0, group=self.pg)
             dist.broadcast(f.buffers, 0, group=self.pg)
             f.mark_weights_changed()
+            self._plan()
+            if overlap:
+                from . import autograd as _ag
+                _ag.GRAD_READY_HOOK = self._on_conv_grad_ready
+
+    # ---- chunk plan: the conv-weight segment is cut into ~chunk_mb pieces on layer boundaries --------------
+    def _plan(self):
+        f = self.module.flat_state()
+        wo, wn = f.w_range
+        slots = sorted(f.conv_slots.values(), key=lambda s: s.index)
+        base = f.grads.data_ptr()
+        self._chunks = []            # [offset, numel, remaining_layers]
+        self._slot_chunk = {}
+        cur_o, cur_n, members = None, 0, []
+        for s in slots:
+            o = (s.gw.data_ptr() - base) // 4
+            if cur_o is None:
+                cur_o = o
+            members.append(s.index)
+            cur_n = o + s.gw.numel() - cur_o
+            if cur_n >= self.chunk:
+                self._chunks.append([cur_o, cur_n, len(members)])
+                for m in members:
+                    self._slot_chunk[m] = len(self._chunks) - 1
+                cur_o, cur_n, members = None, 0, []
+        if members:
+            self._chunks.append([cur_o, wo + wn - cur_o, len(members)])
+            for m in members:
+                self._slot_chunk[m] = len(self._chunks) - 1
+        if self._chunks:                      # cover alignment padding between layers / at the segment end
+            self._chunks[0][1] += self._chunks[0][0] - wo
+            self._chunks[0][0] = wo
+            for i in range(len(self._chunks) - 1):
+                self._chunks[i][1] = self._chunks[i + 1][0] - self._chunks[i][0]
+            self._chunks[-1][1] = wo + wn - self._chunks[-1][0]
+        self._remaining = [c[2] for c in self._chunks]
+
+    def _all_reduce(self, view):
+        avg = dist.get_backend(self.pg) == "nccl"        # RCCL averages inside the collective
+        w = dist.all_reduce(view, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        self._works.append((w, None if avg else view))
+
+    def _on_conv_grad_ready(self, slot):
+        """Called from the conv backward right after its wgrad launch: when every layer of a chunk has
+        produced its gradient, the chunk's all-reduce starts while backward continues upstream."""
+        ci = self._slot_chunk.get(slot.index)
+        if ci is None or ci in self._launched:
+            return
+        self._remaining[ci] -= 1
+        if self._remaining[ci] == 0:
+            o, n, _ = self._chunks[ci]
+            self._launched.add(ci)
+            self._all_reduce(self.module.flat_state().grads[o:o + n])
 
     def forward(self, *a, **k):
         if self.world > 1 and self.broadcast_buffers and self.module.training:
@@ -37,19 +93,23 @@ class FlatDataParallel(nn.Module):
         return self.module(*a, **k)
 
     def reduce_gradients(self):
-        """All-reduce (mean) the flat gradient arena in large chunks; call after backward()."""
+        """Finish the gradient all-reduce (mean over ranks); call after backward()."""
         if self.world <= 1:
             return
         g = self.module.flat_state().grads
-        avg = dist.get_backend(self.pg) == "nccl"        # RCCL averages in the collective itself
-        works = []
-        for o in range(0, g.numel(), self.chunk):
-            works.append(dist.all_reduce(g[o:o + self.chunk], op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM,
-                                         group=self.pg, async_op=True))
-        for w in works:
+        wo, wn = self.module.flat_state().w_range
+        for ci, (o, n, _) in enumerate(self._chunks):      # chunks whose layers did not all run (frozen / unused)
+            if ci not in self._launched:
+                self._all_reduce(g[o:o + n])
+        self._all_reduce(g[:wo])                           # biases (BN + conv)
+        self._all_reduce(g[wo + wn:])                      # BN weights
+        for w, view in self._works:
             w.wait()
-        if not avg:                                       # gloo (CPU tests) has no AVG
-            g.mul_(1.0 / self.world)
+            if view is not None:                           # gloo (CPU tests) has no AVG
+                view.mul_(1.0 / self.world)
+        self._works = []
+        self._launched = set()
+        self._remaining = [c[2] for c in self._chunks]
 
     def flat_state(self):
         return self.module.flat_state()
