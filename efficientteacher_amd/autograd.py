@@ -20,7 +20,7 @@ class ConvBnActFn(Function):
     train mode, plus the Bottleneck shortcut (common.py:544)."""
 
     @staticmethod
-    def forward(ctx, x, residual, wparam, cs, bs, act, nbt):
+    def forward(ctx, x, residual, wparam, cs, bs, act, nbt, dst=None):
         # wparam (the nn.Parameter) only ties the op into the autograd graph; its gradient is written
         # by the wgrad kernel directly into the flat arena, so backward returns None for it.
         ctx.w_needs_grad = wparam.requires_grad
@@ -30,7 +30,10 @@ class ConvBnActFn(Function):
                                                      bs.rmean, bs.rvar)
         if nbt is not None:
             nbt.add_(1)
-        z = ops.bn_act_fwd(y, scale, shift, act, residual=residual)
+        # dst = (buffer, channel offset): write the block output straight into its slice of a concat
+        # buffer (JoinSlicesFn turns the filled buffer into the differentiable concat result)
+        out = None if dst is None else dst[0][..., dst[1]:dst[1] + cs.coutp]
+        z = ops.bn_act_fwd(y, scale, shift, act, residual=residual, out=out)
         ctx.cs, ctx.bs, ctx.act = cs, bs, act
         ctx.has_res = residual is not None
         ctx.x_needs_grad = x.requires_grad
@@ -51,7 +54,7 @@ class ConvBnActFn(Function):
         if ctx.x_needs_grad:
             wT = ops.weight_transpose(cs.w_lp)
             dx = ops.conv2d_dgrad(dy, wT, (x.shape[1], x.shape[2]), cs.stride, cs.pad)
-        return dx, (dz if ctx.has_res else None), None, None, None, None, None
+        return dx, (dz if ctx.has_res else None), None, None, None, None, None, None
 
 
 class ConvBiasFn(Function):
@@ -108,6 +111,28 @@ def head_grad_to_nhwc(g, yshape, na, no):
     buf = torch.zeros((B, ny, nx, CP), dtype=g.dtype, device=g.device)
     buf.as_strided((B, na, ny, nx, no), want).copy_(g)
     return buf
+
+
+class JoinSlicesFn(Function):
+    """torch.cat(parts, C) for parts that were PRODUCED IN PLACE as adjacent channel slices of ``buf``
+    (C3.forward, common.py:590-591, without the copy).  Backward hands each producer its slice of the
+    concat gradient as a view."""
+
+    @staticmethod
+    def forward(ctx, holder, *parts):
+        buf = holder[0]
+        off = 0
+        for p in parts:
+            assert p.data_ptr() == buf.data_ptr() + off * buf.element_size() and p.stride() == buf[..., :1].stride()
+            off += p.shape[3]
+        assert off == buf.shape[3]
+        ctx.splits = [p.shape[3] for p in parts]
+        return buf
+
+    @staticmethod
+    def backward(ctx, dcat):
+        dcat = _dense_or_slice(dcat)
+        return (None, *torch.split(dcat, ctx.splits, dim=3))
 
 
 class SppfPoolFn(Function):

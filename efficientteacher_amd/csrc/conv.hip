@@ -21,6 +21,7 @@
 // next chunk's global loads are issued before the MFMAs of the current one.
 #include "et_device.h"
 #include "../../include/et_hip.h"
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -560,7 +561,11 @@ static int fill_common(GatherGeom& g, int N, int IH, int IW, int Cin, int ldx, i
 template <typename T>
 static int launch_gemm(const void* X, const void* W, void* Y, const GatherGeom& g, const Epilogue& ep, hipStream_t s) {
     if (g.M <= 0) return 0;
-    const bool wide = g.Cout > 64;
+    // tile choice: 128x128 unless the layer has <= 64 output channels.  ET_CONV_NARROW_K=<K> (tuning
+    // knob, read once) additionally sends GEMMs with K <= that many elements to the 128x64 tile, whose
+    // smaller register/LDS footprint gives 3 workgroups per CU for HBM-bound short-K 1x1 layers.
+    static const int narrow_k = getenv("ET_CONV_NARROW_K") ? atoi(getenv("ET_CONV_NARROW_K")) : 0;
+    const bool wide = g.Cout > 64 && !(narrow_k > 0 && g.T * g.Cin <= narrow_k);
     const int bn = wide ? 128 : 64;
     const dim3 grid((g.M + 127) / 128, (g.Cout + bn - 1) / bn), block(256);
     const T* x = (const T*)X; const T* w = (const T*)W; T* y = (T*)Y;
@@ -652,8 +657,9 @@ static void launch_wgrad(const void* x, const void* dy, float* dw, WgradGeom& g,
     constexpr int VEC = et_elem<T>::VEC;
     constexpr int BKP = 8 * VEC;
     const bool wideN = g.NC > 64;
-    const int bn = wideN ? 128 : 64;
-    const int tiles = ((g.NC + bn - 1) / bn) * ((g.Cout + 127) / 128);
+    const bool tallM = g.Cout > 64;            // Cout <= 64 layers: a 64-row tile wastes no MFMA rows
+    const int bn = wideN ? 128 : 64, bm = tallM ? 128 : 64;
+    const int tiles = ((g.NC + bn - 1) / bn) * ((g.Cout + bm - 1) / bm);
     // split K so that ~4 waves of blocks cover the chip, each slice >= 8 chunks
     int sk = (1024 + tiles - 1) / tiles;
     const int max_sk = max(1, g.P / (BKP * 8));
@@ -662,9 +668,15 @@ static void launch_wgrad(const void* x, const void* dy, float* dw, WgradGeom& g,
     per = ((per + BKP - 1) / BKP) * BKP;
     sk = (g.P + per - 1) / per;
     g.Pper = per;
-    const dim3 grid((g.NC + bn - 1) / bn, (g.Cout + 127) / 128, sk), block(256);
-    if (wideN) hipLaunchKernelGGL((conv_wgrad_kernel<T, 128, 128>), grid, block, 0, s, (const T*)x, (const T*)dy, dw, g);
-    else hipLaunchKernelGGL((conv_wgrad_kernel<T, 128, 64>), grid, block, 0, s, (const T*)x, (const T*)dy, dw, g);
+    const dim3 grid((g.NC + bn - 1) / bn, (g.Cout + bm - 1) / bm, sk), block(256);
+    const T* xx = (const T*)x; const T* yy = (const T*)dy;
+    if (tallM) {
+        if (wideN) hipLaunchKernelGGL((conv_wgrad_kernel<T, 128, 128>), grid, block, 0, s, xx, yy, dw, g);
+        else hipLaunchKernelGGL((conv_wgrad_kernel<T, 128, 64>), grid, block, 0, s, xx, yy, dw, g);
+    } else {
+        if (wideN) hipLaunchKernelGGL((conv_wgrad_kernel<T, 64, 128>), grid, block, 0, s, xx, yy, dw, g);
+        else hipLaunchKernelGGL((conv_wgrad_kernel<T, 64, 64>), grid, block, 0, s, xx, yy, dw, g);
+    }
 }
 
 extern "C" int et_conv2d_wgrad(const void* x, const void* dy, float* dw, int dtype, int N, int IH, int IW, int Cin,

@@ -164,6 +164,20 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const T* __restr
         sc[i] = scale[cv * N + i]; sh[i] = shift[cv * N + i]; mu[i] = mean[cv * N + i]; is[i] = invstd[cv * N + i];
         s1[i] = 0.f; s2[i] = 0.f;
     }
+    for (; p + pstep < P; p += 2 * pstep) {          // two pixels in flight per thread
+        float g[N], v[N], g2[N], v2[N];
+        Vec16<T>::load(dz + p * lddz + cv * N, g);
+        Vec16<T>::load(y + p * ldy + cv * N, v);
+        Vec16<T>::load(dz + (p + pstep) * lddz + cv * N, g2);
+        Vec16<T>::load(y + (p + pstep) * ldy + cv * N, v2);
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const float du = g[i] * act_grad(v[i] * sc[i] + sh[i], act);
+            const float du2 = g2[i] * act_grad(v2[i] * sc[i] + sh[i], act);
+            s1[i] += du + du2;
+            s2[i] += du * ((v[i] - mu[i]) * is[i]) + du2 * ((v2[i] - mu[i]) * is[i]);
+        }
+    }
     for (; p < P; p += pstep) {
         float g[N], v[N];
         Vec16<T>::load(dz + p * lddz + cv * N, g);
@@ -257,7 +271,11 @@ static int ew_blocks(long long P, int CV) {
     while (b) { const int t = a % b; a = b; b = t; }
     const int unit = CV / a;                                   // blocks must be a multiple of this
     const long long need = (P * CV + 255) / 256;
-    long long blocks = need < 2048 ? need : 2048;
+    // ~8+ vectors per thread (amortises the per-thread channel constants and the partial-sum rows),
+    // but never fewer than ~2 blocks per CU
+    long long blocks = need / 8;
+    if (blocks < 512) blocks = need < 512 ? need : 512;
+    if (blocks > 2048) blocks = 2048;
     blocks = ((blocks + unit - 1) / unit) * unit;
     return (int)blocks;
 }

@@ -10,7 +10,7 @@ import torch
 import torch.nn as nn
 
 from ... import ops
-from ...autograd import ConvBnActFn, SppfPoolFn
+from ...autograd import ConvBnActFn, JoinSlicesFn, SppfPoolFn
 
 
 def get_activation(act=True):
@@ -58,7 +58,8 @@ class Conv(nn.Module):
         self.bn = nn.BatchNorm2d(c2)
         self.act, self.act_name = get_activation(act=act)
 
-    def forward(self, x, residual=None):
+    def forward(self, x, residual=None, dst=None):
+        """dst = (buffer, channel offset): produce the output in place inside a wider NHWC buffer."""
         cs = getattr(self.conv, "_et_slot", None)
         if cs is None:
             raise RuntimeError("model state is not on the device arenas yet: move the Model to a GPU "
@@ -66,12 +67,13 @@ class Conv(nn.Module):
         bs = self.bn._et_slot
         act = _act_code(self.act)
         if self.bn.training:
-            return ConvBnActFn.apply(x, residual, self.conv.weight, cs, bs, act, self.bn.num_batches_tracked)
+            return ConvBnActFn.apply(x, residual, self.conv.weight, cs, bs, act, self.bn.num_batches_tracked, dst)
         # eval (EMA teacher): BatchNorm is an affine of the running statistics, folded into the conv epilogue
         flat = self._et_flat()
         o = bs.aff_off
+        out = None if dst is None else dst[0][..., dst[1]:dst[1] + cs.coutp]
         return ops.conv2d_fwd(x, cs.w_lp, cs.stride, cs.pad, scale=flat.eval_scale[o:o + bs.c],
-                              bias=flat.eval_shift[o:o + bs.c], act=act, residual=residual)
+                              bias=flat.eval_shift[o:o + bs.c], act=act, residual=residual, out=out)
 
     def forward_fuse(self, x):
         return self.forward(x)
@@ -89,8 +91,8 @@ class Bottleneck(nn.Module):
         self.cv2 = Conv(c_, c2, k[1], 1, g=g, act=act)
         self.add = shortcut and c1 == c2
 
-    def forward(self, x):
-        return self.cv2(self.cv1(x), residual=x if self.add else None)
+    def forward(self, x, dst=None):
+        return self.cv2(self.cv1(x), residual=x if self.add else None, dst=dst)
 
 
 class C3(nn.Module):
@@ -114,7 +116,20 @@ class C3(nn.Module):
         self.m = nn.Sequential(*[Bottleneck(c_, c_, shortcut, g, e=1.0, act=act) for _ in range(n)])
 
     def forward(self, x):
-        return self.cv3(torch.cat((self.m(self.cv1(x)), self.cv2(x)), dim=3))
+        # cv3(cat(m(cv1(x)), cv2(x))): both halves are written in place into one buffer (no cat copy)
+        N, H, W, _ = x.shape
+        c_ = self.cv2.conv.out_channels
+        buf = torch.empty((N, H, W, 2 * c_), dtype=x.dtype, device=x.device)
+        y2 = self.cv2(x, dst=(buf, c_))
+        t = self.cv1(x)
+        last = len(self.m) - 1
+        for i, b in enumerate(self.m):
+            t = b(t, dst=(buf, 0) if i == last else None)
+        if torch.is_grad_enabled() and (t.requires_grad or y2.requires_grad):
+            cat = JoinSlicesFn.apply((buf,), t, y2)
+        else:
+            cat = buf
+        return self.cv3(cat)
 
 
 class SPPF(nn.Module):
