@@ -50,6 +50,8 @@ SIGNATURES = {
     "et_yolo_loss": (c_int, [P, P]),
     "et_select_targets": (c_int, [P, P, c_int, P, P, c_int, c_int, P, P]),
     "et_scale_cast": (c_int, [P, P, c_int, c_int64, c_float, P, P]),
+    "et_domain_focal": (c_int, [P, c_int, c_int, c_int64, c_int, c_float, P, c_int, P, P]),
+    "et_scale_inplace": (c_int, [P, c_int, c_int64, c_float, P, P]),
 }
 
 

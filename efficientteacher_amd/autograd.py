@@ -188,7 +188,25 @@ class GradReverseFn(Function):  # reference models/detector/yolo_ssod.py:158-171
 
     @staticmethod
     def backward(ctx, g):
-        raise NotImplementedError("domain-adaptation backward (SSOD.with_da_loss) is not built yet")
+        return ops.scale_inplace(g.contiguous().clone(), -1.0)
+
+
+class DomainFocalFn(Function):
+    """0.5 * mean over the pixels of all levels of -(1-p)^2 log p  (DomainLoss label 0 / TargetLoss
+    label 1, models/loss/loss.py:376-421).  Inputs: the netD logits as (B,H,W,2) NHWC tensors."""
+
+    @staticmethod
+    def forward(ctx, label, *feats):
+        total = sum(f.shape[0] * f.shape[1] * f.shape[2] for f in feats)
+        acc = torch.zeros(1, dtype=torch.float32, device=feats[0].device)
+        grads = [ops.domain_focal(f, label, 0.5 / total, acc, want_grad=True) for f in feats]
+        ctx.save_for_backward(*grads)
+        return ops.scale_cast(acc, torch.float32, scale=0.5 / total)
+
+    @staticmethod
+    def backward(ctx, gout):
+        g = gout.reshape(1).float().contiguous()
+        return (None, *[ops.scale_inplace(gr.clone(), 1.0, dev_scale=g) for gr in ctx.saved_tensors])
 
 
 def _dense_or_slice(g):

@@ -54,6 +54,8 @@ struct GatherGeom {
     int osy, osx, ooy, oox;      // written coord  = q*os + oo
     int T, TT;                   // taps in this launch / taps per weight row (row = TT*Cin)
     int CV, KV;                  // Cin/VEC, T*CV
+    int tap_inner;               // K-chunk order: 1 = channel-chunk outer / tap inner (L2-friendly), 0 = tap outer
+    int xcd_swz;                 // 1 = remap blockIdx.x so that neighbouring pixel tiles share an XCD (L2)
     FastDiv dQW, dQH, dCV;
     signed char dy[CONV_MAX_TAPS], dx[CONV_MAX_TAPS];
     unsigned char wt[CONV_MAX_TAPS];
@@ -129,7 +131,16 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const T* __restrict__ X,
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    // Workgroups are dealt round-robin to the 8 XCDs (private L2 each).  With xcd_swz the pixel-tile index
+    // is remapped so that each XCD owns a contiguous range of tiles: the halo rows shared by neighbouring
+    // tiles of a 3x3 conv, and the weights, are then re-read from that XCD's L2 (placement only: results
+    // do not depend on it).
+    int bx = blockIdx.x;
+    if (g.xcd_swz) {
+        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bx & 7, k = bx >> 3;
+        bx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;     // bijective for any nb
+    }
+    const int m0 = bx * BM, n0 = blockIdx.y * BN;
     const int lvec = tid % BKV, lrow = tid / BKV;
 
     // loader state: A rows are lattice pixels, B rows are output channels
@@ -165,13 +176,18 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const T* __restrict__ X,
 
     const int nchunks = (g.KV + BKV - 1) / BKV;
     u32x4 ra[RA], rb[RB];
+    unsigned okmask = 0u;      // validity of the vectors in flight; zero-fill is applied at LDS-store time,
+                               // AFTER the MFMAs of the current chunk, so the loads stay in flight under them
     int tap_u = 0, cv_u = 0;   // UTAP: chunk-uniform tap / channel-vector cursor
 
-    auto gload = [&](int chunk) {
+    // Loads are UNCONDITIONAL (an out-of-image / out-of-range lane reads the tensor base and the value is
+    // replaced by zero with a select): no exec-mask branches around the 8 global loads of a chunk, so
+    // they issue back to back.  tap / channel cursor are passed by value (kept in SGPRs/VGPRs).
+    auto gload = [&](int chunk, int tap_c, int cv_c) {
         int tap, cv;
         bool kok = true;
         if constexpr (UTAP) {
-            tap = tap_u; cv = cv_u + lvec;
+            tap = tap_c; cv = cv_c + lvec;
         } else {
             const uint32_t kv = chunk * BKV + lvec;
             kok = kv < (uint32_t)g.KV;
@@ -181,44 +197,58 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const T* __restrict__ X,
         const int dy = g.dy[tap], dx = g.dx[tap];
         const int doff = (dy * g.IW + dx) * g.ldx + cv * VEC;
         const int woff = (int)g.wt[tap] * g.Cin + cv * VEC;
-        const u32x4 zero = mk4(0, 0, 0, 0);
+        okmask = 0u;
 #pragma unroll
         for (int j = 0; j < RA; ++j) {
             const bool ok = kok && a_ok[j] && (unsigned)(a_iy[j] + dy) < (unsigned)g.IH &&
                             (unsigned)(a_ix[j] + dx) < (unsigned)g.IW;
-            ra[j] = ok ? *(const u32x4*)(X + (a_off[j] + doff)) : zero;
+            ra[j] = *(const u32x4*)(X + (ok ? a_off[j] + doff : 0));
+            okmask |= ok ? (1u << j) : 0u;
         }
 #pragma unroll
-        for (int j = 0; j < RB; ++j) rb[j] = (kok && b_ok[j]) ? *(const u32x4*)(W + (b_off[j] + woff)) : zero;
-        if constexpr (UTAP) {
-            cv_u += BKV;
-            if (cv_u >= g.CV) { cv_u = 0; ++tap_u; }
+        for (int j = 0; j < RB; ++j) {
+            const bool ok = kok && b_ok[j];
+            rb[j] = *(const u32x4*)(W + (ok ? b_off[j] + woff : 0));
+            okmask |= ok ? (1u << (16 + j)) : 0u;
         }
     };
+#define ET_ADVANCE_CURSOR()                                              \
+    if constexpr (UTAP) {                                                \
+        if (g.tap_inner) {                                               \
+            if (++tap_u >= g.T) { tap_u = 0; cv_u += BKV; }              \
+        } else {                                                         \
+            cv_u += BKV;                                                 \
+            if (cv_u >= g.CV) { cv_u = 0; ++tap_u; }                     \
+        }                                                                \
+    }
     auto lstore = [&](int buf) {
+        const u32x4 zero = mk4(0, 0, 0, 0);
 #pragma unroll
         for (int j = 0; j < RA; ++j) {
             const int r = lrow + j * RPT;
-            (buf ? lds1 : lds0)[r * BKV + (lvec ^ lds_swz<BKV>(r))] = ra[j];
+            (buf ? lds1 : lds0)[r * BKV + (lvec ^ lds_swz<BKV>(r))] = ((okmask >> j) & 1u) ? ra[j] : zero;
         }
 #pragma unroll
         for (int j = 0; j < RB; ++j) {
             const int r = lrow + j * RPT;
-            (buf ? lds1 : lds0)[(BM + r) * BKV + (lvec ^ lds_swz<BKV>(r))] = rb[j];
+            (buf ? lds1 : lds0)[(BM + r) * BKV + (lvec ^ lds_swz<BKV>(r))] = ((okmask >> (16 + j)) & 1u) ? rb[j] : zero;
         }
     };
 
-    gload(0);
+    gload(0, tap_u, cv_u);
+    ET_ADVANCE_CURSOR();
     lstore(0);
     __syncthreads();
     for (int c = 0; c < nchunks; ++c) {
         const bool more = c + 1 < nchunks;
-        if (more) gload(c + 1);
+        if (more) { gload(c + 1, tap_u, cv_u); ET_ADVANCE_CURSOR(); }
         mma_chunk<T, BM, BN, WM, WN, BKV>((c & 1) ? lds1 : lds0, acc, wm, wn, lane);
+        __builtin_amdgcn_sched_barrier(0);     // keep the consumers of the prefetched vectors below the MFMAs
         if (more) lstore((c + 1) & 1);
         __syncthreads();
     }
 
+#undef ET_ADVANCE_CURSOR
     // ---- epilogue ----------------------------------------------------------------------------------
     // scale/bias/activation in registers (a lane owns ONE output channel per 32x32 tile), BN partial
     // statistics from the raw accumulators, then the tile goes through LDS (fp32, one 64-row half of the
@@ -347,8 +377,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const T* __restrict__ X,
             for (int w = 0; w < WM; ++w) { s += red[(w * BN + tid) * 2]; q += red[(w * BN + tid) * 2 + 1]; }
             const int co = n0 + tid;
             if (co < g.Cout) {
-                ep.stats[((size_t)blockIdx.x * 2 + 0) * g.Cout + co] = s;
-                ep.stats[((size_t)blockIdx.x * 2 + 1) * g.Cout + co] = q;
+                ep.stats[((size_t)bx * 2 + 0) * g.Cout + co] = s;
+                ep.stats[((size_t)bx * 2 + 1) * g.Cout + co] = q;
             }
         }
     }
@@ -446,19 +476,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const T* __restrict__ X
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
 
-    u32x4 stage[ITER][VEC];
+    // Prefetch: raw 16-byte loads only (unconditional, invalid lanes read the tensor base); the
+    // zero-fill select, the VECxVEC register transpose and the LDS stores all happen AFTER the MFMAs of
+    // the current chunk, so the global loads stay in flight underneath them.
+    u32x4 raw[ITER][VEC];
+    unsigned okm[ITER];
     auto gload = [&](int pk0) {
-        const u32x4 zero = mk4(0, 0, 0, 0);
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
+            okm[it] = 0u;
             if (!live[it]) continue;
             const int p0 = pk0 + kvv[it] * VEC;
-            u32x4 in[VEC];
             if (isA[it]) {
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) {
                     const int p = p0 + i;
-                    in[i] = (chan_ok[it] && p < pk_end) ? *(const u32x4*)(DY + ((long long)p * g.ldy + coff[it])) : zero;
+                    const bool ok = chan_ok[it] && p < pk_end;
+                    raw[it][i] = *(const u32x4*)(DY + (ok ? (long long)p * g.ldy + coff[it] : 0));
+                    okm[it] |= ok ? (1u << i) : 0u;
                 }
             } else {
                 const uint32_t pp = min(p0, g.P - 1);
@@ -472,22 +507,27 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const T* __restrict__ X
                     const int p = p0 + i;
                     const int iy = qy * g.isy + tdy[it], ix = qx * g.isx + tdx[it];
                     const bool ok = chan_ok[it] && p < pk_end && (unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW;
-                    in[i] = ok ? *(const u32x4*)(X + ((((long long)n * g.IH + iy) * g.IW + ix) * g.ldx + coff[it])) : zero;
+                    raw[it][i] = *(const u32x4*)(X + (ok ? (((long long)n * g.IH + iy) * g.IW + ix) * g.ldx + coff[it] : 0));
+                    okm[it] |= ok ? (1u << i) : 0u;
                     if (++qx == g.QW) { qx = 0; if (++qy == g.QH) { qy = 0; ++n; } }
                 }
             }
-            Transposer<T>::run(in, stage[it]);
         }
     };
     auto lstore = [&](int buf) {
+        const u32x4 zero = mk4(0, 0, 0, 0);
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
             if (!live[it]) continue;
+            u32x4 in[VEC], tr[VEC];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) in[i] = ((okm[it] >> i) & 1u) ? raw[it][i] : zero;
+            Transposer<T>::run(in, tr);
             const int rbase = (isA[it] ? 0 : BM) + grp[it] * VEC;
 #pragma unroll
             for (int c = 0; c < VEC; ++c) {
                 const int rl = grp[it] * VEC + c;          // row inside its operand tile
-                lds[buf][(rbase + c) * BKV + (kvv[it] ^ lds_swz<BKV>(rl))] = stage[it][c];
+                lds[buf][(rbase + c) * BKV + (kvv[it] ^ lds_swz<BKV>(rl))] = tr[c];
             }
         }
     };
@@ -502,6 +542,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const T* __restrict__ X
         const bool more = c + 1 < nchunks;
         if (more) gload(pk_begin + (c + 1) * BKP);
         mma_chunk<T, BM, BN, WM, WN, BKV>(lds[c & 1], acc, wm, wn, lane);
+        __builtin_amdgcn_sched_barrier(0);
         if (more) lstore((c + 1) & 1);
         __syncthreads();
     }
@@ -554,6 +595,9 @@ static int fill_common(GatherGeom& g, int N, int IH, int IW, int Cin, int ldx, i
     g.OH = OH; g.OW = OW; g.Cout = Cout; g.ldy = ldy;
     g.CV = Cin / vec; g.KV = g.T * g.CV;
     g.dQW = make_fastdiv(QW); g.dQH = make_fastdiv(QH); g.dCV = make_fastdiv(g.CV);
+    static const int tap_inner = getenv("ET_CONV_TAP_INNER") ? atoi(getenv("ET_CONV_TAP_INNER")) : 0;
+    static const int xcd_swz = getenv("ET_CONV_XCD") ? atoi(getenv("ET_CONV_XCD")) : 0;
+    g.tap_inner = tap_inner; g.xcd_swz = xcd_swz;
     if ((long long)N * IH * IW * ldx >= (1ll << 31) || (long long)Cout * g.TT * Cin >= (1ll << 31)) return -2;
     return 0;
 }
@@ -564,7 +608,7 @@ static int launch_gemm(const void* X, const void* W, void* Y, const GatherGeom& 
     // tile choice: 128x128 unless the layer has <= 64 output channels.  ET_CONV_NARROW_K=<K> (tuning
     // knob, read once) additionally sends GEMMs with K <= that many elements to the 128x64 tile, whose
     // smaller register/LDS footprint gives 3 workgroups per CU for HBM-bound short-K 1x1 layers.
-    static const int narrow_k = getenv("ET_CONV_NARROW_K") ? atoi(getenv("ET_CONV_NARROW_K")) : 0;
+    static const int narrow_k = getenv("ET_CONV_NARROW_K") ? atoi(getenv("ET_CONV_NARROW_K")) : 256;
     const bool wide = g.Cout > 64 && !(narrow_k > 0 && g.T * g.Cin <= narrow_k);
     const int bn = wide ? 128 : 64;
     const dim3 grid((g.M + 127) / 128, (g.Cout + bn - 1) / bn), block(256);

@@ -387,3 +387,65 @@ extern "C" int et_scale_cast(const float* src, void* dst, int dtype, int64_t n, 
     ET_CHECK_LAUNCH();
     return 0;
 }
+
+// ---- domain-adaptation focal loss (DomainLoss / TargetLoss, models/loss/loss.py:376-421 with
+// DomainFocalLoss :312-368, class_num 2, alpha 1, gamma 2, mean): per pixel p = softmax(l0,l1)[label],
+// L = -(1-p)^2 log p.  One launch per pyramid level: accumulates sum(L) into out[0] (atomic) and writes
+// dL/dlogits * gscale into the (B,H,W,ldg) gradient buffer (channels 0,1), other channels untouched.
+template <typename T>
+__global__ __launch_bounds__(256) void domain_focal_kernel(const T* __restrict__ f, int ldf, long long P, int label,
+                                                           float gscale, T* __restrict__ g, int ldg, float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    float l = 0.f;
+    if (i < P) {
+        const float a = et_elem<T>::ld(f[i * ldf + 0]), b = et_elem<T>::ld(f[i * ldf + 1]);
+        const float m = fmaxf(a, b);
+        const float ea = expf(a - m), eb = expf(b - m);
+        const float inv = 1.0f / (ea + eb);
+        const float p = (label == 0 ? ea : eb) * inv;
+        const float q = 1.0f - p;
+        const float lp = logf(p);
+        l = -(q * q) * lp;
+        // dL/dp = 2 q log p - q^2 / p ; dp/dx_label = p q ; dp/dx_other = -p q
+        const float dldp = 2.0f * q * lp - (q * q) / p;
+        const float gt = dldp * p * q * gscale;
+        if (g) {
+            g[i * ldg + label] = et_elem<T>::st(gt);
+            g[i * ldg + (1 - label)] = et_elem<T>::st(-gt);
+        }
+    }
+    l = et_wave_sum(l);
+    if ((threadIdx.x & 63) == 0 && l != 0.f) atomicAdd(out, l);
+}
+
+// x *= alpha in place (GradReverse backward, models/detector/yolo_ssod.py:158-171: alpha = -1)
+template <typename T>
+__global__ __launch_bounds__(256) void scale_inplace_kernel(T* __restrict__ x, long long n, float alpha,
+                                                            const float* __restrict__ dev_scale) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const float f = dev_scale ? alpha * dev_scale[0] : alpha;
+    if (i < n) x[i] = et_elem<T>::st(et_elem<T>::ld(x[i]) * f);
+}
+
+extern "C" int et_domain_focal(const void* feat, int ldf, int dtype, int64_t P, int label, float gscale, void* grad,
+                               int ldg, float* loss_sum, et_stream_t stream) {
+    if (!feat || !loss_sum) return -1;
+    if (P <= 0 || (label != 0 && label != 1)) return -2;
+    const dim3 grid(et_cdiv(P, 256));
+    if (dtype == ET_F32) hipLaunchKernelGGL((domain_focal_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)feat, ldf, (long long)P, label, gscale, (float*)grad, ldg, loss_sum);
+    else if (dtype == ET_BF16) hipLaunchKernelGGL((domain_focal_kernel<uint16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)feat, ldf, (long long)P, label, gscale, (uint16_t*)grad, ldg, loss_sum);
+    else return -2;
+    ET_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int et_scale_inplace(void* x, int dtype, int64_t n, float alpha, const float* dev_scale, et_stream_t stream) {
+    if (!x) return -1;
+    if (n <= 0) return n == 0 ? 0 : -2;
+    const dim3 grid(et_cdiv(n, 256));
+    if (dtype == ET_F32) hipLaunchKernelGGL((scale_inplace_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (float*)x, (long long)n, alpha, dev_scale);
+    else if (dtype == ET_BF16) hipLaunchKernelGGL((scale_inplace_kernel<uint16_t>), grid, dim3(256), 0, (hipStream_t)stream, (uint16_t*)x, (long long)n, alpha, dev_scale);
+    else return -2;
+    ET_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,4 +1,4 @@
-from .loss import ComputeLoss  # noqa: F401
+from .loss import ComputeLoss, DomainLoss, TargetLoss  # noqa: F401
 from .ssod.ssod_loss import ComputeStudentMatchLoss  # noqa: F401
 
 

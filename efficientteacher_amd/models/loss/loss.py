@@ -88,3 +88,22 @@ class ComputeLoss:
 
     def __call__(self, p, targets):
         return self.default_loss(p, targets)
+
+
+class _DomainFocal:
+    """Shared body of DomainLoss / TargetLoss (reference models/loss/loss.py:376-421): the three netD
+    outputs (B,2,H,W) -> 0.5 * softmax-focal loss against a constant domain label."""
+    label = 0
+
+    def __call__(self, feature):
+        from ...autograd import DomainFocalFn
+        feats = [f.permute(0, 2, 3, 1) for f in feature]      # NHWC views of the netD results
+        return DomainFocalFn.apply(self.label, *feats)[0]
+
+
+class DomainLoss(_DomainFocal):     # source domain: label 0 (loss.py:398)
+    label = 0
+
+
+class TargetLoss(_DomainFocal):     # target domain: label 1 (loss.py:376)
+    label = 1

@@ -373,3 +373,22 @@ def detect_decode(raw5, anchor_px, stride, z, a_offset):
                                             raw5.stride(1), raw5.stride(2), raw5.stride(3), _lib.ptr(anchor_px),
                                             float(stride), _lib.ptr(z), z.shape[1], a_offset, _lib.stream(z)),
                "et_detect_decode")
+
+
+# ---- domain adaptation branch ----------------------------------------------------------------------------
+def domain_focal(feat_nhwc, label, gscale, loss_sum, want_grad=True):
+    """feat (B,H,W,CP) netD output (channels 0,1 = logits); accumulates the focal sum into loss_sum[0] and
+    returns the gradient buffer (same shape, zeros outside channels 0,1) scaled by gscale."""
+    N, H, W, CP = feat_nhwc.shape
+    g = torch.zeros_like(feat_nhwc) if want_grad else None
+    _lib.check(_lib.load().et_domain_focal(_lib.ptr(feat_nhwc), _nhwc(feat_nhwc), et_dtype(feat_nhwc), N * H * W, int(label),
+                                           float(gscale), _lib.ptr(g), _nhwc(g) if g is not None else 0,
+                                           _lib.ptr(loss_sum), _lib.stream(feat_nhwc)), "et_domain_focal")
+    return g
+
+
+def scale_inplace(x, alpha, dev_scale=None):
+    assert x.is_contiguous()
+    _lib.check(_lib.load().et_scale_inplace(_lib.ptr(x), et_dtype(x), x.numel(), float(alpha), _lib.ptr(dev_scale),
+                                            _lib.stream(x)), "et_scale_inplace")
+    return x

@@ -10,7 +10,7 @@ stream-ordered: no ``.cpu()``, no per-detection python loops, no deepcopy of the
 import numpy as np
 import torch
 
-from ..models.loss import ComputeLoss, build_ssod_loss
+from ..models.loss import ComputeLoss, DomainLoss, TargetLoss, build_ssod_loss
 from ..parallel import FlatDataParallel
 from ..utils.self_supervised_utils import FairPseudoLabel
 from ..utils.torch_utils import CosineEMA, ModelEMA, SemiSupModelEMA
@@ -39,8 +39,6 @@ class SSODTrainer(Trainer):
         self.fixed_accumulate = cfg.SSOD.fixed_accumulate
         self.extra_teacher_models = []
         self.teacher_pred_hook = None      # optional callable(teacher_pred) -> teacher_pred (bench: synthetic scores)
-        if cfg.SSOD.with_da_loss:
-            raise NotImplementedError("SSOD.with_da_loss (domain-adaptation gradient) is not built yet")
 
     def build_model(self, cfg, device):
         super().build_model(cfg, device)            # student + ModelEMA (the teacher is self.ema.ema)
@@ -54,6 +52,8 @@ class SSODTrainer(Trainer):
     def build_ddp_model(self, cfg, device):
         super().build_ddp_model(cfg, device)
         self.compute_un_sup_loss = build_ssod_loss(self.model, cfg)
+        self.domain_loss = DomainLoss()
+        self.target_loss = TargetLoss()
 
     def update_optimizer(self, loss, ni):
         loss.backward()
@@ -95,6 +95,10 @@ class SSODTrainer(Trainer):
         sup_pred, sup_feature, un_sup_pred, un_sup_feature = self.split_predict_and_feature(total_pred, total_feature, n_img)
         # 4 losses (:628-649); the zero-weighted domain losses (:631-636) contribute nothing
         sup_loss, sup_loss_items = self.compute_loss(sup_pred, targets.to(self.device))
+        if self.cfg.SSOD.with_da_loss:                 # ssod_trainer.py:631-634
+            d_loss = self.domain_loss(sup_feature)
+            t_loss = self.target_loss(un_sup_feature)
+            sup_loss = sup_loss + d_loss * self.da_loss_weights + t_loss * self.da_loss_weights
         if self.RANK != -1:
             sup_loss = sup_loss * self.WORLD_SIZE
         un_sup_loss, un_sup_loss_items = self.compute_un_sup_loss(un_sup_pred, t9, valid)

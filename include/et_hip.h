@@ -194,6 +194,18 @@ int et_select_targets(const double* targets9, const uint8_t* valid, int N, const
 int et_scale_cast(const float* src, void* dst, int dtype, int64_t n, float scale,
                   const float* dev_scale /*device scalar or NULL*/, et_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Domain-adaptation branch (SSOD.with_da_loss): DomainLoss / TargetLoss
+ * (models/loss/loss.py:376-421, DomainFocalLoss :312-368: softmax over the 2 netD logits, alpha 1,
+ * gamma 2) for one pyramid level: loss_sum[0] += sum_pixels -(1-p_label)^2 log p_label, and
+ * grad[pix*ldg + {0,1}] = dL/dlogit * gscale (grad may be NULL).  feat/grad: NHWC, channels 0,1 used.
+ * et_scale_inplace: x *= alpha * (dev_scale ? *dev_scale : 1)  (GradReverse backward,
+ * models/detector/yolo_ssod.py:158-171, alpha = -1; upstream factor of the focal gradient).       */
+int et_domain_focal(const void* feat, int ldf, int dtype, int64_t P, int label, float gscale, void* grad,
+                    int ldg, float* loss_sum, et_stream_t stream);
+int et_scale_inplace(void* x, int dtype, int64_t n, float alpha, const float* dev_scale /*or NULL*/,
+                     et_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -116,3 +116,26 @@ def test_pseudo_label_golden(hip):
     refd, _ = o_nms.non_max_suppression_ssod(pred, 0.1, 0.65)
     reft, inv = o_pl.create_pseudo_label(refd, M_s, W, H)
     assert np.allclose(t9[valid.bool()].cpu().numpy(), reft, rtol=1e-12, atol=1e-12)
+
+
+def test_domain_and_target_loss_golden(hip):
+    """DomainLoss / TargetLoss (softmax focal, models/loss/loss.py:312-421) forward + gradient."""
+    from efficientteacher_amd.models.loss import DomainLoss, TargetLoss
+    g = golden("domain_loss")
+    feats = []
+    for i in range(3):
+        f = g[f"f{i}"]                                   # (B,2,H,W)
+        buf = torch.zeros((f.shape[0], f.shape[2], f.shape[3], 8), dtype=torch.float32)
+        buf[..., :2] = torch.from_numpy(f).permute(0, 2, 3, 1)
+        feats.append(hip.t(buf).requires_grad_(True))
+    views = [b[..., :2].permute(0, 3, 1, 2) for b in feats]     # what netD.forward returns
+    d = DomainLoss()(views)
+    t = TargetLoss()(views)
+    assert abs(d.item() - float(g["d"])) <= 1e-5 * abs(float(g["d"])) + 1e-7
+    assert abs(t.item() - float(g["t"])) <= 1e-5 * abs(float(g["t"])) + 1e-7
+    (d + 2 * t).backward()
+    for i in range(3):
+        ref = torch.from_numpy(g[f"g{i}"]).permute(0, 2, 3, 1)
+        got = feats[i].grad[..., :2].cpu()
+        assert (got - ref).abs().max().item() <= 1e-5 * ref.abs().max().item() + 1e-9
+        assert (feats[i].grad[..., 2:] == 0).all()
