@@ -175,15 +175,17 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const T* __restrict__ X,
             for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
 
     const int nchunks = (g.KV + BKV - 1) / BKV;
-    u32x4 ra[RA], rb[RB];
-    unsigned okmask = 0u;      // validity of the vectors in flight; zero-fill is applied at LDS-store time,
-                               // AFTER the MFMAs of the current chunk, so the loads stay in flight under them
-    int tap_u = 0, cv_u = 0;   // UTAP: chunk-uniform tap / channel-vector cursor
+    // Software pipeline, prefetch distance 2: two register sets (A/B) hold the K-chunks c+1 and c+2 while
+    // chunk c is multiplied out of LDS.  A chunk's global loads are issued TWO MFMA phases (plus the
+    // barrier) before its LDS store, which is what covers HBM latency at 2 workgroups per CU; with
+    // distance 1 the kernel was latency-bound (~22 % MFMA utilisation on the 3x3 layers).
+    // Loads are UNCONDITIONAL (an out-of-image / out-of-range lane reads the tensor base); the zero-fill
+    // select happens at LDS-store time, AFTER the MFMAs, so nothing waits on a load early.
+    u32x4 raA[RA], rbA[RB], raB[RA], rbB[RB];
+    unsigned okA = 0u, okB = 0u;
+    int tap_u = 0, cv_u = 0;   // UTAP: chunk-uniform tap / channel-vector cursor of the NEXT chunk to load
 
-    // Loads are UNCONDITIONAL (an out-of-image / out-of-range lane reads the tensor base and the value is
-    // replaced by zero with a select): no exec-mask branches around the 8 global loads of a chunk, so
-    // they issue back to back.  tap / channel cursor are passed by value (kept in SGPRs/VGPRs).
-    auto gload = [&](int chunk, int tap_c, int cv_c) {
+    auto gload = [&](int chunk, int tap_c, int cv_c, u32x4 (&ra)[RA], u32x4 (&rb)[RB]) -> unsigned {
         int tap, cv;
         bool kok = true;
         if constexpr (UTAP) {
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const T* __restrict__ X,
         const int dy = g.dy[tap], dx = g.dx[tap];
         const int doff = (dy * g.IW + dx) * g.ldx + cv * VEC;
         const int woff = (int)g.wt[tap] * g.Cin + cv * VEC;
-        okmask = 0u;
+        unsigned okmask = 0u;
 #pragma unroll
         for (int j = 0; j < RA; ++j) {
             const bool ok = kok && a_ok[j] && (unsigned)(a_iy[j] + dy) < (unsigned)g.IH &&
@@ -211,6 +213,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const T* __restrict__ X,
             rb[j] = *(const u32x4*)(W + (ok ? b_off[j] + woff : 0));
             okmask |= ok ? (1u << (16 + j)) : 0u;
         }
+        return okmask;
     };
 #define ET_ADVANCE_CURSOR()                                              \
     if constexpr (UTAP) {                                                \
@@ -221,31 +224,39 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const T* __restrict__ X,
             if (cv_u >= g.CV) { cv_u = 0; ++tap_u; }                     \
         }                                                                \
     }
-    auto lstore = [&](int buf) {
+    auto lstore = [&](u32x4* __restrict__ dst, const u32x4 (&ra)[RA], const u32x4 (&rb)[RB], unsigned okmask) {
         const u32x4 zero = mk4(0, 0, 0, 0);
 #pragma unroll
         for (int j = 0; j < RA; ++j) {
             const int r = lrow + j * RPT;
-            (buf ? lds1 : lds0)[r * BKV + (lvec ^ lds_swz<BKV>(r))] = ((okmask >> j) & 1u) ? ra[j] : zero;
+            dst[r * BKV + (lvec ^ lds_swz<BKV>(r))] = ((okmask >> j) & 1u) ? ra[j] : zero;
         }
 #pragma unroll
         for (int j = 0; j < RB; ++j) {
             const int r = lrow + j * RPT;
-            (buf ? lds1 : lds0)[(BM + r) * BKV + (lvec ^ lds_swz<BKV>(r))] = ((okmask >> (16 + j)) & 1u) ? rb[j] : zero;
+            dst[(BM + r) * BKV + (lvec ^ lds_swz<BKV>(r))] = ((okmask >> (16 + j)) & 1u) ? rb[j] : zero;
         }
     };
 
-    gload(0, tap_u, cv_u);
+    okA = gload(0, tap_u, cv_u, raA, rbA);
     ET_ADVANCE_CURSOR();
-    lstore(0);
+    if (nchunks > 1) { okB = gload(1, tap_u, cv_u, raB, rbB); ET_ADVANCE_CURSOR(); }
+    lstore(lds0, raA, rbA, okA);
     __syncthreads();
-    for (int c = 0; c < nchunks; ++c) {
-        const bool more = c + 1 < nchunks;
-        if (more) { gload(c + 1, tap_u, cv_u); ET_ADVANCE_CURSOR(); }
-        mma_chunk<T, BM, BN, WM, WN, BKV>((c & 1) ? lds1 : lds0, acc, wm, wn, lane);
+    // invariant at the top of an even phase c: LDS0 = chunk c, set B = chunk c+1 (in flight / landed)
+    for (int c = 0; c < nchunks; c += 2) {
+        if (c + 2 < nchunks) { okA = gload(c + 2, tap_u, cv_u, raA, rbA); ET_ADVANCE_CURSOR(); }
+        mma_chunk<T, BM, BN, WM, WN, BKV>(lds0, acc, wm, wn, lane);
         __builtin_amdgcn_sched_barrier(0);     // keep the consumers of the prefetched vectors below the MFMAs
-        if (more) lstore((c + 1) & 1);
+        if (c + 1 < nchunks) lstore(lds1, raB, rbB, okB);
         __syncthreads();
+        if (c + 1 < nchunks) {
+            if (c + 3 < nchunks) { okB = gload(c + 3, tap_u, cv_u, raB, rbB); ET_ADVANCE_CURSOR(); }
+            mma_chunk<T, BM, BN, WM, WN, BKV>(lds1, acc, wm, wn, lane);
+            __builtin_amdgcn_sched_barrier(0);
+            if (c + 2 < nchunks) lstore(lds0, raA, rbA, okA);
+            __syncthreads();
+        }
     }
 
 #undef ET_ADVANCE_CURSOR
@@ -476,12 +487,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const T* __restrict__ X
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
 
-    // Prefetch: raw 16-byte loads only (unconditional, invalid lanes read the tensor base); the
-    // zero-fill select, the VECxVEC register transpose and the LDS stores all happen AFTER the MFMAs of
-    // the current chunk, so the global loads stay in flight underneath them.
-    u32x4 raw[ITER][VEC];
-    unsigned okm[ITER];
-    auto gload = [&](int pk0) {
+    // Prefetch distance 2 (two raw register sets), exactly as in conv_gemm_kernel: raw 16-byte loads only
+    // (unconditional, invalid lanes read the tensor base); the zero-fill select, the VECxVEC register
+    // transpose and the LDS stores happen AFTER the MFMAs of the current chunk.
+    u32x4 rawA[ITER][VEC], rawB[ITER][VEC];
+    unsigned okA[ITER], okB[ITER];
+    auto gload = [&](int pk0, u32x4 (&raw)[ITER][VEC], unsigned (&okm)[ITER]) {
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
             okm[it] = 0u;
@@ -514,7 +525,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const T* __restrict__ X
             }
         }
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](int buf, const u32x4 (&raw)[ITER][VEC], const unsigned (&okm)[ITER]) {
         const u32x4 zero = mk4(0, 0, 0, 0);
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
@@ -534,17 +545,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const T* __restrict__ X
 
     const int nchunks = (pk_end - pk_begin + BKP - 1) / BKP;
     if (nchunks > 0) {
-        gload(pk_begin);
-        lstore(0);
+        gload(pk_begin, rawA, okA);
+        if (nchunks > 1) gload(pk_begin + BKP, rawB, okB);
+        lstore(0, rawA, okA);
     }
     __syncthreads();
-    for (int c = 0; c < nchunks; ++c) {
-        const bool more = c + 1 < nchunks;
-        if (more) gload(pk_begin + (c + 1) * BKP);
-        mma_chunk<T, BM, BN, WM, WN, BKV>(lds[c & 1], acc, wm, wn, lane);
+    for (int c = 0; c < nchunks; c += 2) {
+        if (c + 2 < nchunks) gload(pk_begin + (c + 2) * BKP, rawA, okA);
+        mma_chunk<T, BM, BN, WM, WN, BKV>(lds[0], acc, wm, wn, lane);
         __builtin_amdgcn_sched_barrier(0);
-        if (more) lstore((c + 1) & 1);
+        if (c + 1 < nchunks) lstore(1, rawB, okB);
         __syncthreads();
+        if (c + 1 < nchunks) {
+            if (c + 3 < nchunks) gload(pk_begin + (c + 3) * BKP, rawB, okB);
+            mma_chunk<T, BM, BN, WM, WN, BKV>(lds[1], acc, wm, wn, lane);
+            __builtin_amdgcn_sched_barrier(0);
+            if (c + 2 < nchunks) lstore(0, rawA, okA);
+            __syncthreads();
+        }
     }
     if (nchunks <= 0) return;
     const int l31 = lane & 31, hi = lane >> 5;
@@ -704,8 +722,10 @@ static void launch_wgrad(const void* x, const void* dy, float* dw, WgradGeom& g,
     const bool tallM = g.Cout > 64;            // Cout <= 64 layers: a 64-row tile wastes no MFMA rows
     const int bn = wideN ? 128 : 64, bm = tallM ? 128 : 64;
     const int tiles = ((g.NC + bn - 1) / bn) * ((g.Cout + bm - 1) / bm);
-    // split K so that ~4 waves of blocks cover the chip, each slice >= 8 chunks
-    int sk = (1024 + tiles - 1) / tiles;
+    // split K so that the grid covers the chip about twice (2 workgroups fit per CU), each slice >= 8
+    // chunks; fewer splits = fewer fp32 atomics on dW.  ET_WGRAD_BLOCKS is a tuning knob.
+    static const int target = getenv("ET_WGRAD_BLOCKS") ? atoi(getenv("ET_WGRAD_BLOCKS")) : 1024;
+    int sk = (target + tiles - 1) / tiles;
     const int max_sk = max(1, g.P / (BKP * 8));
     sk = max(1, min(sk, max_sk));
     int per = (g.P + sk - 1) / sk;
