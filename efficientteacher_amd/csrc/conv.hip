@@ -59,7 +59,17 @@ struct GatherGeom {
     FastDiv dQW, dQH, dCV;
     signed char dy[CONV_MAX_TAPS], dx[CONV_MAX_TAPS];
     unsigned char wt[CONV_MAX_TAPS];
+    int tapinfo[CONV_MAX_TAPS];  // (dy & 0xff) | (dx & 0xff) << 8 | wt << 16 : one scalar load per chunk
 };
+
+// chunk-uniform tap lookup: the index is made provably wave-uniform so that the table read is a scalar
+// (SMEM) load -- a vector load here would put an s_waitcnt vmcnt(0) in the middle of the LDS-DMA burst
+__device__ __forceinline__ void tap_lookup_uniform(const GatherGeom& g, int tap, int& dy, int& dx, int& wt) {
+    const int ti = g.tapinfo[__builtin_amdgcn_readfirstlane(tap)];
+    dy = (int)(signed char)(ti & 0xff);
+    dx = (int)(signed char)((ti >> 8) & 0xff);
+    wt = (ti >> 16) & 0xff;
+}
 
 enum { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2 };
 
@@ -114,152 +124,12 @@ __device__ __forceinline__ void mma_chunk(const u32x4* __restrict__ sm, f32x16 (
     }
 }
 
-// ---- forward / dgrad gather-GEMM ----------------------------------------------------------------
-template <typename T, int BM, int BN, int WM, int WN, int BKV, bool UTAP>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(const T* __restrict__ X, const T* __restrict__ W,
-                                                        T* __restrict__ Y, GatherGeom g, Epilogue ep) {
-    constexpr int VEC = et_elem<T>::VEC;
+// ---- shared epilogue of the gather-GEMM kernels -----------------------------------------------------
+template <typename T, int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN / 32], u32x4* lds_raw, T* __restrict__ Y,
+                                              const GatherGeom& g, const Epilogue& ep, int bx, int m0, int n0, int tid,
+                                              int lane, int wm, int wn) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int RPT = 256 / BKV;                 // rows covered by one pass of the 256 loader threads
-    constexpr int RA = BM / RPT, RB = BN / RPT;    // 16-byte vectors per thread per chunk
-    constexpr int STAGE_VEC = (BM + BN) * BKV;                       // one K-chunk of A and B
-    constexpr int EPI_VEC = ((BM / WM) * (BN + 4) * 4 + 15) / 16;     // fp32 staging of half a block tile
-    constexpr int LDS_VEC = 2 * STAGE_VEC > EPI_VEC ? 2 * STAGE_VEC : EPI_VEC;
-    __shared__ __attribute__((aligned(16))) u32x4 lds_raw[LDS_VEC];
-    u32x4* const lds0 = lds_raw;
-    u32x4* const lds1 = lds_raw + STAGE_VEC;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    // Workgroups are dealt round-robin to the 8 XCDs (private L2 each).  With xcd_swz the pixel-tile index
-    // is remapped so that each XCD owns a contiguous range of tiles: the halo rows shared by neighbouring
-    // tiles of a 3x3 conv, and the weights, are then re-read from that XCD's L2 (placement only: results
-    // do not depend on it).
-    int bx = blockIdx.x;
-    if (g.xcd_swz) {
-        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bx & 7, k = bx >> 3;
-        bx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;     // bijective for any nb
-    }
-    const int m0 = bx * BM, n0 = blockIdx.y * BN;
-    const int lvec = tid % BKV, lrow = tid / BKV;
-
-    // loader state: A rows are lattice pixels, B rows are output channels
-    int a_off[RA], a_iy[RA], a_ix[RA];
-    bool a_ok[RA];
-#pragma unroll
-    for (int j = 0; j < RA; ++j) {
-        const int p = m0 + lrow + j * RPT;
-        a_ok[j] = p < g.M;
-        const uint32_t pp = a_ok[j] ? p : 0;
-        const uint32_t t1 = fdiv(pp, g.dQW), qx = pp - t1 * g.QW;
-        const uint32_t n = fdiv(t1, g.dQH), qy = t1 - n * g.QH;
-        a_iy[j] = qy * g.isy;
-        a_ix[j] = qx * g.isx;
-        a_off[j] = ((n * g.IH + a_iy[j]) * g.IW + a_ix[j]) * g.ldx;
-    }
-    int b_off[RB];
-    bool b_ok[RB];
-#pragma unroll
-    for (int j = 0; j < RB; ++j) {
-        const int co = n0 + lrow + j * RPT;
-        b_ok[j] = co < g.Cout;
-        b_off[j] = (b_ok[j] ? co : 0) * g.TT * g.Cin;
-    }
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
-
-    const int nchunks = (g.KV + BKV - 1) / BKV;
-    // Software pipeline, prefetch distance 2: two register sets (A/B) hold the K-chunks c+1 and c+2 while
-    // chunk c is multiplied out of LDS.  A chunk's global loads are issued TWO MFMA phases (plus the
-    // barrier) before its LDS store, which is what covers HBM latency at 2 workgroups per CU; with
-    // distance 1 the kernel was latency-bound (~22 % MFMA utilisation on the 3x3 layers).
-    // Loads are UNCONDITIONAL (an out-of-image / out-of-range lane reads the tensor base); the zero-fill
-    // select happens at LDS-store time, AFTER the MFMAs, so nothing waits on a load early.
-    u32x4 raA[RA], rbA[RB], raB[RA], rbB[RB];
-    unsigned okA = 0u, okB = 0u;
-    int tap_u = 0, cv_u = 0;   // UTAP: chunk-uniform tap / channel-vector cursor of the NEXT chunk to load
-
-    auto gload = [&](int chunk, int tap_c, int cv_c, u32x4 (&ra)[RA], u32x4 (&rb)[RB]) -> unsigned {
-        int tap, cv;
-        bool kok = true;
-        if constexpr (UTAP) {
-            tap = tap_c; cv = cv_c + lvec;
-        } else {
-            const uint32_t kv = chunk * BKV + lvec;
-            kok = kv < (uint32_t)g.KV;
-            const uint32_t kk = kok ? kv : 0;
-            tap = fdiv(kk, g.dCV); cv = kk - tap * g.CV;
-        }
-        const int dy = g.dy[tap], dx = g.dx[tap];
-        const int doff = (dy * g.IW + dx) * g.ldx + cv * VEC;
-        const int woff = (int)g.wt[tap] * g.Cin + cv * VEC;
-        unsigned okmask = 0u;
-#pragma unroll
-        for (int j = 0; j < RA; ++j) {
-            const bool ok = kok && a_ok[j] && (unsigned)(a_iy[j] + dy) < (unsigned)g.IH &&
-                            (unsigned)(a_ix[j] + dx) < (unsigned)g.IW;
-            ra[j] = *(const u32x4*)(X + (ok ? a_off[j] + doff : 0));
-            okmask |= ok ? (1u << j) : 0u;
-        }
-#pragma unroll
-        for (int j = 0; j < RB; ++j) {
-            const bool ok = kok && b_ok[j];
-            rb[j] = *(const u32x4*)(W + (ok ? b_off[j] + woff : 0));
-            okmask |= ok ? (1u << (16 + j)) : 0u;
-        }
-        return okmask;
-    };
-#define ET_ADVANCE_CURSOR()                                              \
-    if constexpr (UTAP) {                                                \
-        if (g.tap_inner) {                                               \
-            if (++tap_u >= g.T) { tap_u = 0; cv_u += BKV; }              \
-        } else {                                                         \
-            cv_u += BKV;                                                 \
-            if (cv_u >= g.CV) { cv_u = 0; ++tap_u; }                     \
-        }                                                                \
-    }
-    auto lstore = [&](u32x4* __restrict__ dst, const u32x4 (&ra)[RA], const u32x4 (&rb)[RB], unsigned okmask) {
-        const u32x4 zero = mk4(0, 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < RA; ++j) {
-            const int r = lrow + j * RPT;
-            dst[r * BKV + (lvec ^ lds_swz<BKV>(r))] = ((okmask >> j) & 1u) ? ra[j] : zero;
-        }
-#pragma unroll
-        for (int j = 0; j < RB; ++j) {
-            const int r = lrow + j * RPT;
-            dst[(BM + r) * BKV + (lvec ^ lds_swz<BKV>(r))] = ((okmask >> (16 + j)) & 1u) ? rb[j] : zero;
-        }
-    };
-
-    okA = gload(0, tap_u, cv_u, raA, rbA);
-    ET_ADVANCE_CURSOR();
-    if (nchunks > 1) { okB = gload(1, tap_u, cv_u, raB, rbB); ET_ADVANCE_CURSOR(); }
-    lstore(lds0, raA, rbA, okA);
-    __syncthreads();
-    // invariant at the top of an even phase c: LDS0 = chunk c, set B = chunk c+1 (in flight / landed)
-    for (int c = 0; c < nchunks; c += 2) {
-        if (c + 2 < nchunks) { okA = gload(c + 2, tap_u, cv_u, raA, rbA); ET_ADVANCE_CURSOR(); }
-        mma_chunk<T, BM, BN, WM, WN, BKV>(lds0, acc, wm, wn, lane);
-        __builtin_amdgcn_sched_barrier(0);     // keep the consumers of the prefetched vectors below the MFMAs
-        if (c + 1 < nchunks) lstore(lds1, raB, rbB, okB);
-        __syncthreads();
-        if (c + 1 < nchunks) {
-            if (c + 3 < nchunks) { okB = gload(c + 3, tap_u, cv_u, raB, rbB); ET_ADVANCE_CURSOR(); }
-            mma_chunk<T, BM, BN, WM, WN, BKV>(lds1, acc, wm, wn, lane);
-            __builtin_amdgcn_sched_barrier(0);
-            if (c + 2 < nchunks) lstore(lds0, raA, rbA, okA);
-            __syncthreads();
-        }
-    }
-
-#undef ET_ADVANCE_CURSOR
     // ---- epilogue ----------------------------------------------------------------------------------
     // scale/bias/activation in registers (a lane owns ONE output channel per 32x32 tile), BN partial
     // statistics from the raw accumulators, then the tile goes through LDS (fp32, one 64-row half of the
@@ -393,6 +263,297 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const T* __restrict__ X,
             }
         }
     }
+}
+
+// ---- forward / dgrad gather-GEMM ----------------------------------------------------------------
+template <typename T, int BM, int BN, int WM, int WN, int BKV, bool UTAP>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const T* __restrict__ X, const T* __restrict__ W,
+                                                        T* __restrict__ Y, GatherGeom g, Epilogue ep) {
+    constexpr int VEC = et_elem<T>::VEC;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int RPT = 256 / BKV;                 // rows covered by one pass of the 256 loader threads
+    constexpr int RA = BM / RPT, RB = BN / RPT;    // 16-byte vectors per thread per chunk
+    constexpr int STAGE_VEC = (BM + BN) * BKV;                       // one K-chunk of A and B
+    constexpr int EPI_VEC = ((BM / WM) * (BN + 4) * 4 + 15) / 16;     // fp32 staging of half a block tile
+    constexpr int LDS_VEC = 2 * STAGE_VEC > EPI_VEC ? 2 * STAGE_VEC : EPI_VEC;
+    __shared__ __attribute__((aligned(16))) u32x4 lds_raw[LDS_VEC];
+    u32x4* const lds0 = lds_raw;
+    u32x4* const lds1 = lds_raw + STAGE_VEC;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    // Workgroups are dealt round-robin to the 8 XCDs (private L2 each).  With xcd_swz the pixel-tile index
+    // is remapped so that each XCD owns a contiguous range of tiles: the halo rows shared by neighbouring
+    // tiles of a 3x3 conv, and the weights, are then re-read from that XCD's L2 (placement only: results
+    // do not depend on it).
+    int bx = blockIdx.x;
+    if (g.xcd_swz) {
+        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bx & 7, k = bx >> 3;
+        bx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;     // bijective for any nb
+    }
+    const int m0 = bx * BM, n0 = blockIdx.y * BN;
+    const int lvec = tid % BKV, lrow = tid / BKV;
+
+    // loader state: A rows are lattice pixels, B rows are output channels
+    int a_off[RA], a_iy[RA], a_ix[RA];
+    bool a_ok[RA];
+#pragma unroll
+    for (int j = 0; j < RA; ++j) {
+        const int p = m0 + lrow + j * RPT;
+        a_ok[j] = p < g.M;
+        const uint32_t pp = a_ok[j] ? p : 0;
+        const uint32_t t1 = fdiv(pp, g.dQW), qx = pp - t1 * g.QW;
+        const uint32_t n = fdiv(t1, g.dQH), qy = t1 - n * g.QH;
+        a_iy[j] = qy * g.isy;
+        a_ix[j] = qx * g.isx;
+        a_off[j] = ((n * g.IH + a_iy[j]) * g.IW + a_ix[j]) * g.ldx;
+    }
+    int b_off[RB];
+    bool b_ok[RB];
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+        const int co = n0 + lrow + j * RPT;
+        b_ok[j] = co < g.Cout;
+        b_off[j] = (b_ok[j] ? co : 0) * g.TT * g.Cin;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+    const int nchunks = (g.KV + BKV - 1) / BKV;
+    // Software pipeline, prefetch distance 2: two register sets (A/B) hold the K-chunks c+1 and c+2 while
+    // chunk c is multiplied out of LDS.  A chunk's global loads are issued TWO MFMA phases (plus the
+    // barrier) before its LDS store, which is what covers HBM latency at 2 workgroups per CU; with
+    // distance 1 the kernel was latency-bound (~22 % MFMA utilisation on the 3x3 layers).
+    // Loads are UNCONDITIONAL (an out-of-image / out-of-range lane reads the tensor base); the zero-fill
+    // select happens at LDS-store time, AFTER the MFMAs, so nothing waits on a load early.
+    u32x4 raA[RA], rbA[RB], raB[RA], rbB[RB];
+    unsigned okA = 0u, okB = 0u;
+    int tap_u = 0, cv_u = 0;   // UTAP: chunk-uniform tap / channel-vector cursor of the NEXT chunk to load
+
+    auto gload = [&](int chunk, int tap_c, int cv_c, u32x4 (&ra)[RA], u32x4 (&rb)[RB]) -> unsigned {
+        int tap, cv;
+        bool kok = true;
+        if constexpr (UTAP) {
+            tap = tap_c; cv = cv_c + lvec;
+        } else {
+            const uint32_t kv = chunk * BKV + lvec;
+            kok = kv < (uint32_t)g.KV;
+            const uint32_t kk = kok ? kv : 0;
+            tap = fdiv(kk, g.dCV); cv = kk - tap * g.CV;
+        }
+        int dy, dx, wt;
+        if constexpr (UTAP) tap_lookup_uniform(g, tap, dy, dx, wt);
+        else { dy = g.dy[tap]; dx = g.dx[tap]; wt = g.wt[tap]; }
+        const int doff = (dy * g.IW + dx) * g.ldx + cv * VEC;
+        const int woff = wt * g.Cin + cv * VEC;
+        unsigned okmask = 0u;
+#pragma unroll
+        for (int j = 0; j < RA; ++j) {
+            const bool ok = kok && a_ok[j] && (unsigned)(a_iy[j] + dy) < (unsigned)g.IH &&
+                            (unsigned)(a_ix[j] + dx) < (unsigned)g.IW;
+            ra[j] = *(const u32x4*)(X + (ok ? a_off[j] + doff : 0));
+            okmask |= ok ? (1u << j) : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+            const bool ok = kok && b_ok[j];
+            rb[j] = *(const u32x4*)(W + (ok ? b_off[j] + woff : 0));
+            okmask |= ok ? (1u << (16 + j)) : 0u;
+        }
+        return okmask;
+    };
+#define ET_ADVANCE_CURSOR()                                              \
+    if constexpr (UTAP) {                                                \
+        if (g.tap_inner) {                                               \
+            if (++tap_u >= g.T) { tap_u = 0; cv_u += BKV; }              \
+        } else {                                                         \
+            cv_u += BKV;                                                 \
+            if (cv_u >= g.CV) { cv_u = 0; ++tap_u; }                     \
+        }                                                                \
+    }
+    auto lstore = [&](u32x4* __restrict__ dst, const u32x4 (&ra)[RA], const u32x4 (&rb)[RB], unsigned okmask) {
+        const u32x4 zero = mk4(0, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < RA; ++j) {
+            const int r = lrow + j * RPT;
+            dst[r * BKV + (lvec ^ lds_swz<BKV>(r))] = ((okmask >> j) & 1u) ? ra[j] : zero;
+        }
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+            const int r = lrow + j * RPT;
+            dst[(BM + r) * BKV + (lvec ^ lds_swz<BKV>(r))] = ((okmask >> (16 + j)) & 1u) ? rb[j] : zero;
+        }
+    };
+
+    okA = gload(0, tap_u, cv_u, raA, rbA);
+    ET_ADVANCE_CURSOR();
+    if (nchunks > 1) { okB = gload(1, tap_u, cv_u, raB, rbB); ET_ADVANCE_CURSOR(); }
+    lstore(lds0, raA, rbA, okA);
+    __syncthreads();
+    // invariant at the top of an even phase c: LDS0 = chunk c, set B = chunk c+1 (in flight / landed)
+    for (int c = 0; c < nchunks; c += 2) {
+        if (c + 2 < nchunks) { okA = gload(c + 2, tap_u, cv_u, raA, rbA); ET_ADVANCE_CURSOR(); }
+        mma_chunk<T, BM, BN, WM, WN, BKV>(lds0, acc, wm, wn, lane);
+        __builtin_amdgcn_sched_barrier(0);     // keep the consumers of the prefetched vectors below the MFMAs
+        if (c + 1 < nchunks) lstore(lds1, raB, rbB, okB);
+        __syncthreads();
+        if (c + 1 < nchunks) {
+            if (c + 3 < nchunks) { okB = gload(c + 3, tap_u, cv_u, raB, rbB); ET_ADVANCE_CURSOR(); }
+            mma_chunk<T, BM, BN, WM, WN, BKV>(lds1, acc, wm, wn, lane);
+            __builtin_amdgcn_sched_barrier(0);
+            if (c + 2 < nchunks) lstore(lds0, raA, rbA, okA);
+            __syncthreads();
+        }
+    }
+
+#undef ET_ADVANCE_CURSOR
+    conv_epilogue<T, BM, BN, WM, WN>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn);
+}
+
+// ---- forward / dgrad gather-GEMM, LDS-DMA staging ------------------------------------------------------
+// Same tiling, LDS image and epilogue as conv_gemm_kernel, but the K-chunks go global -> LDS with
+// global_load_lds_dwordx4 (no VGPR staging, no ds_write_b128: on the register-staged kernel the 8
+// ds_write_b128 per lane per chunk cost about as many LDS cycles as all the fragment reads).
+// The DMA writes LDS lane-linearly (wave base + lane*16), i.e. lane (row = t/BKV, slot = t%BKV) always
+// fills physical slot `slot` of its row; the XOR swizzle is therefore applied to the SOURCE: the lane
+// fetches the logical K-vector  slot ^ swz(row)  (same 128-byte global segment, so coalescing is
+// unchanged) and the fragment reads keep using  physical = logical ^ swz(row).  Out-of-image taps, rows
+// beyond M and channels beyond Cout fetch from a 16-byte zero page instead of branching.
+template <typename T, int BM, int BN, int WM, int WN, int BKV, bool UTAP>
+__global__ __launch_bounds__(256) void conv_gemm_glds_kernel(const T* __restrict__ X, const T* __restrict__ W,
+                                                             T* __restrict__ Y, const T* __restrict__ ZERO,
+                                                             GatherGeom g, Epilogue ep) {
+    constexpr int VEC = et_elem<T>::VEC;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int RPT = 256 / BKV;
+    constexpr int RA = BM / RPT, RB = BN / RPT;
+    constexpr int STAGE_VEC = (BM + BN) * BKV;
+    constexpr int EPI_VEC = ((BM / WM) * (BN + 4) * 4 + 15) / 16;
+    constexpr int LDS_VEC = 2 * STAGE_VEC > EPI_VEC ? 2 * STAGE_VEC : EPI_VEC;
+    __shared__ __attribute__((aligned(16))) u32x4 lds_raw[LDS_VEC];
+    u32x4* const lds0 = lds_raw;
+    u32x4* const lds1 = lds_raw + STAGE_VEC;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    int bx = blockIdx.x;
+    if (g.xcd_swz) {
+        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bx & 7, k = bx >> 3;
+        bx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    const int m0 = bx * BM, n0 = blockIdx.y * BN;
+    const int lvec = tid % BKV, lrow = tid / BKV;
+
+    int a_off[RA], a_iy[RA], a_ix[RA], a_lv[RA];
+    bool a_ok[RA];
+#pragma unroll
+    for (int j = 0; j < RA; ++j) {
+        const int rl = lrow + j * RPT;
+        const int p = m0 + rl;
+        a_ok[j] = p < g.M;
+        const uint32_t pp = a_ok[j] ? p : 0;
+        const uint32_t t1 = fdiv(pp, g.dQW), qx = pp - t1 * g.QW;
+        const uint32_t n = fdiv(t1, g.dQH), qy = t1 - n * g.QH;
+        a_iy[j] = qy * g.isy;
+        a_ix[j] = qx * g.isx;
+        a_off[j] = ((n * g.IH + a_iy[j]) * g.IW + a_ix[j]) * g.ldx;
+        a_lv[j] = lvec ^ lds_swz<BKV>(rl);                 // logical K-vector this lane stages for row rl
+    }
+    int b_off[RB], b_lv[RB];
+    bool b_ok[RB];
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+        const int rl = lrow + j * RPT;
+        const int co = n0 + rl;
+        b_ok[j] = co < g.Cout;
+        b_off[j] = (b_ok[j] ? co : 0) * g.TT * g.Cin;
+        b_lv[j] = lvec ^ lds_swz<BKV>(rl);
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+    const int nchunks = (g.KV + BKV - 1) / BKV;
+    int tap_u = 0, cv_u = 0;
+
+    // issue the LDS-DMA of one K-chunk into `dst` (all 256 threads, RA + RB instructions each)
+    auto stage = [&](u32x4* dst, int chunk, int tap_c, int cv_c) {
+        u32x4* const wbase = dst + wave * 64;              // wave-uniform: lanes land at wbase[j*256 + lane]
+        int udy = 0, udx = 0, uwt = 0;
+        if constexpr (UTAP) tap_lookup_uniform(g, tap_c, udy, udx, uwt);   // once per chunk, before the burst
+#pragma unroll
+        for (int j = 0; j < RA; ++j) {
+            int dy = udy, dx = udx, cv;
+            bool kok = true;
+            if constexpr (UTAP) {
+                cv = cv_c + a_lv[j];
+            } else {
+                const uint32_t kv = chunk * BKV + a_lv[j];
+                kok = kv < (uint32_t)g.KV;
+                const uint32_t kk = kok ? kv : 0;
+                const int tap = fdiv(kk, g.dCV);
+                cv = kk - tap * g.CV;
+                dy = g.dy[tap]; dx = g.dx[tap];
+            }
+            const bool ok = kok && a_ok[j] && (unsigned)(a_iy[j] + dy) < (unsigned)g.IH &&
+                            (unsigned)(a_ix[j] + dx) < (unsigned)g.IW;
+            const T* src = ok ? X + (a_off[j] + (dy * g.IW + dx) * g.ldx + cv * VEC) : ZERO;
+            et_glds16(src, wbase + j * 256);
+        }
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+            int wt = uwt, cv;
+            bool kok = true;
+            if constexpr (UTAP) {
+                cv = cv_c + b_lv[j];
+            } else {
+                const uint32_t kv = chunk * BKV + b_lv[j];
+                kok = kv < (uint32_t)g.KV;
+                const uint32_t kk = kok ? kv : 0;
+                const int tap = fdiv(kk, g.dCV);
+                cv = kk - tap * g.CV;
+                wt = g.wt[tap];
+            }
+            const bool ok = kok && b_ok[j];
+            const T* src = ok ? W + (b_off[j] + wt * g.Cin + cv * VEC) : ZERO;
+            et_glds16(src, wbase + BM * BKV + j * 256);
+        }
+    };
+#define ET_ADVANCE_CURSOR()                                              \
+    if constexpr (UTAP) {                                                \
+        if (g.tap_inner) {                                               \
+            if (++tap_u >= g.T) { tap_u = 0; cv_u += BKV; }              \
+        } else {                                                         \
+            cv_u += BKV;                                                 \
+            if (cv_u >= g.CV) { cv_u = 0; ++tap_u; }                     \
+        }                                                                \
+    }
+
+    stage(lds0, 0, tap_u, cv_u);
+    ET_ADVANCE_CURSOR();
+    et_wait_vmem();
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        u32x4* const cur = (c & 1) ? lds1 : lds0;
+        u32x4* const nxt = (c & 1) ? lds0 : lds1;
+        if (c + 1 < nchunks) { stage(nxt, c + 1, tap_u, cv_u); ET_ADVANCE_CURSOR(); }
+        mma_chunk<T, BM, BN, WM, WN, BKV>(cur, acc, wm, wn, lane);
+        et_wait_vmem();          // this wave's DMA of chunk c+1 has landed ...
+        __syncthreads();         // ... and so has everybody else's; all reads of `cur` are done
+    }
+#undef ET_ADVANCE_CURSOR
+    conv_epilogue<T, BM, BN, WM, WN>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn);
 }
 
 // ---- wgrad ----------------------------------------------------------------------------------------
@@ -621,7 +782,8 @@ static int fill_common(GatherGeom& g, int N, int IH, int IW, int Cin, int ldx, i
 }
 
 template <typename T>
-static int launch_gemm(const void* X, const void* W, void* Y, const GatherGeom& g, const Epilogue& ep, hipStream_t s) {
+static int launch_gemm(const void* X, const void* W, void* Y, const void* zero16, const GatherGeom& g, const Epilogue& ep,
+                       hipStream_t s) {
     if (g.M <= 0) return 0;
     // tile choice: 128x128 unless the layer has <= 64 output channels.  ET_CONV_NARROW_K=<K> (tuning
     // knob, read once) additionally sends GEMMs with K <= that many elements to the 128x64 tile, whose
@@ -631,8 +793,16 @@ static int launch_gemm(const void* X, const void* W, void* Y, const GatherGeom& 
     const int bn = wide ? 128 : 64;
     const dim3 grid((g.M + 127) / 128, (g.Cout + bn - 1) / bn), block(256);
     const T* x = (const T*)X; const T* w = (const T*)W; T* y = (T*)Y;
-#define ET_LAUNCH(BN_, WM_, WN_, BKV_, UT_) \
-    hipLaunchKernelGGL((conv_gemm_kernel<T, 128, BN_, WM_, WN_, BKV_, UT_>), grid, block, 0, s, x, w, y, g, ep)
+    // staging: LDS-DMA (global_load_lds) when the caller supplies a zero page, else VGPR staging.
+    // ET_CONV_GLDS=0 forces the register-staged kernel (A/B knob).
+    static const int use_glds = getenv("ET_CONV_GLDS") ? atoi(getenv("ET_CONV_GLDS")) : 1;
+    const T* z = (const T*)zero16;
+    const bool glds = use_glds && z != nullptr;
+#define ET_LAUNCH(BN_, WM_, WN_, BKV_, UT_)                                                                              \
+    do {                                                                                                                  \
+        if (glds) hipLaunchKernelGGL((conv_gemm_glds_kernel<T, 128, BN_, WM_, WN_, BKV_, UT_>), grid, block, 0, s, x, w, y, z, g, ep); \
+        else hipLaunchKernelGGL((conv_gemm_kernel<T, 128, BN_, WM_, WN_, BKV_, UT_>), grid, block, 0, s, x, w, y, g, ep);  \
+    } while (0)
     if (g.CV % 8 == 0) {
         if (wide) ET_LAUNCH(128, 2, 2, 8, true); else ET_LAUNCH(64, 2, 2, 8, true);
     } else if (g.CV % 4 == 0) {
@@ -649,7 +819,7 @@ extern "C" int et_conv2d_stats_rows(int N, int OH, int OW) { return (N * OH * OW
 extern "C" int et_conv2d_fwd(const void* x, const void* w, void* y, int dtype, int N, int IH, int IW, int Cin,
                              int ldx, int Cout, int KH, int KW, int stride, int pad, int ldy, const float* scale,
                              const float* bias, int act, const void* residual, int ldr, float* stats_partial,
-                             et_stream_t stream) {
+                             const void* zero16, et_stream_t stream) {
     if (!x || !w || !y) return -1;
     if (KH * KW > CONV_MAX_TAPS || stride < 1 || N <= 0 || Cout <= 0) return -2;
     GatherGeom g;
@@ -660,13 +830,14 @@ extern "C" int et_conv2d_fwd(const void* x, const void* w, void* y, int dtype, i
             const int t = ky * KW + kx;
             g.dy[t] = (signed char)(ky - pad); g.dx[t] = (signed char)(kx - pad); g.wt[t] = (unsigned char)t;
         }
+    for (int t = 0; t < g.T; ++t) g.tapinfo[t] = (g.dy[t] & 0xff) | ((g.dx[t] & 0xff) << 8) | ((int)g.wt[t] << 16);
     g.isy = g.isx = stride; g.osy = g.osx = 1; g.ooy = g.oox = 0;
     const int vec = dtype == ET_F32 ? 4 : 8;
     int rc = fill_common(g, N, IH, IW, Cin, ldx, OH, OW, OH, OW, Cout, ldy, vec);
     if (rc) return rc;
     Epilogue ep{scale, bias, act, residual, ldr, stats_partial, 0};
-    if (dtype == ET_F32) rc = launch_gemm<float>(x, w, y, g, ep, (hipStream_t)stream);
-    else if (dtype == ET_BF16) rc = launch_gemm<uint16_t>(x, w, y, g, ep, (hipStream_t)stream);
+    if (dtype == ET_F32) rc = launch_gemm<float>(x, w, y, zero16, g, ep, (hipStream_t)stream);
+    else if (dtype == ET_BF16) rc = launch_gemm<uint16_t>(x, w, y, zero16, g, ep, (hipStream_t)stream);
     else return -2;
     if (rc) return rc;
     ET_CHECK_LAUNCH();
@@ -675,7 +846,7 @@ extern "C" int et_conv2d_fwd(const void* x, const void* w, void* y, int dtype, i
 
 extern "C" int et_conv2d_dgrad(const void* dy, const void* wT, void* dx, int dtype, int N, int IH, int IW, int Cin,
                                int ldx, int Cout, int KH, int KW, int stride, int pad, int ldy, int accumulate,
-                               et_stream_t stream) {
+                               const void* zero16, et_stream_t stream) {
     // dx[n,iy,ix,ci] = sum_{ky,kx,co} dy[n,(iy+pad-ky)/s,(ix+pad-kx)/s,co] * wT[ci,ky,kx,co]
     if (!dy || !wT || !dx) return -1;
     if (KH * KW > CONV_MAX_TAPS || stride < 1 || stride > 2 || N <= 0) return -2;
@@ -698,6 +869,7 @@ extern "C" int et_conv2d_dgrad(const void* dy, const void* wT, void* dx, int dty
                 }
             }
             g.T = t;
+            for (int q = 0; q < t; ++q) g.tapinfo[q] = (g.dy[q] & 0xff) | ((g.dx[q] & 0xff) << 8) | ((int)g.wt[q] << 16);
             g.isy = g.isx = 1; g.osy = g.osx = stride; g.ooy = py; g.oox = px;
             const int QH = (IH - py + stride - 1) / stride, QW = (IW - px + stride - 1) / stride;
             // the "gathered" tensor of dgrad is dy (OH x OW x Cout), the written one is dx (IH x IW x Cin)
@@ -705,8 +877,8 @@ extern "C" int et_conv2d_dgrad(const void* dy, const void* wT, void* dx, int dty
             if (rc) return rc;
             Epilogue ep{nullptr, nullptr, ACT_NONE, nullptr, 0, nullptr, accumulate};
             if (t == 0) return -2;   // would need a zero fill; does not occur for k>=stride
-            if (dtype == ET_F32) rc = launch_gemm<float>(dy, wT, dx, g, ep, (hipStream_t)stream);
-            else if (dtype == ET_BF16) rc = launch_gemm<uint16_t>(dy, wT, dx, g, ep, (hipStream_t)stream);
+            if (dtype == ET_F32) rc = launch_gemm<float>(dy, wT, dx, zero16, g, ep, (hipStream_t)stream);
+            else if (dtype == ET_BF16) rc = launch_gemm<uint16_t>(dy, wT, dx, zero16, g, ep, (hipStream_t)stream);
             else return -2;
             if (rc) return rc;
         }

@@ -56,3 +56,13 @@ __device__ __forceinline__ int et_wave_sum_i(int v) {
 }
 
 __device__ __forceinline__ float et_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// ---- LDS-DMA (gfx950 global_load_lds_dwordx4): 16 bytes per lane straight from global memory into LDS,
+// no VGPR staging and no ds_write.  The LDS destination is WAVE-UNIFORM base + lane*16: pass the same
+// `lds_wave_base` in every lane of the wave; the per-lane part is the global address.
+__device__ __forceinline__ void et_glds16(const void* g, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+// s_waitcnt vmcnt(0): all of this wave's LDS-DMA writes have landed (expcnt / lgkmcnt left at max)
+__device__ __forceinline__ void et_wait_vmem() { __builtin_amdgcn_s_waitcnt(0x0F70); }

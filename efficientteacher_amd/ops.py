@@ -45,6 +45,17 @@ def _gemm_tag(kind, x_dtype, cout, cin_padded):
     return f"conv_gemm_kernel<{t}, 128, {128 if cout > 64 else 64}, 2, 2, {bkv}, {ut}>"
 
 
+_ZERO_PAGES = {}
+
+
+def zero_page(device):
+    """256 zero bytes on `device`: the source of padding / tail lanes of the LDS-DMA conv kernels."""
+    z = _ZERO_PAGES.get(device)
+    if z is None:
+        z = _ZERO_PAGES[device] = torch.zeros(256, dtype=torch.uint8, device=device)
+    return z
+
+
 def et_dtype(t):
     if t.dtype == torch.float32:
         return ET_F32
@@ -86,7 +97,8 @@ def conv2d_fwd(x, w, stride, pad, *, scale=None, bias=None, act=ACT_NONE, residu
         ev[0].record()
     _lib.check(lib.et_conv2d_fwd(_lib.ptr(x), _lib.ptr(w), _lib.ptr(out), et_dtype(x), N, IH, IW, Cin, _nhwc(x),
                                  Cout, KH, KW, stride, pad, _nhwc(out), _lib.ptr(scale), _lib.ptr(bias), act,
-                                 _lib.ptr(residual), ldr, _lib.ptr(stats), _lib.stream(x)), "et_conv2d_fwd")
+                                 _lib.ptr(residual), ldr, _lib.ptr(stats), _lib.ptr(zero_page(x.device)),
+                                 _lib.stream(x)), "et_conv2d_fwd")
     if ev:
         ev[1].record()
     return (out, stats) if want_stats else out
@@ -117,7 +129,7 @@ def conv2d_dgrad(dy, wT, in_hw, stride, pad, *, out=None, accumulate=False):
         ev[0].record()
     _lib.check(_lib.load().et_conv2d_dgrad(_lib.ptr(dy), _lib.ptr(wT), _lib.ptr(out), et_dtype(dy), N, IH, IW, Cin,
                                            _nhwc(out), Cout, KH, KW, stride, pad, _nhwc(dy), int(accumulate),
-                                           _lib.stream(dy)), "et_conv2d_dgrad")
+                                           _lib.ptr(zero_page(dy.device)), _lib.stream(dy)), "et_conv2d_dgrad")
     if ev:
         ev[1].record()
     return out

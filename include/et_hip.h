@@ -80,6 +80,9 @@ int et_cast_f32_to_bf16(const float* src, void* dst, int64_t n, et_stream_t stre
  *   stats_partial, if not NULL: (et_conv2d_stats_rows(N,OH,OW), 2, Cout) fp32 partial per-channel
  *   sum / sum-of-squares of the raw accumulators (BatchNorm batch statistics, reduced later by
  *   et_bn_finalize) -- every row is fully overwritten.
+ *   zero16: device pointer to >= 16 zero bytes (16-byte aligned).  When given, the K-chunks are staged with
+ *   LDS-DMA (global_load_lds_dwordx4) and padding / tail lanes fetch from this page; NULL selects the
+ *   register-staged kernel.
  *   dgrad: dx = conv_transpose(dy, w) with wT = (Cin, KH, KW, Cout) from et_weight_transpose;
  *          stride 2 is executed as 4 parity-class launches; accumulate != 0 adds into dx.
  *   wgrad: dw (Cout, KH, KW, Cin) fp32 += ... (split-K over pixels, atomicAdd: zero or reuse the
@@ -88,10 +91,10 @@ int et_conv2d_stats_rows(int N, int OH, int OW);
 int et_conv2d_fwd(const void* x, const void* w, void* y, int dtype, int N, int IH, int IW, int Cin,
                   int ldx, int Cout, int KH, int KW, int stride, int pad, int ldy, const float* scale,
                   const float* bias, int act, const void* residual, int ldr, float* stats_partial,
-                  et_stream_t stream);
+                  const void* zero16, et_stream_t stream);
 int et_conv2d_dgrad(const void* dy, const void* wT, void* dx, int dtype, int N, int IH, int IW, int Cin,
                     int ldx, int Cout, int KH, int KW, int stride, int pad, int ldy, int accumulate,
-                    et_stream_t stream);
+                    const void* zero16, et_stream_t stream);
 int et_conv2d_wgrad(const void* x, const void* dy, float* dw, int dtype, int N, int IH, int IW, int Cin,
                     int ldx, int Cout, int KH, int KW, int stride, int pad, int ldy, et_stream_t stream);
 int et_weight_transpose(const void* w, void* wT, int dtype, int Cout, int taps, int Cin, et_stream_t stream);

@@ -227,6 +227,15 @@ static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((un
 using std::max;
 using std::min;
 
+// LDS-DMA: every lane copies `size` bytes from its own global address to  M0_base + offset + lane*size,
+// where M0_base is the LDS pointer of the first live lane (the compiler readfirstlane's it).
+static inline void emu_global_load_lds(const void* g, void* l, unsigned size, int offset) {
+    void* base = __builtin_amdgcn_readfirstlane_emu(l);
+    memcpy((char*)base + offset + (size_t)emu::cur().lane * size, g, size);
+}
+#define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) emu_global_load_lds((const void*)(g), (void*)(l), (size), (off))
+#define __builtin_amdgcn_s_waitcnt(x) ((void)0)
+
 // ----------------------------------------------------------------------------------- MFMA
 typedef __attribute__((ext_vector_type(16))) float emu_f32x16;
 typedef __attribute__((ext_vector_type(4))) float emu_f32x4;
