@@ -774,8 +774,8 @@ static int fill_common(GatherGeom& g, int N, int IH, int IW, int Cin, int ldx, i
     g.OH = OH; g.OW = OW; g.Cout = Cout; g.ldy = ldy;
     g.CV = Cin / vec; g.KV = g.T * g.CV;
     g.dQW = make_fastdiv(QW); g.dQH = make_fastdiv(QH); g.dCV = make_fastdiv(g.CV);
-    static const int tap_inner = getenv("ET_CONV_TAP_INNER") ? atoi(getenv("ET_CONV_TAP_INNER")) : 0;
-    static const int xcd_swz = getenv("ET_CONV_XCD") ? atoi(getenv("ET_CONV_XCD")) : 0;
+    static const int tap_inner = getenv("ET_CONV_TAP_INNER") ? atoi(getenv("ET_CONV_TAP_INNER")) : 1;
+    static const int xcd_swz = getenv("ET_CONV_XCD") ? atoi(getenv("ET_CONV_XCD")) : 1;
     g.tap_inner = tap_inner; g.xcd_swz = xcd_swz;
     if ((long long)N * IH * IW * ldx >= (1ll << 31) || (long long)Cout * g.TT * Cin >= (1ll << 31)) return -2;
     return 0;
