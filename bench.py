@@ -129,6 +129,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--per-rank", type=int, default=32, help="labeled (= unlabeled) images per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="run the teacher on the main stream (A/B)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -154,6 +155,7 @@ def main():
         tp[..., 4:] = synth
         return tp
     tr.teacher_pred_hook = hook
+    tr.overlap_teacher = not a.no_overlap
 
     ni = 2000               # past the warm-up ramp's first iterations, inside warm-up like early training
 

@@ -167,7 +167,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BM / WM / 32][BN / W
                         ssum[tn] += v;
                         ssq[tn] += v * v;
                         v = v * csc[tn] + cbi[tn];
-                        if (ep.act == ACT_SILU) v = v / (1.0f + expf(-v));
+                        if (ep.act == ACT_SILU) v = v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
                         else if (ep.act == ACT_RELU) v = fmaxf(v, 0.f);
                         stg[row * SLD + wn * (BN / WN) + tn * 32 + l31] = v;
                     }
@@ -564,6 +564,7 @@ struct WgradGeom {
     int isy, isx;
     int T, NC;                   // taps, NC = T*Cin columns of dW
     int Pper;                    // pixels per split-K slice (multiple of the K-chunk)
+    int ntn, ntm, nsk;           // tile grid: column tiles, cout tiles, K splits (1-D launch, decoded in-kernel)
     FastDiv dQW, dQH, dCin;
     signed char dy[CONV_MAX_TAPS], dx[CONV_MAX_TAPS];
 };
@@ -608,8 +609,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const T* __restrict__ X
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
-    const int pk_begin = blockIdx.z * g.Pper;
+    // 1-D grid, remapped so that each XCD owns a contiguous range of block ids: all (cout tile, column tile)
+    // blocks of one K-split read the SAME pixels of dY / X, so they should share one XCD's L2
+    // (the round-robin dispatch otherwise makes every XCD fetch every pixel range: 6x fabric over-fetch).
+    int bid = blockIdx.x;
+    {
+        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bid & 7, k = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    const int tx = bid % g.ntn, ty = (bid / g.ntn) % g.ntm, tz = bid / (g.ntn * g.ntm);
+    const int n0 = tx * BN, m0 = ty * BM;
+    const int pk_begin = tz * g.Pper;
     const int pk_end = min(g.P, pk_begin + g.Pper);
 
     // per-thread block descriptors (fixed over the K loop)
@@ -904,7 +914,8 @@ static void launch_wgrad(const void* x, const void* dy, float* dw, WgradGeom& g,
     per = ((per + BKP - 1) / BKP) * BKP;
     sk = (g.P + per - 1) / per;
     g.Pper = per;
-    const dim3 grid((g.NC + bn - 1) / bn, (g.Cout + bm - 1) / bm, sk), block(256);
+    g.ntn = (g.NC + bn - 1) / bn; g.ntm = (g.Cout + bm - 1) / bm; g.nsk = sk;
+    const dim3 grid(g.ntn * g.ntm * sk), block(256);
     const T* xx = (const T*)x; const T* yy = (const T*)dy;
     if (tallM) {
         if (wideN) hipLaunchKernelGGL((conv_wgrad_kernel<T, 128, 128>), grid, block, 0, s, xx, yy, dw, g);

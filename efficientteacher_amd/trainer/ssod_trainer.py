@@ -7,6 +7,8 @@ backward -> (every ``accumulate`` iterations) SGD step, ModelEMA update, semi-EM
 Everything between the two image batches arriving and the optimizer step is device-resident and
 stream-ordered: no ``.cpu()``, no per-detection python loops, no deepcopy of the image batches.
 """
+from contextlib import nullcontext as _nullcontext
+
 import numpy as np
 import torch
 
@@ -39,6 +41,13 @@ class SSODTrainer(Trainer):
         self.fixed_accumulate = cfg.SSOD.fixed_accumulate
         self.extra_teacher_models = []
         self.teacher_pred_hook = None      # optional callable(teacher_pred) -> teacher_pred (bench: synthetic scores)
+        self.overlap_teacher = True        # teacher forward + pseudo labels on a second stream
+        self._side = None
+
+    def _side_stream(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return self._side
 
     def build_model(self, cfg, device):
         super().build_model(cfg, device)            # student + ModelEMA (the teacher is self.ema.ema)
@@ -81,17 +90,27 @@ class SSODTrainer(Trainer):
                        pbar=None, callbacks=None):
         n_img = imgs.shape[0]
         height, width = unlabeled_imgs.shape[2], unlabeled_imgs.shape[3]
-        # 1 teacher forward (ssod_trainer.py:595-599): EMA model, eval mode, no grad
-        with torch.no_grad():
+        # 1+2 teacher forward (ssod_trainer.py:595-599: EMA model, eval, no grad) and pseudo labels (:618).
+        # Their result is first needed by the unsupervised loss, AFTER the student forward, so on a GPU
+        # they run on a second HIP stream next to it: the teacher's HBM-bound 1x1 layers and partially
+        # filled last waves interleave with the student's MFMA-bound kernels.
+        side = self._side_stream() if self.cuda and self.overlap_teacher else None
+        cur = torch.cuda.current_stream(self.device) if side is not None else None
+        if side is not None:
+            side.wait_stream(cur)
+        with torch.no_grad(), (torch.cuda.stream(side) if side is not None else _nullcontext()):
             (teacher_pred, _), _ = self.ema.ema(unlabeled_imgs_ori, augment=False)
             if self.teacher_pred_hook is not None:
                 teacher_pred = self.teacher_pred_hook(teacher_pred)
-        # 2 pseudo labels (:618), device resident
-        t9, valid = self.pseudo_label_creator.create_pseudo_label_padded(teacher_pred, unlabeled_M, width, height)
-        has_targets = valid.any().float()            # == not invalid_target_shape, as a device flag
+            t9, valid = self.pseudo_label_creator.create_pseudo_label_padded(teacher_pred, unlabeled_M, width, height)
+            has_targets = valid.any().float()        # == not invalid_target_shape, as a device flag
         # 3 student forward on the concatenated batch (:623-627)
         total_imgs = torch.cat([imgs, unlabeled_imgs], 0)
         total_pred, total_feature = self.model(total_imgs)
+        if side is not None:
+            cur.wait_stream(side)
+            for t in (t9, valid, has_targets):
+                t.record_stream(cur)
         sup_pred, sup_feature, un_sup_pred, un_sup_feature = self.split_predict_and_feature(total_pred, total_feature, n_img)
         # 4 losses (:628-649); the zero-weighted domain losses (:631-636) contribute nothing
         sup_loss, sup_loss_items = self.compute_loss(sup_pred, targets.to(self.device))

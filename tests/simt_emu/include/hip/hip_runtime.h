@@ -214,6 +214,7 @@ static inline void __threadfence() {}
 static inline void __threadfence_block() {}
 
 #define __expf(x) expf(x)
+#define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 #define __logf(x) logf(x)
 static inline float __fdividef(float a, float b) { return a / b; }
 static inline float __frcp_rn(float a) { return 1.0f / a; }
