@@ -130,19 +130,26 @@ def main():
     ap.add_argument("--per-rank", type=int, default=32, help="labeled (= unlabeled) images per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="run the teacher on the main stream (A/B)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); 'gloo' lets two "
+                    "ranks share ONE GPU to exercise the N>1 code path where only a single GPU is available")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", 1))
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(a.backend)
 
     from efficientteacher_amd import ops
-    cfg, tr = build_trainer(device, rank, world, local_rank, a.per_rank)
+    cfg, tr = build_trainer(device, rank, world, dev_index, a.per_rank)
     rng = np.random.default_rng(1234 + rank)
     S = cfg.Dataset.img_size
     Bl = Bu = a.per_rank

@@ -611,9 +611,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const T* __restrict__ X
     const int wm = wave / WN, wn = wave % WN;
     // 1-D grid, remapped so that each XCD owns a contiguous range of block ids: all (cout tile, column tile)
     // blocks of one K-split read the SAME pixels of dY / X, so they should share one XCD's L2
-    // (the round-robin dispatch otherwise makes every XCD fetch every pixel range: 6x fabric over-fetch).
+    // (the round-robin dispatch otherwise makes every XCD fetch every pixel range).
     int bid = blockIdx.x;
-    {
+    if (g.T == 1) {      // measured: helps the 1x1 layers (few tiles per K-split), not the 3x3 ones
         const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bid & 7, k = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
     }

@@ -160,10 +160,12 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const T* __restr
     const int cv = (int)(gt % CV);
     long long p = gt / CV;
     const long long pstep = ((long long)gridDim.x * 256) / CV;
-    float sc[N], sh[N], mu[N], is[N], s1[N], s2[N];
+    // accumulate s1 = sum(du) and s2r = sum(du * y); sum(du * xhat) = invstd * (s2r - mean * s1) is formed once
+    // per thread at the end, so mean / invstd stay out of the streaming loop (fewer live registers)
+    float sc[N], sh[N], s1[N], s2[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        sc[i] = scale[cv * N + i]; sh[i] = shift[cv * N + i]; mu[i] = mean[cv * N + i]; is[i] = invstd[cv * N + i];
+        sc[i] = scale[cv * N + i]; sh[i] = shift[cv * N + i];
         s1[i] = 0.f; s2[i] = 0.f;
     }
     for (; p + pstep < P; p += 2 * pstep) {          // two pixels in flight per thread
@@ -177,7 +179,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const T* __restr
             const float du = g[i] * act_grad(v[i] * sc[i] + sh[i], act);
             const float du2 = g2[i] * act_grad(v2[i] * sc[i] + sh[i], act);
             s1[i] += du + du2;
-            s2[i] += du * ((v[i] - mu[i]) * is[i]) + du2 * ((v2[i] - mu[i]) * is[i]);
+            s2[i] += du * v[i] + du2 * v2[i];
         }
     }
     for (; p < P; p += pstep) {
@@ -188,11 +190,15 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const T* __restr
         for (int i = 0; i < N; ++i) {
             const float du = g[i] * act_grad(v[i] * sc[i] + sh[i], act);
             s1[i] += du;
-            s2[i] += du * ((v[i] - mu[i]) * is[i]);
+            s2[i] += du * v[i];
         }
     }
 #pragma unroll
-    for (int i = 0; i < N; ++i) { atomicAdd(&acc[0][cv * N + i], s1[i]); atomicAdd(&acc[1][cv * N + i], s2[i]); }
+    for (int i = 0; i < N; ++i) {
+        const float mu = mean[cv * N + i], is = invstd[cv * N + i];
+        atomicAdd(&acc[0][cv * N + i], s1[i]);
+        atomicAdd(&acc[1][cv * N + i], is * (s2[i] - mu * s1[i]));
+    }
     __syncthreads();
     for (int i = threadIdx.x; i < C; i += 256) {
         part[((size_t)blockIdx.x * 2 + 0) * C + i] = acc[0][i];
