@@ -750,6 +750,168 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const T* __restrict__ X
         }
 }
 
+// ---- wgrad, bf16, LDS-DMA staging + transposing LDS reads -------------------------------------------------
+// Same GEMM as conv_wgrad_kernel (dW[cout, (tap,ci)] += sum_pixel dY[pixel,cout] * X[gather(pixel,tap),ci]) but the
+// operand tiles stay in their natural [pixel][channel] order in LDS: they are staged with
+// global_load_lds_dwordx4 (a wave lands 4 pixel rows of 256 contiguous bytes per instruction) and the
+// K(=pixel)-contiguous MFMA fragments are produced by ds_read_b64_tr_b16, gfx950's transposing LDS read:
+// a 16-lane group reads a [4 pixels][16 channels] block (lane t: pixel t/4, channels 4*(t%4)..+3, 8 bytes)
+// and lane c receives channel c of the 4 pixels.  No VGPR staging, no register transposes, no ds_write.
+// The 16-byte slots of a pixel row are XOR-swizzled by the pixel index (applied to the DMA SOURCE and to the
+// read address) so that the 8 row segments a half-wave reads cover all 64 banks exactly once.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+template <int SLOTS> __device__ __forceinline__ int tr_swz(int p) {
+    if constexpr (SLOTS >= 16) return 4 * (p & 3);
+    else return 4 * ((p >> 1) & 1);
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ DY,
+                                                            float* __restrict__ DW, const uint16_t* __restrict__ ZERO,
+                                                            WgradGeom g) {
+    constexpr int WM = 2, WN = 2, BKP = 64;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int SA = BM / 8, SB = BN / 8;            // 16-byte slots per pixel row of the A / B tile
+    constexpr int RPA = 256 / SA, RPB = 256 / SB;      // pixel rows staged per pass of the 256 threads
+    constexpr int RA = BKP / RPA, RB = BKP / RPB;      // LDS-DMA instructions per thread per chunk
+    constexpr int A_VEC = BKP * SA, B_VEC = BKP * SB;  // tile sizes in 16-byte vectors
+    __shared__ __attribute__((aligned(16))) u32x4 lds_raw[2 * (A_VEC + B_VEC)];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    int bid = blockIdx.x;
+    if (g.T == 1) {
+        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bid & 7, k = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    const int tx = bid % g.ntn, ty = (bid / g.ntn) % g.ntm, tz = bid / (g.ntn * g.ntm);
+    const int n0 = tx * BN, m0 = ty * BM;
+    const int pk_begin = tz * g.Pper;
+    const int pk_end = min(g.P, pk_begin + g.Pper);
+
+    // per-thread staging descriptors: which (pixel row, logical 8-channel group) this lane fetches
+    int a_pl[RA], a_co[RA];
+    bool a_ok[RA];
+#pragma unroll
+    for (int j = 0; j < RA; ++j) {
+        a_pl[j] = tid / SA + j * RPA;
+        const int ls = (tid % SA) ^ tr_swz<SA>(a_pl[j]);
+        a_co[j] = m0 + ls * 8;
+        a_ok[j] = a_co[j] < g.Cout;                    // Cout % 8 == 0 (host)
+    }
+    int b_pl[RB], b_ci[RB], b_dy[RB], b_dx[RB];
+    bool b_ok[RB];
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+        b_pl[j] = tid / SB + j * RPB;
+        const int ls = (tid % SB) ^ tr_swz<SB>(b_pl[j]);
+        const int col = n0 + ls * 8;
+        b_ok[j] = col < g.NC;
+        const uint32_t cc = b_ok[j] ? col : 0;
+        const uint32_t tap = fdiv(cc, g.dCin);
+        b_ci[j] = cc - tap * g.Cin;
+        b_dy[j] = g.dy[tap];
+        b_dx[j] = g.dx[tap];
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+    auto stage = [&](u32x4* dstA, u32x4* dstB, int pk0) {
+        u32x4* const wa = dstA + wave * 64;
+        u32x4* const wb = dstB + wave * 64;
+#pragma unroll
+        for (int j = 0; j < RA; ++j) {
+            const int p = pk0 + a_pl[j];
+            const bool ok = a_ok[j] && p < pk_end;
+            const uint16_t* src = ok ? DY + ((long long)p * g.ldy + a_co[j]) : ZERO;
+            et_glds16(src, wa + j * 256);
+        }
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+            const int p = pk0 + b_pl[j];
+            const uint32_t pp = min(p, g.P - 1);
+            const uint32_t t1 = fdiv(pp, g.dQW), qx = pp - t1 * g.QW;
+            const uint32_t n = fdiv(t1, g.dQH), qy = t1 - n * g.QH;
+            const int iy = qy * g.isy + b_dy[j], ix = qx * g.isx + b_dx[j];
+            const bool ok = b_ok[j] && p < pk_end && (unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW;
+            const uint16_t* src = ok ? X + ((((long long)n * g.IH + iy) * g.IW + ix) * g.ldx + b_ci[j]) : ZERO;
+            et_glds16(src, wb + j * 256);
+        }
+    };
+
+    // fragment addressing (bytes inside one operand tile): lane l reads, for k-step ks and half r,
+    // pixel 16*ks + 8*(l>>5) + 4*r + ((l&15)>>2), channels c0 + 16*((l>>4)&1) + 4*(l&3) .. +3
+    const int fp = 8 * (lane >> 5) + ((lane & 15) >> 2);
+    const int fc = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    auto frag = [&](const char* tile, int slots, int ks, int c0, auto swz) -> s16x8 {
+        s16x8 o;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int p = 16 * ks + 4 * r + fp;
+            const int ch = c0 + fc;
+            const int off = (p * slots + ((ch >> 3) ^ swz(p))) * 16 + (ch & 4) * 2;
+            const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + off));
+            o[4 * r + 0] = v[0]; o[4 * r + 1] = v[1]; o[4 * r + 2] = v[2]; o[4 * r + 3] = v[3];
+        }
+        return o;
+    };
+    auto mma = [&](const u32x4* bufA, const u32x4* bufB) {
+        const char* ta = (const char*)bufA;
+        const char* tb = (const char*)bufB;
+#pragma unroll
+        for (int ks = 0; ks < BKP / 16; ++ks) {
+            s16x8 af[TM], bf[TN];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) af[tm] = frag(ta, SA, ks, wm * (BM / WM) + tm * 32, [](int p) { return tr_swz<SA>(p); });
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) bf[tn] = frag(tb, SB, ks, wn * (BN / WN) + tn * 32, [](int p) { return tr_swz<SB>(p); });
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[tm]),
+                                                                         __builtin_bit_cast(bf16x8, bf[tn]), acc[tm][tn], 0, 0, 0);
+        }
+    };
+
+    u32x4* const A0 = lds_raw;
+    u32x4* const B0 = lds_raw + A_VEC;
+    u32x4* const A1 = lds_raw + A_VEC + B_VEC;
+    u32x4* const B1 = A1 + A_VEC;
+    const int nchunks = (pk_end - pk_begin + BKP - 1) / BKP;
+    if (nchunks > 0) stage(A0, B0, pk_begin);
+    et_wait_vmem();
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const bool odd = c & 1;
+        if (c + 1 < nchunks) stage(odd ? A0 : A1, odd ? B0 : B1, pk_begin + (c + 1) * BKP);
+        mma(odd ? A1 : A0, odd ? B1 : B0);
+        et_wait_vmem();
+        __syncthreads();
+    }
+    if (nchunks <= 0) return;
+    const int l31 = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = m0 + wm * (BM / WM) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const int col = n0 + wn * (BN / WN) + tn * 32 + l31;
+                if (co < g.Cout && col < g.NC) atomicAdd(DW + ((size_t)co * g.NC + col), acc[tm][tn][r]);
+            }
+        }
+}
+
 // ---- small helpers ---------------------------------------------------------------------------------
 // W [Cout][TT][Cin] -> WT [Cin][TT][Cout]  (operand of dgrad)
 template <typename T>
@@ -897,7 +1059,7 @@ extern "C" int et_conv2d_dgrad(const void* dy, const void* wT, void* dx, int dty
 }
 
 template <typename T>
-static void launch_wgrad(const void* x, const void* dy, float* dw, WgradGeom& g, hipStream_t s) {
+static void launch_wgrad(const void* x, const void* dy, float* dw, const void* zero16, WgradGeom& g, hipStream_t s) {
     constexpr int VEC = et_elem<T>::VEC;
     constexpr int BKP = 8 * VEC;
     const bool wideN = g.NC > 64;
@@ -917,6 +1079,21 @@ static void launch_wgrad(const void* x, const void* dy, float* dw, WgradGeom& g,
     g.ntn = (g.NC + bn - 1) / bn; g.ntm = (g.Cout + bm - 1) / bm; g.nsk = sk;
     const dim3 grid(g.ntn * g.ntm * sk), block(256);
     const T* xx = (const T*)x; const T* yy = (const T*)dy;
+    // bf16 + zero page: LDS-DMA staging with transposing LDS reads (ET_WGRAD_TR=0 forces the register path)
+    static const int use_tr = getenv("ET_WGRAD_TR") ? atoi(getenv("ET_WGRAD_TR")) : 1;
+    if constexpr (sizeof(T) == 2) {
+        if (use_tr && zero16) {
+            const uint16_t* z = (const uint16_t*)zero16;
+            if (tallM) {
+                if (wideN) hipLaunchKernelGGL((conv_wgrad_tr_kernel<128, 128>), grid, block, 0, s, xx, yy, dw, z, g);
+                else hipLaunchKernelGGL((conv_wgrad_tr_kernel<128, 64>), grid, block, 0, s, xx, yy, dw, z, g);
+            } else {
+                if (wideN) hipLaunchKernelGGL((conv_wgrad_tr_kernel<64, 128>), grid, block, 0, s, xx, yy, dw, z, g);
+                else hipLaunchKernelGGL((conv_wgrad_tr_kernel<64, 64>), grid, block, 0, s, xx, yy, dw, z, g);
+            }
+            return;
+        }
+    }
     if (tallM) {
         if (wideN) hipLaunchKernelGGL((conv_wgrad_kernel<T, 128, 128>), grid, block, 0, s, xx, yy, dw, g);
         else hipLaunchKernelGGL((conv_wgrad_kernel<T, 128, 64>), grid, block, 0, s, xx, yy, dw, g);
@@ -927,7 +1104,8 @@ static void launch_wgrad(const void* x, const void* dy, float* dw, WgradGeom& g,
 }
 
 extern "C" int et_conv2d_wgrad(const void* x, const void* dy, float* dw, int dtype, int N, int IH, int IW, int Cin,
-                               int ldx, int Cout, int KH, int KW, int stride, int pad, int ldy, et_stream_t stream) {
+                               int ldx, int Cout, int KH, int KW, int stride, int pad, int ldy, const void* zero16,
+                               et_stream_t stream) {
     // dw[co,ky,kx,ci] += sum_{n,oy,ox} dy[n,oy,ox,co] * x[n,oy*s+ky-pad,ox*s+kx-pad,ci]   (fp32, atomic)
     if (!x || !dy || !dw) return -1;
     if (KH * KW > CONV_MAX_TAPS || stride < 1 || N <= 0) return -2;
@@ -945,8 +1123,8 @@ extern "C" int et_conv2d_wgrad(const void* x, const void* dy, float* dw, int dty
             g.dx[ky * KW + kx] = (signed char)(kx - pad);
         }
     if (g.P <= 0) return 0;
-    if (dtype == ET_F32) launch_wgrad<float>(x, dy, dw, g, (hipStream_t)stream);
-    else if (dtype == ET_BF16) launch_wgrad<uint16_t>(x, dy, dw, g, (hipStream_t)stream);
+    if (dtype == ET_F32) launch_wgrad<float>(x, dy, dw, zero16, g, (hipStream_t)stream);
+    else if (dtype == ET_BF16) launch_wgrad<uint16_t>(x, dy, dw, zero16, g, (hipStream_t)stream);
     else return -2;
     ET_CHECK_LAUNCH();
     return 0;

@@ -36,13 +36,21 @@ class KernelTimer:
 TIMER = None
 
 
-def _gemm_tag(kind, x_dtype, cout, cin_padded):
+def _gemm_tag(x_dtype, cout, cin_padded, taps, mixed=False):
+    """Name of the kernel instantiation csrc/conv.hip:launch_gemm picks for this GEMM, spelled the way
+    rocprofv3 prints it, so that bench.py's HIP-event timing can be checked against the rocprof summary."""
+    import os
     vec = 4 if x_dtype == torch.float32 else 8
     cv = cin_padded // vec
     bkv = 8 if cv % 8 == 0 else 4
     ut = "true" if cv % 4 == 0 else "false"
     t = "float" if x_dtype == torch.float32 else "unsigned short"
-    return f"conv_gemm_kernel<{t}, 128, {128 if cout > 64 else 64}, 2, 2, {bkv}, {ut}>"
+    narrow_k = int(os.environ.get("ET_CONV_NARROW_K", "256"))
+    wide = cout > 64 and not (narrow_k > 0 and taps * cin_padded <= narrow_k)
+    name = "conv_gemm_glds_kernel" if int(os.environ.get("ET_CONV_GLDS", "1")) else "conv_gemm_kernel"
+    if mixed:   # stride-2 dgrad: 4 parity-class launches whose tap counts (hence tiles) differ
+        return f"{name}<{t}, ...> (stride-2 dgrad parity classes)"
+    return f"{name}<{t}, 128, {128 if wide else 64}, 2, 2, {bkv}, {ut}>"
 
 
 _ZERO_PAGES = {}
@@ -92,7 +100,7 @@ def conv2d_fwd(x, w, stride, pad, *, scale=None, bias=None, act=ACT_NONE, residu
         rows = lib.et_conv2d_stats_rows(N, OH, OW)
         stats = torch.empty((rows, 2, Cout), dtype=torch.float32, device=x.device)
     ldr = _nhwc(residual) if residual is not None else 0
-    ev = TIMER.span(_gemm_tag("fwd", x.dtype, Cout, Cin), 2.0 * N * OH * OW * Cout * Cin * KH * KW) if TIMER else None
+    ev = TIMER.span(_gemm_tag(x.dtype, Cout, Cin, KH * KW), 2.0 * N * OH * OW * Cout * Cin * KH * KW) if TIMER else None
     if ev:
         ev[0].record()
     _lib.check(lib.et_conv2d_fwd(_lib.ptr(x), _lib.ptr(w), _lib.ptr(out), et_dtype(x), N, IH, IW, Cin, _nhwc(x),
@@ -123,7 +131,7 @@ def conv2d_dgrad(dy, wT, in_hw, stride, pad, *, out=None, accumulate=False):
     if out is None:
         assert not accumulate
         out = torch.empty((N, IH, IW, Cin), dtype=dy.dtype, device=dy.device)
-    ev = TIMER.span(_gemm_tag("dgrad", dy.dtype, Cin, Cout), 2.0 * N * OH * OW * Cout * Cin * KH * KW,
+    ev = TIMER.span(_gemm_tag(dy.dtype, Cin, Cout, KH * KW, mixed=stride > 1), 2.0 * N * OH * OW * Cout * Cin * KH * KW,
                     stride * stride) if TIMER else None
     if ev:
         ev[0].record()
@@ -141,12 +149,12 @@ def conv2d_wgrad(x, dy, dw, ksize, stride, pad):
     _, OH, OW, Cout = dy.shape
     assert dw.dtype == torch.float32 and dw.is_contiguous() and dw.shape == (Cout, ksize, ksize, Cin)
     assert x.dtype == dy.dtype
-    ev = TIMER.span("conv_wgrad_kernel", 2.0 * N * OH * OW * Cout * Cin * ksize * ksize) if TIMER else None
+    ev = TIMER.span("conv_wgrad_tr_kernel" if x.dtype == torch.bfloat16 else "conv_wgrad_kernel", 2.0 * N * OH * OW * Cout * Cin * ksize * ksize) if TIMER else None
     if ev:
         ev[0].record()
     _lib.check(_lib.load().et_conv2d_wgrad(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), et_dtype(x), N, IH, IW, Cin,
-                                           _nhwc(x), Cout, ksize, ksize, stride, pad, _nhwc(dy), _lib.stream(x)),
-               "et_conv2d_wgrad")
+                                           _nhwc(x), Cout, ksize, ksize, stride, pad, _nhwc(dy),
+                                           _lib.ptr(zero_page(x.device)), _lib.stream(x)), "et_conv2d_wgrad")
     if ev:
         ev[1].record()
     return dw

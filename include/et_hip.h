@@ -96,7 +96,8 @@ int et_conv2d_dgrad(const void* dy, const void* wT, void* dx, int dtype, int N, 
                     int ldx, int Cout, int KH, int KW, int stride, int pad, int ldy, int accumulate,
                     const void* zero16, et_stream_t stream);
 int et_conv2d_wgrad(const void* x, const void* dy, float* dw, int dtype, int N, int IH, int IW, int Cin,
-                    int ldx, int Cout, int KH, int KW, int stride, int pad, int ldy, et_stream_t stream);
+                    int ldx, int Cout, int KH, int KW, int stride, int pad, int ldy, const void* zero16,
+                    et_stream_t stream);
 int et_weight_transpose(const void* w, void* wT, int dtype, int Cout, int taps, int Cin, et_stream_t stream);
 /* out[c] += sum_p x[p*ld + c]  (bias gradient of the Detect convs) */
 int et_colsum(const void* x, int dtype, int P, int C, int ld, float* out, et_stream_t stream);

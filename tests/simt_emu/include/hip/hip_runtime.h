@@ -237,6 +237,28 @@ static inline void emu_global_load_lds(const void* g, void* l, unsigned size, in
 #define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) emu_global_load_lds((const void*)(g), (void*)(l), (size), (off))
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 
+// ds_read_b64_tr_b16 (gfx950), semantics PROBED on hardware (tools/probe/probe_tr.py, profiles/r01_probe_tr.json):
+// every lane loads the 8 bytes (4 x 16-bit) at its own LDS address; inside each 16-lane group the
+// 16 x 4 elements are redistributed as  out[lane c][j] = in[lane 4*j + c/4][c % 4]   (a 4x16 -> 16x4 transpose
+// when lane t holds row t/4, columns 4*(t%4)..+3 of a row-major 4x16 block).
+typedef short emu_s16x4 __attribute__((ext_vector_type(4)));
+static inline emu_s16x4 emu_ds_read_tr16_b64(const void* p) {
+    emu::Wave& w = emu::mywave();
+    const int lane = emu::cur().lane;
+    memcpy(w.buf[lane], p, 8);
+    emu::wave_sync();
+    emu_s16x4 r;
+    const int gb = lane & ~15, c = lane & 15;
+    for (int j = 0; j < 4; ++j) {
+        short v;
+        memcpy(&v, w.buf[gb + 4 * j + (c >> 2)] + 2 * (c & 3), 2);
+        r[j] = v;
+    }
+    emu::wave_sync();
+    return r;
+}
+#define __builtin_amdgcn_ds_read_tr16_b64_v4i16(p) emu_ds_read_tr16_b64((const void*)(p))
+
 // ----------------------------------------------------------------------------------- MFMA
 typedef __attribute__((ext_vector_type(16))) float emu_f32x16;
 typedef __attribute__((ext_vector_type(4))) float emu_f32x4;
