@@ -12,7 +12,7 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libet_hip.so")
+LIB_PATH = os.environ.get("ET_HIP_LIB") or os.path.join(_HERE, "libet_hip.so")   # ET_HIP_LIB: experiment builds
 
 ET_F32, ET_BF16 = 0, 1
 

@@ -94,18 +94,35 @@ __device__ __forceinline__ void mma_chunk(const u32x4* __restrict__ sm, f32x16 (
                                           int wm, int wn, int lane) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     const int l31 = lane & 31, g = lane >> 5;
-#pragma unroll
-    for (int kk = 0; kk < BKV / 2; ++kk) {
-        u32x4 af[TM], bf[TN];
+    // Software-pipelined over the k-steps: the fragments of step kk+1 are requested BEFORE the MFMAs of step
+    // kk are issued (two fragment register sets), so the LDS latency overlaps TM*TN MFMAs instead of
+    // stalling the wave in front of them.  The sched_barrier keeps the compiler from sinking the reads
+    // back below the MFMAs; the waitcnt pass then waits for the older set only (lgkmcnt(TM+TN)).
+    u32x4 af[2][TM], bf[2][TN];
+    auto fetch = [&](int kk, int set) {
+#if defined(ET_ABLATE) && (ET_ABLATE == 4 || ET_ABLATE == 5)
+        for (int tm = 0; tm < TM; ++tm) af[set][tm] = mk4(kk, lane, kk, lane);
+        for (int tn = 0; tn < TN; ++tn) bf[set][tn] = mk4(lane, kk, lane, kk);
+        return;
+#endif
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
             const int r = wm * (BM / WM) + tm * 32 + l31;
-            af[tm] = sm[r * BKV + ((kk * 2 + g) ^ lds_swz<BKV>(r))];
+            af[set][tm] = sm[r * BKV + ((kk * 2 + g) ^ lds_swz<BKV>(r))];
         }
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
             const int r = wn * (BN / WN) + tn * 32 + l31;
-            bf[tn] = sm[(BM + r) * BKV + ((kk * 2 + g) ^ lds_swz<BKV>(r))];
+            bf[set][tn] = sm[(BM + r) * BKV + ((kk * 2 + g) ^ lds_swz<BKV>(r))];
+        }
+    };
+    fetch(0, 0);
+#pragma unroll
+    for (int kk = 0; kk < BKV / 2; ++kk) {
+        const int cur = kk & 1;
+        if (kk + 1 < BKV / 2) {
+            fetch(kk + 1, cur ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
@@ -113,12 +130,12 @@ __device__ __forceinline__ void mma_chunk(const u32x4* __restrict__ sm, f32x16 (
             for (int tn = 0; tn < TN; ++tn) {
                 if constexpr (sizeof(T) == 2) {
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                        __builtin_bit_cast(bf16x8, af[tm]), __builtin_bit_cast(bf16x8, bf[tn]), acc[tm][tn], 0, 0, 0);
+                        __builtin_bit_cast(bf16x8, af[cur][tm]), __builtin_bit_cast(bf16x8, bf[cur][tn]), acc[tm][tn], 0, 0, 0);
                 } else {
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(af[tm].x), __uint_as_float(bf[tn].x), acc[tm][tn], 0, 0, 0);
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(af[tm].y), __uint_as_float(bf[tn].y), acc[tm][tn], 0, 0, 0);
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(af[tm].z), __uint_as_float(bf[tn].z), acc[tm][tn], 0, 0, 0);
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(af[tm].w), __uint_as_float(bf[tn].w), acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(af[cur][tm].x), __uint_as_float(bf[cur][tn].x), acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(af[cur][tm].y), __uint_as_float(bf[cur][tn].y), acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(af[cur][tm].z), __uint_as_float(bf[cur][tn].z), acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(af[cur][tm].w), __uint_as_float(bf[cur][tn].w), acc[tm][tn], 0, 0, 0);
                 }
             }
     }
@@ -258,8 +275,18 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BM / WM / 32][BN / W
             for (int w = 0; w < WM; ++w) { s += red[(w * BN + tid) * 2]; q += red[(w * BN + tid) * 2 + 1]; }
             const int co = n0 + tid;
             if (co < g.Cout) {
-                ep.stats[((size_t)bx * 2 + 0) * g.Cout + co] = s;
-                ep.stats[((size_t)bx * 2 + 1) * g.Cout + co] = q;
+                // the partial buffer has one row per 128 output rows (et_conv2d_stats_rows): a taller tile
+                // writes its sums into its first row and zeros the others it covers
+                constexpr int SR = BM / 128;
+                const int nrows = (g.M + 127) / 128;
+                ep.stats[((size_t)bx * SR * 2 + 0) * g.Cout + co] = s;
+                ep.stats[((size_t)bx * SR * 2 + 1) * g.Cout + co] = q;
+#pragma unroll
+                for (int e = 1; e < SR; ++e)
+                    if (bx * SR + e < nrows) {
+                        ep.stats[((size_t)(bx * SR + e) * 2 + 0) * g.Cout + co] = 0.f;
+                        ep.stats[((size_t)(bx * SR + e) * 2 + 1) * g.Cout + co] = 0.f;
+                    }
             }
         }
     }
@@ -425,7 +452,18 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const T* __restrict__ X,
 // fetches the logical K-vector  slot ^ swz(row)  (same 128-byte global segment, so coalescing is
 // unchanged) and the fragment reads keep using  physical = logical ^ swz(row).  Out-of-image taps, rows
 // beyond M and channels beyond Cout fetch from a 16-byte zero page instead of branching.
-template <typename T, int BM, int BN, int WM, int WN, int BKV, bool UTAP>
+// s_waitcnt vmcnt(N): at most N of this wave's vector-memory operations (here: LDS-DMA loads) still in flight
+template <int N> __device__ __forceinline__ void et_wait_vmem_le() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 0xF) | ((N >> 4) << 14));
+}
+
+// NS = depth of the LDS ring of K-chunks.  Chunk c+NS-1 is issued while chunk c is being multiplied, so up to
+// NS-1 chunks per workgroup are in flight all the time.  What bounds this kernel is bytes in flight per CU
+// over the loaded L2/fabric latency (measured: ~10 TB/s of L2->LDS traffic with 2 x 32 KB bursts per CU,
+// MFMA busy ~30 %), not LDS or MFMA issue -- hence deeper rings and, where the layer has the rows, a
+// 256-row tile (1.33x the flops per staged byte).
+template <typename T, int BM, int BN, int WM, int WN, int BKV, int NS, bool UTAP>
 __global__ __launch_bounds__(256) void conv_gemm_glds_kernel(const T* __restrict__ X, const T* __restrict__ W,
                                                              T* __restrict__ Y, const T* __restrict__ ZERO,
                                                              GatherGeom g, Epilogue ep) {
@@ -435,10 +473,10 @@ __global__ __launch_bounds__(256) void conv_gemm_glds_kernel(const T* __restrict
     constexpr int RA = BM / RPT, RB = BN / RPT;
     constexpr int STAGE_VEC = (BM + BN) * BKV;
     constexpr int EPI_VEC = ((BM / WM) * (BN + 4) * 4 + 15) / 16;
-    constexpr int LDS_VEC = 2 * STAGE_VEC > EPI_VEC ? 2 * STAGE_VEC : EPI_VEC;
+    constexpr int LDS_VEC = NS * STAGE_VEC > EPI_VEC ? NS * STAGE_VEC : EPI_VEC;
+    constexpr int PER = RA + RB;                 // LDS-DMA instructions per thread per chunk
+    static_assert(NS >= 2 && NS <= 5 && (NS - 2) * PER < 64, "ring depth");
     __shared__ __attribute__((aligned(16))) u32x4 lds_raw[LDS_VEC];
-    u32x4* const lds0 = lds_raw;
-    u32x4* const lds1 = lds_raw + STAGE_VEC;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -508,7 +546,11 @@ __global__ __launch_bounds__(256) void conv_gemm_glds_kernel(const T* __restrict
             }
             const bool ok = kok && a_ok[j] && (unsigned)(a_iy[j] + dy) < (unsigned)g.IH &&
                             (unsigned)(a_ix[j] + dx) < (unsigned)g.IW;
+#if defined(ET_ABLATE) && (ET_ABLATE == 3 || ET_ABLATE == 5)
+            const T* src = ZERO; (void)ok; (void)cv; (void)dy; (void)dx;
+#else
             const T* src = ok ? X + (a_off[j] + (dy * g.IW + dx) * g.ldx + cv * VEC) : ZERO;
+#endif
             et_glds16(src, wbase + j * 256);
         }
 #pragma unroll
@@ -526,7 +568,11 @@ __global__ __launch_bounds__(256) void conv_gemm_glds_kernel(const T* __restrict
                 wt = g.wt[tap];
             }
             const bool ok = kok && b_ok[j];
+#if defined(ET_ABLATE) && (ET_ABLATE == 3 || ET_ABLATE == 5)
+            const T* src = ZERO; (void)ok; (void)cv; (void)wt;
+#else
             const T* src = ok ? W + (b_off[j] + wt * g.Cin + cv * VEC) : ZERO;
+#endif
             et_glds16(src, wbase + BM * BKV + j * 256);
         }
     };
@@ -540,18 +586,33 @@ __global__ __launch_bounds__(256) void conv_gemm_glds_kernel(const T* __restrict
         }                                                                \
     }
 
-    stage(lds0, 0, tap_u, cv_u);
-    ET_ADVANCE_CURSOR();
-    et_wait_vmem();
-    __syncthreads();
+    // prologue: chunks 0 .. NS-2
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < nchunks) { stage(lds_raw + s * STAGE_VEC, s, tap_u, cv_u); ET_ADVANCE_CURSOR(); }
+    int rd = 0, wr = NS - 1;                       // ring slots of chunk c and of chunk c+NS-1
     for (int c = 0; c < nchunks; ++c) {
-        u32x4* const cur = (c & 1) ? lds1 : lds0;
-        u32x4* const nxt = (c & 1) ? lds0 : lds1;
-        if (c + 1 < nchunks) { stage(nxt, c + 1, tap_u, cv_u); ET_ADVANCE_CURSOR(); }
-        mma_chunk<T, BM, BN, WM, WN, BKV>(cur, acc, wm, wn, lane);
-        et_wait_vmem();          // this wave's DMA of chunk c+1 has landed ...
-        __syncthreads();         // ... and so has everybody else's; all reads of `cur` are done
+        // chunk c has landed once at most `ahead` younger chunks of this wave are still in flight
+        const int ahead = min(NS - 2, nchunks - 1 - c);
+        if constexpr (!UTAP) {
+            et_wait_vmem();                        // table loads share vmcnt on this path: no partial waits
+        } else {
+            if (NS >= 5 && ahead == 3) et_wait_vmem_le<(NS >= 5 ? 3 : 0) * PER>();
+            else if (NS >= 4 && ahead == 2) et_wait_vmem_le<(NS >= 4 ? 2 : 0) * PER>();
+            else if (NS >= 3 && ahead == 1) et_wait_vmem_le<(NS >= 3 ? 1 : 0) * PER>();
+            else et_wait_vmem();
+        }
+        __syncthreads();                           // ... for every wave; and all reads of slot `wr` (chunk c-1) are done
+#if !defined(ET_ABLATE) || (ET_ABLATE != 2)
+        if (c + NS - 1 < nchunks) { stage(lds_raw + wr * STAGE_VEC, c + NS - 1, tap_u, cv_u); ET_ADVANCE_CURSOR(); }
+#endif
+#if !defined(ET_ABLATE) || (ET_ABLATE != 1)
+        mma_chunk<T, BM, BN, WM, WN, BKV>(lds_raw + rd * STAGE_VEC, acc, wm, wn, lane);
+#endif
+        rd = rd + 1 == NS ? 0 : rd + 1;
+        wr = wr + 1 == NS ? 0 : wr + 1;
     }
+    __syncthreads();                               // the epilogue reuses the ring as its staging area
 #undef ET_ADVANCE_CURSOR
     conv_epilogue<T, BM, BN, WM, WN>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn);
 }
@@ -767,16 +828,17 @@ template <int SLOTS> __device__ __forceinline__ int tr_swz(int p) {
     else return 4 * ((p >> 1) & 1);
 }
 
-template <int BM, int BN>
-__global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ DY,
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_tr_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ DY,
                                                             float* __restrict__ DW, const uint16_t* __restrict__ ZERO,
                                                             WgradGeom g) {
-    constexpr int WM = 2, WN = 2, BKP = 64;
+    constexpr int NT = 64 * WM * WN, BKP = 64;       // threads per workgroup; pixels (GEMM-K) per chunk
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int SA = BM / 8, SB = BN / 8;            // 16-byte slots per pixel row of the A / B tile
-    constexpr int RPA = 256 / SA, RPB = 256 / SB;      // pixel rows staged per pass of the 256 threads
+    constexpr int RPA = NT / SA, RPB = NT / SB;        // pixel rows staged per pass of the workgroup
     constexpr int RA = BKP / RPA, RB = BKP / RPB;      // LDS-DMA instructions per thread per chunk
     constexpr int A_VEC = BKP * SA, B_VEC = BKP * SB;  // tile sizes in 16-byte vectors
+    static_assert(BKP % RPA == 0 && BKP % RPB == 0 && RPA >= 1 && RPB >= 1, "staging passes");
     __shared__ __attribute__((aligned(16))) u32x4 lds_raw[2 * (A_VEC + B_VEC)];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -832,7 +894,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(const uint16_t* __re
             const int p = pk0 + a_pl[j];
             const bool ok = a_ok[j] && p < pk_end;
             const uint16_t* src = ok ? DY + ((long long)p * g.ldy + a_co[j]) : ZERO;
-            et_glds16(src, wa + j * 256);
+            et_glds16(src, wa + j * NT);
         }
 #pragma unroll
         for (int j = 0; j < RB; ++j) {
@@ -843,7 +905,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(const uint16_t* __re
             const int iy = qy * g.isy + b_dy[j], ix = qx * g.isx + b_dx[j];
             const bool ok = b_ok[j] && p < pk_end && (unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW;
             const uint16_t* src = ok ? X + ((((long long)n * g.IH + iy) * g.IW + ix) * g.ldx + b_ci[j]) : ZERO;
-            et_glds16(src, wb + j * 256);
+            et_glds16(src, wb + j * NT);
         }
     };
 
@@ -963,16 +1025,41 @@ static int launch_gemm(const void* X, const void* W, void* Y, const void* zero16
     static const int narrow_k = getenv("ET_CONV_NARROW_K") ? atoi(getenv("ET_CONV_NARROW_K")) : 256;
     const bool wide = g.Cout > 64 && !(narrow_k > 0 && g.T * g.Cin <= narrow_k);
     const int bn = wide ? 128 : 64;
-    const dim3 grid((g.M + 127) / 128, (g.Cout + bn - 1) / bn), block(256);
     const T* x = (const T*)X; const T* w = (const T*)W; T* y = (T*)Y;
     // staging: LDS-DMA (global_load_lds) when the caller supplies a zero page, else VGPR staging.
     // ET_CONV_GLDS=0 forces the register-staged kernel (A/B knob).
     static const int use_glds = getenv("ET_CONV_GLDS") ? atoi(getenv("ET_CONV_GLDS")) : 1;
     const T* z = (const T*)zero16;
     const bool glds = use_glds && z != nullptr;
+    const dim3 block(256);
+    // ET_CONV_RING=<rows><kvec><depth> (e.g. 25683 = 256-row tile, 8-vector chunks, 3-deep ring): tuning knob
+    // for the bf16 LDS-DMA kernel, read once
+    static const int ring = getenv("ET_CONV_RING") ? atoi(getenv("ET_CONV_RING")) : 12882;
+    if constexpr (sizeof(T) == 2) {
+        if (glds && g.CV % 8 == 0 && ring != 12882) {
+#define ET_RING(BM_, BKV_, NS_)                                                                                       \
+    do {                                                                                                              \
+        const dim3 grid((g.M + BM_ - 1) / BM_, (g.Cout + bn - 1) / bn);                                               \
+        if (wide) hipLaunchKernelGGL((conv_gemm_glds_kernel<T, BM_, 128, 2, 2, BKV_, NS_, true>), grid, block, 0, s, x, w, y, z, g, ep); \
+        else hipLaunchKernelGGL((conv_gemm_glds_kernel<T, BM_, 64, 2, 2, BKV_, NS_, true>), grid, block, 0, s, x, w, y, z, g, ep);       \
+        return 0;                                                                                                     \
+    } while (0)
+            switch (ring) {
+                case 12883: ET_RING(128, 8, 3);
+                case 12843: ET_RING(128, 4, 3);
+                case 12844: ET_RING(128, 4, 4);
+                case 25683: ET_RING(256, 8, 3);
+                case 25644: ET_RING(256, 4, 4);
+                case 25645: ET_RING(256, 4, 5);
+                default: break;
+            }
+#undef ET_RING
+        }
+    }
+    const dim3 grid((g.M + 127) / 128, (g.Cout + bn - 1) / bn);
 #define ET_LAUNCH(BN_, WM_, WN_, BKV_, UT_)                                                                              \
     do {                                                                                                                  \
-        if (glds) hipLaunchKernelGGL((conv_gemm_glds_kernel<T, 128, BN_, WM_, WN_, BKV_, UT_>), grid, block, 0, s, x, w, y, z, g, ep); \
+        if (glds) hipLaunchKernelGGL((conv_gemm_glds_kernel<T, 128, BN_, WM_, WN_, BKV_, 2, UT_>), grid, block, 0, s, x, w, y, z, g, ep); \
         else hipLaunchKernelGGL((conv_gemm_kernel<T, 128, BN_, WM_, WN_, BKV_, UT_>), grid, block, 0, s, x, w, y, g, ep);  \
     } while (0)
     if (g.CV % 8 == 0) {
@@ -1064,13 +1151,44 @@ static void launch_wgrad(const void* x, const void* dy, float* dw, const void* z
     constexpr int BKP = 8 * VEC;
     const bool wideN = g.NC > 64;
     const bool tallM = g.Cout > 64;            // Cout <= 64 layers: a 64-row tile wastes no MFMA rows
-    const int bn = wideN ? 128 : 64, bm = tallM ? 128 : 64;
+    int bn = wideN ? 128 : 64, bm = tallM ? 128 : 64;
+    // bf16 + zero page: LDS-DMA staging with transposing LDS reads (ET_WGRAD_TR=0 forces the register path)
+    static const int use_tr = getenv("ET_WGRAD_TR") ? atoi(getenv("ET_WGRAD_TR")) : 1;
+    const bool tr = sizeof(T) == 2 && use_tr && zero16;
+    // 256-wide tiles (8 waves, one workgroup per CU): half the L2->LDS bytes per flop of the 128^2 tile.
+    // ET_WGRAD_BIG: 0 = never, 1 = where the layer has the rows/columns (tuning knob)
+    static const int big = getenv("ET_WGRAD_BIG") ? atoi(getenv("ET_WGRAD_BIG")) : 1;
+    if (tr && big) {
+        // measured (B=64 YOLOv5l shapes): the 256^2 tile wins on the 3x3 layers with >= 256 output channels
+        // (691-765 TFLOP/s vs ~600), 128x256 on the 128-channel stride-1 3x3 layers; 1x1 layers keep 128^2
+        if (g.T > 1 && g.Cout >= 256 && g.NC >= 256) { bm = 256; bn = 256; }
+        else if (g.T > 1 && g.isy == 1 && g.NC >= 256 && g.Cout == 128 && (big & 1)) bn = 256;
+        if (big & 2) { if (g.NC >= 256) bn = 256; if (g.Cout >= 256) bm = 256; }   // experiment: always
+    }
     const int tiles = ((g.NC + bn - 1) / bn) * ((g.Cout + bm - 1) / bm);
-    // split K so that the grid covers the chip about twice (2 workgroups fit per CU), each slice >= 8
-    // chunks; fewer splits = fewer fp32 atomics on dW.  ET_WGRAD_BLOCKS is a tuning knob.
-    static const int target = getenv("ET_WGRAD_BLOCKS") ? atoi(getenv("ET_WGRAD_BLOCKS")) : 1024;
-    int sk = (target + tiles - 1) / tiles;
-    const int max_sk = max(1, g.P / (BKP * 8));
+    // Split K so that the grid is a whole number of residency rounds: `slots` workgroups of this tile fit on
+    // a CU (LDS- or register-limited), so up to slots*CUs run at once and a grid a little OVER a multiple of
+    // that costs a whole extra round (e.g. 36 tiles x 29 splits = 1044 workgroups on 1024 slots).  Fewer
+    // splits also mean fewer fp32 atomics on dW.  ET_WGRAD_BLOCKS overrides the target (tuning knob).
+    static const int n_cu = [] { hipDeviceProp_t p; int d = 0; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; }();
+    const int lds_kb = tr ? (bm + bn) / 4 : 64;                // 2 stages x 64 pixels x (bm+bn) channels x 2 B
+    int slots = tr ? max(1, min(160 / lds_kb, bm * bn <= 64 * 64 ? 5 : (bm * bn <= 128 * 64 ? 3 : 2))) : 2;
+    // measured: ONE full round of co-resident workgroups with >= ~25 chunks (1600 pixels) each beats two
+    // shorter rounds (prologue, first-chunk latency and the atomic epilogue are per workgroup)
+    const int cap = slots * n_cu;
+    static const int target_env = getenv("ET_WGRAD_BLOCKS") ? atoi(getenv("ET_WGRAD_BLOCKS")) : 0;
+    const int max_sk = max(1, g.P / (BKP * 25));
+    int sk;
+    if (target_env > 0) {
+        sk = target_env / tiles;
+    } else {
+        auto eff = [&](int k) { const int b = tiles * k; return (double)b / ((double)((b + cap - 1) / cap) * cap); };
+        sk = max(1, min(cap / tiles, max_sk));
+        // grids that cannot fill one round evenly: take the split (a few rounds at most) that wastes least
+        if (eff(sk) < 0.8)
+            for (int k = sk + 1; k <= min(max_sk, max(4, 2 * cap / tiles)); ++k)
+                if (eff(k) > eff(sk) + 0.1) sk = k;
+    }
     sk = max(1, min(sk, max_sk));
     int per = (g.P + sk - 1) / sk;
     per = ((per + BKP - 1) / BKP) * BKP;
@@ -1079,18 +1197,14 @@ static void launch_wgrad(const void* x, const void* dy, float* dw, const void* z
     g.ntn = (g.NC + bn - 1) / bn; g.ntm = (g.Cout + bm - 1) / bm; g.nsk = sk;
     const dim3 grid(g.ntn * g.ntm * sk), block(256);
     const T* xx = (const T*)x; const T* yy = (const T*)dy;
-    // bf16 + zero page: LDS-DMA staging with transposing LDS reads (ET_WGRAD_TR=0 forces the register path)
-    static const int use_tr = getenv("ET_WGRAD_TR") ? atoi(getenv("ET_WGRAD_TR")) : 1;
     if constexpr (sizeof(T) == 2) {
-        if (use_tr && zero16) {
+        if (tr) {
             const uint16_t* z = (const uint16_t*)zero16;
-            if (tallM) {
-                if (wideN) hipLaunchKernelGGL((conv_wgrad_tr_kernel<128, 128>), grid, block, 0, s, xx, yy, dw, z, g);
-                else hipLaunchKernelGGL((conv_wgrad_tr_kernel<128, 64>), grid, block, 0, s, xx, yy, dw, z, g);
-            } else {
-                if (wideN) hipLaunchKernelGGL((conv_wgrad_tr_kernel<64, 128>), grid, block, 0, s, xx, yy, dw, z, g);
-                else hipLaunchKernelGGL((conv_wgrad_tr_kernel<64, 64>), grid, block, 0, s, xx, yy, dw, z, g);
-            }
+#define ET_WG(BM_, BN_, WM_, WN_) hipLaunchKernelGGL((conv_wgrad_tr_kernel<BM_, BN_, WM_, WN_>), grid, dim3(64 * WM_ * WN_), 0, s, xx, yy, dw, z, g)
+            if (bm == 256) { if (bn == 256) ET_WG(256, 256, 2, 4); else if (bn == 128) ET_WG(256, 128, 4, 2); else ET_WG(256, 64, 4, 1); }
+            else if (bm == 128) { if (bn == 256) ET_WG(128, 256, 2, 4); else if (bn == 128) ET_WG(128, 128, 2, 2); else ET_WG(128, 64, 2, 2); }
+            else { if (bn == 256) ET_WG(64, 256, 1, 4); else if (bn == 128) ET_WG(64, 128, 2, 2); else ET_WG(64, 64, 2, 2); }
+#undef ET_WG
             return;
         }
     }

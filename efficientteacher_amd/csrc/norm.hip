@@ -7,6 +7,7 @@
 // elementwise pass  z = silu(y*scale + shift) (+ residual), 16 bytes per lane, every thread pinned to
 // one channel vector so scale/shift live in registers.  Backward is the classic two passes:
 // reduce (sum du, sum du*xhat) -> finalize -> apply.
+#include <stdlib.h>
 #include "et_device.h"
 #include "../../include/et_hip.h"
 
@@ -105,21 +106,31 @@ __global__ __launch_bounds__(256) void bn_eval_affine_kernel(int C, const float*
 
 // SiLU with the hardware exp / rcp (v_exp_f32, v_rcp_f32: ~1 ulp): these passes are HBM-bound only as
 // long as the per-element VALU work stays small; an IEEE division costs ~10 extra instructions.
-__device__ __forceinline__ float act_fwd(float u, int act) {
-    if (act == ACT_SILU) return u * __builtin_amdgcn_rcpf(1.0f + __expf(-u));
-    if (act == ACT_RELU) return fmaxf(u, 0.f);
-    return u;
+// The activation is a template parameter: a run-time switch inside the per-element loops compiles to scalar
+// branches around every element and serialises the loads behind them (measured: the reduce pass ran at
+// 2-3 TB/s with the switch, the apply pass at 5-6 TB/s).
+template <int ACT> __device__ __forceinline__ float act_fwd(float u) {
+    if constexpr (ACT == ACT_SILU) return u * __builtin_amdgcn_rcpf(1.0f + __expf(-u));
+    else if constexpr (ACT == ACT_RELU) return fmaxf(u, 0.f);
+    else return u;
 }
-__device__ __forceinline__ float act_grad(float u, int act) {
-    if (act == ACT_SILU) { const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-u)); return s * (1.0f + u * (1.0f - s)); }
-    if (act == ACT_RELU) return u > 0.f ? 1.f : 0.f;
-    return 1.f;
+template <int ACT> __device__ __forceinline__ float act_grad(float u) {
+    if constexpr (ACT == ACT_SILU) { const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-u)); return s * (1.0f + u * (1.0f - s)); }
+    else if constexpr (ACT == ACT_RELU) return u > 0.f ? 1.f : 0.f;
+    else return 1.f;
 }
+// host: instantiate `KERNEL<T, ACT>` for the run-time (dtype, act) pair
+#define ET_ACT_LAUNCH(KERNEL, T, act, ...)                                                                    \
+    do {                                                                                                      \
+        if ((act) == ACT_SILU) hipLaunchKernelGGL((KERNEL<T, ACT_SILU>), __VA_ARGS__);                        \
+        else if ((act) == ACT_RELU) hipLaunchKernelGGL((KERNEL<T, ACT_RELU>), __VA_ARGS__);                   \
+        else hipLaunchKernelGGL((KERNEL<T, ACT_NONE>), __VA_ARGS__);                                          \
+    } while (0)
 
-template <typename T>
+template <typename T, int ACT>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y, int ldy, T* __restrict__ z, int ldz,
                                                          const T* __restrict__ res, int ldr, int P, int CV,
-                                                         const float* __restrict__ scale, const float* __restrict__ shift, int act) {
+                                                         const float* __restrict__ scale, const float* __restrict__ shift) {
     constexpr int N = Vec16<T>::N;
     const long long gt = (long long)blockIdx.x * 256 + threadIdx.x;
     const int cv = (int)(gt % CV);
@@ -132,7 +143,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
         float v[N];
         Vec16<T>::load(y + p * ldy + cv * N, v);
 #pragma unroll
-        for (int i = 0; i < N; ++i) v[i] = act_fwd(v[i] * sc[i] + sh[i], act);
+        for (int i = 0; i < N; ++i) v[i] = act_fwd<ACT>(v[i] * sc[i] + sh[i]);
         if (res) {
             float r[N];
             Vec16<T>::load(res + p * ldr + cv * N, r);
@@ -145,12 +156,11 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
 
 // ---- backward -----------------------------------------------------------------------------------------
 // pass 1: per-block partial sums of du and du*xhat, du = dz * act'(y*scale+shift), xhat = (y-mean)*invstd
-template <typename T>
+template <typename T, int ACT>
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const T* __restrict__ dz, int lddz, const T* __restrict__ y, int ldy,
                                                                 int P, int CV, const float* __restrict__ scale,
                                                                 const float* __restrict__ shift, const float* __restrict__ mean,
-                                                                const float* __restrict__ invstd, int act,
-                                                                float* __restrict__ part) {
+                                                                const float* __restrict__ invstd, float* __restrict__ part) {
     constexpr int N = Vec16<T>::N;
     __shared__ float acc[2][2048];
     const int C = CV * N;
@@ -176,8 +186,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const T* __restr
         Vec16<T>::load(y + (p + pstep) * ldy + cv * N, v2);
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-            const float du = g[i] * act_grad(v[i] * sc[i] + sh[i], act);
-            const float du2 = g2[i] * act_grad(v2[i] * sc[i] + sh[i], act);
+            const float du = g[i] * act_grad<ACT>(v[i] * sc[i] + sh[i]);
+            const float du2 = g2[i] * act_grad<ACT>(v2[i] * sc[i] + sh[i]);
             s1[i] += du + du2;
             s2[i] += du * v[i] + du2 * v2[i];
         }
@@ -188,21 +198,35 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const T* __restr
         Vec16<T>::load(y + p * ldy + cv * N, v);
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-            const float du = g[i] * act_grad(v[i] * sc[i] + sh[i], act);
+            const float du = g[i] * act_grad<ACT>(v[i] * sc[i] + sh[i]);
             s1[i] += du;
             s2[i] += du * v[i];
         }
     }
+    // block reduction.  LDS layout acc[.][i*CV + cv]: the 64 lanes of a wave hit consecutive banks (the
+    // channel-major layout cv*N+i is an 8-way bank conflict on every ds_add, which made this tail -- 8.4 M
+    // conflicted LDS atomics per launch -- cost more than the streaming loop on the small maps).  When CV is
+    // a power of two below 64 the lanes that share a channel group (lane % CV) are first summed with
+    // xor-shuffles, so each wave issues one conflict-free atomic per address.
+    const int lane = threadIdx.x & 63;
+    const bool fold = CV < 64 && (CV & (CV - 1)) == 0;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         const float mu = mean[cv * N + i], is = invstd[cv * N + i];
-        atomicAdd(&acc[0][cv * N + i], s1[i]);
-        atomicAdd(&acc[1][cv * N + i], is * (s2[i] - mu * s1[i]));
+        float a = s1[i], b = is * (s2[i] - mu * s1[i]);
+        if (fold) {
+            for (int m = 32; m >= CV; m >>= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }
+        }
+        if (!fold || lane < CV) {
+            atomicAdd(&acc[0][i * CV + cv], a);
+            atomicAdd(&acc[1][i * CV + cv], b);
+        }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < C; i += 256) {
-        part[((size_t)blockIdx.x * 2 + 0) * C + i] = acc[0][i];
-        part[((size_t)blockIdx.x * 2 + 1) * C + i] = acc[1][i];
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const int j = (c % N) * CV + c / N;
+        part[((size_t)blockIdx.x * 2 + 0) * C + c] = acc[0][j];
+        part[((size_t)blockIdx.x * 2 + 1) * C + c] = acc[1][j];
     }
 }
 
@@ -222,23 +246,26 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
 }
 
 // pass 2: dy = k0 * (du - k1 - xhat*k2)
-template <typename T>
+template <typename T, int ACT>
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restrict__ dz, int lddz, const T* __restrict__ y, int ldy,
                                                                T* __restrict__ dy, int lddy, int P, int CV,
                                                                const float* __restrict__ scale, const float* __restrict__ shift,
                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                const float* __restrict__ k0, const float* __restrict__ k1,
-                                                               const float* __restrict__ k2, int act) {
+                                                               const float* __restrict__ k2) {
     constexpr int N = Vec16<T>::N;
     const long long gt = (long long)blockIdx.x * 256 + threadIdx.x;
     const int cv = (int)(gt % CV);
     long long p = gt / CV;
     const long long pstep = ((long long)gridDim.x * 256) / CV;
-    float sc[N], sh[N], mu[N], is[N], a0[N], a1[N], a2[N];
+    // dy = k0*(du - k1 - xhat*k2), xhat = (y-mean)*invstd  ==  A*du + B*y + D with per-channel A, B, D
+    float sc[N], sh[N], A[N], B[N], D[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         const int c = cv * N + i;
-        sc[i] = scale[c]; sh[i] = shift[c]; mu[i] = mean[c]; is[i] = invstd[c]; a0[i] = k0[c]; a1[i] = k1[c]; a2[i] = k2[c];
+        sc[i] = scale[c]; sh[i] = shift[c];
+        const float a0 = k0[c], w = invstd[c] * k2[c];
+        A[i] = a0; B[i] = -a0 * w; D[i] = a0 * (mean[c] * w - k1[c]);
     }
     for (; p < P; p += pstep) {
         float g[N], v[N];
@@ -246,17 +273,17 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restri
         Vec16<T>::load(y + p * ldy + cv * N, v);
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-            const float du = g[i] * act_grad(v[i] * sc[i] + sh[i], act);
-            g[i] = a0[i] * (du - a1[i] - ((v[i] - mu[i]) * is[i]) * a2[i]);
+            const float du = g[i] * act_grad<ACT>(v[i] * sc[i] + sh[i]);
+            g[i] = A[i] * du + (B[i] * v[i] + D[i]);
         }
         Vec16<T>::store(dy + p * lddy + cv * N, g);
     }
 }
 
 // plain activation backward (netD ReLU between its two 1x1 convs, yolo_ssod.py:231-238): dy = dz * act'(y)
-template <typename T>
+template <typename T, int ACT>
 __global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ dz, int lddz, const T* __restrict__ y, int ldy,
-                                                      T* __restrict__ dy, int lddy, int P, int CV, int act) {
+                                                      T* __restrict__ dy, int lddy, int P, int CV) {
     constexpr int N = Vec16<T>::N;
     const long long gt = (long long)blockIdx.x * 256 + threadIdx.x;
     const int cv = (int)(gt % CV);
@@ -267,7 +294,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ dz, 
         Vec16<T>::load(dz + p * lddz + cv * N, g);
         Vec16<T>::load(y + p * ldy + cv * N, v);
 #pragma unroll
-        for (int i = 0; i < N; ++i) g[i] *= act_grad(v[i], act);
+        for (int i = 0; i < N; ++i) g[i] *= act_grad<ACT>(v[i]);
         Vec16<T>::store(dy + p * lddy + cv * N, g);
     }
 }
@@ -281,7 +308,8 @@ static int ew_blocks(long long P, int CV) {
     const long long need = (P * CV + 255) / 256;
     // ~8+ vectors per thread (amortises the per-thread channel constants and the partial-sum rows),
     // but never fewer than ~2 blocks per CU
-    long long blocks = need / 8;
+    static const int vpt = getenv("ET_EW_VPT") ? atoi(getenv("ET_EW_VPT")) : 8;   // tuning knob, read once
+    long long blocks = need / (vpt > 0 ? vpt : 8);
     if (blocks < 512) blocks = need < 512 ? need : 512;
     if (blocks > 2048) blocks = 2048;
     blocks = ((blocks + unit - 1) / unit) * unit;
@@ -323,11 +351,11 @@ extern "C" int et_bn_act_fwd(const void* y, int ldy, void* z, int ldz, const voi
     const int CV = C / vec;
     const dim3 grid(ew_blocks(P, CV));
     if (dtype == ET_F32)
-        hipLaunchKernelGGL((bn_act_fwd_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)y, ldy, (float*)z, ldz,
-                           (const float*)residual, ldr, P, CV, scale, shift, act);
+        ET_ACT_LAUNCH(bn_act_fwd_kernel, float, act, grid, dim3(256), 0, (hipStream_t)stream, (const float*)y, ldy, (float*)z, ldz,
+                      (const float*)residual, ldr, P, CV, scale, shift);
     else if (dtype == ET_BF16)
-        hipLaunchKernelGGL((bn_act_fwd_kernel<uint16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)y, ldy, (uint16_t*)z, ldz,
-                           (const uint16_t*)residual, ldr, P, CV, scale, shift, act);
+        ET_ACT_LAUNCH(bn_act_fwd_kernel, uint16_t, act, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)y, ldy,
+                      (uint16_t*)z, ldz, (const uint16_t*)residual, ldr, P, CV, scale, shift);
     else return -2;
     ET_CHECK_LAUNCH();
     return 0;
@@ -351,21 +379,21 @@ extern "C" int et_bn_act_bwd(const void* dz, int lddz, const void* y, int ldy, v
     float* k2 = k1 + C;
     const dim3 grid(rows);
     if (dtype == ET_F32)
-        hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)dz, lddz,
-                           (const float*)y, ldy, P, CV, scale, shift, save_mean, save_invstd, act, part);
+        ET_ACT_LAUNCH(bn_act_bwd_reduce_kernel, float, act, grid, dim3(256), 0, (hipStream_t)stream, (const float*)dz, lddz,
+                      (const float*)y, ldy, P, CV, scale, shift, save_mean, save_invstd, part);
     else if (dtype == ET_BF16)
-        hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<uint16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)dz, lddz,
-                           (const uint16_t*)y, ldy, P, CV, scale, shift, save_mean, save_invstd, act, part);
+        ET_ACT_LAUNCH(bn_act_bwd_reduce_kernel, uint16_t, act, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)dz, lddz,
+                      (const uint16_t*)y, ldy, P, CV, scale, shift, save_mean, save_invstd, part);
     else return -2;
     launch_rows_reduce(part, rows, C, tot, (hipStream_t)stream);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, tot, C, (float)P, gamma,
                        save_invstd, dgamma, dbeta, k0, k1, k2);
     if (dtype == ET_F32)
-        hipLaunchKernelGGL((bn_act_bwd_apply_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)dz, lddz,
-                           (const float*)y, ldy, (float*)dy, lddy, P, CV, scale, shift, save_mean, save_invstd, k0, k1, k2, act);
+        ET_ACT_LAUNCH(bn_act_bwd_apply_kernel, float, act, grid, dim3(256), 0, (hipStream_t)stream, (const float*)dz, lddz,
+                      (const float*)y, ldy, (float*)dy, lddy, P, CV, scale, shift, save_mean, save_invstd, k0, k1, k2);
     else
-        hipLaunchKernelGGL((bn_act_bwd_apply_kernel<uint16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)dz, lddz,
-                           (const uint16_t*)y, ldy, (uint16_t*)dy, lddy, P, CV, scale, shift, save_mean, save_invstd, k0, k1, k2, act);
+        ET_ACT_LAUNCH(bn_act_bwd_apply_kernel, uint16_t, act, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)dz, lddz,
+                      (const uint16_t*)y, ldy, (uint16_t*)dy, lddy, P, CV, scale, shift, save_mean, save_invstd, k0, k1, k2);
     ET_CHECK_LAUNCH();
     return 0;
 }
@@ -378,11 +406,11 @@ extern "C" int et_act_bwd(const void* dz, int lddz, const void* y, int ldy, void
     const int CV = C / vec;
     const dim3 grid(ew_blocks(P, CV));
     if (dtype == ET_F32)
-        hipLaunchKernelGGL((act_bwd_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)dz, lddz, (const float*)y, ldy,
-                           (float*)dy, lddy, P, CV, act);
+        ET_ACT_LAUNCH(act_bwd_kernel, float, act, grid, dim3(256), 0, (hipStream_t)stream, (const float*)dz, lddz, (const float*)y, ldy,
+                      (float*)dy, lddy, P, CV);
     else if (dtype == ET_BF16)
-        hipLaunchKernelGGL((act_bwd_kernel<uint16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)dz, lddz, (const uint16_t*)y, ldy,
-                           (uint16_t*)dy, lddy, P, CV, act);
+        ET_ACT_LAUNCH(act_bwd_kernel, uint16_t, act, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)dz, lddz,
+                      (const uint16_t*)y, ldy, (uint16_t*)dy, lddy, P, CV);
     else return -2;
     ET_CHECK_LAUNCH();
     return 0;

@@ -16,6 +16,7 @@ CASES = [
     (2, 12, 12, 16, 128, 3, 2, 1),    # stride 2, BKV=4 (fp32) / non-uniform tap (bf16: CV=2)
     (1, 16, 16, 8, 32, 6, 2, 2),      # the stem: Cin padded to 8, 36 taps
     (1, 6, 6, 128, 136, 1, 1, 0),     # wide N tile with a ragged second tile
+    (1, 5, 5, 32, 264, 3, 1, 1),      # Cout and Cin*taps beyond 256: the 256-wide wgrad tiles, ragged
 ]
 
 

@@ -84,6 +84,32 @@ def bench_conv(B=64, dtype=torch.bfloat16, with_ref=True):
     return rows, summ
 
 
+def bench_bn(B=64, dtype=torch.bfloat16):
+    """BN+SiLU forward / backward elementwise kernels at every (pixels, channels) of the YOLOv5l step;
+    GB/s counts the algorithmic passes: fwd = read y + write z; bwd = 2 reads (reduce) + 2 reads + 1 write (apply)."""
+    dev = torch.device("cuda:0")
+    tot = dict(fwd=0.0, bwd=0.0, bytes=0.0)
+    for (cin, cout, k, s, h, cnt) in V5L:
+        ho = h // s
+        y = torch.randn(B, ho, ho, cout, device=dev).to(dtype)
+        dz = torch.randn(B, ho, ho, cout, device=dev).to(dtype)
+        z = torch.empty_like(y); dy = torch.empty_like(y)
+        gamma = torch.rand(cout, device=dev) + 0.5
+        mean = torch.zeros(cout, device=dev); invstd = torch.ones(cout, device=dev)
+        scale = gamma * invstd; shift = -mean * scale
+        dg = torch.zeros(cout, device=dev); db = torch.zeros(cout, device=dev)
+        t_f = timeit(lambda: ops.bn_act_fwd(y, scale, shift, ops.ACT_SILU, out=z))
+        t_b = timeit(lambda: ops.bn_act_bwd(dz, y, gamma, scale, shift, mean, invstd, ops.ACT_SILU, dg, db, out=dy))
+        nb = y.numel() * y.element_size()
+        r = dict(P=B * ho * ho, C=cout, count=cnt, MB=nb / 1e6, fwd_us=t_f * 1e6, bwd_us=t_b * 1e6,
+                 fwd_GBps=2 * nb / t_f / 1e9, bwd_GBps=5 * nb / t_b / 1e9)
+        tot["fwd"] += t_f * cnt; tot["bwd"] += t_b * cnt; tot["bytes"] += nb * cnt
+        print("BN " + json.dumps(r), flush=True)
+    print("BNSUMMARY " + json.dumps(dict(fwd_ms=tot["fwd"] * 1e3, bwd_ms=tot["bwd"] * 1e3, GB_per_pass=tot["bytes"] / 1e9,
+                                         fwd_GBps=2 * tot["bytes"] / tot["fwd"] / 1e9,
+                                         bwd_GBps=5 * tot["bytes"] / tot["bwd"] / 1e9)), flush=True)
+
+
 def bench_nms(B=32, A=25200, no=85):
     from efficientteacher_amd.utils.general import nms_ssod_padded
     dev = torch.device("cuda:0")
@@ -107,5 +133,7 @@ if __name__ == "__main__":
     print(torch.cuda.get_device_name(0), flush=True)
     if what in ("nms", "all"):
         bench_nms()
+    if what in ("bn", "all"):
+        bench_bn(B=int(os.environ.get("MB_B", 64)))
     if what in ("conv", "all"):
         bench_conv(B=int(os.environ.get("MB_B", 64)), with_ref=os.environ.get("MB_REF", "1") == "1")
