@@ -56,6 +56,7 @@ struct GatherGeom {
     int CV, KV;                  // Cin/VEC, T*CV
     int tap_inner;               // K-chunk order: 1 = channel-chunk outer / tap inner (L2-friendly), 0 = tap outer
     int xcd_swz;                 // 1 = remap blockIdx.x so that neighbouring pixel tiles share an XCD (L2)
+    int ntm, ntn, nfast;         // tile grid (1-D launch, decoded in-kernel); nfast: channel tiles of a pixel tile adjacent
     FastDiv dQW, dQH, dCV;
     signed char dy[CONV_MAX_TAPS], dx[CONV_MAX_TAPS];
     unsigned char wt[CONV_MAX_TAPS];
@@ -83,10 +84,47 @@ struct Epilogue {
     int accumulate;         // out += result
 };
 
+// Workgroup -> tile.  The launch is 1-D over ntm x ntn tiles.  Workgroups are dealt round-robin to the 8 XCDs
+// (private L2 each): with xcd_swz the linear id is remapped so that each XCD owns a contiguous range of the
+// tile sequence, and with nfast that sequence runs over the channel tiles of one pixel tile first -- the
+// workgroups that read the same activation rows (and, for 3x3, the halo rows of the neighbouring pixel
+// tiles) are then co-resident on one XCD and share them through its L2 instead of each pass over the
+// channel tiles re-fetching the whole activation tensor through the fabric (placement only: results do not
+// depend on it).
+__device__ __forceinline__ void tile_of_block(const GatherGeom& g, int& bx, int& by) {
+    int id = blockIdx.x;
+    if (g.nfast) {
+        if (g.xcd_swz) {
+            const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = id & 7, k = id >> 3;
+            id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;     // bijective for any nb
+        }
+        bx = id / g.ntn;
+        by = id - bx * g.ntn;
+    } else {
+        by = id / g.ntm;
+        bx = id - by * g.ntm;
+        if (g.xcd_swz) {
+            const int nb = g.ntm, q = nb >> 3, r = nb & 7, xcd = bx & 7, k = bx >> 3;
+            bx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+        }
+    }
+}
+
 template <int BKV> __device__ __forceinline__ int lds_swz(int r) {
     if constexpr (BKV == 8) return ((r >> 1) & 7) ^ ((r >> 4) & 3);
     else return (r >> 2) & 3;
 }
+
+#if defined(ET_ABLATE) && (ET_ABLATE == 9)
+// experiment build only: per-workgroup phase timestamps (s_memtime) of the LDS-DMA gather-GEMM
+__device__ unsigned long long et_dbg_ts[8 * 16384];
+extern "C" int et_debug_read(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(et_dbg_ts), sizeof(unsigned long long) * n, 0, hipMemcpyDeviceToHost);
+}
+#define ET_TS(slot) do { if (threadIdx.x == 0) { const int b_ = blockIdx.x; if (b_ < 16384) et_dbg_ts[b_ * 8 + (slot)] = __builtin_readcyclecounter(); } } while (0)
+#else
+#define ET_TS(slot) do { } while (0)
+#endif
 
 // ---- one K-chunk of MFMAs from LDS --------------------------------------------------------------
 template <typename T, int BM, int BN, int WM, int WN, int BKV>
@@ -142,61 +180,70 @@ __device__ __forceinline__ void mma_chunk(const u32x4* __restrict__ sm, f32x16 (
 }
 
 // ---- shared epilogue of the gather-GEMM kernels -----------------------------------------------------
-template <typename T, int BM, int BN, int WM, int WN>
-__device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN / 32], u32x4* lds_raw, T* __restrict__ Y,
-                                              const GatherGeom& g, const Epilogue& ep, int bx, int m0, int n0, int tid,
-                                              int lane, int wm, int wn) {
+// LDS floats the epilogue needs: one private [32][BN/WN + 4] fp32 slab per wave + the [WM][BN][2] statistics
+template <int BM, int BN, int WM, int WN> struct EpiLds {
+    static constexpr int WCOLS = BN / WN, SLD = WCOLS + 4, SLAB = 32 * SLD;
+    static constexpr int FLOATS = WM * WN * SLAB + WM * BN * 2;
+    static constexpr int VEC16 = (FLOATS * 4 + 15) / 16;
+};
+
+// scale/bias/activation in registers (a lane owns ONE output channel per 32x32 tile), BN partial statistics
+// from the raw accumulators; then every wave transposes its own accumulator tile, 32 rows at a time, through
+// a PRIVATE fp32 LDS slab so that the global stores are 16-byte vectors along the channel axis -- no
+// workgroup barrier anywhere in the store path (measured with s_memtime stamps: the previous version, which
+// staged half the block tile per __syncthreads round with a run-time activation switch per element, spent
+// 12.5 k cycles on a 128x64 tile and 23 k on 128x128 -- 22 % of a 3x3 and 45-60 % of a 1x1 layer's
+// workgroup lifetime).  residual / accumulate are vector loads.
+template <typename T, int BM, int BN, int WM, int WN, int ACT>
+__device__ __forceinline__ void conv_epilogue_act(f32x16 (&acc)[BM / WM / 32][BN / WN / 32], u32x4* lds_raw, T* __restrict__ Y,
+                                                  const GatherGeom& g, const Epilogue& ep, int bx, int m0, int n0, int tid,
+                                                  int lane, int wm, int wn) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    // ---- epilogue ----------------------------------------------------------------------------------
-    // scale/bias/activation in registers (a lane owns ONE output channel per 32x32 tile), BN partial
-    // statistics from the raw accumulators, then the tile goes through LDS (fp32, one 64-row half of the
-    // block tile at a time) so that the global stores are 16-byte vectors along the channel axis
-    // (256 B contiguous per pixel) instead of 2-byte scatters; residual / accumulate are vector loads.
+    using L = EpiLds<BM, BN, WM, WN>;
+    constexpr int WCOLS = L::WCOLS, SLD = L::SLD;
+    constexpr int CVN = WCOLS / 8;                 // 8-channel groups per slab row
+    constexpr int RPI = 64 / CVN;                  // slab rows stored per wave iteration
     const int l31 = lane & 31, hi = lane >> 5;
+    const int wave = wm * WN + wn;
+    float* const stg = (float*)lds_raw + wave * L::SLAB;
     float ssum[TN], ssq[TN];
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) { ssum[tn] = 0.f; ssq[tn] = 0.f; }
     const bool ident = (g.osy == 1 && g.osx == 1 && g.ooy == 0 && g.oox == 0 && g.QH == g.OH && g.QW == g.OW);
-    constexpr int HROWS = BM / WM;                 // rows staged per pass (64)
-    constexpr int SLD = BN + 4;                    // fp32 row stride in LDS (pad keeps 16-byte alignment)
-    constexpr int CVN = BN / 8;                    // 8-channel groups per row
-    constexpr int PER_T = HROWS * CVN / 256;       // groups per thread per pass
-    float* stg = (float*)lds_raw;
     float csc[TN], cbi[TN];
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
-        const int co = n0 + wn * (BN / WN) + tn * 32 + l31;
+        const int co = n0 + wn * WCOLS + tn * 32 + l31;
         const bool cok = co < g.Cout;
         csc[tn] = (ep.scale && cok) ? ep.scale[co] : 1.0f;
         cbi[tn] = (ep.bias && cok) ? ep.bias[co] : 0.0f;
     }
+    const int srow = lane / CVN, scv = lane % CVN;  // this lane's (row, channel group) in the store phase
+    const int co = n0 + wn * WCOLS + scv * 8;
 #pragma unroll
-    for (int w = 0; w < WM; ++w) {
-        if (wm == w) {
+    for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-#pragma unroll
-                    for (int tn = 0; tn < TN; ++tn) {
-                        float v = acc[tm][tn][r];
-                        ssum[tn] += v;
-                        ssq[tn] += v * v;
-                        v = v * csc[tn] + cbi[tn];
-                        if (ep.act == ACT_SILU) v = v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
-                        else if (ep.act == ACT_RELU) v = fmaxf(v, 0.f);
-                        stg[row * SLD + wn * (BN / WN) + tn * 32 + l31] = v;
-                    }
-                }
+            for (int tn = 0; tn < TN; ++tn) {
+                float v = acc[tm][tn][r];
+                ssum[tn] += v;
+                ssq[tn] += v * v;
+                v = v * csc[tn] + cbi[tn];
+                if constexpr (ACT == ACT_SILU) v = v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+                else if constexpr (ACT == ACT_RELU) v = fmaxf(v, 0.f);
+                stg[row * SLD + tn * 32 + l31] = v;
+            }
         }
-        __syncthreads();
+        // the slab is private to this wave: LDS executes a wave's operations in order; the wait + wave barrier
+        // only keep the compiler (and the CPU emulator's per-lane fibers) from reordering across it
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int it = 0; it < PER_T; ++it) {
-            const int gidx = tid + it * 256;
-            const int row = gidx / CVN, cv = gidx % CVN;
-            const int p = m0 + w * HROWS + row;
-            const int co = n0 + cv * 8;
+        for (int it = 0; it < 32 / RPI; ++it) {
+            const int row = it * RPI + srow;
+            const int p = m0 + wm * (BM / WM) + tm * 32 + row;
             if (p < g.M && co < g.Cout) {
                 long long pix;
                 if (ident) {
@@ -207,8 +254,8 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BM / WM / 32][BN / W
                     pix = ((long long)n * g.OH + (qy * g.osy + g.ooy)) * g.OW + (qx * g.osx + g.oox);
                 }
                 float v[8];
-                const float4 a = *(const float4*)(stg + row * SLD + cv * 8);
-                const float4 b = *(const float4*)(stg + row * SLD + cv * 8 + 4);
+                const float4 a = *(const float4*)(stg + row * SLD + scv * 8);
+                const float4 b = *(const float4*)(stg + row * SLD + scv * 8 + 4);
                 v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
                 T* yp = Y + pix * g.ldy + co;
                 if (co + 8 <= g.Cout) {
@@ -252,18 +299,20 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BM / WM / 32][BN / W
                 }
             }
         }
-        __syncthreads();
+        __builtin_amdgcn_s_waitcnt(0xC07F);        // slab reads done before the next 32 rows overwrite it
+        __builtin_amdgcn_wave_barrier();
     }
+    ET_TS(6);
     if (ep.stats) {
         // rows beyond M were zero-filled, so they add nothing.  Reduce lane halves, then the WM waves
         // that share these channels (through LDS), then one plain store per channel per block.
-        float* red = (float*)lds_raw;              // [WM][BN][2], the staging area is free now
+        float* red = (float*)lds_raw + WM * WN * L::SLAB;     // [WM][BN][2], behind the slabs
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
             const float s = ssum[tn] + __shfl_xor(ssum[tn], 32);
             const float q = ssq[tn] + __shfl_xor(ssq[tn], 32);
             if (hi == 0) {
-                const int c = wn * (BN / WN) + tn * 32 + l31;
+                const int c = wn * WCOLS + tn * 32 + l31;
                 red[(wm * BN + c) * 2 + 0] = s;
                 red[(wm * BN + c) * 2 + 1] = q;
             }
@@ -273,23 +322,33 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BM / WM / 32][BN / W
             float s = 0.f, q = 0.f;
 #pragma unroll
             for (int w = 0; w < WM; ++w) { s += red[(w * BN + tid) * 2]; q += red[(w * BN + tid) * 2 + 1]; }
-            const int co = n0 + tid;
-            if (co < g.Cout) {
+            const int cc = n0 + tid;
+            if (cc < g.Cout) {
                 // the partial buffer has one row per 128 output rows (et_conv2d_stats_rows): a taller tile
                 // writes its sums into its first row and zeros the others it covers
                 constexpr int SR = BM / 128;
                 const int nrows = (g.M + 127) / 128;
-                ep.stats[((size_t)bx * SR * 2 + 0) * g.Cout + co] = s;
-                ep.stats[((size_t)bx * SR * 2 + 1) * g.Cout + co] = q;
+                ep.stats[((size_t)bx * SR * 2 + 0) * g.Cout + cc] = s;
+                ep.stats[((size_t)bx * SR * 2 + 1) * g.Cout + cc] = q;
 #pragma unroll
                 for (int e = 1; e < SR; ++e)
                     if (bx * SR + e < nrows) {
-                        ep.stats[((size_t)(bx * SR + e) * 2 + 0) * g.Cout + co] = 0.f;
-                        ep.stats[((size_t)(bx * SR + e) * 2 + 1) * g.Cout + co] = 0.f;
+                        ep.stats[((size_t)(bx * SR + e) * 2 + 0) * g.Cout + cc] = 0.f;
+                        ep.stats[((size_t)(bx * SR + e) * 2 + 1) * g.Cout + cc] = 0.f;
                     }
             }
         }
     }
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN / 32], u32x4* lds_raw, T* __restrict__ Y,
+                                              const GatherGeom& g, const Epilogue& ep, int bx, int m0, int n0, int tid,
+                                              int lane, int wm, int wn) {
+    // one uniform branch per workgroup instead of one per element
+    if (ep.act == ACT_SILU) conv_epilogue_act<T, BM, BN, WM, WN, ACT_SILU>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn);
+    else if (ep.act == ACT_RELU) conv_epilogue_act<T, BM, BN, WM, WN, ACT_RELU>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn);
+    else conv_epilogue_act<T, BM, BN, WM, WN, ACT_NONE>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn);
 }
 
 // ---- forward / dgrad gather-GEMM ----------------------------------------------------------------
@@ -301,7 +360,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const T* __restrict__ X,
     constexpr int RPT = 256 / BKV;                 // rows covered by one pass of the 256 loader threads
     constexpr int RA = BM / RPT, RB = BN / RPT;    // 16-byte vectors per thread per chunk
     constexpr int STAGE_VEC = (BM + BN) * BKV;                       // one K-chunk of A and B
-    constexpr int EPI_VEC = ((BM / WM) * (BN + 4) * 4 + 15) / 16;     // fp32 staging of half a block tile
+    constexpr int EPI_VEC = EpiLds<BM, BN, WM, WN>::VEC16;
     constexpr int LDS_VEC = 2 * STAGE_VEC > EPI_VEC ? 2 * STAGE_VEC : EPI_VEC;
     __shared__ __attribute__((aligned(16))) u32x4 lds_raw[LDS_VEC];
     u32x4* const lds0 = lds_raw;
@@ -313,12 +372,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const T* __restrict__ X,
     // is remapped so that each XCD owns a contiguous range of tiles: the halo rows shared by neighbouring
     // tiles of a 3x3 conv, and the weights, are then re-read from that XCD's L2 (placement only: results
     // do not depend on it).
-    int bx = blockIdx.x;
-    if (g.xcd_swz) {
-        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bx & 7, k = bx >> 3;
-        bx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;     // bijective for any nb
-    }
-    const int m0 = bx * BM, n0 = blockIdx.y * BN;
+    int bx, by;
+    tile_of_block(g, bx, by);
+    const int m0 = bx * BM, n0 = by * BN;
     const int lvec = tid % BKV, lrow = tid / BKV;
 
     // loader state: A rows are lattice pixels, B rows are output channels
@@ -472,20 +528,18 @@ __global__ __launch_bounds__(256) void conv_gemm_glds_kernel(const T* __restrict
     constexpr int RPT = 256 / BKV;
     constexpr int RA = BM / RPT, RB = BN / RPT;
     constexpr int STAGE_VEC = (BM + BN) * BKV;
-    constexpr int EPI_VEC = ((BM / WM) * (BN + 4) * 4 + 15) / 16;
+    constexpr int EPI_VEC = EpiLds<BM, BN, WM, WN>::VEC16;
     constexpr int LDS_VEC = NS * STAGE_VEC > EPI_VEC ? NS * STAGE_VEC : EPI_VEC;
     constexpr int PER = RA + RB;                 // LDS-DMA instructions per thread per chunk
     static_assert(NS >= 2 && NS <= 5 && (NS - 2) * PER < 64, "ring depth");
     __shared__ __attribute__((aligned(16))) u32x4 lds_raw[LDS_VEC];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    ET_TS(0);
     const int wm = wave / WN, wn = wave % WN;
-    int bx = blockIdx.x;
-    if (g.xcd_swz) {
-        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bx & 7, k = bx >> 3;
-        bx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
-    }
-    const int m0 = bx * BM, n0 = blockIdx.y * BN;
+    int bx, by;
+    tile_of_block(g, bx, by);
+    const int m0 = bx * BM, n0 = by * BN;
     const int lvec = tid % BKV, lrow = tid / BKV;
 
     int a_off[RA], a_iy[RA], a_ix[RA], a_lv[RA];
@@ -591,7 +645,9 @@ __global__ __launch_bounds__(256) void conv_gemm_glds_kernel(const T* __restrict
     for (int s = 0; s < NS - 1; ++s)
         if (s < nchunks) { stage(lds_raw + s * STAGE_VEC, s, tap_u, cv_u); ET_ADVANCE_CURSOR(); }
     int rd = 0, wr = NS - 1;                       // ring slots of chunk c and of chunk c+NS-1
+    ET_TS(1);
     for (int c = 0; c < nchunks; ++c) {
+        if (c == 1) ET_TS(2);
         // chunk c has landed once at most `ahead` younger chunks of this wave are still in flight
         const int ahead = min(NS - 2, nchunks - 1 - c);
         if constexpr (!UTAP) {
@@ -613,8 +669,11 @@ __global__ __launch_bounds__(256) void conv_gemm_glds_kernel(const T* __restrict
         wr = wr + 1 == NS ? 0 : wr + 1;
     }
     __syncthreads();                               // the epilogue reuses the ring as its staging area
+    ET_TS(3);
 #undef ET_ADVANCE_CURSOR
     conv_epilogue<T, BM, BN, WM, WN>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn);
+    __syncthreads();
+    ET_TS(4);
 }
 
 // ---- wgrad ----------------------------------------------------------------------------------------
@@ -1016,7 +1075,7 @@ static int fill_common(GatherGeom& g, int N, int IH, int IW, int Cin, int ldx, i
 }
 
 template <typename T>
-static int launch_gemm(const void* X, const void* W, void* Y, const void* zero16, const GatherGeom& g, const Epilogue& ep,
+static int launch_gemm(const void* X, const void* W, void* Y, const void* zero16, GatherGeom g, const Epilogue& ep,
                        hipStream_t s) {
     if (g.M <= 0) return 0;
     // tile choice: 128x128 unless the layer has <= 64 output channels.  ET_CONV_NARROW_K=<K> (tuning
@@ -1025,6 +1084,9 @@ static int launch_gemm(const void* X, const void* W, void* Y, const void* zero16
     static const int narrow_k = getenv("ET_CONV_NARROW_K") ? atoi(getenv("ET_CONV_NARROW_K")) : 256;
     const bool wide = g.Cout > 64 && !(narrow_k > 0 && g.T * g.Cin <= narrow_k);
     const int bn = wide ? 128 : 64;
+    static const int nfast = getenv("ET_CONV_NFAST") ? atoi(getenv("ET_CONV_NFAST")) : 1;
+    g.ntn = (g.Cout + bn - 1) / bn;
+    g.nfast = nfast;
     const T* x = (const T*)X; const T* w = (const T*)W; T* y = (T*)Y;
     // staging: LDS-DMA (global_load_lds) when the caller supplies a zero page, else VGPR staging.
     // ET_CONV_GLDS=0 forces the register-staged kernel (A/B knob).
@@ -1039,7 +1101,8 @@ static int launch_gemm(const void* X, const void* W, void* Y, const void* zero16
         if (glds && g.CV % 8 == 0 && ring != 12882) {
 #define ET_RING(BM_, BKV_, NS_)                                                                                       \
     do {                                                                                                              \
-        const dim3 grid((g.M + BM_ - 1) / BM_, (g.Cout + bn - 1) / bn);                                               \
+        g.ntm = (g.M + BM_ - 1) / BM_;                                                       \
+        const dim3 grid(g.ntm * g.ntn);                                                                               \
         if (wide) hipLaunchKernelGGL((conv_gemm_glds_kernel<T, BM_, 128, 2, 2, BKV_, NS_, true>), grid, block, 0, s, x, w, y, z, g, ep); \
         else hipLaunchKernelGGL((conv_gemm_glds_kernel<T, BM_, 64, 2, 2, BKV_, NS_, true>), grid, block, 0, s, x, w, y, z, g, ep);       \
         return 0;                                                                                                     \
@@ -1056,7 +1119,8 @@ static int launch_gemm(const void* X, const void* W, void* Y, const void* zero16
 #undef ET_RING
         }
     }
-    const dim3 grid((g.M + 127) / 128, (g.Cout + bn - 1) / bn);
+    g.ntm = (g.M + 127) / 128;
+    const dim3 grid(g.ntm * g.ntn);
 #define ET_LAUNCH(BN_, WM_, WN_, BKV_, UT_)                                                                              \
     do {                                                                                                                  \
         if (glds) hipLaunchKernelGGL((conv_gemm_glds_kernel<T, 128, BN_, WM_, WN_, BKV_, 2, UT_>), grid, block, 0, s, x, w, y, z, g, ep); \
