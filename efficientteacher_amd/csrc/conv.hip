@@ -658,7 +658,10 @@ __global__ __launch_bounds__(256) void conv_gemm_glds_kernel(const T* __restrict
             else if (NS >= 3 && ahead == 1) et_wait_vmem_le<(NS >= 3 ? 1 : 0) * PER>();
             else et_wait_vmem();
         }
-        __syncthreads();                           // ... for every wave; and all reads of slot `wr` (chunk c-1) are done
+        // ... for every wave; and all reads of slot `wr` (chunk c-1) are done.  With younger chunks in flight the
+        // barrier must be the bare s_barrier: __syncthreads() carries a fence that waits vmcnt(0), i.e. drains
+        // the very LDS-DMA the ring keeps in flight
+        if constexpr (NS > 2) __builtin_amdgcn_s_barrier(); else __syncthreads();
 #if !defined(ET_ABLATE) || (ET_ABLATE != 2)
         if (c + NS - 1 < nchunks) { stage(lds_raw + wr * STAGE_VEC, c + NS - 1, tap_u, cv_u); ET_ADVANCE_CURSOR(); }
 #endif
@@ -1096,7 +1099,11 @@ static int launch_gemm(const void* X, const void* W, void* Y, const void* zero16
     const dim3 block(256);
     // ET_CONV_RING=<rows><kvec><depth> (e.g. 25683 = 256-row tile, 8-vector chunks, 3-deep ring): tuning knob
     // for the bf16 LDS-DMA kernel, read once
-    static const int ring = getenv("ET_CONV_RING") ? atoi(getenv("ET_CONV_RING")) : 12882;
+    static const int ring_env = getenv("ET_CONV_RING") ? atoi(getenv("ET_CONV_RING")) : 0;
+    // default: short-K GEMMs (K <= 256, i.e. <= 4 chunks of 64) run 32-wide chunks in a 3-deep ring -- 48 KB of
+    // LDS, three workgroups per CU, two chunks in flight each (measured 3-10 % on the 1x1 layers); everything
+    // else the 64-wide double buffer (deeper rings or taller tiles cost occupancy and lose: profiles/)
+    const int ring = ring_env ? ring_env : (g.T * g.Cin <= 256 ? 12843 : 12882);
     if constexpr (sizeof(T) == 2) {
         if (glds && g.CV % 8 == 0 && ring != 12882) {
 #define ET_RING(BM_, BKV_, NS_)                                                                                       \
@@ -1112,8 +1119,6 @@ static int launch_gemm(const void* X, const void* W, void* Y, const void* zero16
                 case 12843: ET_RING(128, 4, 3);
                 case 12844: ET_RING(128, 4, 4);
                 case 25683: ET_RING(256, 8, 3);
-                case 25644: ET_RING(256, 4, 4);
-                case 25645: ET_RING(256, 4, 5);
                 default: break;
             }
 #undef ET_RING

@@ -46,11 +46,16 @@ def _gemm_tag(x_dtype, cout, cin_padded, taps, mixed=False):
     ut = "true" if cv % 4 == 0 else "false"
     t = "float" if x_dtype == torch.float32 else "unsigned short"
     narrow_k = int(os.environ.get("ET_CONV_NARROW_K", "256"))
-    wide = cout > 64 and not (narrow_k > 0 and taps * cin_padded <= narrow_k)
-    name = "conv_gemm_glds_kernel" if int(os.environ.get("ET_CONV_GLDS", "1")) else "conv_gemm_kernel"
+    k_elems = taps * cin_padded
+    wide = cout > 64 and not (narrow_k > 0 and k_elems <= narrow_k)
+    glds = int(os.environ.get("ET_CONV_GLDS", "1"))
     if mixed:   # stride-2 dgrad: 4 parity-class launches whose tap counts (hence tiles) differ
-        return f"{name}<{t}, ...> (stride-2 dgrad parity classes)"
-    return f"{name}<{t}, 128, {128 if wide else 64}, 2, 2, {bkv}, {ut}>"
+        return f"conv_gemm{'_glds' if glds else ''}_kernel<{t}, ...> (stride-2 dgrad parity classes)"
+    bn = 128 if wide else 64
+    if not glds:
+        return f"conv_gemm_kernel<{t}, 128, {bn}, 2, 2, {bkv}, {ut}>"
+    ring = (4, 3) if (x_dtype != torch.float32 and cv % 8 == 0 and k_elems <= 256) else (bkv, 2)
+    return f"conv_gemm_glds_kernel<{t}, 128, {bn}, 2, 2, {ring[0]}, {ring[1]}, {ut}>"
 
 
 _ZERO_PAGES = {}
