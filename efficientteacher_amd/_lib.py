@@ -22,6 +22,9 @@ SIGNATURES = {
     "et_build_arch": (c_char_p, []),
     "et_abi_version": (c_int, []),
     "et_nms_ssod_workspace_bytes": (c_int, [c_int, c_int, ctypes.POINTER(c_size_t)]),
+    "et_nms_workspace_bytes": (c_int, [c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_size_t)]),
+    "et_nms": (c_int, [P, c_int, c_int, c_int, c_float, c_float, c_int, c_int, ctypes.c_uint64, ctypes.c_uint64, c_int,
+                       c_float, c_int, P, P, P, P, P, c_size_t, P]),
     "et_nms_ssod": (c_int, [P, c_int, c_int, c_int, c_float, c_float, c_int, c_int, P, P, P, P, P, c_size_t, P]),
     "et_detect_decode": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int64,
                                  P, c_float, P, c_int64, c_int64, P]),

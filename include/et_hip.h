@@ -46,6 +46,17 @@ int et_nms_ssod(const float* pred, int B, int A, int no, float conf_thres, float
                 int agnostic, int max_det, float* dets, int* counts, int64_t* keep,
                 int* n_candidates, void* workspace, size_t ws_bytes, et_stream_t stream);
 
+/* General non_max_suppression: reference utils/general.py:994-1100 (val.py:335 calls it with
+ * multi_label=True, conf_thres=0.001).  Same outputs as et_nms_ssod; dets rows are
+ * [x1,y1,x2,y2,conf,cls,0,0].  class_mask_{lo,hi}: bit c set = class c allowed (the `classes=` filter,
+ * :1061); pass ~0 for no filter.  max_nms = 30000 and max_wh = 7680 in the reference (:1013-1014).
+ * `keep` indexes the candidate matrix after the max_nms cut, in (anchor, class) order. */
+int et_nms_workspace_bytes(int B, int A, int no, int multi_label, int max_nms, size_t* bytes /*host out*/);
+int et_nms(const float* pred, int B, int A, int no, float conf_thres, float iou_thres, int agnostic,
+           int multi_label, uint64_t class_mask_lo, uint64_t class_mask_hi, int max_nms, float max_wh,
+           int max_det, float* dets, int* counts, int64_t* keep, int* n_candidates, void* workspace,
+           size_t ws_bytes, et_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Detect head inference decode.  Replaces models/head/yolov5_head.py:68-78 (+ _make_grid_old
  * :127-136) for one level: reads the head conv output through element strides

@@ -114,7 +114,7 @@ def non_max_suppression_ssod(prediction, conf_thres=0.25, iou_thres=0.45, agnost
 
 
 def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, agnostic=False,
-                        multi_label=False, max_det=300):
+                        multi_label=False, max_det=300, classes=None, max_nms=MAX_NMS):
     """utils/general.py:994-1100 (val.py:335 uses multi_label=True)."""
     prediction = np.asarray(prediction, dtype=F32)
     nc = prediction.shape[2] - 5
@@ -135,11 +135,13 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, agnostic=Fa
             j = x[:, 5:].argmax(1)[:, None]
             conf = np.take_along_axis(x[:, 5:], j, 1)
             x = np.concatenate((box, conf, j.astype(F32)), 1)[conf.reshape(-1) > ct]
+        if classes is not None:                            # :1061
+            x = x[np.isin(x[:, 5], np.asarray(classes, F32))]
         n = x.shape[0]
         if not n:
             out.append(np.zeros((0, 6), F32)); continue
-        if n > MAX_NMS:
-            x = x[np.argsort(-x[:, 4], kind="stable")[:MAX_NMS]]
+        if n > max_nms:                                    # :1071 (torch argsort is unstable; pinned as stable)
+            x = x[np.argsort(-x[:, 4], kind="stable")[:max_nms]]
         c = x[:, 5:6] * F32(0 if agnostic else MAX_WH)
         i = nms(x[:, :4] + c, x[:, 4], iou_thres)[:max_det]
         out.append(x[i])

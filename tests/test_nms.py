@@ -59,3 +59,71 @@ def test_nms_max_det_and_list_api(hip):
     assert len(out) == 2
     for o, r in zip(out, ref):
         assert o.shape == (50, 8) and np.array_equal(o.cpu().numpy(), r)
+
+
+# ---- general non_max_suppression: the val.py path and boundary entry (8b) -----------------
+def _run_general(hip, pred, ct, it, **kw):
+    from efficientteacher_amd.utils.general import nms_padded
+    dets, counts, keep, ncand = nms_padded(hip.t(pred), ct, it, **kw)
+    return dets.cpu().numpy(), counts.cpu().numpy(), keep.cpu().numpy(), ncand.cpu().numpy()
+
+
+@pytest.mark.parametrize("case", ["a", "b", "c", "empty"])
+def test_nms_val_golden(hip, case):
+    """multi_label NMS vs the reference's own non_max_suppression(multi_label=True) output."""
+    g = golden("nms")
+    pred, (ct, it) = g[f"{case}_pred"], g[f"{case}_thr"]
+    dets, counts, _, _ = _run_general(hip, pred, float(ct), float(it), multi_label=True)
+    assert np.array_equal(counts, g[f"{case}_val_counts"])
+    got = np.concatenate([dets[i, :c] for i, c in enumerate(counts)], 0).reshape(-1, 6)
+    assert np.array_equal(got, g[f"{case}_val_dets"].reshape(-1, 6))    # bit exact rows
+
+
+def _clustered(seed, B, A, nc, ties=True):
+    rng = np.random.default_rng(seed)
+    pred = np.zeros((B, A, 5 + nc), np.float32)
+    centers = rng.uniform(80, 560, (B, 9, 2)).astype(np.float32)
+    idx = rng.integers(0, 9, (B, A))
+    pred[..., 0:2] = np.take_along_axis(centers, idx[..., None].repeat(2, 2), 1) + rng.normal(0, 5, (B, A, 2))
+    pred[..., 2:4] = 70 + rng.normal(0, 10, (B, A, 2))
+    pred[..., 4] = rng.uniform(0, 1, (B, A)) ** 2
+    pred[..., 5:] = rng.uniform(0, 1, (B, A, nc)) ** 2
+    if ties and A > 22:
+        pred[:, ::11] = pred[:, 1::11][:, : pred[:, ::11].shape[1]]
+    return pred
+
+
+@pytest.mark.parametrize("multi", [False, True])
+@pytest.mark.parametrize("seed,B,A,nc", [(0, 2, 700, 80), (1, 1, 64, 3), (2, 3, 333, 1), (3, 2, 1300, 20)])
+def test_nms_general_vs_oracle(hip, seed, B, A, nc, multi):
+    pred = _clustered(seed, B, A, nc)
+    ref = o_nms.non_max_suppression(pred, 0.05, 0.6, multi_label=multi)
+    dets, counts, _, _ = _run_general(hip, pred, 0.05, 0.6, multi_label=multi)
+    for i in range(B):
+        assert counts[i] == ref[i].shape[0]
+        assert np.array_equal(dets[i, :counts[i]], ref[i])
+
+
+def test_nms_general_classes_agnostic_and_list_api(hip):
+    from efficientteacher_amd.utils.general import non_max_suppression
+    pred = _clustered(5, 2, 500, 12)
+    ref = o_nms.non_max_suppression(pred, 0.05, 0.5, multi_label=True, classes=[1, 4, 11], agnostic=True, max_det=40)
+    out = non_max_suppression(hip.t(pred), 0.05, 0.5, classes=[1, 4, 11], agnostic=True, multi_label=True, max_det=40)
+    assert len(out) == 2
+    for o, r in zip(out, ref):
+        assert o.shape[1] == 6 and np.array_equal(o.cpu().numpy(), r)
+
+
+@pytest.mark.parametrize("max_nms", [97, 500, 2000])
+def test_nms_general_max_nms_cut_with_ties(hip, max_nms):
+    """More candidates than max_nms: the cut keeps the best scores, ties in candidate order (exact, via the
+    two-level histogram select), including ties that straddle the cut."""
+    pred = _clustered(9, 2, 600, 10)
+    pred[:, 100:400, 4] = 0.5                   # many equal scores: obj and cls identical across anchors
+    pred[:, 100:400, 5:] = pred[:, 100:101, 5:]
+    ref = o_nms.non_max_suppression(pred, 0.01, 0.6, multi_label=True, max_nms=max_nms)
+    dets, counts, _, ncand = _run_general(hip, pred, 0.01, 0.6, multi_label=True, max_nms=max_nms)
+    assert (ncand == max_nms).all()
+    for i in range(2):
+        assert counts[i] == ref[i].shape[0]
+        assert np.array_equal(dets[i, :counts[i]], ref[i])

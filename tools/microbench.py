@@ -125,6 +125,12 @@ def bench_nms(B=32, A=25200, no=85):
     r = dict(B=B, A=A, no=no, ms=t * 1e3, scan_GBps=pred.numel() * 4 / t / 1e9,
              mean_candidates=float(ncand.float().mean()), mean_kept=float(counts.float().mean()))
     print("NMS " + json.dumps(r), flush=True)
+    # val.py configuration of the general NMS: multi_label, conf 0.001, iou 0.65
+    from efficientteacher_amd.utils.general import nms_padded
+    tv = timeit(lambda: nms_padded(pred, 0.001, 0.65, multi_label=True), iters=5)
+    _, cv, _, ncv = nms_padded(pred, 0.001, 0.65, multi_label=True)
+    print("NMS_VAL " + json.dumps(dict(B=B, A=A, no=no, ms=tv * 1e3, mean_candidates=float(ncv.float().mean()),
+                                       mean_kept=float(cv.float().mean()))), flush=True)
     return r
 
 
