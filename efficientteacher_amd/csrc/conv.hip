@@ -686,6 +686,7 @@ struct WgradGeom {
     int Cout, ldy;               // dY channels / pixel stride
     int isy, isx;
     int T, NC;                   // taps, NC = T*Cin columns of dW
+    int xcd;                     // 1 = remap the linear workgroup id so that one K-split's tiles share an XCD
     int Pper;                    // pixels per split-K slice (multiple of the K-chunk)
     int ntn, ntm, nsk;           // tile grid: column tiles, cout tiles, K splits (1-D launch, decoded in-kernel)
     FastDiv dQW, dQH, dCin;
@@ -736,7 +737,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const T* __restrict__ X
     // blocks of one K-split read the SAME pixels of dY / X, so they should share one XCD's L2
     // (the round-robin dispatch otherwise makes every XCD fetch every pixel range).
     int bid = blockIdx.x;
-    if (g.T == 1) {      // measured: helps the 1x1 layers (few tiles per K-split), not the 3x3 ones
+    if (g.xcd) {
         const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bid & 7, k = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
     }
@@ -906,7 +907,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_tr_kernel(const uint1
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     int bid = blockIdx.x;
-    if (g.T == 1) {
+    if (g.xcd) {
         const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bid & 7, k = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
     }
@@ -1262,6 +1263,8 @@ static void launch_wgrad(const void* x, const void* dy, float* dw, const void* z
     int per = (g.P + sk - 1) / sk;
     per = ((per + BKP - 1) / BKP) * BKP;
     sk = (g.P + per - 1) / per;
+    static const int wxcd = getenv("ET_WGRAD_XCD") ? atoi(getenv("ET_WGRAD_XCD")) : 2;   // 0 never, 1 1x1 only, 2 always
+    g.xcd = wxcd == 2 || (wxcd == 1 && g.T == 1);
     g.Pper = per;
     g.ntn = (g.NC + bn - 1) / bn; g.ntm = (g.Cout + bm - 1) / bm; g.nsk = sk;
     const dim3 grid(g.ntn * g.ntm * sk), block(256);

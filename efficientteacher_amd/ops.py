@@ -17,19 +17,19 @@ class KernelTimer:
     leg).  ``ops.TIMER = KernelTimer()`` switches it on; nothing is recorded otherwise."""
 
     def __init__(self):
-        self.rows = []          # (tag, flops, launches, start_event, end_event)
+        self.rows = []          # (tag, flops, launches, algorithmic bytes, start_event, end_event)
 
-    def span(self, tag, flops, launches=1):
+    def span(self, tag, flops, launches=1, nbytes=0):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        self.rows.append((tag, flops, launches, a, b))
+        self.rows.append((tag, flops, launches, nbytes, a, b))
         return a, b
 
     def summary(self):
         agg = {}
-        for tag, fl, n, a, b in self.rows:
+        for tag, fl, n, nb, a, b in self.rows:
             ms = a.elapsed_time(b)
-            t = agg.setdefault(tag, dict(ms=0.0, flops=0.0, launches=0))
-            t["ms"] += ms; t["flops"] += fl; t["launches"] += n
+            t = agg.setdefault(tag, dict(ms=0.0, flops=0.0, launches=0, bytes=0.0))
+            t["ms"] += ms; t["flops"] += fl; t["launches"] += n; t["bytes"] += nb
         return agg
 
 
@@ -105,7 +105,8 @@ def conv2d_fwd(x, w, stride, pad, *, scale=None, bias=None, act=ACT_NONE, residu
         rows = lib.et_conv2d_stats_rows(N, OH, OW)
         stats = torch.empty((rows, 2, Cout), dtype=torch.float32, device=x.device)
     ldr = _nhwc(residual) if residual is not None else 0
-    ev = TIMER.span(_gemm_tag(x.dtype, Cout, Cin, KH * KW), 2.0 * N * OH * OW * Cout * Cin * KH * KW) if TIMER else None
+    ev = TIMER.span(_gemm_tag(x.dtype, Cout, Cin, KH * KW), 2.0 * N * OH * OW * Cout * Cin * KH * KW,
+                    nbytes=(x.numel() + N * OH * OW * Cout + w.numel()) * x.element_size()) if TIMER else None
     if ev:
         ev[0].record()
     _lib.check(lib.et_conv2d_fwd(_lib.ptr(x), _lib.ptr(w), _lib.ptr(out), et_dtype(x), N, IH, IW, Cin, _nhwc(x),
@@ -137,7 +138,7 @@ def conv2d_dgrad(dy, wT, in_hw, stride, pad, *, out=None, accumulate=False):
         assert not accumulate
         out = torch.empty((N, IH, IW, Cin), dtype=dy.dtype, device=dy.device)
     ev = TIMER.span(_gemm_tag(dy.dtype, Cin, Cout, KH * KW, mixed=stride > 1), 2.0 * N * OH * OW * Cout * Cin * KH * KW,
-                    stride * stride) if TIMER else None
+                    stride * stride, nbytes=(dy.numel() + N * IH * IW * Cin + wT.numel()) * dy.element_size()) if TIMER else None
     if ev:
         ev[0].record()
     _lib.check(_lib.load().et_conv2d_dgrad(_lib.ptr(dy), _lib.ptr(wT), _lib.ptr(out), et_dtype(dy), N, IH, IW, Cin,
