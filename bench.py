@@ -187,6 +187,7 @@ def main():
         ops.TIMER = timer if i in timed else None
         items = step(a.warmup + i)
     ops.TIMER = None
+    t_enq = time.perf_counter() - t0          # host time to enqueue the K steps (no device sync inside a step)
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -232,7 +233,8 @@ def main():
                        "parallelism": f"dp{world}", "optimizer_every_step": True,
                        "algorithmic_tflop_per_step_per_gpu": step_flop / 1e12,
                        "step_tflops_per_gpu": step_flop / (dt / a.steps) / 1e12,
-                       "frac_of_bf16_mfma_peak": step_flop / (dt / a.steps) / PEAK_BF16, "loss_finite": loss_ok},
+                       "frac_of_bf16_mfma_peak": step_flop / (dt / a.steps) / PEAK_BF16, "loss_finite": loss_ok,
+                       "host_enqueue_ms_per_step": t_enq / a.steps * 1e3},
             "roofline": roof,
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -520,12 +520,13 @@ template <int N> __device__ __forceinline__ void et_wait_vmem_le() {
 // MFMA busy ~30 %), not LDS or MFMA issue -- hence deeper rings and, where the layer has the rows, a
 // 256-row tile (1.33x the flops per staged byte).
 template <typename T, int BM, int BN, int WM, int WN, int BKV, int NS, bool UTAP>
-__global__ __launch_bounds__(256) void conv_gemm_glds_kernel(const T* __restrict__ X, const T* __restrict__ W,
+__global__ __launch_bounds__(64 * WM * WN, (NS == 3 && BKV == 4 && BM == 128) ? 3 : 1) void conv_gemm_glds_kernel(const T* __restrict__ X, const T* __restrict__ W,
                                                              T* __restrict__ Y, const T* __restrict__ ZERO,
                                                              GatherGeom g, Epilogue ep) {
     constexpr int VEC = et_elem<T>::VEC;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int RPT = 256 / BKV;
+    constexpr int NT = 64 * WM * WN;             // 4 waves (2x2) or 8 waves (2x4) per workgroup
+    constexpr int RPT = NT / BKV;
     constexpr int RA = BM / RPT, RB = BN / RPT;
     constexpr int STAGE_VEC = (BM + BN) * BKV;
     constexpr int EPI_VEC = EpiLds<BM, BN, WM, WN>::VEC16;
@@ -579,9 +580,9 @@ __global__ __launch_bounds__(256) void conv_gemm_glds_kernel(const T* __restrict
     const int nchunks = (g.KV + BKV - 1) / BKV;
     int tap_u = 0, cv_u = 0;
 
-    // issue the LDS-DMA of one K-chunk into `dst` (all 256 threads, RA + RB instructions each)
+    // issue the LDS-DMA of one K-chunk into `dst` (all NT threads, RA + RB instructions each)
     auto stage = [&](u32x4* dst, int chunk, int tap_c, int cv_c) {
-        u32x4* const wbase = dst + wave * 64;              // wave-uniform: lanes land at wbase[j*256 + lane]
+        u32x4* const wbase = dst + wave * 64;              // wave-uniform: lanes land at wbase[j*NT + lane]
         int udy = 0, udx = 0, uwt = 0;
         if constexpr (UTAP) tap_lookup_uniform(g, tap_c, udy, udx, uwt);   // once per chunk, before the burst
 #pragma unroll
@@ -605,7 +606,7 @@ __global__ __launch_bounds__(256) void conv_gemm_glds_kernel(const T* __restrict
 #else
             const T* src = ok ? X + (a_off[j] + (dy * g.IW + dx) * g.ldx + cv * VEC) : ZERO;
 #endif
-            et_glds16(src, wbase + j * 256);
+            et_glds16(src, wbase + j * NT);
         }
 #pragma unroll
         for (int j = 0; j < RB; ++j) {
@@ -627,7 +628,7 @@ __global__ __launch_bounds__(256) void conv_gemm_glds_kernel(const T* __restrict
 #else
             const T* src = ok ? W + (b_off[j] + wt * g.Cin + cv * VEC) : ZERO;
 #endif
-            et_glds16(src, wbase + BM * BKV + j * 256);
+            et_glds16(src, wbase + BM * BKV + j * NT);
         }
     };
 #define ET_ADVANCE_CURSOR()                                              \
@@ -1104,7 +1105,18 @@ static int launch_gemm(const void* X, const void* W, void* Y, const void* zero16
     // default: short-K GEMMs (K <= 256, i.e. <= 4 chunks of 64) run 32-wide chunks in a 3-deep ring -- 48 KB of
     // LDS, three workgroups per CU, two chunks in flight each (measured 3-10 % on the 1x1 layers); everything
     // else the 64-wide double buffer (deeper rings or taller tiles cost occupancy and lose: profiles/)
-    const int ring = ring_env ? ring_env : (g.T * g.Cin <= 256 ? 12843 : 12882);
+    int ring = ring_env ? ring_env : (g.T * g.Cin <= 256 ? 12843 : 12882);
+    // 8-wave 256x256 tile (one workgroup per CU, half the L2->LDS bytes per flop): measured 860-970 TFLOP/s vs
+    // 740 on the 3x3 layers with >= 256 output channels, and a win on the deep 1x1 layers when the grid fills
+    // whole residency rounds reasonably (ET_CONV_BIG=0 disables, tuning knob)
+    static const int big = getenv("ET_CONV_BIG") ? atoi(getenv("ET_CONV_BIG")) : 1;
+    if (!ring_env && big && sizeof(T) == 2 && g.Cout >= 256 && g.CV % 8 == 0) {
+        static const int n_cu = [] { hipDeviceProp_t p; int d = 0; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; }();
+        const long long blocks = (long long)((g.M + 255) / 256) * ((g.Cout + 255) / 256);
+        const double rounds = (double)blocks / n_cu;
+        const bool fills = (double)((blocks + n_cu - 1) / n_cu) / rounds <= 1.35;
+        if (g.TT > 1 || (g.T * g.Cin >= 512 && fills)) ring = 25682;
+    }
     if constexpr (sizeof(T) == 2) {
         if (glds && g.CV % 8 == 0 && ring != 12882) {
 #define ET_RING(BM_, BKV_, NS_)                                                                                       \
@@ -1115,6 +1127,12 @@ static int launch_gemm(const void* X, const void* W, void* Y, const void* zero16
         else hipLaunchKernelGGL((conv_gemm_glds_kernel<T, BM_, 64, 2, 2, BKV_, NS_, true>), grid, block, 0, s, x, w, y, z, g, ep);       \
         return 0;                                                                                                     \
     } while (0)
+            if (ring == 25682) {           // 8 waves, 256x256 tile, 64-wide chunks double-buffered (128 KB of LDS)
+                g.ntm = (g.M + 255) / 256; g.ntn = (g.Cout + 255) / 256;
+                hipLaunchKernelGGL((conv_gemm_glds_kernel<T, 256, 256, 2, 4, 8, 2, true>), dim3(g.ntm * g.ntn), dim3(512), 0, s,
+                                   x, w, y, z, g, ep);
+                return 0;
+            }
             switch (ring) {
                 case 12883: ET_RING(128, 8, 3);
                 case 12843: ET_RING(128, 4, 3);

@@ -36,7 +36,7 @@ class KernelTimer:
 TIMER = None
 
 
-def _gemm_tag(x_dtype, cout, cin_padded, taps, mixed=False):
+def _gemm_tag(x_dtype, cout, cin_padded, taps, mixed=False, M=0, full_taps=None):
     """Name of the kernel instantiation csrc/conv.hip:launch_gemm picks for this GEMM, spelled the way
     rocprofv3 prints it, so that bench.py's HIP-event timing can be checked against the rocprof summary."""
     import os
@@ -54,7 +54,14 @@ def _gemm_tag(x_dtype, cout, cin_padded, taps, mixed=False):
     bn = 128 if wide else 64
     if not glds:
         return f"conv_gemm_kernel<{t}, 128, {bn}, 2, 2, {bkv}, {ut}>"
-    ring = (4, 3) if (x_dtype != torch.float32 and cv % 8 == 0 and k_elems <= 256) else (bkv, 2)
+    bf16 = x_dtype != torch.float32
+    if bf16 and cv % 8 == 0 and cout >= 256 and int(os.environ.get("ET_CONV_BIG", "1")) and not os.environ.get("ET_CONV_RING"):
+        n_cu = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count if torch.cuda.is_available() else 256
+        blocks = ((M + 255) // 256) * ((cout + 255) // 256)
+        fills = blocks > 0 and (-(-blocks // n_cu)) / (blocks / n_cu) <= 1.35
+        if (full_taps or taps) > 1 or (k_elems >= 512 and fills):
+            return f"conv_gemm_glds_kernel<{t}, 256, 256, 2, 4, 8, 2, true>"
+    ring = (4, 3) if (bf16 and cv % 8 == 0 and k_elems <= 256) else (bkv, 2)
     return f"conv_gemm_glds_kernel<{t}, 128, {bn}, 2, 2, {ring[0]}, {ring[1]}, {ut}>"
 
 
@@ -105,7 +112,7 @@ def conv2d_fwd(x, w, stride, pad, *, scale=None, bias=None, act=ACT_NONE, residu
         rows = lib.et_conv2d_stats_rows(N, OH, OW)
         stats = torch.empty((rows, 2, Cout), dtype=torch.float32, device=x.device)
     ldr = _nhwc(residual) if residual is not None else 0
-    ev = TIMER.span(_gemm_tag(x.dtype, Cout, Cin, KH * KW), 2.0 * N * OH * OW * Cout * Cin * KH * KW,
+    ev = TIMER.span(_gemm_tag(x.dtype, Cout, Cin, KH * KW, M=N * OH * OW), 2.0 * N * OH * OW * Cout * Cin * KH * KW,
                     nbytes=(x.numel() + N * OH * OW * Cout + w.numel()) * x.element_size()) if TIMER else None
     if ev:
         ev[0].record()
@@ -137,7 +144,7 @@ def conv2d_dgrad(dy, wT, in_hw, stride, pad, *, out=None, accumulate=False):
     if out is None:
         assert not accumulate
         out = torch.empty((N, IH, IW, Cin), dtype=dy.dtype, device=dy.device)
-    ev = TIMER.span(_gemm_tag(dy.dtype, Cin, Cout, KH * KW, mixed=stride > 1), 2.0 * N * OH * OW * Cout * Cin * KH * KW,
+    ev = TIMER.span(_gemm_tag(dy.dtype, Cin, Cout, KH * KW, mixed=stride > 1, M=N * IH * IW), 2.0 * N * OH * OW * Cout * Cin * KH * KW,
                     stride * stride, nbytes=(dy.numel() + N * IH * IW * Cin + wT.numel()) * dy.element_size()) if TIMER else None
     if ev:
         ev[0].record()
