@@ -41,7 +41,7 @@ SIGNATURES = {
     "et_bn_finalize": (c_int, [P, c_int, c_int, c_double, P, P, c_float, c_float, P, P, P, P, P, P, P, P]),
     "et_bn_eval_affine": (c_int, [c_int, P, P, P, P, c_float, P, P, P]),
     "et_bn_act_fwd": (c_int, [P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, P, P, c_int, P]),
-    "et_bn_act_bwd": (c_int, [P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, P, P, P, P, P, c_int, P, P, P,
+    "et_bn_act_bwd": (c_int, [P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, P, P, P, P, P, c_int, P, P, P, P,
                               c_size_t, P]),
     "et_act_bwd": (c_int, [P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
     "et_pack_input": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),

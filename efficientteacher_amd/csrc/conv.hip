@@ -1133,6 +1133,12 @@ static int launch_gemm(const void* X, const void* W, void* Y, const void* zero16
                                    x, w, y, z, g, ep);
                 return 0;
             }
+            if (ring == 25612) {           // 8 waves, 256x128 tile (experiment)
+                g.ntm = (g.M + 255) / 256; g.ntn = (g.Cout + 127) / 128;
+                hipLaunchKernelGGL((conv_gemm_glds_kernel<T, 256, 128, 4, 2, 8, 2, true>), dim3(g.ntm * g.ntn), dim3(512), 0, s,
+                                   x, w, y, z, g, ep);
+                return 0;
+            }
             switch (ring) {
                 case 12883: ET_RING(128, 8, 3);
                 case 12843: ET_RING(128, 4, 3);

@@ -61,8 +61,9 @@ __global__ __launch_bounds__(256) void rows_reduce_kernel(const float* __restric
     }
 }
 
+// `ws` (2*C fp64 totals) must be ZERO on entry: the finalize kernels re-zero it after reading, so a caller that
+// keeps one zero-initialised scratch per stream never pays a memset launch per layer
 static void launch_rows_reduce(const float* part, int rows, int C, double* ws, hipStream_t s) {
-    (void)hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, s);
     int rb = rows / 64;
     rb = rb < 1 ? 1 : (rb > 64 ? 64 : rb);
     const int per = (rows + rb - 1) / rb;
@@ -70,7 +71,7 @@ static void launch_rows_reduce(const float* part, int rows, int C, double* ws, h
 }
 
 // ws[2][C] totals -> scale/shift (+ saved mean / invstd, running statistics update)
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ ws, int C, double count,
+__global__ __launch_bounds__(256) void bn_finalize_kernel(double* __restrict__ ws, int C, double count,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float eps, float momentum, float* __restrict__ rmean,
                                                           float* __restrict__ rvar, float* __restrict__ scale,
@@ -80,6 +81,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
     if (c >= C) return;
     const double mean = ws[c] / count;
     double var = ws[C + c] / count - mean * mean;
+    ws[c] = 0.0; ws[C + c] = 0.0;                          // leave the scratch zeroed for the next layer
     if (var < 0.0) var = 0.0;
     const float invstd = (float)(1.0 / sqrt(var + (double)eps));
     const float sc = gamma[c] * invstd;
@@ -231,13 +233,14 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const T* __restr
 }
 
 // finalize: dbeta += s1, dgamma += s2, coefficients of pass 2 (ws = fp64 totals from rows_reduce_kernel)
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ ws, int C, float count,
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(double* __restrict__ ws, int C, float count,
                                                               const float* __restrict__ gamma, const float* __restrict__ invstd,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                               float* __restrict__ k0, float* __restrict__ k1, float* __restrict__ k2) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
     const double s = ws[c], q = ws[C + c];
+    ws[c] = 0.0; ws[C + c] = 0.0;
     if (dbeta) dbeta[c] += (float)s;
     if (dgamma) dgamma[c] += (float)q;
     k0[c] = gamma[c] * invstd[c];
@@ -363,18 +366,19 @@ extern "C" int et_bn_act_fwd(const void* y, int ldy, void* z, int ldz, const voi
 
 extern "C" int et_bn_act_bwd(const void* dz, int lddz, const void* y, int ldy, void* dy, int lddy, int dtype, int P, int C,
                              const float* gamma, const float* scale, const float* shift, const float* save_mean,
-                             const float* save_invstd, int act, float* dgamma, float* dbeta, float* workspace,
-                             size_t ws_floats, et_stream_t stream) {
-    // workspace (fp32 units): 4*C (= 2*C fp64 totals) + rows*2*C partial sums + 3*C coefficients
-    if (!dz || !y || !dy || !gamma || !scale || !shift || !save_mean || !save_invstd || !workspace) return -1;
+                             const float* save_invstd, int act, float* dgamma, float* dbeta, double* totals,
+                             float* workspace, size_t ws_floats, et_stream_t stream) {
+    // totals: 2*C fp64, zero on entry, zero again on return.  workspace (fp32 units): rows*2*C partial sums +
+    // 3*C coefficients
+    if (!dz || !y || !dy || !gamma || !scale || !shift || !save_mean || !save_invstd || !workspace || !totals) return -1;
     const int vec = dtype == ET_F32 ? 4 : 8;
     if (P <= 0 || C <= 0 || C > 2048 || C % vec || lddz % vec || ldy % vec || lddy % vec) return -2;
     const int CV = C / vec;
     // 16 vectors per thread: the per-block partial rows and the block reduction amortise better (measured)
     const int rows = ew_blocks(P, CV, 16);
-    if (ws_floats < (size_t)rows * 2 * C + 7 * (size_t)C || (((uintptr_t)workspace) & 7)) return -3;
-    double* tot = (double*)workspace;
-    float* part = workspace + 4 * (size_t)C;
+    if (ws_floats < (size_t)rows * 2 * C + 3 * (size_t)C || (((uintptr_t)totals) & 7)) return -3;
+    double* tot = totals;
+    float* part = workspace;
     float* k0 = part + (size_t)rows * 2 * C;
     float* k1 = k0 + C;
     float* k2 = k1 + C;

@@ -135,6 +135,16 @@ class FlatState:
             b.running_var = s.rvar
             self.bn_slots[id(b)] = s
             b._et_slot = s
+        # num_batches_tracked of every BatchNorm as views of ONE int64 vector: a training forward bumps all of
+        # them with a single launch (was 101 one-element kernels per step)
+        self.nbt = torch.zeros(max(1, len(bns)), dtype=torch.int64, device=dev)
+        self._bns = bns
+        self.bulk_nbt = False
+        for i, b in enumerate(bns):
+            if b.num_batches_tracked is not None:
+                with torch.no_grad():
+                    self.nbt[i] = b.num_batches_tracked.to(dev)
+                b.num_batches_tracked = self.nbt[i]
         bo = 2 * bn_total
         owner = dict(model.named_modules())
         for name, buf in other:
@@ -180,6 +190,10 @@ class FlatState:
             self.weights_dirty = False
         if not training:
             self.refresh_eval_affine()
+        # reference: every BatchNorm in training mode increments its counter once per forward
+        self.bulk_nbt = bool(training) and all(b.training for b in self._bns)
+        if self.bulk_nbt:
+            self.nbt.add_(1)
 
     def zero_grad(self):
         self.grads.zero_()

@@ -67,7 +67,8 @@ class Conv(nn.Module):
         bs = self.bn._et_slot
         act = _act_code(self.act)
         if self.bn.training:
-            return ConvBnActFn.apply(x, residual, self.conv.weight, cs, bs, act, self.bn.num_batches_tracked, dst)
+            nbt = None if self._et_flat().bulk_nbt else self.bn.num_batches_tracked   # bulk: bumped once per forward
+            return ConvBnActFn.apply(x, residual, self.conv.weight, cs, bs, act, nbt, dst)
         # eval (EMA teacher): BatchNorm is an affine of the running statistics, folded into the conv epilogue
         flat = self._et_flat()
         o = bs.aff_off

@@ -76,6 +76,19 @@ def zero_page(device):
     return z
 
 
+_BN_TOTALS = {}
+
+
+def bn_totals_scratch(device):
+    """2*2048 fp64 zeros per (device, stream): the BN kernels need their totals scratch zero on entry and leave
+    it zero on return (include/et_hip.h), so one buffer per stream replaces a memset launch per layer."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
+    z = _BN_TOTALS.get(key)
+    if z is None:
+        z = _BN_TOTALS[key] = torch.zeros(2 * 2048, dtype=torch.float64, device=device)
+    return z
+
+
 def et_dtype(t):
     if t.dtype == torch.float32:
         return ET_F32
@@ -187,7 +200,8 @@ def bn_finalize(stats, count, gamma, beta, eps, momentum, running_mean=None, run
     dev = stats.device
     aff = torch.empty((4, C), dtype=torch.float32, device=dev)
     scale, shift, mean, invstd = aff[0], aff[1], aff[2], aff[3]
-    ws = torch.empty(2 * C, dtype=torch.float64, device=dev)
+    assert C <= 2048
+    ws = bn_totals_scratch(dev)
     _lib.check(_lib.load().et_bn_finalize(_lib.ptr(stats), rows, C, float(count), _lib.ptr(gamma), _lib.ptr(beta),
                                           eps, momentum, _lib.ptr(running_mean), _lib.ptr(running_var),
                                           _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(mean), _lib.ptr(invstd),
@@ -222,12 +236,13 @@ def bn_act_bwd(dz, y, gamma, scale, shift, mean, invstd, act, dgamma, dbeta, out
     if out is None:
         out = torch.empty((N, H, W, C), dtype=y.dtype, device=y.device)
     rows = lib.et_bn_reduce_rows(N * H * W, C, et_dtype(y))
-    nws = rows * 2 * C + 7 * C
+    nws = rows * 2 * C + 3 * C
     ws = torch.empty(nws, dtype=torch.float32, device=y.device)
     _lib.check(lib.et_bn_act_bwd(_lib.ptr(dz), _nhwc(dz), _lib.ptr(y), _nhwc(y), _lib.ptr(out), _nhwc(out),
                                  et_dtype(y), N * H * W, C, _lib.ptr(gamma), _lib.ptr(scale), _lib.ptr(shift),
                                  _lib.ptr(mean), _lib.ptr(invstd), act, _lib.ptr(dgamma), _lib.ptr(dbeta),
-                                 _lib.ptr(ws), nws, _lib.stream(y)), "et_bn_act_bwd")
+                                 _lib.ptr(bn_totals_scratch(y.device)), _lib.ptr(ws), nws, _lib.stream(y)),
+               "et_bn_act_bwd")
     return out
 
 

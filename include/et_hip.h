@@ -123,21 +123,24 @@ int et_colsum(const void* x, int dtype, int P, int C, int ld, float* out, et_str
  *   et_bn_eval_affine: eval-mode (teacher) scale/shift from the running statistics.
  *   et_bn_act_fwd: z = act(y*scale + shift) (+ residual).
  *   et_bn_act_bwd: dy = dBN/dSiLU(dz) in two passes; dgamma/dbeta (fp32) are ACCUMULATED.
- *       workspace (8-byte aligned): >= et_bn_reduce_rows(P,C,dtype)*2*C + 7*C floats.  C <= 2048.
+ *       workspace: >= et_bn_reduce_rows(P,C,dtype)*2*C + 3*C floats.  C <= 2048.
+ *   `ws` / `totals` (2*C fp64): MUST BE ZERO ON ENTRY and is left zero on return (the finalize kernel clears
+ *       what it read), so one zero-initialised scratch per stream serves every layer without a memset.
  *   et_act_bwd: dy = dz * act'(y)   (netD ReLU, models/detector/yolo_ssod.py:231-238).          */
 int et_bn_reduce_rows(int P, int C, int dtype);
 int et_bn_finalize(const float* stats_partial, int rows, int C, double count, const float* gamma,
                    const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                    float* scale, float* shift, float* save_mean, float* save_invstd,
-                   double* ws /* 2*C fp64 scratch */, et_stream_t stream);
+                   double* ws /* 2*C fp64, zero in / zero out */, et_stream_t stream);
 int et_bn_eval_affine(int C, const float* gamma, const float* beta, const float* running_mean,
                       const float* running_var, float eps, float* scale, float* shift, et_stream_t stream);
 int et_bn_act_fwd(const void* y, int ldy, void* z, int ldz, const void* residual, int ldr, int dtype, int P,
                   int C, const float* scale, const float* shift, int act, et_stream_t stream);
 int et_bn_act_bwd(const void* dz, int lddz, const void* y, int ldy, void* dy, int lddy, int dtype, int P, int C,
                   const float* gamma, const float* scale, const float* shift, const float* save_mean,
-                  const float* save_invstd, int act, float* dgamma, float* dbeta, float* workspace,
-                  size_t ws_floats, et_stream_t stream);
+                  const float* save_invstd, int act, float* dgamma, float* dbeta,
+                  double* totals /* 2*C fp64, zero in / zero out */, float* workspace, size_t ws_floats,
+                  et_stream_t stream);
 int et_act_bwd(const void* dz, int lddz, const void* y, int ldy, void* dy, int lddy, int dtype, int P, int C,
                int act, et_stream_t stream);
 
