@@ -33,7 +33,7 @@ SIGNATURES = {
     "et_cast_f32_to_bf16": (c_int, [P, P, c_int64, P]),
     "et_conv2d_stats_rows": (c_int, [c_int, c_int, c_int]),
     "et_conv2d_fwd": (c_int, [P, P, P, c_int] + [c_int] * 11 + [P, P, c_int, P, c_int, P, P, P]),
-    "et_conv2d_dgrad": (c_int, [P, P, P, c_int] + [c_int] * 11 + [c_int, P, P]),
+    "et_conv2d_dgrad": (c_int, [P, P, P, c_int] + [c_int] * 11 + [c_int, P, c_int, P, P]),
     "et_conv2d_wgrad": (c_int, [P, P, P, c_int] + [c_int] * 11 + [P, P]),
     "et_weight_transpose": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "et_colsum": (c_int, [P, c_int, c_int, c_int, c_int, P, P]),

@@ -57,6 +57,54 @@ class ConvBnActFn(Function):
         return dx, (dz if ctx.has_res else None), None, None, None, None, None, None
 
 
+class BottleneckFn(Function):
+    """z = x + cv2(cv1(x))   -- reference Bottleneck.forward with the shortcut (common.py:534-544), both Conv
+    blocks in train mode.  One autograd node instead of two, so that the gradient of the shortcut is added in
+    the epilogue of cv1's dgrad (dx = dgrad(dy1) + dz) instead of a separate accumulation pass by autograd."""
+
+    @staticmethod
+    def forward(ctx, x, w1, w2, cs1, bs1, cs2, bs2, act1, act2, nbt1, nbt2, dst=None):
+        ctx.w_needs_grad = w1.requires_grad or w2.requires_grad
+        y1, st1 = ops.conv2d_fwd(x, cs1.w_lp, cs1.stride, cs1.pad, want_stats=True)
+        N, H1, W1, _ = y1.shape
+        a1 = ops.bn_finalize(st1, N * H1 * W1, bs1.gamma, bs1.beta, bs1.eps, bs1.momentum, bs1.rmean, bs1.rvar)
+        h = ops.bn_act_fwd(y1, a1[0], a1[1], act1)
+        y2, st2 = ops.conv2d_fwd(h, cs2.w_lp, cs2.stride, cs2.pad, want_stats=True)
+        _, H2, W2, _ = y2.shape
+        a2 = ops.bn_finalize(st2, N * H2 * W2, bs2.gamma, bs2.beta, bs2.eps, bs2.momentum, bs2.rmean, bs2.rvar)
+        for nbt in (nbt1, nbt2):
+            if nbt is not None:
+                nbt.add_(1)
+        out = None if dst is None else dst[0][..., dst[1]:dst[1] + cs2.coutp]
+        z = ops.bn_act_fwd(y2, a2[0], a2[1], act2, residual=x, out=out)
+        ctx.meta = (cs1, bs1, cs2, bs2, act1, act2)
+        ctx.x_needs_grad = x.requires_grad
+        ctx.save_for_backward(x, y1, h, y2, *a1, *a2)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, y1, h, y2, s1, b1, m1, i1, s2, b2, m2, i2 = ctx.saved_tensors
+        cs1, bs1, cs2, bs2, act1, act2 = ctx.meta
+        dz = _dense_or_slice(dz)
+        dy2 = ops.bn_act_bwd(dz, y2, bs2.gamma, s2, b2, m2, i2, act2, bs2.ggamma, bs2.gbeta)
+        if ctx.w_needs_grad:
+            ops.conv2d_wgrad(h, dy2, cs2.gw, cs2.k, cs2.stride, cs2.pad)
+            if GRAD_READY_HOOK is not None:
+                GRAD_READY_HOOK(cs2)
+        dh = ops.conv2d_dgrad(dy2, ops.weight_transpose(cs2.w_lp), (h.shape[1], h.shape[2]), cs2.stride, cs2.pad)
+        dy1 = ops.bn_act_bwd(dh, y1, bs1.gamma, s1, b1, m1, i1, act1, bs1.ggamma, bs1.gbeta)
+        if ctx.w_needs_grad:
+            ops.conv2d_wgrad(x, dy1, cs1.gw, cs1.k, cs1.stride, cs1.pad)
+            if GRAD_READY_HOOK is not None:
+                GRAD_READY_HOOK(cs1)
+        dx = None
+        if ctx.x_needs_grad:
+            dx = ops.conv2d_dgrad(dy1, ops.weight_transpose(cs1.w_lp), (x.shape[1], x.shape[2]), cs1.stride, cs1.pad,
+                                  residual=dz)
+        return (dx,) + (None,) * 11
+
+
 class ConvBiasFn(Function):
     """y = act(conv(x, w) + bias): the Detect output convs (yolov5_head.py:30,55) and netD
     (yolo_ssod.py:224-238).  With ``head=(na, no)`` the result is returned as the (B, na, ny, nx, no)

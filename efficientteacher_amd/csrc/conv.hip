@@ -1199,10 +1199,12 @@ extern "C" int et_conv2d_fwd(const void* x, const void* w, void* y, int dtype, i
 
 extern "C" int et_conv2d_dgrad(const void* dy, const void* wT, void* dx, int dtype, int N, int IH, int IW, int Cin,
                                int ldx, int Cout, int KH, int KW, int stride, int pad, int ldy, int accumulate,
+                               const void* residual, int ldr,
                                const void* zero16, et_stream_t stream) {
     // dx[n,iy,ix,ci] = sum_{ky,kx,co} dy[n,(iy+pad-ky)/s,(ix+pad-kx)/s,co] * wT[ci,ky,kx,co]
     if (!dy || !wT || !dx) return -1;
     if (KH * KW > CONV_MAX_TAPS || stride < 1 || stride > 2 || N <= 0) return -2;
+    if (residual && stride != 1) return -2;        // the fused shortcut-gradient add is a stride-1 (Bottleneck) feature
     const int OH = (IH + 2 * pad - KH) / stride + 1, OW = (IW + 2 * pad - KW) / stride + 1;
     const int vec = dtype == ET_F32 ? 4 : 8;
     for (int py = 0; py < stride; ++py)
@@ -1228,7 +1230,7 @@ extern "C" int et_conv2d_dgrad(const void* dy, const void* wT, void* dx, int dty
             // the "gathered" tensor of dgrad is dy (OH x OW x Cout), the written one is dx (IH x IW x Cin)
             int rc = fill_common(g, N, OH, OW, Cout, ldy, QH, QW, IH, IW, Cin, ldx, vec);
             if (rc) return rc;
-            Epilogue ep{nullptr, nullptr, ACT_NONE, nullptr, 0, nullptr, accumulate};
+            Epilogue ep{nullptr, nullptr, ACT_NONE, residual, ldr, nullptr, accumulate};   // dx = dgrad (+ residual)
             if (t == 0) return -2;   // would need a zero fill; does not occur for k>=stride
             if (dtype == ET_F32) rc = launch_gemm<float>(dy, wT, dx, zero16, g, ep, (hipStream_t)stream);
             else if (dtype == ET_BF16) rc = launch_gemm<uint16_t>(dy, wT, dx, zero16, g, ep, (hipStream_t)stream);

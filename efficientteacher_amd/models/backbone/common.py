@@ -10,7 +10,7 @@ import torch
 import torch.nn as nn
 
 from ... import ops
-from ...autograd import ConvBnActFn, JoinSlicesFn, SppfPoolFn
+from ...autograd import BottleneckFn, ConvBnActFn, JoinSlicesFn, SppfPoolFn
 
 
 def get_activation(act=True):
@@ -93,6 +93,15 @@ class Bottleneck(nn.Module):
         self.add = shortcut and c1 == c2
 
     def forward(self, x, dst=None):
+        c1, c2 = self.cv1, self.cv2
+        if (self.add and c1.bn.training and c2.bn.training and torch.is_grad_enabled() and c1.conv.stride[0] == 1
+                and getattr(c1.conv, "_et_slot", None) is not None):
+            # shortcut + train mode: one fused autograd node (the shortcut gradient rides cv1's dgrad epilogue)
+            bulk = c1._et_flat().bulk_nbt
+            return BottleneckFn.apply(x, c1.conv.weight, c2.conv.weight, c1.conv._et_slot, c1.bn._et_slot,
+                                      c2.conv._et_slot, c2.bn._et_slot, _act_code(c1.act), _act_code(c2.act),
+                                      None if bulk else c1.bn.num_batches_tracked,
+                                      None if bulk else c2.bn.num_batches_tracked, dst)
         return self.cv2(self.cv1(x), residual=x if self.add else None, dst=dst)
 
 

@@ -147,7 +147,7 @@ def weight_transpose(w):
     return wt
 
 
-def conv2d_dgrad(dy, wT, in_hw, stride, pad, *, out=None, accumulate=False):
+def conv2d_dgrad(dy, wT, in_hw, stride, pad, *, out=None, accumulate=False, residual=None):
     """dx (N, IH, IW, Cin) from dy (N, OH, OW, Cout) and wT (Cin, KH, KW, Cout)."""
     N, OH, OW, Cout = dy.shape
     Cin, KH, KW, Cout2 = wT.shape
@@ -163,6 +163,7 @@ def conv2d_dgrad(dy, wT, in_hw, stride, pad, *, out=None, accumulate=False):
         ev[0].record()
     _lib.check(_lib.load().et_conv2d_dgrad(_lib.ptr(dy), _lib.ptr(wT), _lib.ptr(out), et_dtype(dy), N, IH, IW, Cin,
                                            _nhwc(out), Cout, KH, KW, stride, pad, _nhwc(dy), int(accumulate),
+                                           _lib.ptr(residual), _nhwc(residual) if residual is not None else 0,
                                            _lib.ptr(zero_page(dy.device)), _lib.stream(dy)), "et_conv2d_dgrad")
     if ev:
         ev[1].record()

@@ -105,6 +105,7 @@ int et_conv2d_fwd(const void* x, const void* w, void* y, int dtype, int N, int I
                   const void* zero16, et_stream_t stream);
 int et_conv2d_dgrad(const void* dy, const void* wT, void* dx, int dtype, int N, int IH, int IW, int Cin,
                     int ldx, int Cout, int KH, int KW, int stride, int pad, int ldy, int accumulate,
+                    const void* residual /* optional, stride 1 only: dx = dgrad + residual */, int ldr,
                     const void* zero16, et_stream_t stream);
 int et_conv2d_wgrad(const void* x, const void* dy, float* dw, int dtype, int N, int IH, int IW, int Cin,
                     int ldx, int Cout, int KH, int KW, int stride, int pad, int ldy, const void* zero16,
