@@ -105,6 +105,78 @@ class BottleneckFn(Function):
         return (dx,) + (None,) * 11
 
 
+def c3_stem_fusable(cs1, bs1, cs2, bs2):
+    """cv1 and cv2 of a C3 can run as ONE GEMM when their weights / BN parameters / gradients / running
+    statistics are adjacent in the flat arenas (they are: consecutive modules of the same shape) and no
+    channel padding separates them."""
+    es = cs1.w_lp.element_size()
+    return (cs1.k == 1 and cs2.k == 1 and cs1.stride == 1 and cs2.stride == 1 and cs1.cinp == cs2.cinp
+            and cs1.coutp == cs1.cout and cs2.coutp == cs2.cout and cs1.cout == cs2.cout
+            and cs2.w_lp.data_ptr() == cs1.w_lp.data_ptr() + cs1.w_lp.numel() * es
+            and cs2.gw.data_ptr() == cs1.gw.data_ptr() + cs1.gw.numel() * 4
+            and bs2.aff_off == bs1.aff_off + bs1.c and bs1.c == cs1.cout and bs2.c == cs2.cout
+            and bs1.eps == bs2.eps and bs1.momentum == bs2.momentum)
+
+
+def _fused_vec(a, b):
+    """[a | b] as one tensor: the two slices are adjacent in their arena"""
+    return a.as_strided((a.numel() + b.numel(),), (1,), a.storage_offset())
+
+
+class C3StemFn(Function):
+    """(t, y2) = (cv1(x), cv2(x)) of a C3 block (common.py:589-591), both 1x1 Conv+BN+act on the SAME input, as
+    one GEMM with the concatenated weights [cv1.w ; cv2.w]: x is read once, and in backward ONE dgrad over
+    K = 2c_ produces the whole dx (autograd would otherwise add the two partial gradients in a separate
+    pass) and one wgrad fills both weight gradients.  t goes to channels [0, c_) and y2 to [2c_, 3c_) of `buf`
+    (N, H, W, 3c_): the bottleneck chain later writes its result to [c_, 2c_), so buf[..., c_:] is the
+    concat [m(cv1(x)) | cv2(x)] that cv3 reads -- no copy."""
+
+    @staticmethod
+    def forward(ctx, x, w1, w2, cs1, bs1, cs2, bs2, act, nbt1, nbt2, buf):
+        ctx.w_needs_grad = w1.requires_grad or w2.requires_grad
+        c = cs1.cout
+        wf = cs1.w_lp.as_strided((2 * c, 1, 1, cs1.cinp), (cs1.cinp, cs1.cinp, cs1.cinp, 1), cs1.w_lp.storage_offset())
+        y, st = ops.conv2d_fwd(x, wf, 1, 0, want_stats=True)
+        N, H, W, _ = y.shape
+        aff = ops.bn_finalize(st, N * H * W, _fused_vec(bs1.gamma, bs2.gamma), _fused_vec(bs1.beta, bs2.beta), bs1.eps,
+                              bs1.momentum, _fused_vec(bs1.rmean, bs2.rmean), _fused_vec(bs1.rvar, bs2.rvar))
+        for nbt in (nbt1, nbt2):
+            if nbt is not None:
+                nbt.add_(1)
+        t = ops.bn_act_fwd(y[..., :c], aff[0][:c], aff[1][:c], act, out=buf[..., :c])
+        y2 = ops.bn_act_fwd(y[..., c:], aff[0][c:], aff[1][c:], act, out=buf[..., 2 * c:])
+        ctx.meta = (cs1, bs1, cs2, bs2, act)
+        ctx.x_needs_grad = x.requires_grad
+        ctx.save_for_backward(x, y, *aff)
+        return t, y2
+
+    @staticmethod
+    def backward(ctx, dt, dy2):
+        x, y, scale, shift, mean, invstd = ctx.saved_tensors
+        cs1, bs1, cs2, bs2, act = ctx.meta
+        c = cs1.cout
+        N, H, W, _ = y.shape
+        dy = torch.empty_like(y)
+        halves = ((dt, slice(0, c), bs1), (dy2, slice(c, 2 * c), bs2))
+        for g, sl, bs in halves:
+            if g is None:
+                dy[..., sl].zero_()
+                continue
+            ops.bn_act_bwd(_dense_or_slice(g), y[..., sl], bs.gamma, scale[sl], shift[sl], mean[sl], invstd[sl], act,
+                           bs.ggamma, bs.gbeta, out=dy[..., sl])
+        if ctx.w_needs_grad:
+            gwf = cs1.gw.as_strided((2 * c, 1, 1, cs1.cinp), (cs1.cinp, cs1.cinp, cs1.cinp, 1), cs1.gw.storage_offset())
+            ops.conv2d_wgrad(x, dy, gwf, 1, 1, 0)
+            if GRAD_READY_HOOK is not None:
+                GRAD_READY_HOOK(cs1)
+                GRAD_READY_HOOK(cs2)
+        dx = None
+        if ctx.x_needs_grad:
+            wf = cs1.w_lp.as_strided((2 * c, 1, 1, cs1.cinp), (cs1.cinp, cs1.cinp, cs1.cinp, 1), cs1.w_lp.storage_offset())
+            dx = ops.conv2d_dgrad(dy, ops.weight_transpose(wf), (x.shape[1], x.shape[2]), 1, 0)
+        return (dx,) + (None,) * 10
+
+
 class ConvBiasFn(Function):
     """y = act(conv(x, w) + bias): the Detect output convs (yolov5_head.py:30,55) and netD
     (yolo_ssod.py:224-238).  With ``head=(na, no)`` the result is returned as the (B, na, ny, nx, no)

@@ -10,7 +10,7 @@ import torch
 import torch.nn as nn
 
 from ... import ops
-from ...autograd import BottleneckFn, ConvBnActFn, JoinSlicesFn, SppfPoolFn
+from ...autograd import BottleneckFn, C3StemFn, ConvBnActFn, JoinSlicesFn, SppfPoolFn, c3_stem_fusable
 
 
 def get_activation(act=True):
@@ -129,10 +129,23 @@ class C3(nn.Module):
         # cv3(cat(m(cv1(x)), cv2(x))): both halves are written in place into one buffer (no cat copy)
         N, H, W, _ = x.shape
         c_ = self.cv2.conv.out_channels
+        c1s, c2s = getattr(self.cv1.conv, "_et_slot", None), getattr(self.cv2.conv, "_et_slot", None)
+        last = len(self.m) - 1
+        if (c1s is not None and self.cv1.bn.training and self.cv2.bn.training and torch.is_grad_enabled()
+                and len(self.m) > 0 and c3_stem_fusable(c1s, self.cv1.bn._et_slot, c2s, self.cv2.bn._et_slot)):
+            # train mode: cv1 | cv2 as one GEMM (C3StemFn); buf = [cv1(x) | m(cv1(x)) | cv2(x)]
+            buf = torch.empty((N, H, W, 3 * c_), dtype=x.dtype, device=x.device)
+            bulk = self.cv1._et_flat().bulk_nbt
+            t, y2 = C3StemFn.apply(x, self.cv1.conv.weight, self.cv2.conv.weight, c1s, self.cv1.bn._et_slot, c2s,
+                                   self.cv2.bn._et_slot, _act_code(self.cv1.act),
+                                   None if bulk else self.cv1.bn.num_batches_tracked,
+                                   None if bulk else self.cv2.bn.num_batches_tracked, buf)
+            for i, b in enumerate(self.m):
+                t = b(t, dst=(buf, c_) if i == last else None)
+            return self.cv3(JoinSlicesFn.apply((buf[..., c_:],), t, y2))
         buf = torch.empty((N, H, W, 2 * c_), dtype=x.dtype, device=x.device)
         y2 = self.cv2(x, dst=(buf, c_))
         t = self.cv1(x)
-        last = len(self.m) - 1
         for i, b in enumerate(self.m):
             t = b(t, dst=(buf, 0) if i == last else None)
         if torch.is_grad_enabled() and (t.requires_grad or y2.requires_grad):
