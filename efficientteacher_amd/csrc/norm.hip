@@ -36,13 +36,51 @@ template <> struct Vec16<uint16_t> {
     }
 };
 
-// ---- forward ------------------------------------------------------------------------------------------
-// (rows, 2, C) fp32 partial sums -> ws[2][C] fp64 totals.  grid (C/32, RB): each block reduces a slice of
-// the rows for 32 channels (256 threads = 32 channels x 8 row groups) and issues 64 fp64 atomics, so
-// the reduction is spread over the chip instead of a handful of workgroups walking 10^4 rows.
-__global__ __launch_bounds__(256) void rows_reduce_kernel(const float* __restrict__ part, int rows, int C, int rows_per_block,
-                                                          double* __restrict__ ws) {
+// ---- partial-sum reduction + per-channel finalize in ONE launch ---------------------------------------------
+// (rows, 2, C) fp32 partial sums -> fp64 totals -> per-channel results.  grid (C/32, RB): each block reduces a
+// slice of the rows for 32 channels (256 threads = 32 channels x 8 row groups) and adds into the fp64 totals
+// with agent-scope atomics, so the reduction is spread over the chip instead of a handful of workgroups
+// walking 10^4 rows.  The LAST block of a channel group to arrive (ticket counter per group) reads the totals
+// back -- with an atomic exchange, which also leaves them zero for the next layer -- and runs the finalize
+// math for its 32 channels: no separate memset / finalize launches (was 3 launches per BN layer per pass).
+// `ws` = [2*C fp64 totals | C/32 int tickets], all ZERO on entry and zero again on return.
+struct BnFwdFin {
+    double count; const float* gamma; const float* beta; float eps, momentum;
+    float* rmean; float* rvar; float* scale; float* shift; float* smean; float* sinvstd;
+};
+struct BnBwdFin {
+    float count; const float* gamma; const float* invstd; float* dgamma; float* dbeta; float* k0; float* k1; float* k2;
+};
+
+__device__ __forceinline__ void bn_finalize_channel(const BnFwdFin& f, int c, double S, double Q) {
+    const double mean = S / f.count;
+    double var = Q / f.count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)f.eps));
+    const float sc = f.gamma[c] * invstd;
+    f.scale[c] = sc;
+    f.shift[c] = f.beta[c] - (float)mean * sc;
+    if (f.smean) { f.smean[c] = (float)mean; f.sinvstd[c] = invstd; }
+    if (f.rmean) {
+        const double unb = f.count > 1.0 ? var * f.count / (f.count - 1.0) : var;
+        f.rmean[c] = (1.0f - f.momentum) * f.rmean[c] + f.momentum * (float)mean;
+        f.rvar[c] = (1.0f - f.momentum) * f.rvar[c] + f.momentum * (float)unb;
+    }
+}
+// dbeta += s1, dgamma += s2, coefficients of pass 2
+__device__ __forceinline__ void bn_finalize_channel(const BnBwdFin& f, int c, double S, double Q) {
+    if (f.dbeta) f.dbeta[c] += (float)S;
+    if (f.dgamma) f.dgamma[c] += (float)Q;
+    f.k0[c] = f.gamma[c] * f.invstd[c];
+    f.k1[c] = (float)(S / f.count);
+    f.k2[c] = (float)(Q / f.count);
+}
+
+template <typename FIN>
+__global__ __launch_bounds__(256) void rows_reduce_finalize_kernel(const float* __restrict__ part, int rows, int C,
+                                                                   int rows_per_block, double* __restrict__ ws, FIN fin) {
     __shared__ double red[2][8][32];
+    __shared__ int s_last;
     const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
     const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
@@ -58,41 +96,30 @@ __global__ __launch_bounds__(256) void rows_reduce_kernel(const float* __restric
         for (int k = 1; k < 8; ++k) { s += red[0][k][cl]; q += red[1][k][cl]; }
         atomicAdd(ws + c, s);
         atomicAdd(ws + C + c, q);
+        __threadfence();                                   // my sums are visible before my ticket is
+    }
+    __syncthreads();
+    int* tickets = (int*)(ws + 2 * C);
+    if (threadIdx.x == 0) s_last = atomicAdd(&tickets[blockIdx.x], 1) == (int)gridDim.y - 1;
+    __syncthreads();
+    if (!s_last) return;                                   // block-uniform
+    if (threadIdx.x == 0) tickets[blockIdx.x] = 0;         // zero again for the next layer
+    if (rg == 0 && c < C) {
+        __threadfence();
+        // read-and-clear at agent scope: never served from this CU's / XCD's stale cache lines
+        const double S = __longlong_as_double((long long)atomicExch((unsigned long long*)(ws + c), 0ull));
+        const double Q = __longlong_as_double((long long)atomicExch((unsigned long long*)(ws + C + c), 0ull));
+        bn_finalize_channel(fin, c, S, Q);
     }
 }
 
-// `ws` (2*C fp64 totals) must be ZERO on entry: the finalize kernels re-zero it after reading, so a caller that
-// keeps one zero-initialised scratch per stream never pays a memset launch per layer
-static void launch_rows_reduce(const float* part, int rows, int C, double* ws, hipStream_t s) {
+template <typename FIN>
+static void launch_rows_reduce_finalize(const float* part, int rows, int C, double* ws, const FIN& fin, hipStream_t s) {
     int rb = rows / 64;
     rb = rb < 1 ? 1 : (rb > 64 ? 64 : rb);
     const int per = (rows + rb - 1) / rb;
-    hipLaunchKernelGGL(rows_reduce_kernel, dim3((C + 31) / 32, (rows + per - 1) / per), dim3(256), 0, s, part, rows, C, per, ws);
-}
-
-// ws[2][C] totals -> scale/shift (+ saved mean / invstd, running statistics update)
-__global__ __launch_bounds__(256) void bn_finalize_kernel(double* __restrict__ ws, int C, double count,
-                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                          float eps, float momentum, float* __restrict__ rmean,
-                                                          float* __restrict__ rvar, float* __restrict__ scale,
-                                                          float* __restrict__ shift, float* __restrict__ smean,
-                                                          float* __restrict__ sinvstd) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    const double mean = ws[c] / count;
-    double var = ws[C + c] / count - mean * mean;
-    ws[c] = 0.0; ws[C + c] = 0.0;                          // leave the scratch zeroed for the next layer
-    if (var < 0.0) var = 0.0;
-    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-    const float sc = gamma[c] * invstd;
-    scale[c] = sc;
-    shift[c] = beta[c] - (float)mean * sc;
-    if (smean) { smean[c] = (float)mean; sinvstd[c] = invstd; }
-    if (rmean) {
-        const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
-        rmean[c] = (1.0f - momentum) * rmean[c] + momentum * (float)mean;
-        rvar[c] = (1.0f - momentum) * rvar[c] + momentum * (float)unb;
-    }
+    hipLaunchKernelGGL((rows_reduce_finalize_kernel<FIN>), dim3((C + 31) / 32, (rows + per - 1) / per), dim3(256), 0, s, part,
+                       rows, C, per, ws, fin);
 }
 
 // eval-mode affine from running statistics (teacher path): scale = g/sqrt(rv+eps), shift = b - rm*scale
@@ -232,22 +259,6 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const T* __restr
     }
 }
 
-// finalize: dbeta += s1, dgamma += s2, coefficients of pass 2 (ws = fp64 totals from rows_reduce_kernel)
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(double* __restrict__ ws, int C, float count,
-                                                              const float* __restrict__ gamma, const float* __restrict__ invstd,
-                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                              float* __restrict__ k0, float* __restrict__ k1, float* __restrict__ k2) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    const double s = ws[c], q = ws[C + c];
-    ws[c] = 0.0; ws[C + c] = 0.0;
-    if (dbeta) dbeta[c] += (float)s;
-    if (dgamma) dgamma[c] += (float)q;
-    k0[c] = gamma[c] * invstd[c];
-    k1[c] = (float)(s / count);
-    k2[c] = (float)(q / count);
-}
-
 // pass 2: dy = k0 * (du - k1 - xhat*k2)
 template <typename T, int ACT>
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restrict__ dz, int lddz, const T* __restrict__ y, int ldy,
@@ -330,9 +341,8 @@ extern "C" int et_bn_finalize(const float* stats_partial, int rows, int C, doubl
                               et_stream_t stream) {
     if (!stats_partial || !gamma || !beta || !scale || !shift || !ws) return -1;
     if (rows <= 0 || C <= 0 || count <= 0) return -2;
-    launch_rows_reduce(stats_partial, rows, C, ws, (hipStream_t)stream);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, C, count,
-                       gamma, beta, eps, momentum, running_mean, running_var, scale, shift, save_mean, save_invstd);
+    const BnFwdFin fin{count, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, save_mean, save_invstd};
+    launch_rows_reduce_finalize(stats_partial, rows, C, ws, fin, (hipStream_t)stream);
     ET_CHECK_LAUNCH();
     return 0;
 }
@@ -390,9 +400,8 @@ extern "C" int et_bn_act_bwd(const void* dz, int lddz, const void* y, int ldy, v
         ET_ACT_LAUNCH(bn_act_bwd_reduce_kernel, uint16_t, act, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)dz, lddz,
                       (const uint16_t*)y, ldy, P, CV, scale, shift, save_mean, save_invstd, part);
     else return -2;
-    launch_rows_reduce(part, rows, C, tot, (hipStream_t)stream);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, tot, C, (float)P, gamma,
-                       save_invstd, dgamma, dbeta, k0, k1, k2);
+    const BnBwdFin fin{(float)P, gamma, save_invstd, dgamma, dbeta, k0, k1, k2};
+    launch_rows_reduce_finalize(part, rows, C, tot, fin, (hipStream_t)stream);
     if (dtype == ET_F32)
         ET_ACT_LAUNCH(bn_act_bwd_apply_kernel, float, act, grid, dim3(256), 0, (hipStream_t)stream, (const float*)dz, lddz,
                       (const float*)y, ldy, (float*)dy, lddy, P, CV, scale, shift, save_mean, save_invstd, k0, k1, k2);

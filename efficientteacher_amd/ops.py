@@ -80,12 +80,13 @@ _BN_TOTALS = {}
 
 
 def bn_totals_scratch(device):
-    """2*2048 fp64 zeros per (device, stream): the BN kernels need their totals scratch zero on entry and leave
-    it zero on return (include/et_hip.h), so one buffer per stream replaces a memset launch per layer."""
+    """(2*2048 fp64 totals + 64 int32 tickets) zeros per (device, stream): the BN kernels need this scratch zero on
+    entry and leave it zero on return (include/et_hip.h), so one buffer per stream replaces a memset launch and
+    a finalize launch per layer."""
     key = (device, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
     z = _BN_TOTALS.get(key)
     if z is None:
-        z = _BN_TOTALS[key] = torch.zeros(2 * 2048, dtype=torch.float64, device=device)
+        z = _BN_TOTALS[key] = torch.zeros(2 * 2048 + 32, dtype=torch.float64, device=device)
     return z
 
 

@@ -125,14 +125,16 @@ int et_colsum(const void* x, int dtype, int P, int C, int ld, float* out, et_str
  *   et_bn_act_fwd: z = act(y*scale + shift) (+ residual).
  *   et_bn_act_bwd: dy = dBN/dSiLU(dz) in two passes; dgamma/dbeta (fp32) are ACCUMULATED.
  *       workspace: >= et_bn_reduce_rows(P,C,dtype)*2*C + 3*C floats.  C <= 2048.
- *   `ws` / `totals` (2*C fp64): MUST BE ZERO ON ENTRY and is left zero on return (the finalize kernel clears
- *       what it read), so one zero-initialised scratch per stream serves every layer without a memset.
+ *   `ws` / `totals` (2*C fp64 totals followed by (C+31)/32 int32 tickets, i.e. 2*C*8 + 4*((C+31)/32) bytes):
+ *       MUST BE ZERO ON ENTRY and is left zero on return (the last workgroup of each channel group reads the
+ *       totals back with an atomic exchange and finalizes), so one zero-initialised scratch per stream serves
+ *       every layer: partial-sum reduction + finalize are ONE launch, no memset.
  *   et_act_bwd: dy = dz * act'(y)   (netD ReLU, models/detector/yolo_ssod.py:231-238).          */
 int et_bn_reduce_rows(int P, int C, int dtype);
 int et_bn_finalize(const float* stats_partial, int rows, int C, double count, const float* gamma,
                    const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                    float* scale, float* shift, float* save_mean, float* save_invstd,
-                   double* ws /* 2*C fp64, zero in / zero out */, et_stream_t stream);
+                   double* ws /* totals + tickets, zero in / zero out */, et_stream_t stream);
 int et_bn_eval_affine(int C, const float* gamma, const float* beta, const float* running_mean,
                       const float* running_var, float eps, float* scale, float* shift, et_stream_t stream);
 int et_bn_act_fwd(const void* y, int ldy, void* z, int ldz, const void* residual, int ldr, int dtype, int P,
@@ -140,7 +142,7 @@ int et_bn_act_fwd(const void* y, int ldy, void* z, int ldz, const void* residual
 int et_bn_act_bwd(const void* dz, int lddz, const void* y, int ldy, void* dy, int lddy, int dtype, int P, int C,
                   const float* gamma, const float* scale, const float* shift, const float* save_mean,
                   const float* save_invstd, int act, float* dgamma, float* dbeta,
-                  double* totals /* 2*C fp64, zero in / zero out */, float* workspace, size_t ws_floats,
+                  double* totals /* totals + tickets, zero in / zero out */, float* workspace, size_t ws_floats,
                   et_stream_t stream);
 int et_act_bwd(const void* dz, int lddz, const void* y, int ldy, void* dy, int lddy, int dtype, int P, int C,
                int act, et_stream_t stream);
