@@ -906,6 +906,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_tr_kernel(const uint1
     __shared__ __attribute__((aligned(16))) u32x4 lds_raw[2 * (A_VEC + B_VEC)];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    ET_TS(0);
     const int wm = wave / WN, wn = wave % WN;
     int bid = blockIdx.x;
     if (g.xcd) {
@@ -1013,9 +1014,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_tr_kernel(const uint1
     u32x4* const A1 = lds_raw + A_VEC + B_VEC;
     u32x4* const B1 = A1 + A_VEC;
     const int nchunks = (pk_end - pk_begin + BKP - 1) / BKP;
+    ET_TS(1);
     if (nchunks > 0) stage(A0, B0, pk_begin);
     et_wait_vmem();
     __syncthreads();
+    ET_TS(2);
     for (int c = 0; c < nchunks; ++c) {
         const bool odd = c & 1;
         if (c + 1 < nchunks) stage(odd ? A0 : A1, odd ? B0 : B1, pk_begin + (c + 1) * BKP);
@@ -1024,6 +1027,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_tr_kernel(const uint1
         __syncthreads();
     }
     if (nchunks <= 0) return;
+    ET_TS(3);
     const int l31 = lane & 31, hi = lane >> 5;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
@@ -1036,6 +1040,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_tr_kernel(const uint1
                 if (co < g.Cout && col < g.NC) atomicAdd(DW + ((size_t)co * g.NC + col), acc[tm][tn][r]);
             }
         }
+#if defined(ET_ABLATE) && (ET_ABLATE == 9)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    ET_TS(4); ET_TS(5); ET_TS(6);
+#endif
 }
 
 // ---- small helpers ---------------------------------------------------------------------------------

@@ -13,8 +13,14 @@ w = (torch.randn(cout, k, k, cin, device=dev) * 0.05).to(torch.bfloat16)
 p = k // 2
 oh, ow = ops.conv_out_hw(h, h, k, s, p)
 y = torch.empty(B, oh, ow, cout, device=dev, dtype=torch.bfloat16)
+mode = os.environ.get("TS_MODE", "fwd")
+dy = torch.randn(B, oh, ow, cout, device=dev).to(torch.bfloat16)
+dw = torch.zeros(cout, k, k, cin, device=dev)
 for _ in range(3):
-    ops.conv2d_fwd(x, w, s, p, out=y, want_stats=True)
+    if mode == "fwd":
+        ops.conv2d_fwd(x, w, s, p, out=y, want_stats=True)
+    else:
+        ops.conv2d_wgrad(x, dy, dw, k, s, p)
 torch.cuda.synchronize()
 lib = _lib.load()
 n = 8 * 16384
