@@ -35,6 +35,7 @@ SIGNATURES = {
     "et_conv2d_fwd": (c_int, [P, P, P, c_int] + [c_int] * 11 + [P, P, c_int, P, c_int, P, P, P]),
     "et_conv2d_dgrad": (c_int, [P, P, P, c_int] + [c_int] * 11 + [c_int, P, c_int, P, P]),
     "et_conv2d_wgrad": (c_int, [P, P, P, c_int] + [c_int] * 11 + [P, P]),
+    "et_conv2d_wgrad_grouped": (c_int, [P, c_int, c_int] + [c_int] * 9 + [P, P]),
     "et_weight_transpose": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "et_colsum": (c_int, [P, c_int, c_int, c_int, c_int, P, P]),
     "et_bn_reduce_rows": (c_int, [c_int, c_int, c_int]),
@@ -57,6 +58,12 @@ SIGNATURES = {
     "et_scale_inplace": (c_int, [P, c_int, c_int64, c_float, P, P]),
 }
 
+
+
+class WgradItem(ctypes.Structure):
+    """et_wgrad_item (include/et_hip.h)"""
+    _fields_ = [("x", ctypes.c_void_p), ("dy", ctypes.c_void_p), ("dw", ctypes.c_void_p), ("ldx", ctypes.c_int),
+                ("ldy", ctypes.c_int)]
 
 
 class LossLevel(ctypes.Structure):

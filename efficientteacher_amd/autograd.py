@@ -15,6 +15,25 @@ ACT_CODE = {"silu": ops.ACT_SILU, "relu": ops.ACT_RELU, "none": ops.ACT_NONE}
 GRAD_READY_HOOK = None
 
 
+def _wgrad(x, dy, cs, *more_slots):
+    """Weight gradient of layer `cs` (grouped with same-shaped layers of this backward pass: ops.WgradQueue);
+    the gradient-ready hook of every slot the launch covers fires once it has been issued."""
+    hook = GRAD_READY_HOOK
+    slots = (cs,) + more_slots
+
+    def done():
+        if hook is not None:
+            for s in slots:
+                hook(s)
+    ops.WGRAD_QUEUE.submit(x, dy, cs.gw if not more_slots else _fused_gw(cs), cs.k, cs.stride, cs.pad,
+                           on_done=done if hook is not None else None)
+
+
+def _fused_gw(cs1):
+    """gradient view of [cv1.w ; cv2.w] (C3StemFn): the two gradient slices are adjacent in the arena"""
+    return cs1.gw.as_strided((2 * cs1.cout, 1, 1, cs1.cinp), (cs1.cinp, cs1.cinp, cs1.cinp, 1), cs1.gw.storage_offset())
+
+
 class ConvBnActFn(Function):
     """z = act(BN_train(conv(x, w))) (+ residual)   -- reference Conv.forward (common.py:480-481) in
     train mode, plus the Bottleneck shortcut (common.py:544)."""
@@ -47,9 +66,7 @@ class ConvBnActFn(Function):
         dz = _dense_or_slice(dz)
         dy = ops.bn_act_bwd(dz, y, bs.gamma, scale, shift, mean, invstd, ctx.act, bs.ggamma, bs.gbeta)
         if ctx.w_needs_grad:
-            ops.conv2d_wgrad(x, dy, cs.gw, cs.k, cs.stride, cs.pad)
-            if GRAD_READY_HOOK is not None:
-                GRAD_READY_HOOK(cs)
+            _wgrad(x, dy, cs)
         dx = None
         if ctx.x_needs_grad:
             wT = ops.weight_transpose(cs.w_lp)
@@ -89,15 +106,11 @@ class BottleneckFn(Function):
         dz = _dense_or_slice(dz)
         dy2 = ops.bn_act_bwd(dz, y2, bs2.gamma, s2, b2, m2, i2, act2, bs2.ggamma, bs2.gbeta)
         if ctx.w_needs_grad:
-            ops.conv2d_wgrad(h, dy2, cs2.gw, cs2.k, cs2.stride, cs2.pad)
-            if GRAD_READY_HOOK is not None:
-                GRAD_READY_HOOK(cs2)
+            _wgrad(h, dy2, cs2)
         dh = ops.conv2d_dgrad(dy2, ops.weight_transpose(cs2.w_lp), (h.shape[1], h.shape[2]), cs2.stride, cs2.pad)
         dy1 = ops.bn_act_bwd(dh, y1, bs1.gamma, s1, b1, m1, i1, act1, bs1.ggamma, bs1.gbeta)
         if ctx.w_needs_grad:
-            ops.conv2d_wgrad(x, dy1, cs1.gw, cs1.k, cs1.stride, cs1.pad)
-            if GRAD_READY_HOOK is not None:
-                GRAD_READY_HOOK(cs1)
+            _wgrad(x, dy1, cs1)
         dx = None
         if ctx.x_needs_grad:
             dx = ops.conv2d_dgrad(dy1, ops.weight_transpose(cs1.w_lp), (x.shape[1], x.shape[2]), cs1.stride, cs1.pad,
@@ -165,11 +178,7 @@ class C3StemFn(Function):
             ops.bn_act_bwd(_dense_or_slice(g), y[..., sl], bs.gamma, scale[sl], shift[sl], mean[sl], invstd[sl], act,
                            bs.ggamma, bs.gbeta, out=dy[..., sl])
         if ctx.w_needs_grad:
-            gwf = cs1.gw.as_strided((2 * c, 1, 1, cs1.cinp), (cs1.cinp, cs1.cinp, cs1.cinp, 1), cs1.gw.storage_offset())
-            ops.conv2d_wgrad(x, dy, gwf, 1, 1, 0)
-            if GRAD_READY_HOOK is not None:
-                GRAD_READY_HOOK(cs1)
-                GRAD_READY_HOOK(cs2)
+            _wgrad(x, dy, cs1, cs2)
         dx = None
         if ctx.x_needs_grad:
             wf = cs1.w_lp.as_strided((2 * c, 1, 1, cs1.cinp), (cs1.cinp, cs1.cinp, cs1.cinp, 1), cs1.w_lp.storage_offset())

@@ -892,10 +892,17 @@ template <int SLOTS> __device__ __forceinline__ int tr_swz(int p) {
     else return 4 * ((p >> 1) & 1);
 }
 
+// Up to WGRAD_MAX_GROUP layers of IDENTICAL geometry in one launch (et_conv2d_wgrad_grouped): the K-split that
+// fills the chip is then shared by the whole group, so every dW address receives group-size times fewer fp32
+// atomics (measured with s_memtime stamps: the atomic epilogue is 23-27 % of a workgroup's lifetime when a
+// single 256-channel layer is split 28-64 ways; the L2 atomic rate, ~1 TB/s, does not depend on scope).
+#define WGRAD_MAX_GROUP 16
+struct WgradItem { const uint16_t* x; const uint16_t* dy; float* dw; int ldx, ldy; };
+struct WgradGroup { WgradItem it[WGRAD_MAX_GROUP]; int n; };
+
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_tr_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ DY,
-                                                            float* __restrict__ DW, const uint16_t* __restrict__ ZERO,
-                                                            WgradGeom g) {
+__global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_tr_kernel(WgradGroup grp, const uint16_t* __restrict__ ZERO,
+                                                                     WgradGeom g) {
     constexpr int NT = 64 * WM * WN, BKP = 64;       // threads per workgroup; pixels (GEMM-K) per chunk
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int SA = BM / 8, SB = BN / 8;            // 16-byte slots per pixel row of the A / B tile
@@ -913,6 +920,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_tr_kernel(const uint1
         const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bid & 7, k = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
     }
+    const int per_layer = g.ntn * g.ntm * g.nsk;
+    const int layer = __builtin_amdgcn_readfirstlane(bid / per_layer);     // wave-uniform: scalar kernarg loads
+    bid -= layer * per_layer;
+    const uint16_t* __restrict__ X = grp.it[layer].x;
+    const uint16_t* __restrict__ DY = grp.it[layer].dy;
+    float* __restrict__ DW = grp.it[layer].dw;
+    const int ldx = grp.it[layer].ldx, ldy = grp.it[layer].ldy;
     const int tx = bid % g.ntn, ty = (bid / g.ntn) % g.ntm, tz = bid / (g.ntn * g.ntm);
     const int n0 = tx * BN, m0 = ty * BM;
     const int pk_begin = tz * g.Pper;
@@ -958,7 +972,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_tr_kernel(const uint1
         for (int j = 0; j < RA; ++j) {
             const int p = pk0 + a_pl[j];
             const bool ok = a_ok[j] && p < pk_end;
-            const uint16_t* src = ok ? DY + ((long long)p * g.ldy + a_co[j]) : ZERO;
+            const uint16_t* src = ok ? DY + ((long long)p * ldy + a_co[j]) : ZERO;
             et_glds16(src, wa + j * NT);
         }
 #pragma unroll
@@ -969,7 +983,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_tr_kernel(const uint1
             const uint32_t n = fdiv(t1, g.dQH), qy = t1 - n * g.QH;
             const int iy = qy * g.isy + b_dy[j], ix = qx * g.isx + b_dx[j];
             const bool ok = b_ok[j] && p < pk_end && (unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW;
-            const uint16_t* src = ok ? X + ((((long long)n * g.IH + iy) * g.IW + ix) * g.ldx + b_ci[j]) : ZERO;
+            const uint16_t* src = ok ? X + ((((long long)n * g.IH + iy) * g.IW + ix) * ldx + b_ci[j]) : ZERO;
             et_glds16(src, wb + j * NT);
         }
     };
@@ -1251,7 +1265,7 @@ extern "C" int et_conv2d_dgrad(const void* dy, const void* wT, void* dx, int dty
 }
 
 template <typename T>
-static void launch_wgrad(const void* x, const void* dy, float* dw, const void* zero16, WgradGeom& g, hipStream_t s) {
+static void launch_wgrad(const WgradGroup& grp, const void* zero16, WgradGeom& g, hipStream_t s) {
     constexpr int VEC = et_elem<T>::VEC;
     constexpr int BKP = 8 * VEC;
     const bool wideN = g.NC > 64;
@@ -1270,7 +1284,7 @@ static void launch_wgrad(const void* x, const void* dy, float* dw, const void* z
         else if (g.T > 1 && g.isy == 1 && g.NC >= 256 && g.Cout == 128 && (big & 1)) bn = 256;
         if (big & 2) { if (g.NC >= 256) bn = 256; if (g.Cout >= 256) bm = 256; }   // experiment: always
     }
-    const int tiles = ((g.NC + bn - 1) / bn) * ((g.Cout + bm - 1) / bm);
+    const int tiles = grp.n * ((g.NC + bn - 1) / bn) * ((g.Cout + bm - 1) / bm);   // the whole group shares the split
     // Split K so that the grid is a whole number of residency rounds: `slots` workgroups of this tile fit on
     // a CU (LDS- or register-limited), so up to slots*CUs run at once and a grid a little OVER a multiple of
     // that costs a whole extra round (e.g. 36 tiles x 29 splits = 1044 workgroups on 1024 slots).  Fewer
@@ -1302,12 +1316,12 @@ static void launch_wgrad(const void* x, const void* dy, float* dw, const void* z
     g.xcd = wxcd == 2 || (wxcd == 1 && g.T == 1);
     g.Pper = per;
     g.ntn = (g.NC + bn - 1) / bn; g.ntm = (g.Cout + bm - 1) / bm; g.nsk = sk;
-    const dim3 grid(g.ntn * g.ntm * sk), block(256);
-    const T* xx = (const T*)x; const T* yy = (const T*)dy;
+    const dim3 block(256);
     if constexpr (sizeof(T) == 2) {
         if (tr) {
+            const dim3 grid(grp.n * g.ntn * g.ntm * sk);
             const uint16_t* z = (const uint16_t*)zero16;
-#define ET_WG(BM_, BN_, WM_, WN_) hipLaunchKernelGGL((conv_wgrad_tr_kernel<BM_, BN_, WM_, WN_>), grid, dim3(64 * WM_ * WN_), 0, s, xx, yy, dw, z, g)
+#define ET_WG(BM_, BN_, WM_, WN_) hipLaunchKernelGGL((conv_wgrad_tr_kernel<BM_, BN_, WM_, WN_>), grid, dim3(64 * WM_ * WN_), 0, s, grp, z, g)
             if (bm == 256) { if (bn == 256) ET_WG(256, 256, 2, 4); else if (bn == 128) ET_WG(256, 128, 4, 2); else ET_WG(256, 64, 4, 1); }
             else if (bm == 128) { if (bn == 256) ET_WG(128, 256, 2, 4); else if (bn == 128) ET_WG(128, 128, 2, 2); else ET_WG(128, 64, 2, 2); }
             else { if (bn == 256) ET_WG(64, 256, 1, 4); else if (bn == 128) ET_WG(64, 128, 2, 2); else ET_WG(64, 64, 2, 2); }
@@ -1315,27 +1329,42 @@ static void launch_wgrad(const void* x, const void* dy, float* dw, const void* z
             return;
         }
     }
-    if (tallM) {
-        if (wideN) hipLaunchKernelGGL((conv_wgrad_kernel<T, 128, 128>), grid, block, 0, s, xx, yy, dw, g);
-        else hipLaunchKernelGGL((conv_wgrad_kernel<T, 128, 64>), grid, block, 0, s, xx, yy, dw, g);
-    } else {
-        if (wideN) hipLaunchKernelGGL((conv_wgrad_kernel<T, 64, 128>), grid, block, 0, s, xx, yy, dw, g);
-        else hipLaunchKernelGGL((conv_wgrad_kernel<T, 64, 64>), grid, block, 0, s, xx, yy, dw, g);
+    // register-staged kernel (fp32 parity mode, ET_WGRAD_TR=0): one launch per item
+    const dim3 grid(g.ntn * g.ntm * sk);
+    for (int i = 0; i < grp.n; ++i) {
+        const T* xx = (const T*)grp.it[i].x; const T* yy = (const T*)grp.it[i].dy;
+        float* dw = grp.it[i].dw;
+        g.ldx = grp.it[i].ldx; g.ldy = grp.it[i].ldy;
+        if (tallM) {
+            if (wideN) hipLaunchKernelGGL((conv_wgrad_kernel<T, 128, 128>), grid, block, 0, s, xx, yy, dw, g);
+            else hipLaunchKernelGGL((conv_wgrad_kernel<T, 128, 64>), grid, block, 0, s, xx, yy, dw, g);
+        } else {
+            if (wideN) hipLaunchKernelGGL((conv_wgrad_kernel<T, 64, 128>), grid, block, 0, s, xx, yy, dw, g);
+            else hipLaunchKernelGGL((conv_wgrad_kernel<T, 64, 64>), grid, block, 0, s, xx, yy, dw, g);
+        }
     }
 }
 
-extern "C" int et_conv2d_wgrad(const void* x, const void* dy, float* dw, int dtype, int N, int IH, int IW, int Cin,
-                               int ldx, int Cout, int KH, int KW, int stride, int pad, int ldy, const void* zero16,
-                               et_stream_t stream) {
-    // dw[co,ky,kx,ci] += sum_{n,oy,ox} dy[n,oy,ox,co] * x[n,oy*s+ky-pad,ox*s+kx-pad,ci]   (fp32, atomic)
-    if (!x || !dy || !dw) return -1;
+extern "C" int et_conv2d_wgrad_grouped(const et_wgrad_item* items, int n_items, int dtype, int N, int IH, int IW, int Cin,
+                                       int Cout, int KH, int KW, int stride, int pad, const void* zero16,
+                                       et_stream_t stream) {
+    // for every item: dw[co,ky,kx,ci] += sum_{n,oy,ox} dy[n,oy,ox,co] * x[n,oy*s+ky-pad,ox*s+kx-pad,ci]   (fp32, atomic)
+    if (!items || n_items <= 0 || n_items > WGRAD_MAX_GROUP) return -1;
     if (KH * KW > CONV_MAX_TAPS || stride < 1 || N <= 0) return -2;
     const int vec = dtype == ET_F32 ? 4 : 8;
     if (Cin % vec || Cout % vec) return -2;
+    WgradGroup grp;
+    grp.n = n_items;
+    for (int i = 0; i < n_items; ++i) {
+        if (!items[i].x || !items[i].dy || !items[i].dw) return -1;
+        grp.it[i].x = (const uint16_t*)items[i].x; grp.it[i].dy = (const uint16_t*)items[i].dy; grp.it[i].dw = items[i].dw;
+        grp.it[i].ldx = items[i].ldx; grp.it[i].ldy = items[i].ldy;
+    }
+    for (int i = n_items; i < WGRAD_MAX_GROUP; ++i) grp.it[i] = grp.it[0];
     WgradGeom g;
     const int OH = (IH + 2 * pad - KH) / stride + 1, OW = (IW + 2 * pad - KW) / stride + 1;
-    g.N = N; g.IH = IH; g.IW = IW; g.Cin = Cin; g.ldx = ldx;
-    g.QH = OH; g.QW = OW; g.P = N * OH * OW; g.Cout = Cout; g.ldy = ldy;
+    g.N = N; g.IH = IH; g.IW = IW; g.Cin = Cin; g.ldx = items[0].ldx;
+    g.QH = OH; g.QW = OW; g.P = N * OH * OW; g.Cout = Cout; g.ldy = items[0].ldy;
     g.isy = g.isx = stride; g.T = KH * KW; g.NC = g.T * Cin;
     g.dQW = make_fastdiv(OW); g.dQH = make_fastdiv(OH); g.dCin = make_fastdiv(Cin);
     for (int ky = 0; ky < KH; ++ky)
@@ -1344,11 +1373,18 @@ extern "C" int et_conv2d_wgrad(const void* x, const void* dy, float* dw, int dty
             g.dx[ky * KW + kx] = (signed char)(kx - pad);
         }
     if (g.P <= 0) return 0;
-    if (dtype == ET_F32) launch_wgrad<float>(x, dy, dw, zero16, g, (hipStream_t)stream);
-    else if (dtype == ET_BF16) launch_wgrad<uint16_t>(x, dy, dw, zero16, g, (hipStream_t)stream);
+    if (dtype == ET_F32) launch_wgrad<float>(grp, zero16, g, (hipStream_t)stream);
+    else if (dtype == ET_BF16) launch_wgrad<uint16_t>(grp, zero16, g, (hipStream_t)stream);
     else return -2;
     ET_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int et_conv2d_wgrad(const void* x, const void* dy, float* dw, int dtype, int N, int IH, int IW, int Cin,
+                               int ldx, int Cout, int KH, int KW, int stride, int pad, int ldy, const void* zero16,
+                               et_stream_t stream) {
+    const et_wgrad_item one{x, dy, dw, ldx, ldy};
+    return et_conv2d_wgrad_grouped(&one, 1, dtype, N, IH, IW, Cin, Cout, KH, KW, stride, pad, zero16, stream);
 }
 
 extern "C" int et_weight_transpose(const void* w, void* wT, int dtype, int Cout, int taps, int Cin, et_stream_t stream) {

@@ -139,6 +139,80 @@ def conv2d_fwd(x, w, stride, pad, *, scale=None, bias=None, act=ACT_NONE, residu
     return (out, stats) if want_stats else out
 
 
+class WgradQueue:
+    """Deferred, grouped weight-gradient launches (et_conv2d_wgrad_grouped).
+
+    Inside a backward pass, layers of identical geometry (the bottleneck stacks of a YOLOv5 stage) are collected
+    and launched together: the K-split that fills the chip is shared by the group, so every dW address gets
+    group-size times fewer fp32 atomics.  A group is launched when it reaches ``group`` items and at the end of
+    the backward pass (autograd engine callback); ``on_done`` callbacks (gradient-ready hooks of the data-parallel
+    wrapper) run right after the launch that covers their layer.  ET_WGRAD_GROUP=1 launches every layer at once."""
+
+    def __init__(self):
+        import os
+        self.group = max(1, min(16, int(os.environ.get("ET_WGRAD_GROUP", "8"))))
+        self.pending = {}
+        self._cb_armed = False
+
+    def submit(self, x, dy, dw, ksize, stride, pad, on_done=None):
+        if self.group <= 1 or x.dtype != torch.bfloat16:
+            conv2d_wgrad(x, dy, dw, ksize, stride, pad)
+            if on_done is not None:
+                on_done()
+            return
+        key = (tuple(x.shape), tuple(dy.shape), ksize, stride, pad, x.device)
+        lst = self.pending.setdefault(key, [])
+        lst.append((x, dy, dw, on_done))
+        if len(lst) >= self.group:
+            self._flush_key(key)
+        elif not self._cb_armed:
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(self.flush)
+                self._cb_armed = True
+            except RuntimeError:            # not inside a backward pass: nothing will call back -- launch now
+                self._flush_key(key)
+
+    def _flush_key(self, key):
+        lst = self.pending.pop(key, None)
+        if not lst:
+            return
+        xs, dys, ksize, stride, pad, _ = key
+        conv2d_wgrad_grouped([(a, b, c) for a, b, c, _ in lst], ksize, stride, pad)
+        for _, _, _, cb in lst:
+            if cb is not None:
+                cb()
+
+    def flush(self):
+        self._cb_armed = False
+        for key in list(self.pending.keys()):
+            self._flush_key(key)
+
+
+WGRAD_QUEUE = WgradQueue()
+
+
+def conv2d_wgrad_grouped(items, ksize, stride, pad):
+    """items: [(x, dy, dw)] of identical shapes; dw (Cout, KH, KW, Cin) fp32 += wgrad(x, dy) for each, one launch."""
+    x0, dy0, dw0 = items[0]
+    N, IH, IW, Cin = x0.shape
+    _, OH, OW, Cout = dy0.shape
+    arr = (_lib.WgradItem * len(items))()
+    for i, (x, dy, dw) in enumerate(items):
+        assert x.shape == x0.shape and dy.shape == dy0.shape and x.dtype == dy.dtype == x0.dtype
+        assert dw.dtype == torch.float32 and dw.is_contiguous() and dw.shape == (Cout, ksize, ksize, Cin)
+        arr[i].x, arr[i].dy, arr[i].dw = _lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw)
+        arr[i].ldx, arr[i].ldy = _nhwc(x), _nhwc(dy)
+    ev = TIMER.span("conv_wgrad_tr_kernel" if x0.dtype == torch.bfloat16 else "conv_wgrad_kernel",
+                    2.0 * len(items) * N * OH * OW * Cout * Cin * ksize * ksize) if TIMER else None
+    if ev:
+        ev[0].record()
+    _lib.check(_lib.load().et_conv2d_wgrad_grouped(arr, len(items), et_dtype(x0), N, IH, IW, Cin, Cout, ksize, ksize,
+                                                   stride, pad, _lib.ptr(zero_page(x0.device)), _lib.stream(x0)),
+               "et_conv2d_wgrad_grouped")
+    if ev:
+        ev[1].record()
+
+
 def weight_transpose(w):
     """(Cout, KH, KW, Cin) -> (Cin, KH, KW, Cout), the dgrad operand."""
     Cout, KH, KW, Cin = w.shape

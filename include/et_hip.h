@@ -110,6 +110,13 @@ int et_conv2d_dgrad(const void* dy, const void* wT, void* dx, int dtype, int N, 
 int et_conv2d_wgrad(const void* x, const void* dy, float* dw, int dtype, int N, int IH, int IW, int Cin,
                     int ldx, int Cout, int KH, int KW, int stride, int pad, int ldy, const void* zero16,
                     et_stream_t stream);
+/* The same for up to 16 layers of IDENTICAL geometry in ONE launch: the K-split that fills the chip is shared by
+ * the group, so each dW address receives group-size times fewer atomics (the atomic epilogue is ~25 % of a
+ * split-28..64 launch).  Items differ only in their pointers and pixel strides. */
+typedef struct et_wgrad_item { const void* x; const void* dy; float* dw; int ldx, ldy; } et_wgrad_item;
+int et_conv2d_wgrad_grouped(const et_wgrad_item* items /* host array */, int n_items, int dtype, int N, int IH, int IW,
+                            int Cin, int Cout, int KH, int KW, int stride, int pad, const void* zero16,
+                            et_stream_t stream);
 int et_weight_transpose(const void* w, void* wT, int dtype, int Cout, int taps, int Cin, et_stream_t stream);
 /* out[c] += sum_p x[p*ld + c]  (bias gradient of the Detect convs) */
 int et_colsum(const void* x, int dtype, int P, int C, int ld, float* out, et_stream_t stream);
