@@ -116,3 +116,28 @@ def test_conv_wgrad(hip, case, dtype):
     assert err <= 1e-4 * max(1.0, ref.abs().max().item()), err
     ops.conv2d_wgrad(x, dy, dw, k, s, p)          # accumulates
     assert torch.allclose(dw.cpu(), 2 * ref, rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_wgrad_grouped(hip, dtype):
+    """et_conv2d_wgrad_grouped: several same-shaped layers in one launch, one of them reading a channel slice of a
+    wider buffer (different pixel stride) -- each dW must equal its own single-layer gradient."""
+    from efficientteacher_amd import ops
+    N, H, W, Cin, Cout, k, s, p = 2, 10, 10, 32, 48, 3, 1, 1
+    items, refs = [], []
+    for i in range(3):
+        if i == 1:
+            wide = _mk(hip, (N, H, W, Cin + 16), dtype, 20 + i)
+            x = wide[..., 8:8 + Cin]
+        else:
+            x = _mk(hip, (N, H, W, Cin), dtype, 20 + i)
+        dy = _mk(hip, (N, H, W, Cout), dtype, 30 + i)
+        dw = torch.zeros((Cout, k, k, Cin), dtype=torch.float32, device=hip.device)
+        items.append((x, dy, dw))
+        wr = torch.zeros((Cout, Cin, k, k), requires_grad=True)
+        F.conv2d(x.float().cpu().permute(0, 3, 1, 2), wr, stride=s, padding=p).backward(dy.float().cpu().permute(0, 3, 1, 2))
+        refs.append(wr.grad.permute(0, 2, 3, 1))
+    ops.conv2d_wgrad_grouped(items, k, s, p)
+    for (_, _, dw), ref in zip(items, refs):
+        err = (dw.cpu() - ref).abs().max().item()
+        assert err <= 1e-4 * max(1.0, ref.abs().max().item()), err
