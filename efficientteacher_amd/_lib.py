@@ -36,6 +36,7 @@ SIGNATURES = {
     "et_conv2d_dgrad": (c_int, [P, P, P, c_int] + [c_int] * 11 + [c_int, P, c_int, P, P]),
     "et_conv2d_wgrad": (c_int, [P, P, P, c_int] + [c_int] * 11 + [P, P]),
     "et_conv2d_wgrad_grouped": (c_int, [P, c_int, c_int] + [c_int] * 9 + [P, P]),
+    "et_weight_transpose_all": (c_int, [P, P, c_int, P, c_int, ctypes.c_longlong, P]),
     "et_weight_transpose": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "et_colsum": (c_int, [P, c_int, c_int, c_int, c_int, P, P]),
     "et_bn_reduce_rows": (c_int, [c_int, c_int, c_int]),

@@ -69,7 +69,7 @@ class ConvBnActFn(Function):
             _wgrad(x, dy, cs)
         dx = None
         if ctx.x_needs_grad:
-            wT = ops.weight_transpose(cs.w_lp)
+            wT = cs.transposed()
             dx = ops.conv2d_dgrad(dy, wT, (x.shape[1], x.shape[2]), cs.stride, cs.pad)
         return dx, (dz if ctx.has_res else None), None, None, None, None, None, None
 
@@ -107,13 +107,13 @@ class BottleneckFn(Function):
         dy2 = ops.bn_act_bwd(dz, y2, bs2.gamma, s2, b2, m2, i2, act2, bs2.ggamma, bs2.gbeta)
         if ctx.w_needs_grad:
             _wgrad(h, dy2, cs2)
-        dh = ops.conv2d_dgrad(dy2, ops.weight_transpose(cs2.w_lp), (h.shape[1], h.shape[2]), cs2.stride, cs2.pad)
+        dh = ops.conv2d_dgrad(dy2, cs2.transposed(), (h.shape[1], h.shape[2]), cs2.stride, cs2.pad)
         dy1 = ops.bn_act_bwd(dh, y1, bs1.gamma, s1, b1, m1, i1, act1, bs1.ggamma, bs1.gbeta)
         if ctx.w_needs_grad:
             _wgrad(x, dy1, cs1)
         dx = None
         if ctx.x_needs_grad:
-            dx = ops.conv2d_dgrad(dy1, ops.weight_transpose(cs1.w_lp), (x.shape[1], x.shape[2]), cs1.stride, cs1.pad,
+            dx = ops.conv2d_dgrad(dy1, cs1.transposed(), (x.shape[1], x.shape[2]), cs1.stride, cs1.pad,
                                   residual=dz)
         return (dx,) + (None,) * 11
 
@@ -219,7 +219,7 @@ class ConvBiasFn(Function):
                 GRAD_READY_HOOK(cs)
         dx = None
         if ctx.x_needs_grad:
-            wT = ops.weight_transpose(cs.w_lp)
+            wT = cs.transposed()
             dx = ops.conv2d_dgrad(dy, wT, (x.shape[1], x.shape[2]), cs.stride, cs.pad)
         return dx, None, None, None, None
 

@@ -1074,6 +1074,29 @@ __global__ __launch_bounds__(256) void weight_transpose_kernel(const T* __restri
     wt[i] = w[((long long)co * TT + t) * Cin + ci];
 }
 
+// All layers of the flat weight arena in ONE launch: table[l] = {element offset of layer l in the arena (the same
+// in the transposed arena), Cout, TT, Cin}, sorted by offset; every thread finds its layer by bisection (the
+// table is a few hundred bytes and stays in cache).  Replaces ~100 per-layer launches per training step.
+template <typename T>
+__global__ __launch_bounds__(256) void weight_transpose_all_kernel(const T* __restrict__ w, T* __restrict__ wt,
+                                                                   const int* __restrict__ table, int nlayers, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    int lo = 0, hi = nlayers - 1;
+    while (lo < hi) {                                      // largest l with table[l].off <= i
+        const int mid = (lo + hi + 1) >> 1;
+        if ((long long)(unsigned)table[mid * 4] <= i) lo = mid; else hi = mid - 1;
+    }
+    const long long off = (unsigned)table[lo * 4];
+    const int Cout = table[lo * 4 + 1], TT = table[lo * 4 + 2], Cin = table[lo * 4 + 3];
+    const long long j = i - off;                           // index into this layer's wt
+    if (j >= (long long)Cout * TT * Cin) return;           // alignment gap between layers
+    const int co = j % Cout;
+    const int t = (j / Cout) % TT;
+    const int ci = j / ((long long)Cout * TT);
+    wt[off + j] = w[off + ((long long)co * TT + t) * Cin + ci];
+}
+
 // column sums of a [P][C] (pixel stride ld) tensor into fp32 out[C] (atomicAdd): bias gradients
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int P, int C, int ld, int rows_per_block,
@@ -1396,6 +1419,22 @@ extern "C" int et_weight_transpose(const void* w, void* wT, int dtype, int Cout,
         hipLaunchKernelGGL((weight_transpose_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)w, (float*)wT, Cout, taps, Cin, n);
     else if (dtype == ET_BF16)
         hipLaunchKernelGGL((weight_transpose_kernel<uint16_t>), grid, block, 0, (hipStream_t)stream, (const uint16_t*)w, (uint16_t*)wT, Cout, taps, Cin, n);
+    else return -2;
+    ET_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int et_weight_transpose_all(const void* w_arena, void* wT_arena, int dtype, const int* table, int n_layers,
+                                       long long total_elems, et_stream_t stream) {
+    if (!w_arena || !wT_arena || !table) return -1;
+    if (n_layers <= 0 || total_elems <= 0) return -2;
+    const dim3 grid(et_cdiv(total_elems, 256)), block(256);
+    if (dtype == ET_F32)
+        hipLaunchKernelGGL((weight_transpose_all_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)w_arena,
+                           (float*)wT_arena, table, n_layers, total_elems);
+    else if (dtype == ET_BF16)
+        hipLaunchKernelGGL((weight_transpose_all_kernel<uint16_t>), grid, block, 0, (hipStream_t)stream,
+                           (const uint16_t*)w_arena, (uint16_t*)wT_arena, table, n_layers, total_elems);
     else return -2;
     ET_CHECK_LAUNCH();
     return 0;

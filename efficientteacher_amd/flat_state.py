@@ -34,7 +34,15 @@ def _round(n, a=ALIGN):
 
 class ConvSlot:
     """Kernel-side view of one nn.Conv2d: padded weight / grad / low-precision shadow, bias."""
-    __slots__ = ("cout", "cin", "coutp", "cinp", "k", "stride", "pad", "w", "gw", "w_lp", "bias", "gbias", "index")
+    __slots__ = ("cout", "cin", "coutp", "cinp", "k", "stride", "pad", "w", "gw", "w_lp", "bias", "gbias", "index",
+                 "wT_lp", "flat")
+
+    def transposed(self):
+        """(Cin, KH, KW, Cout) copy of the compute-precision weight: the dgrad operand.  All layers are
+        re-transposed by ONE launch the first time any of them is needed after a weight update."""
+        f = self.flat()
+        f.ensure_transposed()
+        return self.wT_lp
 
 
 class BnSlot:
@@ -92,6 +100,10 @@ class FlatState:
             param.data = view
             param.grad = gview
 
+        # transposed copy of the compute-precision weights (dgrad operand), same layout as the weight segment
+        self.shadow_T = torch.zeros(self.w_range[1], dtype=compute_dtype, device=dev)
+        self.w_version, self.wT_version = 1, 0
+        rows = []
         self.conv_slots, self.bn_slots = {}, {}
         bias_off = dict((id(m), o) for m, o in cb)
         for idx, (m, o, n) in enumerate(cw):
@@ -104,11 +116,14 @@ class FlatState:
             s.w = self.params[o:o + n].view(shape)
             s.gw = self.grads[o:o + n].view(shape)
             repoint(m.weight, s.w.permute(0, 3, 1, 2)[:s.cout, :s.cin], s.gw.permute(0, 3, 1, 2)[:s.cout, :s.cin])
+            so = o - self.w_range[0]
             if self.shadow is not None:
-                so = o - self.w_range[0]
                 s.w_lp = self.shadow[so:so + n].view(shape)
             else:
                 s.w_lp = s.w
+            s.wT_lp = self.shadow_T[so:so + n].view(s.cinp, s.k, s.k, s.coutp)
+            s.flat = weakref.ref(self)
+            rows.append((so, s.coutp, s.k * s.k, s.cinp))
             s.bias = s.gbias = None
             if m.bias is not None:
                 bo = bias_off[id(m)]
@@ -118,6 +133,7 @@ class FlatState:
             self.conv_slots[id(m)] = s
             m._et_slot = s
             m._et_flat_ref = weakref.ref(self)
+        self.wT_table = torch.tensor(sorted(rows), dtype=torch.int32, device=dev).reshape(-1, 4)
         bw0 = seg["bn_weight"][0]
         for b, o in zip(bns, self.bn_off):
             c = b.num_features
@@ -182,6 +198,13 @@ class FlatState:
     def mark_weights_changed(self):
         """The fp32 master changed outside the fused SGD (EMA update, load_state_dict, torch optimizers)."""
         self.weights_dirty = True
+        self.w_version += 1
+
+    def ensure_transposed(self):
+        if self.wT_version != self.w_version:
+            src = self.shadow if self.shadow is not None else self.params[self.w_range[0]:self.w_range[0] + self.w_range[1]]
+            ops.weight_transpose_all(src, self.shadow_T, self.wT_table, self.w_range[1])
+            self.wT_version = self.w_version
 
     def prepare_forward(self, training):
         """Called by Model.forward: bring the bf16 shadow / eval-mode BN affine up to date if needed."""

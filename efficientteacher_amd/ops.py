@@ -222,6 +222,13 @@ def weight_transpose(w):
     return wt
 
 
+def weight_transpose_all(w_arena, wT_arena, table, total):
+    """Transpose every layer of the flat weight arena (table: (n, 4) int32 rows {offset, Cout, taps, Cin})."""
+    _lib.check(_lib.load().et_weight_transpose_all(_lib.ptr(w_arena), _lib.ptr(wT_arena), et_dtype(w_arena),
+                                                   _lib.ptr(table), table.shape[0], int(total), _lib.stream(w_arena)),
+               "et_weight_transpose_all")
+
+
 def conv2d_dgrad(dy, wT, in_hw, stride, pad, *, out=None, accumulate=False, residual=None):
     """dx (N, IH, IW, Cin) from dy (N, OH, OW, Cout) and wT (Cin, KH, KW, Cout)."""
     N, OH, OW, Cout = dy.shape

@@ -41,6 +41,7 @@ class FlatSGD(torch.optim.Optimizer):
             ops.sgd_nesterov(f.params[o:o + n], f.grads[o:o + n], self.momentum_buf[o:o + n], shadow,
                              g['lr'], g['momentum'], g['weight_decay'], self.first, inv_scale)
         self.first = False
+        f.w_version += 1                 # the compute-precision shadow changed: transposed copies are stale
 
     def zero_grad(self, set_to_none=False):
         self.flat.zero_grad()

@@ -118,6 +118,10 @@ int et_conv2d_wgrad_grouped(const et_wgrad_item* items /* host array */, int n_i
                             int Cin, int Cout, int KH, int KW, int stride, int pad, const void* zero16,
                             et_stream_t stream);
 int et_weight_transpose(const void* w, void* wT, int dtype, int Cout, int taps, int Cin, et_stream_t stream);
+/* every layer of a flat weight arena at once: table = n_layers x {element offset, Cout, taps, Cin} (int32, device,
+ * sorted by offset); wT_arena has the arena's layout with each layer stored (Cin, taps, Cout). */
+int et_weight_transpose_all(const void* w_arena, void* wT_arena, int dtype, const int* table, int n_layers,
+                            long long total_elems, et_stream_t stream);
 /* out[c] += sum_p x[p*ld + c]  (bias gradient of the Detect convs) */
 int et_colsum(const void* x, int dtype, int P, int C, int ld, float* out, et_stream_t stream);
 
