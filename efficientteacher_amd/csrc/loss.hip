@@ -169,6 +169,10 @@ __global__ __launch_bounds__(256) void loss_pos_kernel(LossArgs A, LossLevel L, 
     const int s = blockIdx.x * 256 + threadIdx.x;
     const int pass = blockIdx.y;
     float box_sum = 0.f, cls_sum = 0.f;
+    bool do_cls = false;
+    long long cls_off = 0;
+    int cls_c = 0;
+    float cls_wgt = 0.f;
     if (((A.pass_mask >> pass) & 1) && s < nslot) {
         const Slot r = eval_slot(A, L, pass, s);
         if (r.valid && r.b >= 0 && r.b < A.B) {
@@ -202,13 +206,32 @@ __global__ __launch_bounds__(256) void loss_pos_kernel(LossArgs A, LossLevel L, 
                 atomicMax(L.tobj + cell, ((unsigned long long)r.seq << 32) | __float_as_uint(tv));
             }
             if (want_cls) {
-                const float wgt = A.cls_w / (npos * (float)A.nc);
-                for (int c = 0; c < A.nc; ++c) {
-                    const float x = ld_logit(L.p, A.dtype, off + 5 + c);
-                    float gr_;
-                    cls_sum += bce_logits(x, c == r.c ? A.cp : A.cn, A.cls_pw, gr_);
-                    atomicAdd(L.dp + off + 5 + c, wgt * gr_);
-                }
+                do_cls = true;
+                cls_off = off;
+                cls_c = r.c;
+                cls_wgt = A.cls_w / (npos * (float)A.nc);
+            }
+        }
+    }
+    // class term: the wave walks its slots that have one and spreads the nc class logits of each over the lanes
+    // (coalesced loads and atomics; one lane per slot looping over 80 classes touched 64 different cache lines
+    // per iteration)
+    {
+        const int lane = threadIdx.x & 63;
+        unsigned long long m = __ballot(do_cls);
+        while (m) {
+            const int src = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const unsigned lo = __shfl((unsigned)(cls_off & 0xffffffffll), src);
+            const unsigned hi = __shfl((unsigned)((unsigned long long)cls_off >> 32), src);
+            const long long off_s = (long long)(((unsigned long long)hi << 32) | lo);
+            const int c_s = __shfl(cls_c, src);
+            const float wgt_s = __shfl(cls_wgt, src);
+            for (int c = lane; c < A.nc; c += 64) {
+                const float x = ld_logit(L.p, A.dtype, off_s + 5 + c);
+                float gr_;
+                cls_sum += bce_logits(x, c == c_s ? A.cp : A.cn, A.cls_pw, gr_);
+                atomicAdd(L.dp + off_s + 5 + c, wgt_s * gr_);
             }
         }
     }
