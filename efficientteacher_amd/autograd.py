@@ -186,6 +186,68 @@ class C3StemFn(Function):
         return (dx,) + (None,) * 10
 
 
+class _GradDst:
+    """Shared gradient buffer of one head output that was split along the batch (split_batch): each consumer
+    (the fused loss) writes the gradient of ITS images straight into its range of `buf`; BatchSplitFn.backward
+    then returns `buf` as the gradient of the whole tensor -- no zero-padded halves, no add."""
+
+    def __init__(self, p):
+        self.shape, self.stride, self.dtype, self.device = tuple(p.shape), tuple(p.stride()), p.dtype, p.device
+        self.span = ops._flat_span(p)
+        self.buf = None
+        self.written = [False, False]
+
+    def flat(self, half, n):
+        """flat destination (elements) for images [0,n) (half 0) or [n,B) (half 1)"""
+        if self.buf is None:
+            self.buf = torch.empty(self.span, dtype=self.dtype, device=self.device)
+        cut = n * self.stride[0]
+        self.written[half] = True
+        return self.buf[:cut] if half == 0 else self.buf[cut:]
+
+
+class BatchSplitFn(Function):
+    @staticmethod
+    def forward(ctx, p, n, holder):
+        ctx.n, ctx.holder = n, holder
+        return p[:n], p[n:]
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        h, n = ctx.holder, ctx.n
+        cut = n * h.stride[0]
+
+        def is_slot(g, half):
+            return (g is not None and h.buf is not None and h.written[half] and tuple(g.stride()) == h.stride
+                    and g.data_ptr() == h.buf.data_ptr() + (cut * h.buf.element_size() if half else 0))
+        if h.buf is None:
+            h.buf = torch.empty(h.span, dtype=h.dtype, device=h.device)
+        full = h.buf.as_strided(h.shape, h.stride)
+        for half, g in ((0, ga), (1, gb)):
+            if is_slot(g, half):
+                continue
+            dst = full[:n] if half == 0 else full[n:]
+            if g is None:
+                (h.buf[:cut] if half == 0 else h.buf[cut:]).zero_()
+            else:
+                (h.buf[:cut] if half == 0 else h.buf[cut:]).zero_()     # padding channels of the span
+                dst.copy_(g)
+        return full, None, None
+
+
+def split_batch(p, n):
+    """(p[:n], p[n:]) of a head output whose two halves feed two fused losses (reference
+    SSODTrainer.split_predict_and_feature, ssod_trainer.py:570-585); the views carry `_et_grad_dst` so that the
+    losses can deposit their gradients in place (see _GradDst)."""
+    if not (torch.is_grad_enabled() and p.requires_grad) or n <= 0 or n >= p.shape[0]:
+        return p[:n], p[n:]
+    h = _GradDst(p)
+    a, b = BatchSplitFn.apply(p, n, h)
+    a._et_grad_dst = (h, 0, n)
+    b._et_grad_dst = (h, 1, n)
+    return a, b
+
+
 class ConvBiasFn(Function):
     """y = act(conv(x, w) + bias): the Detect output convs (yolov5_head.py:30,55) and netD
     (yolo_ssod.py:224-238).  With ``head=(na, no)`` the result is returned as the (B, na, ny, nx, no)

@@ -19,6 +19,8 @@ class YoloLossFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, table, hp, anchors_host, balance, *p):
+        hp = dict(hp)
+        ctx.grad_dst = hp.pop("grad_dst", None) or [None] * len(p)
         out, dps = ops.yolo_loss(list(p), table, anchors_host, balance, **hp)
         ctx.dps = dps
         ctx.meta = [(pi.shape, pi.stride(), pi.dtype) for pi in p]
@@ -30,8 +32,14 @@ class YoloLossFn(torch.autograd.Function):
     def backward(ctx, gout):
         g3 = gout[3:4].contiguous().float()
         grads = []
-        for dp, (shape, stride, dtype) in zip(ctx.dps, ctx.meta):
-            g = ops.scale_cast(dp, dtype, scale=float(ctx.bs), dev_scale=g3)
+        for dp, (shape, stride, dtype), dst in zip(ctx.dps, ctx.meta, ctx.grad_dst):
+            out = None
+            if dst is not None:          # this tensor is one batch half of a split head output: write in place
+                holder, half, n = dst
+                flat = holder.flat(half, n)
+                if flat.numel() == dp.numel() and holder.dtype == dtype:
+                    out = flat
+            g = ops.scale_cast(dp, dtype, scale=float(ctx.bs), dev_scale=g3, out=out)
             grads.append(g.as_strided(shape, stride))
         return (None, None, None, None, *grads)
 
@@ -80,7 +88,9 @@ class ComputeLoss:
         t = targets[:, :6].to(device=dev, dtype=torch.float32)
         n = t.shape[0]
         table = torch.cat((t, torch.zeros((n, 1), device=dev), torch.ones((n, 1), device=dev)), 1)
-        out = YoloLossFn.apply(table, self._hp(), self._anchors_host, self.balance, *p)
+        hp = self._hp()
+        hp["grad_dst"] = [getattr(pi, "_et_grad_dst", None) for pi in p]
+        out = YoloLossFn.apply(table, hp, self._anchors_host, self.balance, *p)
         loss = out[3:4]
         det = out.detach()
         loss_dict = dict(box=det[0:1], obj=det[1:2], cls=det[2:3], loss=det[3:4])

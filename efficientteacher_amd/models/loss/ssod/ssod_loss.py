@@ -65,7 +65,9 @@ class ComputeStudentMatchLoss:
             n = t.shape[0]
             table = torch.cat((t, torch.zeros((n, 1), device=dev), torch.ones((n, 1), device=dev)), 1)
             mask = 1
-        out = YoloLossFn.apply(table, self._hp(mask), self._anchors_host, self.balance, *p)
+        hp = self._hp(mask)
+        hp["grad_dst"] = [getattr(pi, "_et_grad_dst", None) for pi in p]
+        out = YoloLossFn.apply(table, hp, self._anchors_host, self.balance, *p)
         det = out.detach()
         return out[3:4], dict(ss_box=det[0:1], ss_obj=det[1:2], ss_cls=det[2:3])
 

@@ -461,8 +461,9 @@ def yolo_loss(p, table, anchors_host, balance, *, nc, anchor_t, gr, cp, cn, cls_
     return out, dps
 
 
-def scale_cast(src_flat, dtype, scale=1.0, dev_scale=None):
-    dst = torch.empty(src_flat.shape, dtype=dtype, device=src_flat.device)
+def scale_cast(src_flat, dtype, scale=1.0, dev_scale=None, out=None):
+    dst = out if out is not None else torch.empty(src_flat.shape, dtype=dtype, device=src_flat.device)
+    assert dst.dtype == dtype and dst.numel() == src_flat.numel() and dst.is_contiguous()
     _lib.check(_lib.load().et_scale_cast(_lib.ptr(src_flat), _lib.ptr(dst), et_dtype(dst), src_flat.numel(), float(scale),
                                          _lib.ptr(dev_scale), _lib.stream(src_flat)), "et_scale_cast")
     return dst

@@ -82,8 +82,10 @@ class SSODTrainer(Trainer):
     def split_predict_and_feature(total_pred, total_feature, n_img):
         sup_feature = [f[:n_img] for f in total_feature]
         un_sup_feature = [f[n_img:] for f in total_feature]
-        sup_pred = [p[:n_img] for p in total_pred]
-        un_sup_pred = [p[n_img:] for p in total_pred]
+        from ..autograd import split_batch     # views whose loss gradients are stitched without copies
+        halves = [split_batch(p, n_img) for p in total_pred]
+        sup_pred = [h[0] for h in halves]
+        un_sup_pred = [h[1] for h in halves]
         return sup_pred, sup_feature, un_sup_pred, un_sup_feature
 
     def train_instance(self, imgs, targets, paths, unlabeled_imgs, unlabeled_imgs_ori, unlabeled_gt, unlabeled_M, ni,
