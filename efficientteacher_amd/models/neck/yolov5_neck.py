@@ -1,7 +1,8 @@
 """PANet neck (host-side mirror of reference models/neck/yolov5_neck.py:6-109)."""
+import torch
 import torch.nn as nn
 
-from ...autograd import UpsampleCatFn
+from ...autograd import JoinSlicesFn, UpsampleCatFn
 from ...utils.general import make_divisible
 from ..backbone.common import C3, Concat, Conv
 
@@ -48,10 +49,35 @@ class YoloV5Neck(nn.Module):
 
     def forward(self, inputs):
         P3, P4, P5 = inputs
-        xp_1 = self.conv1(P5)
+        # the two bottom-up concats [conv3(x2) | xp_2] and [conv4(x3) | xp_1] are produced IN PLACE: the lateral
+        # convs write xp_1 / xp_2 into the second half of the concat buffer when they run, the stride-2 convs
+        # later fill the first half (JoinSlicesFn is the differentiable "cat" of the filled buffer)
+        N, H5, W5, _ = P5.shape
+        c1o = self.conv1.conv.out_channels
+        if c1o % 8 or self.conv4.conv.out_channels % 8 or self.conv2.conv.out_channels % 8 or self.conv3.conv.out_channels % 8:
+            xp_1 = self.conv1(P5)
+            x1 = self.C1(UpsampleCatFn.apply(xp_1, P4))
+            xp_2 = self.conv2(x1)
+            x2 = self.C2(UpsampleCatFn.apply(xp_2, P3))
+            x3 = self.C3(self.concat([self.conv3(x2), xp_2]))
+            x4 = self.C4(self.concat([self.conv4(x3), xp_1]))
+            return x2, x3, x4
+        c4o = self.conv4.conv.out_channels
+        buf4 = torch.empty((N, H5, W5, c4o + c1o), dtype=P5.dtype, device=P5.device)
+        xp_1 = self.conv1(P5, dst=(buf4, c4o))
         x1 = self.C1(UpsampleCatFn.apply(xp_1, P4))     # upsample1 + concat, no intermediate tensor
-        xp_2 = self.conv2(x1)
+        c2o, c3o = self.conv2.conv.out_channels, self.conv3.conv.out_channels
+        buf3 = torch.empty((N, x1.shape[1], x1.shape[2], c3o + c2o), dtype=x1.dtype, device=x1.device)
+        xp_2 = self.conv2(x1, dst=(buf3, c3o))
         x2 = self.C2(UpsampleCatFn.apply(xp_2, P3))     # upsample2 + concat
-        x3 = self.C3(self.concat([self.conv3(x2), xp_2]))
-        x4 = self.C4(self.concat([self.conv4(x3), xp_1]))
+        t3 = self.conv3(x2, dst=(buf3, 0))
+        x3 = self.C3(self._join(buf3, t3, xp_2))
+        t4 = self.conv4(x3, dst=(buf4, 0))
+        x4 = self.C4(self._join(buf4, t4, xp_1))
         return x2, x3, x4
+
+    @staticmethod
+    def _join(buf, a, b):
+        if torch.is_grad_enabled() and (a.requires_grad or b.requires_grad):
+            return JoinSlicesFn.apply((buf,), a, b)
+        return buf
