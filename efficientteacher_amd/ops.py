@@ -151,7 +151,10 @@ class WgradQueue:
     def __init__(self):
         import os
         self.group = max(1, min(16, int(os.environ.get("ET_WGRAD_GROUP", "8"))))
-        self.pending = {}
+        self.stale = 10              # a group nobody added to for this many submissions is launched (its stage of
+        self.pending = {}            # the network is over): keeps the gradient all-reduce overlapped with backward
+        self.last = {}
+        self.tick = 0
         self._cb_armed = False
 
     def submit(self, x, dy, dw, ksize, stride, pad, on_done=None):
@@ -161,8 +164,12 @@ class WgradQueue:
                 on_done()
             return
         key = (tuple(x.shape), tuple(dy.shape), ksize, stride, pad, x.device)
+        self.tick += 1
+        for k in [k for k, t in self.last.items() if k != key and self.tick - t > self.stale]:
+            self._flush_key(k)
         lst = self.pending.setdefault(key, [])
         lst.append((x, dy, dw, on_done))
+        self.last[key] = self.tick
         if len(lst) >= self.group:
             self._flush_key(key)
         elif not self._cb_armed:
@@ -174,6 +181,7 @@ class WgradQueue:
 
     def _flush_key(self, key):
         lst = self.pending.pop(key, None)
+        self.last.pop(key, None)
         if not lst:
             return
         xs, dys, ksize, stride, pad, _ = key
