@@ -151,7 +151,7 @@ class WgradQueue:
     def __init__(self):
         import os
         self.group = max(1, min(16, int(os.environ.get("ET_WGRAD_GROUP", "8"))))
-        self.stale = 10              # a group nobody added to for this many submissions is launched (its stage of
+        self.stale = int(os.environ.get("ET_WGRAD_STALE", "20"))   # a group nobody added to for this many submissions is launched (its stage of
         self.pending = {}            # the network is over): keeps the gradient all-reduce overlapped with backward
         self.last = {}
         self.tick = 0
