@@ -1,0 +1,95 @@
+"""Supervised path (BASELINE configs[0]/[1], reference trainer/trainer.py:381-443): two Trainer.train_step calls of
+this package (tiny widths, fp32 parity mode) against a plain-torch restatement of the same two steps: the
+oracle model + oracle ComputeLoss + torch.optim.SGD(nesterov) with the reference's three parameter groups
+[biases | conv weights (decay) | BN weights], its warm-up interpolation (incl. the group-2 quirk) and ModelEMA."""
+import math
+import os
+
+import numpy as np
+import torch
+
+from tests.conftest import ROOT
+
+YAML = "efficientteacher_amd/configs/sup/public/yolov5s_coco.yaml"
+
+
+def test_two_supervised_steps_match_plain_torch(hip):
+    from efficientteacher_amd.configs import get_cfg
+    from efficientteacher_amd.trainer import Trainer
+    from oracle import losses as o_loss, model as o_model
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(ROOT, YAML))
+    cfg.merge_from_list(["Model.width_multiple", 0.125, "Model.depth_multiple", 0.33, "Dataset.batch_size", 2])
+    cfg.freeze()
+    torch.manual_seed(0)
+    t = Trainer(cfg, hip.device, nb=1000)
+    t.model.set_compute_dtype(torch.float32)
+    t.build_optimizer(cfg)
+    from efficientteacher_amd.utils.torch_utils import ModelEMA
+    t.ema = ModelEMA(t.model)
+    # ---- plain-torch twin on the same initial weights --------------------------------------------------
+    ref = o_model.Model.from_cfg(cfg)
+    sd = {k: v.detach().cpu().clone() for k, v in t.model.state_dict().items()}
+    missing = ref.load_state_dict(sd, strict=False)
+    assert all(k.startswith("det_") for k in missing.missing_keys) and not missing.unexpected_keys
+    ref.train()
+    g_b, g_w, g_bn = [], [], []
+    for name, m in ref.named_modules():
+        if name.startswith("det_"):
+            continue
+        if hasattr(m, "bias") and isinstance(m.bias, torch.nn.Parameter):
+            g_b.append(m.bias)
+        if isinstance(m, torch.nn.BatchNorm2d):
+            g_bn.append(m.weight)
+        elif hasattr(m, "weight") and isinstance(m.weight, torch.nn.Parameter):
+            g_w.append(m.weight)
+    hyp = cfg.hyp
+    opt = torch.optim.SGD(g_b, lr=hyp.lr0, momentum=hyp.momentum, nesterov=True)
+    opt.add_param_group(dict(params=g_w, weight_decay=t.optimizer.param_groups[1]["weight_decay"]))
+    opt.add_param_group(dict(params=g_bn))
+    for gr in opt.param_groups:
+        gr["initial_lr"] = hyp.lr0
+    import copy
+    ema = copy.deepcopy(ref).eval()
+    updates = 0
+    rng = np.random.default_rng(5)
+    closs = t.compute_loss
+    for step in range(2):
+        ni = 3 + step
+        imgs = torch.from_numpy(rng.integers(0, 256, (2, 3, 64, 64), dtype=np.uint8))
+        targets = torch.tensor([[0, 3, .5, .5, .3, .4], [1, 17, .3, .6, .2, .2], [1, 0, .7, .3, .4, .5]])
+        items = t.train_step(imgs.to(hip.device), targets, ni)
+        # reference step
+        x = imgs.float() / 255.0
+        rp, _ = ref(x)
+        rl, ritems = o_loss.compute_loss(rp, targets, ref.head.anchors, nc=cfg.Dataset.nc, box_w=closs.box_w,
+                                         obj_w=closs.obj_w, cls_w=closs.cls_w)
+        opt.zero_grad()
+        rl.backward()
+        xi = [0, t.nw]
+        for j, gr in enumerate(opt.param_groups):
+            gr["lr"] = float(np.interp(ni, xi, [hyp.warmup_bias_lr if j == 2 else 0.0, gr["initial_lr"] * t.lf(0)]))
+            gr["momentum"] = float(np.interp(ni, xi, [hyp.warmup_momentum, hyp.momentum]))
+        opt.step()
+        updates += 1
+        d = 0.9999 * (1 - math.exp(-updates / 2000))
+        with torch.no_grad():
+            msd = ref.state_dict()
+            for k, v in ema.state_dict().items():
+                if v.dtype.is_floating_point:
+                    v.mul_(d).add_(msd[k].detach(), alpha=1 - d)
+        rlv = float(rl.detach())
+        assert abs(float(items["loss"]) - rlv) <= 1e-4 * abs(rlv), (step, float(items["loss"]), rlv)
+        for a, b in zip(t.optimizer.param_groups, opt.param_groups):
+            assert abs(a["lr"] - b["lr"]) < 1e-12 and abs(a["momentum"] - b["momentum"]) < 1e-12
+    mine, theirs = t.model.state_dict(), ref.state_dict()
+    for k in ("backbone.stage1.conv.weight", "backbone.stage3_2.cv3.bn.weight", "neck.C2.cv3.conv.weight",
+              "head.m.0.bias", "backbone.stage2_1.bn.running_var"):
+        a, b, o = mine[k].cpu(), theirs[k], sd[k]
+        upd = (b - o).abs().max().item()
+        assert (a - b).abs().max().item() <= 5e-3 * upd + 1e-7, k
+    e_mine = t.ema.ema.state_dict()
+    for k in ("backbone.stage1.conv.weight", "head.m.2.bias"):
+        a, b, o = e_mine[k].cpu(), ema.state_dict()[k], sd[k]
+        upd = (b - o).abs().max().item()
+        assert (a - b).abs().max().item() <= 1e-3 * upd + 1e-6, k      # one fp32 ulp of the -4.9 biases is 4.8e-7
