@@ -228,8 +228,8 @@ def main():
             "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic (random-init YOLOv5l; teacher obj/cls scores "
             "replaced by U^16 / U^4 so that NMS and the pseudo-label loss do representative work)",
-            "config": {"workload": "YOLOv5l Efficient-Teacher SSOD, 32 labeled + 32 unlabeled 640px per GPU "
-                                   "(BASELINE configs[2])", "global_batch": world * (Bl + Bu), "img_size": S,
+            "config": {"workload": f"YOLOv5l Efficient-Teacher SSOD, {Bl} labeled + {Bu} unlabeled 640px per GPU "
+                                   "(BASELINE configs[2]" + ("" if Bl == 32 else ", reduced per-rank batch") + ")", "global_batch": world * (Bl + Bu), "img_size": S,
                        "parallelism": f"dp{world}", "optimizer_every_step": True,
                        "algorithmic_tflop_per_step_per_gpu": step_flop / 1e12,
                        "step_tflops_per_gpu": step_flop / (dt / a.steps) / 1e12,
