@@ -108,3 +108,47 @@ def test_bf16_mode_close_to_fp32(hip):
         (z, xs), _ = model(hip.t(g["x"]))
     rel = np.abs(z.cpu().numpy() - g["eval_z"]).max() / np.abs(g["eval_z"]).max()
     assert rel <= 3e-2, rel
+
+
+@pytest.mark.parametrize("group,stale", [(2, 1000), (3, 1), (16, 2)])
+def test_grouped_wgrad_queue_matches_ungrouped(hip, group, stale):
+    """ops.WgradQueue: any grouping / staleness policy must give the same parameter gradients as launching every
+    weight gradient on its own (the bf16 path is the one that groups; compare in bf16 against group = 1)."""
+    from efficientteacher_amd import ops
+    from efficientteacher_amd.models.loss import ComputeLoss
+    grads = []
+    q = ops.WGRAD_QUEUE
+    saved = (q.group, q.stale)
+    try:
+        for g_, s_ in ((1, 1000), (group, stale)):
+            q.group, q.stale = g_, s_
+            cfg, model, g = build(hip, torch.bfloat16)
+            model.train()
+            closs = ComputeLoss(model, cfg)
+            pred, _ = model(hip.t(g["x"]))
+            loss, _ = closs(pred, hip.t(g["targets"]))
+            model.zero_grad()
+            loss.backward()
+            assert not q.pending                              # everything was flushed by the end of backward
+            grads.append({k: p.grad.detach().float().cpu().clone() for k, p in model.named_parameters()})
+    finally:
+        q.group, q.stale = saved
+    for k in grads[0]:
+        a, b = grads[0][k], grads[1][k]
+        assert torch.allclose(a, b, rtol=2e-2, atol=2e-3 * max(1.0, a.abs().max().item())), k
+
+
+def test_split_batch_fallback_paths(hip):
+    """autograd.split_batch: halves whose gradient does NOT come from the fused loss (or is missing) are stitched by
+    the copy fallback."""
+    from efficientteacher_amd.autograd import split_batch
+    p = torch.randn(4, 3, 5, 5, 8, device=hip.device, requires_grad=True)
+    a, b = split_batch(p, 1)
+    (a * 2.0).sum().backward()                                # only the first half is used
+    ref = torch.zeros_like(p); ref[:1] = 2.0
+    assert torch.equal(p.grad, ref)
+    p.grad = None
+    a, b = split_batch(p, 3)
+    ((a * 1.5).sum() + (b * -1.0).sum()).backward()           # both halves, ordinary torch gradients
+    ref = torch.full_like(p, 1.5); ref[3:] = -1.0
+    assert torch.equal(p.grad, ref)
