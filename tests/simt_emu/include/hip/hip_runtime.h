@@ -150,6 +150,9 @@ static inline void __syncthreads() { emu::block_sync(); }
 static inline void __builtin_amdgcn_s_barrier_emu() { emu::block_sync(); }
 #define __builtin_amdgcn_s_barrier __builtin_amdgcn_s_barrier_emu
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#ifndef __clang__
+#define __builtin_nontemporal_load(p) (*(p))
+#endif
 #define __builtin_amdgcn_wave_barrier() emu::wave_sync()
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
