@@ -11,7 +11,6 @@ Because all gradients already live in one contiguous fp32 arena there is nothing
 traverse: the arena is cut into a few large chunks sized for xGMI's per-link bandwidth and each chunk
 is all-reduced asynchronously as soon as backward has passed the layers it covers.
 """
-import torch
 import torch.distributed as dist
 import torch.nn as nn
 

@@ -9,13 +9,12 @@ stream-ordered: no ``.cpu()``, no per-detection python loops, no deepcopy of the
 """
 from contextlib import nullcontext as _nullcontext
 
-import numpy as np
 import torch
 
-from ..models.loss import ComputeLoss, DomainLoss, TargetLoss, build_ssod_loss
+from ..models.loss import DomainLoss, TargetLoss, build_ssod_loss
 from ..parallel import FlatDataParallel
 from ..utils.self_supervised_utils import FairPseudoLabel
-from ..utils.torch_utils import CosineEMA, ModelEMA, SemiSupModelEMA
+from ..utils.torch_utils import CosineEMA, SemiSupModelEMA
 from .trainer import Trainer
 
 

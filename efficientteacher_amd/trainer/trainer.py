@@ -16,7 +16,7 @@ from torch.optim import lr_scheduler
 from ..models.loss import ComputeLoss
 from ..optim import FlatSGD
 from ..parallel import FlatDataParallel
-from ..utils.torch_utils import ModelEMA, de_parallel
+from ..utils.torch_utils import ModelEMA
 
 LOGGER = logging.getLogger(__name__)
 

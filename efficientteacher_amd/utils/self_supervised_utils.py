@@ -5,8 +5,6 @@
 (N,9) float64 tensor and ``invalid_target_shape``), which costs one host synchronisation;
 ``create_pseudo_label_padded`` is the device-resident form the trainer uses (no synchronisation).
 """
-import torch
-
 from .. import ops
 from .general import nms_ssod_padded
 

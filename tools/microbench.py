@@ -8,7 +8,6 @@
 import json
 import os
 import sys
-import time
 
 import torch
 import torch.nn.functional as F
