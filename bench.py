@@ -197,30 +197,34 @@ def main():
     loss_ok = all(math.isfinite(float(v)) for v in items.values())
 
     if rank == 0:
-        agg = timer.summary()
-        dom = max((k for k in agg if k.startswith("conv_gemm") and "parity classes" not in k), key=lambda k: agg[k]["ms"])
-        d = agg[dom]
-        per_launch_flops = d["flops"] / d["launches"]
-        per_launch_s = d["ms"] * 1e-3 / d["launches"]
-        conv_ms = sum(v["ms"] for v in agg.values()) / len(timed)
-        conv_fl = sum(v["flops"] for v in agg.values()) / len(timed)
-        # HBM/fabric traffic of the same kernel from the committed PMC passes over this very command
-        # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs; tools/pmc_summarize.py, tools/pmc_to_traffic.py)
-        traffic, traffic_src = None, None
-        try:
-            pt = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")))
-            if dom in pt["kernels"]:
-                traffic, traffic_src = pt["kernels"][dom]["bytes_per_launch"], pt["source"]
-        except (OSError, ValueError, KeyError):
-            pass
-        roof = dict(bound="mfma", kernel=dom, achieved=per_launch_flops / per_launch_s / 1e12, peak=PEAK_BF16 / 1e12,
-                    unit="TFLOP/s", frac=per_launch_flops / per_launch_s / PEAK_BF16, traffic=traffic,
-                    traffic_unit="bytes per launch (2*FETCH_SIZE + WRITE_SIZE)", traffic_source=traffic_src,
-                    algorithmic_bytes_per_launch=d["bytes"] / d["launches"],
-                    launches_per_step=d["launches"] / len(timed), instrumented_steps=len(timed),
-                    avg_launch_us=per_launch_s * 1e6, algorithmic_gflop_per_launch=per_launch_flops / 1e9,
-                    all_conv_kernels=dict(ms_per_step=conv_ms, tflops=conv_fl / (conv_ms * 1e-3) / 1e12,
-                                          algorithmic_tflop_per_step=conv_fl / 1e12))
+        try:                 # the roofline leg must never cost the throughput line
+            agg = timer.summary()
+            dom = max((k for k in agg if k.startswith("conv_gemm") and "parity classes" not in k), key=lambda k: agg[k]["ms"])
+            d = agg[dom]
+            per_launch_flops = d["flops"] / d["launches"]
+            per_launch_s = d["ms"] * 1e-3 / d["launches"]
+            conv_ms = sum(v["ms"] for v in agg.values()) / len(timed)
+            conv_fl = sum(v["flops"] for v in agg.values()) / len(timed)
+            # HBM/fabric traffic of the same kernel from the committed PMC passes over this very command
+            # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs; tools/pmc_summarize.py, tools/pmc_to_traffic.py)
+            traffic, traffic_src = None, None
+            try:
+                pt = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")))
+                if dom in pt["kernels"]:
+                    traffic, traffic_src = pt["kernels"][dom]["bytes_per_launch"], pt["source"]
+            except (OSError, ValueError, KeyError):
+                pass
+            roof = dict(bound="mfma", kernel=dom, achieved=per_launch_flops / per_launch_s / 1e12, peak=PEAK_BF16 / 1e12,
+                        unit="TFLOP/s", frac=per_launch_flops / per_launch_s / PEAK_BF16, traffic=traffic,
+                        traffic_unit="bytes per launch (2*FETCH_SIZE + WRITE_SIZE)", traffic_source=traffic_src,
+                        algorithmic_bytes_per_launch=d["bytes"] / d["launches"],
+                        launches_per_step=d["launches"] / len(timed), instrumented_steps=len(timed),
+                        avg_launch_us=per_launch_s * 1e6, algorithmic_gflop_per_launch=per_launch_flops / 1e9,
+                        all_conv_kernels=dict(ms_per_step=conv_ms, tflops=conv_fl / (conv_ms * 1e-3) / 1e12,
+                                              algorithmic_tflop_per_step=conv_fl / 1e12))
+        except Exception as e:
+            roof = dict(bound="mfma", kernel=None, achieved=None, peak=PEAK_BF16 / 1e12, unit="TFLOP/s", frac=None,
+                        traffic=None, error=f"{type(e).__name__}: {e}")
         step_flop = F_IMG * Bu + 3 * F_IMG * (Bl + Bu)
         out = {
             "metric": "SSOD images/sec (teacher+student step) YOLOv5l 640px",
