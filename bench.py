@@ -130,6 +130,8 @@ def main():
     ap.add_argument("--per-rank", type=int, default=32, help="labeled (= unlabeled) images per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="run the teacher on the main stream (A/B)")
+    ap.add_argument("--host-inputs", action="store_true", help="PCIe-inclusive variant: every step receives its three "
+                    "uint8 image batches from pinned host memory (never the reported `value`; noted in DESIGN.md)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); 'gloo' lets two "
                     "ranks share ONE GPU to exercise the N>1 code path where only a single GPU is available")
     a = ap.parse_args()
@@ -166,7 +168,14 @@ def main():
 
     ni = 2000               # past the warm-up ramp's first iterations, inside warm-up like early training
 
+    host = None
+    if a.host_inputs:           # what a data loader hands over: uint8 NCHW batches in pinned host memory
+        host = [(t * 255).round().to(torch.uint8).cpu().pin_memory() for t in (imgs, u_str, u_ori)]
+
     def step(i):
+        if host is not None:
+            im, us, uo = (h.to(device, non_blocking=True).float() / 255.0 for h in host)
+            return tr.train_instance(im, targets, None, us, uo, None, M_s, ni + i)
         return tr.train_instance(imgs, targets, None, u_str, u_ori, None, M_s, ni + i)
 
     for i in range(a.warmup):
@@ -238,7 +247,7 @@ def main():
                        "algorithmic_tflop_per_step_per_gpu": step_flop / 1e12,
                        "step_tflops_per_gpu": step_flop / (dt / a.steps) / 1e12,
                        "frac_of_bf16_mfma_peak": step_flop / (dt / a.steps) / PEAK_BF16, "loss_finite": loss_ok,
-                       "host_enqueue_ms_per_step": t_enq / a.steps * 1e3},
+                       "host_enqueue_ms_per_step": t_enq / a.steps * 1e3, "inputs": "host uint8 (PCIe inclusive)" if a.host_inputs else "resident in HBM"},
             "roofline": roof,
         }
         if world == 1 and not a.no_cpu_baseline:
