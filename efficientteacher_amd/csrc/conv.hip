@@ -1081,12 +1081,16 @@ template <typename T>
 __global__ __launch_bounds__(256) void weight_transpose_all_kernel(const T* __restrict__ w, T* __restrict__ wt,
                                                                    const int* __restrict__ table, int nlayers, long long total) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    // the layer of the wave's first element, found once per wave (scalar bisection); lanes that already belong to
+    // the next layer step forward linearly (layers are far longer than a wave)
+    const long long i0 = __builtin_amdgcn_readfirstlane((int)((i >> 6) & 0x7fffffff)) * 64ll;
     if (i >= total) return;
     int lo = 0, hi = nlayers - 1;
-    while (lo < hi) {                                      // largest l with table[l].off <= i
+    while (lo < hi) {                                      // largest l with table[l].off <= i0
         const int mid = (lo + hi + 1) >> 1;
-        if ((long long)(unsigned)table[mid * 4] <= i) lo = mid; else hi = mid - 1;
+        if ((long long)(unsigned)table[mid * 4] <= i0) lo = mid; else hi = mid - 1;
     }
+    while (lo + 1 < nlayers && (long long)(unsigned)table[(lo + 1) * 4] <= i) ++lo;
     const long long off = (unsigned)table[lo * 4];
     const int Cout = table[lo * 4 + 1], TT = table[lo * 4 + 2], Cin = table[lo * 4 + 3];
     const long long j = i - off;                           // index into this layer's wt
