@@ -22,6 +22,9 @@
 #include "et_device.h"
 #include "../../include/et_hip.h"
 #include <stdlib.h>
+#include <stdio.h>
+#include <string.h>
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -680,6 +683,222 @@ __global__ __launch_bounds__(64 * WM * WN, (NS == 3 && BKV == 4 && BM == 128) ? 
     ET_TS(4);
 }
 
+// ---- forward / dgrad gather-GEMM, 256x256 tile, two wave groups in anti-phase ("ping-pong") ----------------
+// The 8-wave 256x256x64 tile of conv_gemm_glds_kernel ran its eight waves in lockstep: every wave issued the next
+// chunk's eight LDS-DMA instructions and its first fragment reads at the same moment, with the matrix pipes idle
+// (measured: ~3.6 k cycles per chunk against 2 k of MFMA issue; MFMA busy 34 %).  Here the two waves that share a
+// SIMD (wave w and w+4: the two row groups wm = 0 / 1) run HALF A PHASE APART: while one group is in its load
+// section (fragment ds_reads + one half-tile of LDS-DMA for the next chunk) the other is in its MFMA section, and
+// every workgroup barrier swaps the roles -- matrix work beside memory work on every SIMD all the time
+// (cdna_hip_programming.md 5 "The 256^2 8-phase template", MI355X_MICROARCH.md "Two waves per SIMD" item 5).
+//
+// A K-chunk (64 channels of one tap) is consumed in four phases, one 128x128 quadrant pair each:
+//     ph0 (A0,B0)   ph1 (A0,B1)   ph2 (A1,B1)   ph3 (A1,B0)        8 x v_mfma_f32_32x32x16_bf16 per wave per phase
+// and is staged as four HALF-TILES (128 rows x 64 k, 16 KB; two LDS-DMA instructions per thread), one per phase, each
+// double buffered (8 x 16 KB = 128 KB): ph0 issues A0 of the NEXT chunk, ph1 B0, ph2 B1, ph3 A1.  A half-tile is
+// therefore in flight for three to four phases, and the wait at the end of each load section is a COUNTED
+// s_waitcnt vmcnt(4): "everything except the two youngest half-tiles has landed" -- never vmcnt(0) inside the loop.
+// Ordering rules (cdna_hip_programming.md "Read a staged buffer one phase AFTER the wait that retires it"):
+//   RAW  a wave waits for its own pieces of the half-tiles first read in phase p at the END of its load section of
+//        phase p-1; every wave then passes a workgroup barrier before any wave's phase-p reads (the two groups are
+//        one barrier apart, hence "one phase early").
+//   WAR  buffer b of a half-tile is re-staged in chunk c for chunk c+1; its last reader was chunk c-1, whose load
+//        sections ended at least three barriers earlier.
+// Half-tile row order is chosen so that a wave's accumulators are the same 128x64 block as in the lockstep kernel
+// (rows wm*128.., columns wn*64..): A-half i, row r  <->  tile row (r/64)*128 + i*64 + r%64 ;
+// B-half j, row r  <->  tile column (r/32)*64 + j*32 + r%32.  The epilogue is shared with the other kernels.
+template <int N> __device__ __forceinline__ void et_wait_vmem_le_pp() {
+    __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 0xF) | ((N >> 4) << 14));
+}
+
+__global__ __launch_bounds__(512, 2) void conv_gemm_pp_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W,
+                                                              uint16_t* __restrict__ Y, const uint16_t* __restrict__ ZERO,
+                                                              GatherGeom g, Epilogue ep) {
+    constexpr int BM = 256, BN = 256, WM = 2, WN = 4, BKV = 8, VEC = 8;
+    constexpr int HALF_VEC = 128 * BKV;            // one half-tile in 16-byte vectors (16 KB)
+    constexpr int EPI_VEC = EpiLds<BM, BN, WM, WN>::VEC16;
+    constexpr int LDS_VEC = 8 * HALF_VEC > EPI_VEC ? 8 * HALF_VEC : EPI_VEC;
+    __shared__ __attribute__((aligned(16))) u32x4 lds_raw[LDS_VEC];
+    // half-tile kinds: 0 = A0, 1 = A1, 2 = B0, 3 = B1; buffer b of kind k at lds_raw + (2*k + b) * HALF_VEC
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    ET_TS(0);
+    const int wm = wave >> 2, wn = wave & 3;       // wm = the wave group (waves w and w+4 share a SIMD)
+    int bx, by;
+    tile_of_block(g, bx, by);
+    const int m0 = bx * BM, n0 = by * BN;
+    const int lvec = tid & 7, lrow = tid >> 3;     // staging: 64 rows x 8 K-vectors per instruction of the workgroup
+    const int lv = lvec ^ lds_swz<BKV>(lrow);      // logical K-vector this lane stages (swizzle on the SOURCE)
+
+    int a_off[2][2], a_iy[2][2], a_ix[2][2];
+    unsigned a_okm = 0u, b_okm = 0u;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int p = m0 + jj * 128 + i * 64 + lrow;           // half i, LDS row jj*64 + lrow
+            const bool ok = p < g.M;
+            const uint32_t pp = ok ? p : 0;
+            const uint32_t t1 = fdiv(pp, g.dQW), qx = pp - t1 * g.QW;
+            const uint32_t n = fdiv(t1, g.dQH), qy = t1 - n * g.QH;
+            a_iy[i][jj] = qy * g.isy;
+            a_ix[i][jj] = qx * g.isx;
+            a_off[i][jj] = ((n * g.IH + a_iy[i][jj]) * g.IW + a_ix[i][jj]) * g.ldx;
+            a_okm |= ok ? (1u << (i * 2 + jj)) : 0u;
+        }
+    int b_off[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int r = jj * 64 + lrow;
+            const int co = n0 + (r >> 5) * 64 + j * 32 + (r & 31);
+            const bool ok = co < g.Cout;
+            b_off[j][jj] = (ok ? co : 0) * g.TT * g.Cin;
+            b_okm |= ok ? (1u << (j * 2 + jj)) : 0u;
+        }
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+    const int nchunks = g.KV / BKV;                // host: Cin % 64 == 0
+    // cursor of the chunk being STAGED (wave-uniform scalars; plain selects, no references: they must stay in SGPRs)
+    int tap_u = 0, cv_u = 0;
+    int ti_cur = g.tapinfo[0];                     // tap table entry of the cursor's chunk, loaded one chunk AHEAD of its use
+    int udy = 0, udx = 0, uwt = 0;
+#define ET_PP_DECODE()                                                   \
+    do {                                                                 \
+        udy = (int)(signed char)(ti_cur & 0xff);                         \
+        udx = (int)(signed char)((ti_cur >> 8) & 0xff);                  \
+        uwt = (ti_cur >> 16) & 0xff;                                     \
+    } while (0)
+#define ET_PP_ADVANCE()                                                  \
+    do {                                                                 \
+        const int t2_ = tap_u + 1, c2_ = cv_u + BKV;                     \
+        const bool wt_ = t2_ >= g.T, wc_ = c2_ >= g.CV;                  \
+        const int ta_ = wt_ ? 0 : t2_, ca_ = wt_ ? c2_ : cv_u;           \
+        const int cb_ = wc_ ? 0 : c2_, tb_ = wc_ ? t2_ : tap_u;          \
+        tap_u = g.tap_inner ? ta_ : tb_;                                 \
+        cv_u = g.tap_inner ? ca_ : cb_;                                  \
+        ti_cur = g.tapinfo[__builtin_amdgcn_readfirstlane(tap_u < g.T ? tap_u : 0)]; \
+    } while (0)
+    // issue the LDS-DMA of ONE half-tile of the cursor's chunk (two instructions per thread)
+    auto stage_a = [&](int i, int buf) {
+        u32x4* const wbase = lds_raw + (2 * i + buf) * HALF_VEC + wave * 64;
+        const int doff = (udy * g.IW + udx) * g.ldx + (cv_u + lv) * VEC;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const bool ok = (bool)((a_okm >> (i * 2 + jj)) & 1u) & ((unsigned)(a_iy[i][jj] + udy) < (unsigned)g.IH) &
+                            ((unsigned)(a_ix[i][jj] + udx) < (unsigned)g.IW);
+            const uint16_t* src = ok ? X + (a_off[i][jj] + doff) : ZERO;
+            et_glds16(src, wbase + jj * 512);
+        }
+    };
+    auto stage_b = [&](int j, int buf) {
+        u32x4* const wbase = lds_raw + (2 * (2 + j) + buf) * HALF_VEC + wave * 64;
+        const int woff = uwt * g.Cin + (cv_u + lv) * VEC;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const bool ok = (b_okm >> (j * 2 + jj)) & 1u;
+            const uint16_t* src = ok ? W + (b_off[j][jj] + woff) : ZERO;
+            et_glds16(src, wbase + jj * 512);
+        }
+    };
+
+    const int l31 = lane & 31, gk = lane >> 5;
+    u32x4 af[2][4], bf[4];                         // A fragments of one half (2 row tiles x 4 k-steps), B of one half
+    auto load_a = [&](int i, int buf) {
+        const u32x4* sm = lds_raw + (2 * i + buf) * HALF_VEC;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int r = wm * 64 + t * 32 + l31;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) af[t][kk] = sm[r * BKV + ((kk * 2 + gk) ^ lds_swz<BKV>(r))];
+        }
+    };
+    auto load_b = [&](int j, int buf) {
+        const u32x4* sm = lds_raw + (2 * (2 + j) + buf) * HALF_VEC;
+        const int r = wn * 32 + l31;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) bf[kk] = sm[r * BKV + ((kk * 2 + gk) ^ lds_swz<BKV>(r))];
+    };
+    auto mfma8 = [&](int i, int j) {
+        __builtin_amdgcn_s_setprio(1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                acc[2 * i + t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[t][kk]),
+                                                                           __builtin_bit_cast(bf16x8, bf[kk]), acc[2 * i + t][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    // prologue: the four half-tiles of chunk 0 into buffer 0
+    ET_PP_DECODE();
+    stage_a(0, 0); stage_b(0, 0); stage_b(1, 0); stage_a(1, 0);
+    ET_PP_ADVANCE();
+    et_wait_vmem();
+    __builtin_amdgcn_s_barrier();
+    ET_TS(1);
+    if (wm == 1) __builtin_amdgcn_s_barrier();     // group 1 runs one barrier (half a phase) behind group 0
+
+    // one chunk = four phases; `last`: nothing is staged during the final chunk and the waits drain the queue
+    auto chunk = [&](int buf, auto last_tag) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        const int nb = buf ^ 1;
+        if constexpr (!LAST) ET_PP_DECODE();
+        // ---- ph0: (A0, B0)
+        load_a(0, buf); load_b(0, buf);
+        if constexpr (!LAST) stage_a(0, nb);
+        if constexpr (LAST) et_wait_vmem_le_pp<2>(); else et_wait_vmem_le_pp<4>();     // B1 of this chunk has landed
+        __builtin_amdgcn_s_barrier();
+        mfma8(0, 0);
+        __builtin_amdgcn_s_barrier();
+        // ---- ph1: (A0, B1)
+        load_b(1, buf);
+        if constexpr (!LAST) stage_b(0, nb);
+        if constexpr (LAST) et_wait_vmem_le_pp<0>(); else et_wait_vmem_le_pp<4>();     // A1 of this chunk has landed
+        __builtin_amdgcn_s_barrier();
+        mfma8(0, 1);
+        __builtin_amdgcn_s_barrier();
+        // ---- ph2: (A1, B1)
+        load_a(1, buf);
+        if constexpr (!LAST) stage_b(1, nb);
+        __builtin_amdgcn_s_barrier();
+        mfma8(1, 1);
+        __builtin_amdgcn_s_barrier();
+        // ---- ph3: (A1, B0)
+        load_b(0, buf);
+        if constexpr (!LAST) { stage_a(1, nb); ET_PP_ADVANCE(); et_wait_vmem_le_pp<4>(); }   // A0, B0 of the next chunk
+        __builtin_amdgcn_s_barrier();
+        mfma8(1, 0);
+        __builtin_amdgcn_s_barrier();
+    };
+    int buf = 0;
+    for (int c = 0; c + 1 < nchunks; ++c) {
+        if (c == 1) ET_TS(2);
+        chunk(buf, std::false_type{});
+        buf ^= 1;
+    }
+    chunk(buf, std::true_type{});
+    if (wm == 0) __builtin_amdgcn_s_barrier();     // balances group 1's extra barrier
+    __syncthreads();                               // the epilogue reuses the half-tile buffers as its staging area
+    ET_TS(3);
+    conv_epilogue<uint16_t, BM, BN, WM, WN>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn);
+    __syncthreads();
+    ET_TS(4);
+#undef ET_PP_DECODE
+#undef ET_PP_ADVANCE
+}
+
 // ---- wgrad ----------------------------------------------------------------------------------------
 struct WgradGeom {
     int N, IH, IW, Cin, ldx;     // X (gathered operand)
@@ -1129,92 +1348,127 @@ static int fill_common(GatherGeom& g, int N, int IH, int IW, int Cin, int ldx, i
     return 0;
 }
 
+// ---- kernel selection ---------------------------------------------------------------------------------
+// ONE place decides which instantiation runs; et_conv2d_kernel_name() reports the same decision to the tests and
+// to bench.py's roofline tags (there is no second copy of this logic on the Python side).
+enum { GEMM_REG = 0, GEMM_GLDS = 1, GEMM_PP = 2 };
+struct GemmPlan { int kind, BM, BN, WM, WN, BKV, NS; bool utap; };
+
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+static int device_cus() {
+    static const int n_cu = [] { hipDeviceProp_t p; int d = 0; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; }();
+    return n_cu;
+}
+
+static GemmPlan plan_gemm(const GatherGeom& g, int elem_bytes, bool have_zero_page) {
+    // tuning knobs, read once.  ET_CONV_NARROW_K=<K>: GEMMs with K <= K elements use the 128x64 tile (smaller
+    // register/LDS footprint: 3 workgroups per CU for the HBM-bound short-K 1x1 layers).  ET_CONV_GLDS=0: VGPR staging.
+    // ET_CONV_RING=<rows><kvec><depth> forces one LDS-DMA instantiation.  ET_CONV_BIG=0: no 256x256 tiles.
+    // ET_CONV_PP=0: the lockstep 256x256 kernel instead of the ping-pong one.
+    static const int narrow_k = env_int("ET_CONV_NARROW_K", 256);
+    static const int use_glds = env_int("ET_CONV_GLDS", 1);
+    static const int ring_env = env_int("ET_CONV_RING", 0);
+    static const int big = env_int("ET_CONV_BIG", 1);
+    static const int use_pp = env_int("ET_CONV_PP", 1);
+    const bool bf16 = elem_bytes == 2;
+    const bool wide = g.Cout > 64 && !(narrow_k > 0 && g.T * g.Cin <= narrow_k);
+    const bool glds = use_glds && have_zero_page;
+    GemmPlan p{glds ? GEMM_GLDS : GEMM_REG, 128, wide ? 128 : 64, 2, 2, g.CV % 8 == 0 ? 8 : 4, 2, g.CV % 4 == 0};
+    if (!(bf16 && glds && g.CV % 8 == 0)) return p;
+    // short-K GEMMs (K <= 256, i.e. <= 4 chunks of 64) run 32-wide chunks in a 3-deep ring -- 48 KB of LDS, three
+    // workgroups per CU, two chunks in flight each (measured 3-10 % on the 1x1 layers); everything else the 64-wide
+    // double buffer (deeper rings or taller 4-wave tiles cost occupancy and lose: profiles/)
+    int ring = ring_env ? ring_env : (g.T * g.Cin <= 256 ? 12843 : 12882);
+    // 8-wave 256x256 tile (one workgroup per CU, half the L2->LDS bytes per flop): 3x3 layers with >= 256 output
+    // channels, and deep 1x1 layers when the grid fills whole residency rounds reasonably
+    if (!ring_env && big && g.Cout >= 256) {
+        const int n_cu = device_cus();
+        const long long blocks = (long long)((g.M + 255) / 256) * ((g.Cout + 255) / 256);
+        const double rounds = (double)blocks / n_cu;
+        const bool fills = (double)((blocks + n_cu - 1) / n_cu) / rounds <= 1.35;
+        if (g.TT > 1 || (g.T * g.Cin >= 512 && fills)) ring = use_pp ? 25680 : 25682;
+    }
+    switch (ring) {
+        case 25680: p = GemmPlan{GEMM_PP, 256, 256, 2, 4, 8, 2, true}; break;
+        case 25682: p = GemmPlan{GEMM_GLDS, 256, 256, 2, 4, 8, 2, true}; break;
+        case 25612: p = GemmPlan{GEMM_GLDS, 256, 128, 4, 2, 8, 2, true}; break;       // experiment
+        case 12883: p.NS = 3; break;
+        case 12843: p.BKV = 4; p.NS = 3; break;
+        case 12844: p.BKV = 4; p.NS = 4; break;
+        case 25683: p.BM = 256; p.NS = 3; break;
+        default: break;
+    }
+    return p;
+}
+
+// the name rocprofv3 prints for the plan's kernel (template arguments spelled as the demangler does)
+static void plan_name(const GemmPlan& p, int elem_bytes, char* buf, int n) {
+    const char* t = elem_bytes == 2 ? "unsigned short" : "float";
+    if (p.kind == GEMM_PP) snprintf(buf, n, "conv_gemm_pp_kernel");
+    else if (p.kind == GEMM_GLDS) snprintf(buf, n, "conv_gemm_glds_kernel<%s, %d, %d, %d, %d, %d, %d, %s>", t, p.BM, p.BN, p.WM, p.WN, p.BKV, p.NS, p.utap ? "true" : "false");
+    else snprintf(buf, n, "conv_gemm_kernel<%s, %d, %d, %d, %d, %d, %s>", t, p.BM, p.BN, p.WM, p.WN, p.BKV, p.utap ? "true" : "false");
+}
+
 template <typename T>
 static int launch_gemm(const void* X, const void* W, void* Y, const void* zero16, GatherGeom g, const Epilogue& ep,
                        hipStream_t s) {
     if (g.M <= 0) return 0;
-    // tile choice: 128x128 unless the layer has <= 64 output channels.  ET_CONV_NARROW_K=<K> (tuning
-    // knob, read once) additionally sends GEMMs with K <= that many elements to the 128x64 tile, whose
-    // smaller register/LDS footprint gives 3 workgroups per CU for HBM-bound short-K 1x1 layers.
-    static const int narrow_k = getenv("ET_CONV_NARROW_K") ? atoi(getenv("ET_CONV_NARROW_K")) : 256;
-    const bool wide = g.Cout > 64 && !(narrow_k > 0 && g.T * g.Cin <= narrow_k);
-    const int bn = wide ? 128 : 64;
-    static const int nfast = getenv("ET_CONV_NFAST") ? atoi(getenv("ET_CONV_NFAST")) : 1;
-    g.ntn = (g.Cout + bn - 1) / bn;
+    static const int nfast = env_int("ET_CONV_NFAST", 1);
     g.nfast = nfast;
-    const T* x = (const T*)X; const T* w = (const T*)W; T* y = (T*)Y;
-    // staging: LDS-DMA (global_load_lds) when the caller supplies a zero page, else VGPR staging.
-    // ET_CONV_GLDS=0 forces the register-staged kernel (A/B knob).
-    static const int use_glds = getenv("ET_CONV_GLDS") ? atoi(getenv("ET_CONV_GLDS")) : 1;
-    const T* z = (const T*)zero16;
-    const bool glds = use_glds && z != nullptr;
-    const dim3 block(256);
-    // ET_CONV_RING=<rows><kvec><depth> (e.g. 25683 = 256-row tile, 8-vector chunks, 3-deep ring): tuning knob
-    // for the bf16 LDS-DMA kernel, read once
-    static const int ring_env = getenv("ET_CONV_RING") ? atoi(getenv("ET_CONV_RING")) : 0;
-    // default: short-K GEMMs (K <= 256, i.e. <= 4 chunks of 64) run 32-wide chunks in a 3-deep ring -- 48 KB of
-    // LDS, three workgroups per CU, two chunks in flight each (measured 3-10 % on the 1x1 layers); everything
-    // else the 64-wide double buffer (deeper rings or taller tiles cost occupancy and lose: profiles/)
-    int ring = ring_env ? ring_env : (g.T * g.Cin <= 256 ? 12843 : 12882);
-    // 8-wave 256x256 tile (one workgroup per CU, half the L2->LDS bytes per flop): measured 860-970 TFLOP/s vs
-    // 740 on the 3x3 layers with >= 256 output channels, and a win on the deep 1x1 layers when the grid fills
-    // whole residency rounds reasonably (ET_CONV_BIG=0 disables, tuning knob)
-    static const int big = getenv("ET_CONV_BIG") ? atoi(getenv("ET_CONV_BIG")) : 1;
-    if (!ring_env && big && sizeof(T) == 2 && g.Cout >= 256 && g.CV % 8 == 0) {
-        static const int n_cu = [] { hipDeviceProp_t p; int d = 0; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; }();
-        const long long blocks = (long long)((g.M + 255) / 256) * ((g.Cout + 255) / 256);
-        const double rounds = (double)blocks / n_cu;
-        const bool fills = (double)((blocks + n_cu - 1) / n_cu) / rounds <= 1.35;
-        if (g.TT > 1 || (g.T * g.Cin >= 512 && fills)) ring = 25682;
+    const GemmPlan p = plan_gemm(g, (int)sizeof(T), zero16 != nullptr);
+    g.ntm = (g.M + p.BM - 1) / p.BM;
+    g.ntn = (g.Cout + p.BN - 1) / p.BN;
+    const T* x = (const T*)X; const T* w = (const T*)W; T* y = (T*)Y; const T* z = (const T*)zero16;
+    const dim3 grid(g.ntm * g.ntn), block(64 * p.WM * p.WN);
+#define ET_GLDS(BM_, BN_, WM_, WN_, BKV_, NS_, UT_) \
+    hipLaunchKernelGGL((conv_gemm_glds_kernel<T, BM_, BN_, WM_, WN_, BKV_, NS_, UT_>), grid, block, 0, s, x, w, y, z, g, ep)
+#define ET_REG(BN_, BKV_, UT_) \
+    hipLaunchKernelGGL((conv_gemm_kernel<T, 128, BN_, 2, 2, BKV_, UT_>), grid, block, 0, s, x, w, y, g, ep)
+    const int key = p.BM * 100000 + p.BN * 100 + p.BKV * 10 + p.NS;
+    if (p.kind == GEMM_PP) {
+        if constexpr (sizeof(T) == 2) {
+            hipLaunchKernelGGL(conv_gemm_pp_kernel, grid, block, 0, s, (const uint16_t*)x, (const uint16_t*)w, (uint16_t*)y, (const uint16_t*)z, g, ep);
+            return 0;
+        }
+        return -2;
     }
-    if constexpr (sizeof(T) == 2) {
-        if (glds && g.CV % 8 == 0 && ring != 12882) {
-#define ET_RING(BM_, BKV_, NS_)                                                                                       \
-    do {                                                                                                              \
-        g.ntm = (g.M + BM_ - 1) / BM_;                                                       \
-        const dim3 grid(g.ntm * g.ntn);                                                                               \
-        if (wide) hipLaunchKernelGGL((conv_gemm_glds_kernel<T, BM_, 128, 2, 2, BKV_, NS_, true>), grid, block, 0, s, x, w, y, z, g, ep); \
-        else hipLaunchKernelGGL((conv_gemm_glds_kernel<T, BM_, 64, 2, 2, BKV_, NS_, true>), grid, block, 0, s, x, w, y, z, g, ep);       \
-        return 0;                                                                                                     \
-    } while (0)
-            if (ring == 25682) {           // 8 waves, 256x256 tile, 64-wide chunks double-buffered (128 KB of LDS)
-                g.ntm = (g.M + 255) / 256; g.ntn = (g.Cout + 255) / 256;
-                hipLaunchKernelGGL((conv_gemm_glds_kernel<T, 256, 256, 2, 4, 8, 2, true>), dim3(g.ntm * g.ntn), dim3(512), 0, s,
-                                   x, w, y, z, g, ep);
-                return 0;
-            }
-            if (ring == 25612) {           // 8 waves, 256x128 tile (experiment)
-                g.ntm = (g.M + 255) / 256; g.ntn = (g.Cout + 127) / 128;
-                hipLaunchKernelGGL((conv_gemm_glds_kernel<T, 256, 128, 4, 2, 8, 2, true>), dim3(g.ntm * g.ntn), dim3(512), 0, s,
-                                   x, w, y, z, g, ep);
-                return 0;
-            }
-            switch (ring) {
-                case 12883: ET_RING(128, 8, 3);
-                case 12843: ET_RING(128, 4, 3);
-                case 12844: ET_RING(128, 4, 4);
-                case 25683: ET_RING(256, 8, 3);
+    if (p.kind == GEMM_GLDS) {
+        if constexpr (sizeof(T) == 2) {
+            if (p.WN == 4) { ET_GLDS(256, 256, 2, 4, 8, 2, true); return 0; }
+            if (p.WM == 4) { ET_GLDS(256, 128, 4, 2, 8, 2, true); return 0; }
+            switch (key) {
+                case 12812883: ET_GLDS(128, 128, 2, 2, 8, 3, true); return 0;
+                case 12806483: ET_GLDS(128, 64, 2, 2, 8, 3, true); return 0;
+                case 12812843: ET_GLDS(128, 128, 2, 2, 4, 3, true); return 0;
+                case 12806443: ET_GLDS(128, 64, 2, 2, 4, 3, true); return 0;
+                case 12812844: ET_GLDS(128, 128, 2, 2, 4, 4, true); return 0;
+                case 12806444: ET_GLDS(128, 64, 2, 2, 4, 4, true); return 0;
+                case 25612883: ET_GLDS(256, 128, 2, 2, 8, 3, true); return 0;
+                case 25606483: ET_GLDS(256, 64, 2, 2, 8, 3, true); return 0;
                 default: break;
             }
-#undef ET_RING
+        }
+        switch (p.BN * 100 + p.BKV * 10 + (p.utap ? 1 : 0)) {
+            case 12881: ET_GLDS(128, 128, 2, 2, 8, 2, true); return 0;
+            case 6481: ET_GLDS(128, 64, 2, 2, 8, 2, true); return 0;
+            case 12841: ET_GLDS(128, 128, 2, 2, 4, 2, true); return 0;
+            case 6441: ET_GLDS(128, 64, 2, 2, 4, 2, true); return 0;
+            case 12840: ET_GLDS(128, 128, 2, 2, 4, 2, false); return 0;
+            case 6440: ET_GLDS(128, 64, 2, 2, 4, 2, false); return 0;
+            default: return -2;
         }
     }
-    g.ntm = (g.M + 127) / 128;
-    const dim3 grid(g.ntm * g.ntn);
-#define ET_LAUNCH(BN_, WM_, WN_, BKV_, UT_)                                                                              \
-    do {                                                                                                                  \
-        if (glds) hipLaunchKernelGGL((conv_gemm_glds_kernel<T, 128, BN_, WM_, WN_, BKV_, 2, UT_>), grid, block, 0, s, x, w, y, z, g, ep); \
-        else hipLaunchKernelGGL((conv_gemm_kernel<T, 128, BN_, WM_, WN_, BKV_, UT_>), grid, block, 0, s, x, w, y, g, ep);  \
-    } while (0)
-    if (g.CV % 8 == 0) {
-        if (wide) ET_LAUNCH(128, 2, 2, 8, true); else ET_LAUNCH(64, 2, 2, 8, true);
-    } else if (g.CV % 4 == 0) {
-        if (wide) ET_LAUNCH(128, 2, 2, 4, true); else ET_LAUNCH(64, 2, 2, 4, true);
-    } else {
-        if (wide) ET_LAUNCH(128, 2, 2, 4, false); else ET_LAUNCH(64, 2, 2, 4, false);
+    switch (p.BN * 100 + p.BKV * 10 + (p.utap ? 1 : 0)) {
+        case 12881: ET_REG(128, 8, true); return 0;
+        case 6481: ET_REG(64, 8, true); return 0;
+        case 12841: ET_REG(128, 4, true); return 0;
+        case 6441: ET_REG(64, 4, true); return 0;
+        case 12840: ET_REG(128, 4, false); return 0;
+        case 6440: ET_REG(64, 4, false); return 0;
+        default: return -2;
     }
-#undef ET_LAUNCH
-    return 0;
+#undef ET_GLDS
+#undef ET_REG
 }
 
 extern "C" int et_conv2d_stats_rows(int N, int OH, int OW) { return (N * OH * OW + 127) / 128; }
@@ -1291,32 +1545,49 @@ extern "C" int et_conv2d_dgrad(const void* dy, const void* wT, void* dx, int dty
     return 0;
 }
 
+struct WgradPlan { bool tr; int bm, bn; };
+static WgradPlan plan_wgrad(const WgradGeom& g, int elem_bytes, bool have_zero_page) {
+    const bool wideN = g.NC > 64;
+    const bool tallM = g.Cout > 64;            // Cout <= 64 layers: a 64-row tile wastes no MFMA rows
+    WgradPlan p{false, tallM ? 128 : 64, wideN ? 128 : 64};
+    // bf16 + zero page: LDS-DMA staging with transposing LDS reads (ET_WGRAD_TR=0 forces the register path)
+    static const int use_tr = env_int("ET_WGRAD_TR", 1);
+    p.tr = elem_bytes == 2 && use_tr && have_zero_page;
+    // 256-wide tiles (8 waves, one workgroup per CU): half the L2->LDS bytes per flop of the 128^2 tile.
+    // ET_WGRAD_BIG: 0 = never, 1 = where the layer has the rows/columns (tuning knob)
+    static const int big = env_int("ET_WGRAD_BIG", 1);
+    if (p.tr && big) {
+        // measured (B=64 YOLOv5l shapes): the 256^2 tile wins on the 3x3 layers with >= 256 output channels
+        // (691-765 TFLOP/s vs ~600), 128x256 on the 128-channel stride-1 3x3 layers; 1x1 layers keep 128^2
+        if (g.T > 1 && g.Cout >= 256 && g.NC >= 256) { p.bm = 256; p.bn = 256; }
+        else if (g.T > 1 && g.isy == 1 && g.NC >= 256 && g.Cout == 128 && (big & 1)) p.bn = 256;
+        if (big & 2) { if (g.NC >= 256) p.bn = 256; if (g.Cout >= 256) p.bm = 256; }   // experiment: always
+    }
+    return p;
+}
+static void wgrad_plan_name(const WgradPlan& p, int elem_bytes, char* buf, int n) {
+    if (p.tr) {
+        const int wm = p.bm == 256 ? (p.bn == 256 ? 2 : 4) : (p.bm == 128 ? 2 : (p.bn == 256 ? 1 : 2));
+        const int wn = p.bm == 256 ? (p.bn == 256 ? 4 : (p.bn == 128 ? 2 : 1)) : (p.bn == 256 ? 4 : 2);
+        snprintf(buf, n, "conv_wgrad_tr_kernel<%d, %d, %d, %d>", p.bm, p.bn, wm, wn);
+    } else {
+        snprintf(buf, n, "conv_wgrad_kernel<%s, %d, %d>", elem_bytes == 2 ? "unsigned short" : "float", p.bm > 64 ? 128 : 64, p.bn > 64 ? 128 : 64);
+    }
+}
+
 template <typename T>
 static void launch_wgrad(const WgradGroup& grp, const void* zero16, WgradGeom& g, hipStream_t s) {
     constexpr int VEC = et_elem<T>::VEC;
     constexpr int BKP = 8 * VEC;
-    const bool wideN = g.NC > 64;
-    const bool tallM = g.Cout > 64;            // Cout <= 64 layers: a 64-row tile wastes no MFMA rows
-    int bn = wideN ? 128 : 64, bm = tallM ? 128 : 64;
-    // bf16 + zero page: LDS-DMA staging with transposing LDS reads (ET_WGRAD_TR=0 forces the register path)
-    static const int use_tr = getenv("ET_WGRAD_TR") ? atoi(getenv("ET_WGRAD_TR")) : 1;
-    const bool tr = sizeof(T) == 2 && use_tr && zero16;
-    // 256-wide tiles (8 waves, one workgroup per CU): half the L2->LDS bytes per flop of the 128^2 tile.
-    // ET_WGRAD_BIG: 0 = never, 1 = where the layer has the rows/columns (tuning knob)
-    static const int big = getenv("ET_WGRAD_BIG") ? atoi(getenv("ET_WGRAD_BIG")) : 1;
-    if (tr && big) {
-        // measured (B=64 YOLOv5l shapes): the 256^2 tile wins on the 3x3 layers with >= 256 output channels
-        // (691-765 TFLOP/s vs ~600), 128x256 on the 128-channel stride-1 3x3 layers; 1x1 layers keep 128^2
-        if (g.T > 1 && g.Cout >= 256 && g.NC >= 256) { bm = 256; bn = 256; }
-        else if (g.T > 1 && g.isy == 1 && g.NC >= 256 && g.Cout == 128 && (big & 1)) bn = 256;
-        if (big & 2) { if (g.NC >= 256) bn = 256; if (g.Cout >= 256) bm = 256; }   // experiment: always
-    }
+    const WgradPlan wp = plan_wgrad(g, (int)sizeof(T), zero16 != nullptr);
+    const bool tr = wp.tr, wideN = g.NC > 64, tallM = g.Cout > 64;
+    const int bm = wp.bm, bn = wp.bn;
     const int tiles = grp.n * ((g.NC + bn - 1) / bn) * ((g.Cout + bm - 1) / bm);   // the whole group shares the split
     // Split K so that the grid is a whole number of residency rounds: `slots` workgroups of this tile fit on
     // a CU (LDS- or register-limited), so up to slots*CUs run at once and a grid a little OVER a multiple of
     // that costs a whole extra round (e.g. 36 tiles x 29 splits = 1044 workgroups on 1024 slots).  Fewer
     // splits also mean fewer fp32 atomics on dW.  ET_WGRAD_BLOCKS overrides the target (tuning knob).
-    static const int n_cu = [] { hipDeviceProp_t p; int d = 0; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; }();
+    const int n_cu = device_cus();
     const int lds_kb = tr ? (bm + bn) / 4 : 64;                // 2 stages x 64 pixels x (bm+bn) channels x 2 B
     int slots = tr ? max(1, min(160 / lds_kb, bm * bn <= 64 * 64 ? 5 : (bm * bn <= 128 * 64 ? 3 : 2))) : 2;
     // measured: ONE full round of co-resident workgroups with >= ~25 chunks (1600 pixels) each beats two
@@ -1453,5 +1724,61 @@ extern "C" int et_colsum(const void* x, int dtype, int P, int C, int ld, float* 
     else if (dtype == ET_BF16) hipLaunchKernelGGL((colsum_kernel<uint16_t>), grid, block, 0, (hipStream_t)stream, (const uint16_t*)x, P, C, ld, rpb, out);
     else return -2;
     ET_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---- introspection (tests, bench.py) -----------------------------------------------------------------------
+extern "C" int et_conv2d_kernel_name(int op, int dtype, int N, int IH, int IW, int Cin, int Cout, int KH, int KW, int stride,
+                                     int pad, int have_zero_page, int parity_class, char* buf, int buflen) {
+    // op 0 = forward, 1 = dgrad (stride 2: parity_class 0..3 selects one of its four launches), 2 = wgrad.
+    // Arguments as for et_conv2d_fwd (Cin/Cout of the FORWARD conv).  Writes the name of the kernel instantiation the
+    // corresponding entry point launches, spelled as rocprofv3 prints it.  Host only; launches nothing.
+    if (!buf || buflen < 8) return -1;
+    if (KH * KW > CONV_MAX_TAPS || stride < 1 || N <= 0) return -2;
+    const int eb = dtype == ET_F32 ? 4 : 2, vec = dtype == ET_F32 ? 4 : 8;
+    const int OH = (IH + 2 * pad - KH) / stride + 1, OW = (IW + 2 * pad - KW) / stride + 1;
+    if (op == 2) {
+        WgradGeom g;
+        g.Cout = Cout; g.T = KH * KW; g.NC = g.T * Cin; g.isy = g.isx = stride;
+        wgrad_plan_name(plan_wgrad(g, eb, have_zero_page != 0), eb, buf, buflen);
+        return 0;
+    }
+    GatherGeom g;
+    if (op == 0) {
+        g.T = g.TT = KH * KW;
+        if (Cin % vec) return -2;
+        g.Cin = Cin; g.Cout = Cout; g.CV = Cin / vec; g.KV = g.T * g.CV; g.M = N * OH * OW;
+    } else if (op == 1) {
+        if (stride > 2 || Cout % vec) return -2;
+        const int py = parity_class / stride, px = parity_class % stride;
+        if (py >= stride) return -2;
+        int t = 0;
+        for (int ky = 0; ky < KH; ++ky) {
+            if ((py + pad - ky) % stride) continue;
+            for (int kx = 0; kx < KW; ++kx) if (!((px + pad - kx) % stride)) ++t;
+        }
+        g.T = t; g.TT = KH * KW;
+        const int QH = (IH - py + stride - 1) / stride, QW = (IW - px + stride - 1) / stride;
+        g.Cin = Cout; g.Cout = Cin; g.CV = Cout / vec; g.KV = g.T * g.CV; g.M = N * QH * QW;
+    } else return -2;
+    plan_name(plan_gemm(g, eb, have_zero_page != 0), eb, buf, buflen);
+    return 0;
+}
+
+extern "C" int et_env_knobs(char* buf, int buflen) {
+    // every ET_* tuning knob that is SET in this process's environment, as "NAME=value;..." (bench.py records it)
+    static const char* names[] = {"ET_CONV_TAP_INNER", "ET_CONV_XCD", "ET_CONV_NARROW_K", "ET_CONV_NFAST", "ET_CONV_GLDS",
+                                  "ET_CONV_RING", "ET_CONV_BIG", "ET_CONV_PP", "ET_WGRAD_TR", "ET_WGRAD_BIG", "ET_WGRAD_BLOCKS",
+                                  "ET_WGRAD_XCD", "ET_EW_VPT", "ET_WGRAD_GROUP", "ET_WGRAD_STALE", "ET_HIP_LIB"};
+    if (!buf || buflen < 1) return -1;
+    int off = 0;
+    buf[0] = 0;
+    for (const char* n : names) {
+        const char* v = getenv(n);
+        if (!v) continue;
+        const int w = snprintf(buf + off, buflen - off, "%s=%s;", n, v);
+        if (w < 0 || w >= buflen - off) return -3;
+        off += w;
+    }
     return 0;
 }

@@ -36,33 +36,25 @@ class KernelTimer:
 TIMER = None
 
 
-def _gemm_tag(x_dtype, cout, cin_padded, taps, mixed=False, M=0, full_taps=None):
-    """Name of the kernel instantiation csrc/conv.hip:launch_gemm picks for this GEMM, spelled the way
-    rocprofv3 prints it, so that bench.py's HIP-event timing can be checked against the rocprof summary."""
-    import os
-    vec = 4 if x_dtype == torch.float32 else 8
-    cv = cin_padded // vec
-    bkv = 8 if cv % 8 == 0 else 4
-    ut = "true" if cv % 4 == 0 else "false"
-    t = "float" if x_dtype == torch.float32 else "unsigned short"
-    narrow_k = int(os.environ.get("ET_CONV_NARROW_K", "256"))
-    k_elems = taps * cin_padded
-    wide = cout > 64 and not (narrow_k > 0 and k_elems <= narrow_k)
-    glds = int(os.environ.get("ET_CONV_GLDS", "1"))
-    if mixed:   # stride-2 dgrad: 4 parity-class launches whose tap counts (hence tiles) differ
-        return f"conv_gemm{'_glds' if glds else ''}_kernel<{t}, ...> (stride-2 dgrad parity classes)"
-    bn = 128 if wide else 64
-    if not glds:
-        return f"conv_gemm_kernel<{t}, 128, {bn}, 2, 2, {bkv}, {ut}>"
-    bf16 = x_dtype != torch.float32
-    if bf16 and cv % 8 == 0 and cout >= 256 and int(os.environ.get("ET_CONV_BIG", "1")) and not os.environ.get("ET_CONV_RING"):
-        n_cu = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count if torch.cuda.is_available() else 256
-        blocks = ((M + 255) // 256) * ((cout + 255) // 256)
-        fills = blocks > 0 and (-(-blocks // n_cu)) / (blocks / n_cu) <= 1.35
-        if (full_taps or taps) > 1 or (k_elems >= 512 and fills):
-            return f"conv_gemm_glds_kernel<{t}, 256, 256, 2, 4, 8, 2, true>"
-    ring = (4, 3) if (bf16 and cv % 8 == 0 and k_elems <= 256) else (bkv, 2)
-    return f"conv_gemm_glds_kernel<{t}, 128, {bn}, 2, 2, {ring[0]}, {ring[1]}, {ut}>"
+def kernel_name(op, dtype, N, IH, IW, Cin, Cout, k, stride, pad, parity_class=0, zero_page=True):
+    """Name of the kernel instantiation the library launches for this conv problem (op: 'fwd' | 'dgrad' | 'wgrad';
+    arguments of the FORWARD conv), as rocprofv3 prints it.  The selection lives in csrc/conv.hip only
+    (et_conv2d_kernel_name); tests assert on it and bench.py tags its HIP-event timings with it."""
+    import ctypes
+    buf = ctypes.create_string_buffer(256)
+    code = {"fwd": 0, "dgrad": 1, "wgrad": 2}[op]
+    dt = ET_F32 if dtype == torch.float32 else ET_BF16
+    _lib.check(_lib.load().et_conv2d_kernel_name(code, dt, N, IH, IW, Cin, Cout, k, k, stride, pad, int(bool(zero_page)),
+                                                 parity_class, buf, 256), "et_conv2d_kernel_name")
+    return buf.value.decode()
+
+
+def env_knobs():
+    """The ET_* tuning knobs set in this process ("" = all defaults); recorded in bench.py's JSON line."""
+    import ctypes
+    buf = ctypes.create_string_buffer(1024)
+    _lib.check(_lib.load().et_env_knobs(buf, 1024), "et_env_knobs")
+    return buf.value.decode()
 
 
 _ZERO_PAGES = {}
@@ -126,7 +118,7 @@ def conv2d_fwd(x, w, stride, pad, *, scale=None, bias=None, act=ACT_NONE, residu
         rows = lib.et_conv2d_stats_rows(N, OH, OW)
         stats = torch.empty((rows, 2, Cout), dtype=torch.float32, device=x.device)
     ldr = _nhwc(residual) if residual is not None else 0
-    ev = TIMER.span(_gemm_tag(x.dtype, Cout, Cin, KH * KW, M=N * OH * OW), 2.0 * N * OH * OW * Cout * Cin * KH * KW,
+    ev = TIMER.span(kernel_name("fwd", x.dtype, N, IH, IW, Cin, Cout, KH, stride, pad), 2.0 * N * OH * OW * Cout * Cin * KH * KW,
                     nbytes=(x.numel() + N * OH * OW * Cout + w.numel()) * x.element_size()) if TIMER else None
     if ev:
         ev[0].record()
@@ -210,7 +202,7 @@ def conv2d_wgrad_grouped(items, ksize, stride, pad):
         assert dw.dtype == torch.float32 and dw.is_contiguous() and dw.shape == (Cout, ksize, ksize, Cin)
         arr[i].x, arr[i].dy, arr[i].dw = _lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw)
         arr[i].ldx, arr[i].ldy = _nhwc(x), _nhwc(dy)
-    ev = TIMER.span("conv_wgrad_tr_kernel" if x0.dtype == torch.bfloat16 else "conv_wgrad_kernel",
+    ev = TIMER.span(kernel_name("wgrad", x0.dtype, N, IH, IW, Cin, Cout, ksize, stride, pad),
                     2.0 * len(items) * N * OH * OW * Cout * Cin * ksize * ksize) if TIMER else None
     if ev:
         ev[0].record()
@@ -247,7 +239,9 @@ def conv2d_dgrad(dy, wT, in_hw, stride, pad, *, out=None, accumulate=False, resi
     if out is None:
         assert not accumulate
         out = torch.empty((N, IH, IW, Cin), dtype=dy.dtype, device=dy.device)
-    ev = TIMER.span(_gemm_tag(dy.dtype, Cin, Cout, KH * KW, mixed=stride > 1, M=N * IH * IW), 2.0 * N * OH * OW * Cout * Cin * KH * KW,
+    tag = (kernel_name("dgrad", dy.dtype, N, IH, IW, Cin, Cout, KH, stride, pad) if stride == 1 else
+           "conv_gemm (stride-2 dgrad parity classes)") if TIMER else None
+    ev = TIMER.span(tag, 2.0 * N * OH * OW * Cout * Cin * KH * KW,
                     stride * stride, nbytes=(dy.numel() + N * IH * IW * Cin + wT.numel()) * dy.element_size()) if TIMER else None
     if ev:
         ev[0].record()
@@ -266,7 +260,7 @@ def conv2d_wgrad(x, dy, dw, ksize, stride, pad):
     _, OH, OW, Cout = dy.shape
     assert dw.dtype == torch.float32 and dw.is_contiguous() and dw.shape == (Cout, ksize, ksize, Cin)
     assert x.dtype == dy.dtype
-    ev = TIMER.span("conv_wgrad_tr_kernel" if x.dtype == torch.bfloat16 else "conv_wgrad_kernel", 2.0 * N * OH * OW * Cout * Cin * ksize * ksize) if TIMER else None
+    ev = TIMER.span(kernel_name("wgrad", x.dtype, N, IH, IW, Cin, Cout, ksize, stride, pad), 2.0 * N * OH * OW * Cout * Cin * ksize * ksize) if TIMER else None
     if ev:
         ev[0].record()
     _lib.check(_lib.load().et_conv2d_wgrad(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), et_dtype(x), N, IH, IW, Cin,

@@ -118,6 +118,15 @@ int et_conv2d_wgrad_grouped(const et_wgrad_item* items /* host array */, int n_i
                             int Cin, int Cout, int KH, int KW, int stride, int pad, const void* zero16,
                             et_stream_t stream);
 int et_weight_transpose(const void* w, void* wT, int dtype, int Cout, int taps, int Cin, et_stream_t stream);
+/* Introspection (host only, launches nothing): the kernel instantiation et_conv2d_fwd (op 0), et_conv2d_dgrad
+ * (op 1; for stride 2 `parity_class` 0..3 selects one of its four launches) or et_conv2d_wgrad (op 2) would launch
+ * for this problem -- arguments as for et_conv2d_fwd -- spelled the way rocprofv3 prints it.  The tile selection
+ * depends on the shape, the dtype, the CU count of the current device and the ET_* tuning knobs; tests assert on
+ * this name and bench.py tags its HIP-event timings with it, so there is ONE copy of the selection logic.
+ * et_env_knobs: every ET_* tuning knob set in the environment, "NAME=value;..." ("" = all defaults). */
+int et_conv2d_kernel_name(int op, int dtype, int N, int IH, int IW, int Cin, int Cout, int KH, int KW, int stride,
+                          int pad, int have_zero_page, int parity_class, char* buf /*host out*/, int buflen);
+int et_env_knobs(char* buf /*host out*/, int buflen);
 /* every layer of a flat weight arena at once: table = n_layers x {element offset, Cout, taps, Cin} (int32, device,
  * sorted by offset); wT_arena has the arena's layout with each layer stored (Cin, taps, Cout). */
 int et_weight_transpose_all(const void* w_arena, void* wT_arena, int dtype, const int* table, int n_layers,

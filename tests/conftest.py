@@ -50,6 +50,22 @@ class _Mode:
         return x.to(self.device)
 
 
+@pytest.fixture
+def emu(emu_lib_path):
+    """Emulator only, with its race-exposing modes (tests/simt_emu/include/hip/hip_runtime.h): ``configure(dma_late, seed)``
+    -- LDS-DMA landing at the LATEST legal moment (the s_waitcnt that retires it) instead of the earliest, and waves
+    scheduled one at a time in a seeded random order between workgroup barriers."""
+    import ctypes
+    from efficientteacher_amd import _lib
+    _lib._use_library_for_tests(emu_lib_path, emulated=True)
+    dll = ctypes.CDLL(emu_lib_path)
+    m = _Mode("cpu", True)
+    m.configure = lambda dma_late, seed: dll.emu_configure(int(dma_late), int(seed))
+    yield m
+    dll.emu_configure(0, -1)
+    _lib._use_library_for_tests(None, False)
+
+
 @pytest.fixture(params=["emu", pytest.param("gpu", marks=pytest.mark.gpu)])
 def hip(request):
     """Run the test body once on the emulator (CPU) and once on the GPU (marked gpu)."""

@@ -1,5 +1,6 @@
 // SIMT emulator runtime -- TEST INFRASTRUCTURE ONLY.  See include/hip/hip_runtime.h.
 #include <hip/hip_runtime.h>
+#include <cstring>
 
 namespace emu {
 
@@ -28,6 +29,19 @@ emu_switch:
 static Block g_blk;
 Block& blk() { return g_blk; }
 
+// ET_EMU_DMA=late: LDS-DMA lands at the s_waitcnt that retires it (see hip_runtime.h)
+// ET_EMU_SCHED=wave[:seed]: between two workgroup barriers the waves run ONE AT A TIME, in a random order that
+// changes every interval -- the adversarial schedule for cross-wave LDS hazards (default: round-robin, all waves
+// advance together, which hides a missing barrier).  Both can also be set at run time: emu_configure().
+static int g_dma_late = [] { const char* e = getenv("ET_EMU_DMA"); return (e && !strcmp(e, "late")) ? 1 : 0; }();
+static int g_sched_seed = [] {
+    const char* e = getenv("ET_EMU_SCHED");
+    if (!e || strncmp(e, "wave", 4)) return -1;
+    return e[4] == ':' ? atoi(e + 5) & 0x7fffffff : 1;
+}();
+bool dma_late() { return g_dma_late != 0; }
+static int sched_seed() { return g_sched_seed; }
+
 static constexpr size_t STACK = 256 * 1024;
 static std::vector<char*> g_stacks;
 
@@ -40,6 +54,8 @@ static void trampoline() {
     Block& b = g_blk;
     b.body();
     Fiber* f = b.cur;
+    for (auto& d : b.dmaq[f->lin]) memcpy(d.dst, d.data, d.size);   // s_endpgm waits for outstanding memory operations
+    b.dmaq[f->lin].clear();
     f->st = DONE;
     b.alive--;
     Wave& w = b.waves[f->wave];
@@ -73,6 +89,7 @@ void run_grid(dim3 grid, dim3 block, std::function<void()> body) {
         b.bid = {bx, by, bz};
         b.fibers.assign(nt, Fiber{});
         b.waves.assign((nt + 63) / 64, Wave{});
+        b.dmaq.assign(nt, {});
         b.alive = nt;
         b.arrived_block = 0;
         for (int t = 0; t < nt; ++t) {
@@ -87,8 +104,32 @@ void run_grid(dim3 grid, dim3 block, std::function<void()> body) {
             for (int i = 0; i < 6; ++i) *--sp = nullptr;
             f.sp = sp;
         }
+        const int seed = sched_seed();
+        const int nw = (nt + 63) / 64;
+        std::vector<int> order(nw);
+        for (int i = 0; i < nw; ++i) order[i] = i;
+        unsigned rng = 0x9e3779b9u * (unsigned)(seed + 1) + bx * 7919u + by * 104729u;
         while (b.alive > 0) {
             bool progressed = false;
+            if (seed >= 0) {
+                for (int i = nw - 1; i > 0; --i) {           // new random wave order for this interval
+                    rng = rng * 1664525u + 1013904223u;
+                    std::swap(order[i], order[(rng >> 8) % (unsigned)(i + 1)]);
+                }
+                for (int wi = 0; wi < nw; ++wi) {
+                    const int w0 = order[wi] * 64, w1 = std::min(nt, w0 + 64);
+                    for (bool again = true; again;) {        // this wave alone, until it blocks on the workgroup
+                        again = false;
+                        for (int t = w0; t < w1; ++t) {
+                            Fiber& f = b.fibers[t];
+                            if (f.st != RUN) continue;
+                            again = progressed = true;
+                            b.cur = &f;
+                            emu_switch(&b.sched_sp, f.sp);
+                        }
+                    }
+                }
+            } else
             for (int t = 0; t < nt; ++t) {
                 Fiber& f = b.fibers[t];
                 if (f.st != RUN) continue;
@@ -105,3 +146,9 @@ void run_grid(dim3 grid, dim3 block, std::function<void()> body) {
 }
 
 }  // namespace emu
+
+// test hook: dma_late 0/1, sched_seed < 0 = round-robin, >= 0 = one wave at a time in a seeded random order
+extern "C" void emu_configure(int dma_late, int sched_seed) {
+    emu::g_dma_late = dma_late;
+    emu::g_sched_seed = sched_seed;
+}

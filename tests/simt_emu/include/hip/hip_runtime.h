@@ -82,9 +82,16 @@ struct Wave {
     alignas(16) unsigned char buf2[64][64];
 };
 
+// LDS-DMA (global_load_lds) in flight: hardware lands the bytes some time between the issue and the s_waitcnt
+// vmcnt(N) that retires it.  ET_EMU_DMA=late defers every landing to that wait (the LATEST legal moment: a
+// reader that did not wait + barrier sees stale LDS), the default lands at issue (the EARLIEST legal moment:
+// a writer that did not let every reader finish clobbers live data).  Tests run both.
+struct PendingDma { void* dst; unsigned size; unsigned char data[16]; };
+
 struct Block {
     std::vector<Fiber> fibers;
     std::vector<Wave> waves;
+    std::vector<std::vector<PendingDma>> dmaq;   // per fiber, oldest first
     int alive, arrived_block;
     uint3_emu bid;
     dim3 bdim, gdim;
@@ -146,7 +153,20 @@ template <typename T> static inline T xlane(T v, int src) {
 #define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) \
     emu::run_grid((grid), (block), [=]() { kern(__VA_ARGS__); })
 
-static inline void __syncthreads() { emu::block_sync(); }
+namespace emu {
+bool dma_late();
+static inline void dma_retire(int keep) {      // land the oldest entries until at most `keep` remain in flight
+    Block& b = blk();
+    auto& q = b.dmaq[b.cur->lin];
+    if ((int)q.size() <= keep) return;
+    const size_t n = q.size() - (size_t)keep;
+    for (size_t i = 0; i < n; ++i) memcpy(q[i].dst, q[i].data, q[i].size);
+    q.erase(q.begin(), q.begin() + n);
+}
+}  // namespace emu
+// __syncthreads() = fence + s_barrier: with an LDS-DMA in flight the fence is an s_waitcnt vmcnt(0)
+// (cdna_hip_programming.md, "Pipelining across barriers"); the bare s_barrier builtin waits for nothing
+static inline void __syncthreads() { emu::dma_retire(0); emu::block_sync(); }
 static inline void __builtin_amdgcn_s_barrier_emu() { emu::block_sync(); }
 #define __builtin_amdgcn_s_barrier __builtin_amdgcn_s_barrier_emu
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
@@ -238,10 +258,15 @@ using std::min;
 // where M0_base is the LDS pointer of the first live lane (the compiler readfirstlane's it).
 static inline void emu_global_load_lds(const void* g, void* l, unsigned size, int offset) {
     void* base = __builtin_amdgcn_readfirstlane_emu(l);
-    memcpy((char*)base + offset + (size_t)emu::cur().lane * size, g, size);
+    char* dst = (char*)base + offset + (size_t)emu::cur().lane * size;
+    if (!emu::dma_late() || size > 16) { memcpy(dst, g, size); return; }
+    emu::PendingDma d; d.dst = dst; d.size = size; memcpy(d.data, g, size);
+    emu::Block& b = emu::blk();
+    b.dmaq[b.cur->lin].push_back(d);
 }
 #define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) emu_global_load_lds((const void*)(g), (void*)(l), (size), (off))
-#define __builtin_amdgcn_s_waitcnt(x) ((void)0)
+// s_waitcnt immediate (gfx9): vmcnt = bits [3:0] | bits [15:14] << 4; only the LDS-DMA queue is modelled
+#define __builtin_amdgcn_s_waitcnt(x) emu::dma_retire((int)(((x) & 0xF) | ((((x) >> 14) & 3) << 4)))
 
 // ds_read_b64_tr_b16 (gfx950), semantics PROBED on hardware (tools/probe/probe_tr.py, profiles/r01_probe_tr.json):
 // every lane loads the 8 bytes (4 x 16-bit) at its own LDS address; inside each 16-lane group the

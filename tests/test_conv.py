@@ -141,3 +141,122 @@ def test_conv_wgrad_grouped(hip, dtype):
     for (_, _, dw), ref in zip(items, refs):
         err = (dw.cpu() - ref).abs().max().item()
         assert err <= 1e-4 * max(1.0, ref.abs().max().item()), err
+
+
+# ---- every kernel instantiation the YOLOv5l / YOLOv5s bench launches, selected on purpose ----------------------
+# (VERDICT r01 "parity gap": the bench-dominant tiles were never compared element-wise with anything.)  Each case
+# names the instantiation csrc/conv.hip must pick for it -- et_conv2d_kernel_name is the selection logic itself, not
+# a copy -- so a change of the tile policy that silently drops a kernel out of test coverage fails here.
+GLDS = "conv_gemm_glds_kernel<unsigned short, "
+SELECT = [
+    # N, H, W, Cin, Cout, k, s, p, fwd kernel, dgrad kernels (per parity class), wgrad kernel
+    ((2, 20, 20, 256, 256, 3, 1, 1), "conv_gemm_pp_kernel", ["conv_gemm_pp_kernel"], "conv_wgrad_tr_kernel<256, 256, 2, 4>"),
+    ((2, 20, 20, 128, 256, 3, 2, 1), "conv_gemm_pp_kernel",
+     [GLDS + "128, 64, 2, 2, 4, 3, true>", GLDS + "128, 128, 2, 2, 8, 2, true>", GLDS + "128, 128, 2, 2, 8, 2, true>",
+      GLDS + "128, 128, 2, 2, 8, 2, true>"], "conv_wgrad_tr_kernel<256, 256, 2, 4>"),
+    ((2, 20, 20, 512, 512, 1, 1, 0), GLDS + "128, 128, 2, 2, 8, 2, true>", [GLDS + "128, 128, 2, 2, 8, 2, true>"],
+     "conv_wgrad_tr_kernel<128, 128, 2, 2>"),
+    ((1, 9, 11, 64, 40, 3, 1, 1), GLDS + "128, 64, 2, 2, 8, 2, true>", [GLDS + "128, 64, 2, 2, 4, 2, false>"],
+     "conv_wgrad_tr_kernel<64, 128, 2, 2>"),
+    ((2, 12, 12, 64, 128, 1, 1, 0), GLDS + "128, 64, 2, 2, 4, 3, true>", [GLDS + "128, 64, 2, 2, 4, 3, true>"],
+     "conv_wgrad_tr_kernel<128, 64, 2, 2>"),
+    ((2, 12, 12, 128, 128, 3, 1, 1), GLDS + "128, 128, 2, 2, 8, 2, true>", [GLDS + "128, 128, 2, 2, 8, 2, true>"],
+     "conv_wgrad_tr_kernel<128, 256, 2, 4>"),
+    ((2, 12, 12, 64, 64, 1, 1, 0), GLDS + "128, 64, 2, 2, 4, 3, true>", [GLDS + "128, 64, 2, 2, 4, 3, true>"],
+     "conv_wgrad_tr_kernel<64, 64, 2, 2>"),
+    ((1, 16, 16, 8, 32, 6, 2, 2), GLDS + "128, 64, 2, 2, 4, 2, false>", None, None),          # the stem (no dgrad in the net)
+    ((1, 5, 5, 64, 264, 3, 1, 1), "conv_gemm_pp_kernel", [GLDS + "128, 64, 2, 2, 4, 2, false>"],
+     "conv_wgrad_tr_kernel<256, 256, 2, 4>"),                                                  # ragged M and Cout on the 256^2 tiles
+    ((3, 14, 14, 192, 320, 3, 1, 1), "conv_gemm_pp_kernel", [GLDS + "128, 128, 2, 2, 8, 2, true>"], "conv_wgrad_tr_kernel<256, 256, 2, 4>"),
+]
+
+
+@pytest.mark.parametrize("case,kf,kd,kw", SELECT, ids=[str(c[0]) for c in SELECT])
+def test_bench_instantiations_elementwise(hip, case, kf, kd, kw):
+    """bf16 fwd (+ stats, scale/bias/SiLU/residual epilogue, output slice), dgrad (+ residual, accumulate) and wgrad of
+    the named instantiation, element-wise against F.conv2d (fp32) on the bf16-rounded operands."""
+    _check_instantiation(hip, case, kf, kd, kw)
+
+
+@pytest.mark.parametrize("dma_late,seed", [(1, 3), (0, 5), (1, 11), (0, 12)])
+def test_lds_dma_pipelines_under_adversarial_schedules(emu, dma_late, seed):
+    """The counted-vmcnt LDS-DMA pipelines (ping-pong 256x256 gather-GEMM, the 3-deep short-K ring, the wgrad double
+    buffer) under the emulator's race-exposing modes: DMA landing as late / as early as the hardware may, waves run
+    one at a time in random order between barriers.  A wait that is one half-tile too weak, or a half-tile staged
+    into a buffer that is still being read, fails here (checked by mutation when the kernel was written)."""
+    emu.configure(dma_late, seed)
+    for case, kf, kd, kw in (SELECT[0], SELECT[4], SELECT[8]):
+        _check_instantiation(emu, case, kf, kd, kw)
+
+
+def _check_instantiation(hip, case, kf, kd, kw):
+    from efficientteacher_amd import ops
+    N, H, W, Cin, Cout, k, s, p = case
+    dt = torch.bfloat16
+    assert ops.kernel_name("fwd", dt, N, H, W, Cin, Cout, k, s, p) == kf
+    x = _mk(hip, (N, H, W, Cin), dt, 41)
+    w = (_mk(hip, (Cout, k, k, Cin), dt, 42) * (1.0 / (k * k * Cin) ** 0.5)).to(dt)
+    OH, OW = ops.conv_out_hw(H, W, k, s, p)
+    ref = _ref_conv(x, w, s, p)
+    y, stats = ops.conv2d_fwd(x, w, s, p, want_stats=True)
+    scale_ref = max(1.0, ref.abs().max().item())
+    assert (y.float().cpu() - ref).abs().max().item() <= 2e-2 * scale_ref
+    flat = ref.reshape(-1, Cout)
+    st = stats.sum(0).cpu()
+    assert torch.allclose(st[0], flat.sum(0), rtol=1e-3, atol=2e-2 * flat.shape[0] ** 0.5 * 4)
+    assert torch.allclose(st[1], (flat ** 2).sum(0), rtol=2e-2, atol=1e-3)
+    # teacher-style epilogue: folded BN scale/bias + SiLU + residual, written into a channel slice of a wider buffer
+    sc = _mk(hip, (Cout,), torch.float32, 43).abs() + 0.5
+    bi = _mk(hip, (Cout,), torch.float32, 44)
+    res = _mk(hip, (N, OH, OW, Cout), dt, 45)
+    wide = torch.zeros((N, OH, OW, Cout + 16), dtype=dt, device=hip.device)
+    ops.conv2d_fwd(x, w, s, p, scale=sc, bias=bi, act=ops.ACT_SILU, residual=res, out=wide[..., 8:8 + Cout])
+    ref2 = F.silu(ref * sc.cpu() + bi.cpu()) + res.float().cpu()
+    assert (wide[..., 8:8 + Cout].float().cpu() - ref2).abs().max().item() <= 3e-2 * max(1.0, ref2.abs().max().item())
+    assert (wide[..., :8] == 0).all() and (wide[..., 8 + Cout:] == 0).all()
+    if kd is None:
+        return
+    # dgrad (the operand roles swap: K = taps * Cout)
+    names = [ops.kernel_name("dgrad", dt, N, H, W, Cin, Cout, k, s, p, parity_class=c) for c in range(s * s)]
+    assert names == kd, names
+    dy = _mk(hip, (N, OH, OW, Cout), dt, 46)
+    w2 = (_mk(hip, (Cout, k, k, Cin), dt, 47) * (1.0 / (k * k * Cout) ** 0.5)).to(dt)
+    wT = ops.weight_transpose(w2)
+    xr = torch.zeros((N, Cin, H, W), requires_grad=True)
+    F.conv2d(xr, w2.float().cpu().permute(0, 3, 1, 2), stride=s, padding=p).backward(dy.float().cpu().permute(0, 3, 1, 2))
+    dref = xr.grad.permute(0, 2, 3, 1)
+    dx = ops.conv2d_dgrad(dy, wT, (H, W), s, p)
+    tol = 2e-2 * max(1.0, dref.abs().max().item())
+    assert (dx.float().cpu() - dref).abs().max().item() <= tol
+    if s == 1:      # the Bottleneck shortcut-gradient form: dx = dgrad + residual
+        r2 = _mk(hip, (N, H, W, Cin), dt, 48)
+        dx2 = ops.conv2d_dgrad(dy, wT, (H, W), s, p, residual=r2)
+        assert (dx2.float().cpu() - (dref + r2.float().cpu())).abs().max().item() <= tol + 2e-2 * r2.float().abs().max().item()
+    # wgrad
+    assert ops.kernel_name("wgrad", dt, N, H, W, Cin, Cout, k, s, p) == kw
+    dw = torch.zeros((Cout, k, k, Cin), dtype=torch.float32, device=hip.device)
+    ops.conv2d_wgrad(x, dy, dw, k, s, p)
+    wr = torch.zeros((Cout, Cin, k, k), requires_grad=True)
+    F.conv2d(x.float().cpu().permute(0, 3, 1, 2), wr, stride=s, padding=p).backward(dy.float().cpu().permute(0, 3, 1, 2))
+    wref = wr.grad.permute(0, 2, 3, 1)
+    assert (dw.cpu() - wref).abs().max().item() <= 1e-4 * max(1.0, wref.abs().max().item())
+
+
+def test_wgrad_grouped_eight_layers_256_tile(hip):
+    """the bench's grouped launch: 8 same-shaped 3x3 layers share one K-split on the 256x256 wgrad tile"""
+    from efficientteacher_amd import ops
+    N, H, W, C, k = 1, 10, 10, 256, 3
+    dt = torch.bfloat16
+    assert ops.kernel_name("wgrad", dt, N, H, W, C, C, k, 1, 1) == "conv_wgrad_tr_kernel<256, 256, 2, 4>"
+    items, refs = [], []
+    for i in range(8):
+        x = _mk(hip, (N, H, W, C), dt, 60 + i)
+        dy = _mk(hip, (N, H, W, C), dt, 70 + i)
+        dw = torch.zeros((C, k, k, C), dtype=torch.float32, device=hip.device)
+        items.append((x, dy, dw))
+        wr = torch.zeros((C, C, k, k), requires_grad=True)
+        F.conv2d(x.float().cpu().permute(0, 3, 1, 2), wr, padding=1).backward(dy.float().cpu().permute(0, 3, 1, 2))
+        refs.append(wr.grad.permute(0, 2, 3, 1))
+    ops.conv2d_wgrad_grouped(items, k, 1, 1)
+    for (_, _, dw), ref in zip(items, refs):
+        assert (dw.cpu() - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item())
