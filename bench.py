@@ -71,45 +71,69 @@ def build_trainer(device, rank, world, local_rank, per_rank):
     return cfg, SSODTrainer(cfg, device, None, local_rank if world > 1 else -1, rank if world > 1 else -1, world, nb=1000)
 
 
-def cpu_baseline(cfg, seconds=25.0):
-    """Plain-torch CPU port of the same step on a bounded sample (1 labeled + 1 unlabeled image)."""
+def cpu_baseline(cfg, device, seconds=25.0):
+    """The oracle (oracle/step.py: plain-torch CPU restatement of trainer/ssod_trainer.py:587-680, `kind: "port"`) timed on
+    the host cores for a bounded number of 1 + 1 image steps -- and, on the way, the PARITY CHECK of the benchmarked
+    configuration: the very first oracle step and one bf16 step of the HIP trainer start from the same weights and see
+    the same two images / targets / M_s / injected teacher scores, and their loss terms, pseudo-label sets and NMS
+    decisions are compared (what tests/test_step_fullsize.py asserts, reported here next to the throughput)."""
     import copy
-    from oracle import losses as o_loss, model as o_model, nms as o_nms, optim as o_opt, pseudo_label as o_pl
+    from efficientteacher_amd.trainer import SSODTrainer
+    from efficientteacher_amd.utils.general import nms_ssod_padded
+    from oracle import model as o_model, nms as o_nms, step as o_step
     # 32 threads: beyond that the many small layers of a 2-image batch only add oversubscription
     # (measured on the 256-core MI355X host: 256 threads are ~100x slower than 8)
     cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     rng = np.random.default_rng(0)
-    S, Bl, Bu = 640, 1, 1
+    S, Bl, Bu = cfg.Dataset.img_size, 1, 1
+    c2 = cfg.clone(); c2.defrost(); c2.merge_from_list(["Dataset.batch_size", Bl + Bu]); c2.freeze()
     torch.manual_seed(0)
-    student = o_model.Model.from_cfg(cfg).train()
+    tr = SSODTrainer(c2, device, None, -1, -1, 1, nb=1000)
+    student = o_model.Model.from_cfg(cfg)
+    student.load_state_dict({k: v.detach().cpu() for k, v in tr.model.state_dict().items()}, strict=True)
+    student.train()
     teacher = copy.deepcopy(student).eval()
     imgs, targets, u_str, u_ori, M_s = make_batch(rng, Bl, Bu, S, "cpu")
     synth = torch.rand(Bu, 25200, 81) ** torch.cat((torch.full((1,), 16.0), torch.full((80,), 4.0)))
     opt = torch.optim.SGD(student.parameters(), lr=0.01, momentum=0.937, nesterov=True)
-    kw = dict(nc=80, box_w=0.05, obj_w=0.7, cls_w=0.3)
 
     def step():
-        with torch.no_grad():
-            (tp, _), _ = teacher(u_ori)
-            tp[..., 4:] = synth
-        dets, _ = o_nms.non_max_suppression_ssod(tp.numpy(), 0.1, 0.65)
-        t9, invalid = o_pl.create_pseudo_label(dets, M_s.numpy(), S, S)
-        pred, _ = student(torch.cat([imgs, u_str], 0))
-        sup = [p[:Bl] for p in pred]; uns = [p[Bl:] for p in pred]
-        loss, _ = o_loss.compute_loss(sup, targets, student.head.anchors, **kw)
-        if not invalid:
-            lu, _ = o_loss.compute_student_match_loss(uns, torch.from_numpy(t9[:60]), student.head.anchors, **kw)
-            loss = loss + 3.0 * lu
-        opt.zero_grad(); loss.backward(); opt.step()
+        opt.zero_grad()
+        r = o_step.ssod_step(student, teacher, imgs, targets, u_str, u_ori, M_s, cfg, synth_scores=synth)
+        opt.step()
         with torch.no_grad():
             for v, m in zip(teacher.state_dict().values(), student.state_dict().values()):
                 if v.dtype.is_floating_point:
                     v.mul_(0.9999).add_(m, alpha=1e-4)
+        return r
 
     t0 = time.time()
-    step()                                   # warm-up (allocator, oneDNN primitive caches)
+    ref = step()                             # warm-up (allocator, oneDNN primitive caches) == the parity reference
     warm = time.time() - t0
+    # ---- parity of the benchmarked configuration (bf16, YOLOv5l, 640 px) ------------------------------------
+    cap = {}
+
+    def hook(tp):
+        tp[..., 4:] = synth.to(device)
+        cap["tp"] = tp.detach().clone()
+        return tp
+    tr.teacher_pred_hook = hook
+    items = tr.train_instance(imgs.to(device), targets.to(device), None, u_str.to(device), u_ori.to(device), None,
+                              M_s.to(device), 2000)
+    want = {**{k: ref["sup_items"][k] for k in ("box", "obj", "cls")}, **ref["un_items"]}
+    loss_rel = {k: abs(float(items[k]) - v) / max(abs(v), 1e-12) for k, v in want.items()}
+    dets, counts, keep, _ = nms_ssod_padded(cap["tp"], cfg.SSOD.nms_conf_thres, cfg.SSOD.nms_iou_thres)
+    rd, rk = o_nms.non_max_suppression_ssod(cap["tp"].cpu().numpy(), cfg.SSOD.nms_conf_thres, cfg.SSOD.nms_iou_thres)
+    keep_ok = all(int(counts[i]) == rk[i].shape[0] and np.array_equal(keep[i, :int(counts[i])].cpu().numpy(), rk[i])
+                  for i in range(Bu))
+    parity = dict(against="oracle/step.py (fp32 CPU restatement of the reference step), same weights and inputs, 1+1 images",
+                  dtype="bf16", loss_rel_dev={k: round(v, 6) for k, v in loss_rel.items()}, max_loss_rel_dev=max(loss_rel.values()),
+                  nms_keep_indices_bit_exact=bool(keep_ok), n_pseudo_labels=[int(counts.sum()), int(sum(k.shape[0] for k in rk))],
+                  tolerance="loss terms 5e-2 (bf16 storage); NMS indices bit-exact on identical decoded inputs; fp32 mode "
+                            "1e-4: tests/test_step_fullsize.py")
+    del tr
+    torch.cuda.empty_cache()
     t0, n = time.time(), 0
     if warm < seconds:                       # bounded: ~`seconds` of timed CPU work, at least one step
         while n < 1 or (time.time() - t0 + warm < seconds and n < 8):
@@ -117,9 +141,24 @@ def cpu_baseline(cfg, seconds=25.0):
         dt = (time.time() - t0) / n
     else:
         n, dt = 1, warm
-    return dict(value=(Bl + Bu) / dt, unit="images/s", cores=cores, kind="port",
+    base = dict(value=(Bl + Bu) / dt, unit="images/s", cores=cores, kind="port",
                 sample=f"YOLOv5l SSOD step, {Bl} labeled + {Bu} unlabeled 640x640, {n} steps, plain-torch fp32 CPU port "
-                       f"(pseudo-label loss on the first 60 labels)")
+                       f"(oracle/step.py; all {ref['t9'].shape[0]} pseudo labels)")
+    return base, parity
+
+
+def _respawn(a):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU over RCCL), exactly
+    as the documented torch.distributed.run command would."""
+    import subprocess
+    ndev = torch.cuda.device_count()
+    if ndev < a.gpus:
+        raise SystemExit(f"bench.py --gpus {a.gpus}: only {ndev} GPU(s) visible -- refusing to report a {ndev}-GPU number as {a.gpus}")
+    port = 29500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -136,11 +175,15 @@ def main():
                     "ranks share ONE GPU to exercise the N>1 code path where only a single GPU is available")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        _respawn(a)
     world = int(os.environ.get("WORLD_SIZE", 1))
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     ndev = torch.cuda.device_count()
+    if a.backend == "nccl" and ndev < world:
+        raise SystemExit(f"bench.py --gpus {a.gpus}: only {ndev} GPU(s) visible (use --backend gloo to share one GPU for a functional check)")
     dev_index = local_rank % max(ndev, 1)
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
@@ -192,13 +235,21 @@ def main():
     timed = set(range(0, a.steps, max(1, a.steps // 2)))
     sync()
     t0 = time.perf_counter()
+    ar_rows = []
+    ddp = tr.model if hasattr(tr.model, "collect_timing") else None
     for i in range(a.steps):
         ops.TIMER = timer if i in timed else None
+        if ddp is not None:
+            ddp.timing = i in timed
         items = step(a.warmup + i)
     ops.TIMER = None
     t_enq = time.perf_counter() - t0          # host time to enqueue the K steps (no device sync inside a step)
     sync()
     dt = time.perf_counter() - t0
+    if ddp is not None:
+        t_ar = ddp.collect_timing()
+        if t_ar is not None:
+            ar_rows.append(t_ar)
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -247,12 +298,19 @@ def main():
                        "algorithmic_tflop_per_step_per_gpu": step_flop / 1e12,
                        "step_tflops_per_gpu": step_flop / (dt / a.steps) / 1e12,
                        "frac_of_bf16_mfma_peak": step_flop / (dt / a.steps) / PEAK_BF16, "loss_finite": loss_ok,
+                       "rccl_ranks": dist.get_world_size() if world > 1 else 1, "env_knobs": ops.env_knobs(),
+                       "grad_allreduce": (dict(bytes=int(tr.model.flat_state().grads.numel() * 4), span_ms=ar_rows[-1][0],
+                                               exposed_ms=ar_rows[-1][1], note="span: first chunk launch (during backward) -> "
+                                               "last collective complete; exposed: compute stream waiting after backward")
+                                          if ar_rows else None),
                        "host_enqueue_ms_per_step": t_enq / a.steps * 1e3, "inputs": "host uint8 (PCIe inclusive)" if a.host_inputs else "resident in HBM"},
             "roofline": roof,
         }
         if world == 1 and not a.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(cfg)
+                del tr, imgs, u_str, u_ori, synth
+                torch.cuda.empty_cache()
+                out["cpu_baseline"], out["parity_check"] = cpu_baseline(cfg, device)
             except Exception as e:   # never lose the GPU number to the baseline leg
                 out["cpu_baseline"] = dict(value=None, unit="images/s", cores=os.cpu_count(), kind="port",
                                            sample=f"failed: {type(e).__name__}: {e}")

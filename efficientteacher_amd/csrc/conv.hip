@@ -789,13 +789,18 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_pp_kernel(const uint16_t* __
         ti_cur = g.tapinfo[__builtin_amdgcn_readfirstlane(tap_u < g.T ? tap_u : 0)]; \
     } while (0)
     // issue the LDS-DMA of ONE half-tile of the cursor's chunk (two instructions per thread)
+#if defined(ET_ABLATE) && (ET_ABLATE >= 20)
+#define ET_PPA(n) (ET_ABLATE == (n))
+#else
+#define ET_PPA(n) 0
+#endif
     auto stage_a = [&](int i, int buf) {
         u32x4* const wbase = lds_raw + (2 * i + buf) * HALF_VEC + wave * 64;
         const int doff = (udy * g.IW + udx) * g.ldx + (cv_u + lv) * VEC;
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
             const bool ok = (bool)((a_okm >> (i * 2 + jj)) & 1u) & ((unsigned)(a_iy[i][jj] + udy) < (unsigned)g.IH) &
-                            ((unsigned)(a_ix[i][jj] + udx) < (unsigned)g.IW);
+                            ((unsigned)(a_ix[i][jj] + udx) < (unsigned)g.IW) & !ET_PPA(22);
             const uint16_t* src = ok ? X + (a_off[i][jj] + doff) : ZERO;
             et_glds16(src, wbase + jj * 512);
         }
@@ -805,7 +810,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_pp_kernel(const uint16_t* __
         const int woff = uwt * g.Cin + (cv_u + lv) * VEC;
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
-            const bool ok = (b_okm >> (j * 2 + jj)) & 1u;
+            const bool ok = ((b_okm >> (j * 2 + jj)) & 1u) & !ET_PPA(22);
             const uint16_t* src = ok ? W + (b_off[j][jj] + woff) : ZERO;
             et_glds16(src, wbase + jj * 512);
         }
@@ -814,6 +819,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_pp_kernel(const uint16_t* __
     const int l31 = lane & 31, gk = lane >> 5;
     u32x4 af[2][4], bf[4];                         // A fragments of one half (2 row tiles x 4 k-steps), B of one half
     auto load_a = [&](int i, int buf) {
+        if (ET_PPA(23)) { for (int t = 0; t < 2; ++t) for (int kk = 0; kk < 4; ++kk) af[t][kk] = mk4(lane, kk, t, i); return; }
         const u32x4* sm = lds_raw + (2 * i + buf) * HALF_VEC;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -823,13 +829,15 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_pp_kernel(const uint16_t* __
         }
     };
     auto load_b = [&](int j, int buf) {
+        if (ET_PPA(23)) { for (int kk = 0; kk < 4; ++kk) bf[kk] = mk4(kk, lane, j, kk); return; }
         const u32x4* sm = lds_raw + (2 * (2 + j) + buf) * HALF_VEC;
         const int r = wn * 32 + l31;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) bf[kk] = sm[r * BKV + ((kk * 2 + gk) ^ lds_swz<BKV>(r))];
     };
     auto mfma8 = [&](int i, int j) {
-        __builtin_amdgcn_s_setprio(1);
+        if (ET_PPA(24)) { for (int t = 0; t < 2; ++t) for (int kk = 0; kk < 4; ++kk) { asm volatile("" :: "v"(af[t][kk]), "v"(bf[kk])); } return; }
+        if (!ET_PPA(27)) __builtin_amdgcn_s_setprio(1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
@@ -848,7 +856,10 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_pp_kernel(const uint16_t* __
     et_wait_vmem();
     __builtin_amdgcn_s_barrier();
     ET_TS(1);
-    if (wm == 1) __builtin_amdgcn_s_barrier();     // group 1 runs one barrier (half a phase) behind group 0
+#define ET_PP_BAR() do { if (!ET_PPA(28)) __builtin_amdgcn_s_barrier(); } while (0)
+#define ET_PP_WAIT(n) do { if (!ET_PPA(25)) et_wait_vmem_le_pp<n>(); } while (0)
+#define ET_PP_STAGE(call) do { if (!ET_PPA(21)) { call; } } while (0)
+    if (wm == 1 && !ET_PPA(26) && !ET_PPA(28)) __builtin_amdgcn_s_barrier();     // group 1 runs one barrier (half a phase) behind group 0
 
     // one chunk = four phases; `last`: nothing is staged during the final chunk and the waits drain the queue
     auto chunk = [&](int buf, auto last_tag) {
@@ -857,30 +868,30 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_pp_kernel(const uint16_t* __
         if constexpr (!LAST) ET_PP_DECODE();
         // ---- ph0: (A0, B0)
         load_a(0, buf); load_b(0, buf);
-        if constexpr (!LAST) stage_a(0, nb);
-        if constexpr (LAST) et_wait_vmem_le_pp<2>(); else et_wait_vmem_le_pp<4>();     // B1 of this chunk has landed
-        __builtin_amdgcn_s_barrier();
+        if constexpr (!LAST) ET_PP_STAGE(stage_a(0, nb));
+        if constexpr (LAST) ET_PP_WAIT(2); else ET_PP_WAIT(4);     // B1 of this chunk has landed
+        ET_PP_BAR();
         mfma8(0, 0);
-        __builtin_amdgcn_s_barrier();
+        ET_PP_BAR();
         // ---- ph1: (A0, B1)
         load_b(1, buf);
-        if constexpr (!LAST) stage_b(0, nb);
-        if constexpr (LAST) et_wait_vmem_le_pp<0>(); else et_wait_vmem_le_pp<4>();     // A1 of this chunk has landed
-        __builtin_amdgcn_s_barrier();
+        if constexpr (!LAST) ET_PP_STAGE(stage_b(0, nb));
+        if constexpr (LAST) ET_PP_WAIT(0); else ET_PP_WAIT(4);     // A1 of this chunk has landed
+        ET_PP_BAR();
         mfma8(0, 1);
-        __builtin_amdgcn_s_barrier();
+        ET_PP_BAR();
         // ---- ph2: (A1, B1)
         load_a(1, buf);
-        if constexpr (!LAST) stage_b(1, nb);
-        __builtin_amdgcn_s_barrier();
+        if constexpr (!LAST) ET_PP_STAGE(stage_b(1, nb));
+        ET_PP_BAR();
         mfma8(1, 1);
-        __builtin_amdgcn_s_barrier();
+        ET_PP_BAR();
         // ---- ph3: (A1, B0)
         load_b(0, buf);
-        if constexpr (!LAST) { stage_a(1, nb); ET_PP_ADVANCE(); et_wait_vmem_le_pp<4>(); }   // A0, B0 of the next chunk
-        __builtin_amdgcn_s_barrier();
+        if constexpr (!LAST) { ET_PP_STAGE(stage_a(1, nb)); ET_PP_ADVANCE(); ET_PP_WAIT(4); }   // A0, B0 of the next chunk
+        ET_PP_BAR();
         mfma8(1, 0);
-        __builtin_amdgcn_s_barrier();
+        ET_PP_BAR();
     };
     int buf = 0;
     for (int c = 0; c + 1 < nchunks; ++c) {
@@ -889,7 +900,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_pp_kernel(const uint16_t* __
         buf ^= 1;
     }
     chunk(buf, std::true_type{});
-    if (wm == 0) __builtin_amdgcn_s_barrier();     // balances group 1's extra barrier
+    if (wm == 0 && !ET_PPA(26) && !ET_PPA(28)) __builtin_amdgcn_s_barrier();     // balances group 1's extra barrier
     __syncthreads();                               // the epilogue reuses the half-tile buffers as its staging area
     ET_TS(3);
     conv_epilogue<uint16_t, BM, BN, WM, WN>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn);
@@ -897,6 +908,10 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_pp_kernel(const uint16_t* __
     ET_TS(4);
 #undef ET_PP_DECODE
 #undef ET_PP_ADVANCE
+#undef ET_PP_BAR
+#undef ET_PP_WAIT
+#undef ET_PP_STAGE
+#undef ET_PPA
 }
 
 // ---- wgrad ----------------------------------------------------------------------------------------

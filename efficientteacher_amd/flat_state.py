@@ -208,6 +208,8 @@ class FlatState:
 
     def prepare_forward(self, training):
         """Called by Model.forward: bring the bf16 shadow / eval-mode BN affine up to date if needed."""
+        if training:
+            ops.WGRAD_QUEUE.reset()      # nothing of an earlier (failed) backward lingers; side stream joined
         if self.weights_dirty:
             self.sync_shadow()
             self.weights_dirty = False

@@ -132,13 +132,22 @@ def conv2d_fwd(x, w, stride, pad, *, scale=None, bias=None, act=ACT_NONE, residu
 
 
 class WgradQueue:
-    """Deferred, grouped weight-gradient launches (et_conv2d_wgrad_grouped).
+    """Deferred, grouped weight-gradient launches (et_conv2d_wgrad_grouped) on a SIDE STREAM.
 
     Inside a backward pass, layers of identical geometry (the bottleneck stacks of a YOLOv5 stage) are collected
     and launched together: the K-split that fills the chip is shared by the group, so every dW address gets
     group-size times fewer fp32 atomics.  A group is launched when it reaches ``group`` items and at the end of
     the backward pass (autograd engine callback); ``on_done`` callbacks (gradient-ready hooks of the data-parallel
-    wrapper) run right after the launch that covers their layer.  ET_WGRAD_GROUP=1 launches every layer at once."""
+    wrapper) run right after the launch that covers their layer.  ET_WGRAD_GROUP=1 launches every layer at once.
+
+    Nothing in backward consumes a weight gradient, so on a GPU the grouped launches go to a second HIP stream
+    (ET_WGRAD_STREAM=0 keeps them on the launching stream): the MFMA-bound wgrad workgroups then fill the CUs the
+    critical path leaves idle -- the partially filled last residency round of every dgrad (YOLOv5's pixel counts are
+    25 * 2^k: 400 tiles on 256 CUs run as two rounds), the HBM-write burst of its epilogue, and the HBM-bound
+    BatchNorm backward passes.  Ordering: the side stream waits for the launching stream at every group launch (dy
+    and x are complete), the launching stream joins the side stream at the end of backward (before the optimizer /
+    the final all-reduces); gradient-ready hooks run with the side stream current, so an RCCL all-reduce they start
+    is ordered behind the wgrads it covers."""
 
     def __init__(self):
         import os
@@ -148,6 +157,24 @@ class WgradQueue:
         self.last = {}
         self.tick = 0
         self._cb_armed = False
+        self.use_side = os.environ.get("ET_WGRAD_STREAM", "1") != "0"
+        self._side = {}              # device -> side stream
+        self._dirty = set()          # devices whose side stream holds work the launching stream has not joined yet
+
+    def side_stream(self, dev):
+        s = self._side.get(dev)
+        if s is None:
+            s = self._side[dev] = torch.cuda.Stream(device=dev)
+        return s
+
+    def reset(self):
+        """Start of a training forward: nothing of an earlier (possibly failed) backward may linger -- pending
+        entries of a pass that raised would otherwise be flushed into a later step's gradient arena, and a stale
+        armed flag would keep later passes from ever arming their end-of-backward flush."""
+        self.pending.clear()
+        self.last.clear()
+        self._cb_armed = False
+        self.join()
 
     def submit(self, x, dy, dw, ksize, stride, pad, on_done=None):
         if self.group <= 1 or x.dtype != torch.bfloat16:
@@ -155,6 +182,15 @@ class WgradQueue:
             if on_done is not None:
                 on_done()
             return
+        if not self._cb_armed:       # one end-of-backward callback per pass: flush the partial groups, join the side stream
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(self.flush)
+                self._cb_armed = True
+            except RuntimeError:     # not inside a backward pass: nothing will call back -- launch now, in order
+                conv2d_wgrad(x, dy, dw, ksize, stride, pad)
+                if on_done is not None:
+                    on_done()
+                return
         key = (tuple(x.shape), tuple(dy.shape), ksize, stride, pad, x.device)
         self.tick += 1
         for k in [k for k, t in self.last.items() if k != key and self.tick - t > self.stale]:
@@ -164,28 +200,43 @@ class WgradQueue:
         self.last[key] = self.tick
         if len(lst) >= self.group:
             self._flush_key(key)
-        elif not self._cb_armed:
-            try:
-                torch.autograd.Variable._execution_engine.queue_callback(self.flush)
-                self._cb_armed = True
-            except RuntimeError:            # not inside a backward pass: nothing will call back -- launch now
-                self._flush_key(key)
 
     def _flush_key(self, key):
         lst = self.pending.pop(key, None)
         self.last.pop(key, None)
         if not lst:
             return
-        xs, dys, ksize, stride, pad, _ = key
-        conv2d_wgrad_grouped([(a, b, c) for a, b, c, _ in lst], ksize, stride, pad)
+        xs, dys, ksize, stride, pad, dev = key
+        items = [(a, b, c) for a, b, c, _ in lst]
+        if self.use_side and dev.type == "cuda":
+            main, side = torch.cuda.current_stream(dev), self.side_stream(dev)
+            side.wait_stream(main)               # every x / dy of the group is complete on the launching stream
+            with torch.cuda.stream(side):
+                conv2d_wgrad_grouped(items, ksize, stride, pad)
+                for a, b, _ in items:            # the caching allocator must not hand these blocks out before the side
+                    a.record_stream(side)        # stream has read them (autograd frees them when the node returns)
+                    b.record_stream(side)
+                for _, _, _, cb in lst:
+                    if cb is not None:
+                        cb()
+            self._dirty.add(dev)
+            return
+        conv2d_wgrad_grouped(items, ksize, stride, pad)
         for _, _, _, cb in lst:
             if cb is not None:
                 cb()
+
+    def join(self):
+        """the launching stream waits for everything the side stream(s) hold (end of backward / before the optimizer)"""
+        for dev in self._dirty:
+            torch.cuda.current_stream(dev).wait_stream(self._side[dev])
+        self._dirty.clear()
 
     def flush(self):
         self._cb_armed = False
         for key in list(self.pending.keys()):
             self._flush_key(key)
+        self.join()
 
 
 WGRAD_QUEUE = WgradQueue()

@@ -35,6 +35,9 @@ class FlatSGD(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None, inv_scale=1.0):
         f = self.flat
+        # deferred weight-gradient launches must be in the arena (and their side stream joined) before it is read
+        assert not ops.WGRAD_QUEUE.pending, "weight gradients still queued: backward() did not finish"
+        ops.WGRAD_QUEUE.join()
         for g in self.param_groups:
             o, n = g['range']
             shadow = f.shadow if (f.shadow is not None and (o, n) == tuple(f.w_range)) else None

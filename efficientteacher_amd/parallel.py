@@ -26,6 +26,9 @@ class FlatDataParallel(nn.Module):
         self.overlap = overlap
         self._works = []
         self._launched = set()
+        self.timing = False              # bench.py: HIP events around the collective phase of a step
+        self.last_timing = None          # (first launch -> all complete, exposed wait after backward) in ms
+        self._ev0 = None
         if self.world > 1:
             f = module.flat_state()
             dist.broadcast(f.params, 0, group=self.pg)
@@ -69,6 +72,10 @@ class FlatDataParallel(nn.Module):
         self._remaining = [c[2] for c in self._chunks]
 
     def _all_reduce(self, view):
+        if self.timing and self._ev0 is None and view.is_cuda:
+            import torch
+            self._ev0 = torch.cuda.Event(enable_timing=True)
+            self._ev0.record()
         avg = dist.get_backend(self.pg) == "nccl"        # RCCL averages inside the collective
         w = dist.all_reduce(view, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=self.pg, async_op=True)
         self._works.append((w, None if avg else view))
@@ -102,13 +109,33 @@ class FlatDataParallel(nn.Module):
                 self._all_reduce(g[o:o + n])
         self._all_reduce(g[:wo])                           # biases (BN + conv)
         self._all_reduce(g[wo + wn:])                      # BN weights
+        ev1 = ev2 = None
+        if self.timing and self._ev0 is not None:
+            import torch
+            ev1, ev2 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev1.record()                                   # backward is over on this stream: what follows is exposed
         for w, view in self._works:
             w.wait()
             if view is not None:                           # gloo (CPU tests) has no AVG
                 view.mul_(1.0 / self.world)
+        if ev2 is not None:
+            ev2.record()
+            self._pending_timing = (self._ev0, ev1, ev2)
+            self._ev0 = None
         self._works = []
         self._launched = set()
         self._remaining = [c[2] for c in self._chunks]
+
+    def collect_timing(self):
+        """(ms from the first all-reduce launch to the completion of the last, ms the compute stream waited for the
+        collectives after backward) of the last timed step; synchronises the events."""
+        t = getattr(self, "_pending_timing", None)
+        if t is None:
+            return None
+        e0, e1, e2 = t
+        e2.synchronize()
+        self._pending_timing = None
+        return e0.elapsed_time(e2), e1.elapsed_time(e2)
 
     def flat_state(self):
         return self.module.flat_state()

@@ -1,0 +1,28 @@
+#!/bin/bash
+# One gpurun call: parity tests + A/B microbenchmarks + step bench.  Usage: tools/gpu_round.sh <tag> [sections...]
+# Everything lands in gpurun_out/<tag>/ (merged back by gpurun); nothing here reads /root/reference.
+set -u
+TAG=${1:-r02}; shift || true
+SECTIONS=${*:-"conv_tests mb_pp mb_lock host bench"}
+OUT=gpurun_out/$TAG; mkdir -p $OUT
+export TMPDIR=/tmp
+run() { echo "=== $1 ($(date +%T))" | tee -a $OUT/log.txt; }
+for s in $SECTIONS; do
+case $s in
+conv_tests) run conv_tests; timeout 900 python -m pytest tests/test_conv.py -x -q -m gpu > $OUT/pytest_conv.log 2>&1; tail -3 $OUT/pytest_conv.log ;;
+all_tests) run all_tests; timeout 2400 python -m pytest tests -x -q -m gpu > $OUT/pytest_gpu.log 2>&1; tail -5 $OUT/pytest_gpu.log ;;
+mb_pp) run mb_pp; MB_REF=0 MB_ONLY=${MB_ONLY:-pp} timeout 600 python tools/microbench.py conv > $OUT/mb_pp1.log 2>&1; tail -1 $OUT/mb_pp1.log ;;
+mb_lock) run mb_lock; ET_CONV_PP=0 MB_REF=0 MB_ONLY=${MB_ONLY:-"256, 256"} timeout 600 python tools/microbench.py conv > $OUT/mb_pp0.log 2>&1; tail -1 $OUT/mb_pp0.log ;;
+mb_all) run mb_all; MB_REF=0 timeout 900 python tools/microbench.py conv > $OUT/mb_all.log 2>&1; tail -1 $OUT/mb_all.log ;;
+mb_bn) run mb_bn; timeout 600 python tools/microbench.py bn > $OUT/mb_bn.log 2>&1; tail -1 $OUT/mb_bn.log ;;
+host) run host; timeout 600 python tools/host_bound.py > $OUT/host_bound.log 2>&1; tail -1 $OUT/host_bound.log ;;
+bench) run bench; timeout 900 python bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err; cut -c1-400 $OUT/bench.json ;;
+bench_lock) run bench_lock; ET_CONV_PP=0 timeout 900 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_pp0.json 2> $OUT/bench_pp0.err; cut -c1-300 $OUT/bench_pp0.json ;;
+bench_nostream) run bench_nostream; ET_WGRAD_STREAM=0 timeout 900 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_nostream.json 2> $OUT/bench_nostream.err; cut -c1-300 $OUT/bench_nostream.json ;;
+bench_quick) run bench_quick; timeout 900 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_quick.json 2> $OUT/bench_quick.err; cut -c1-300 $OUT/bench_quick.json ;;
+smoke) run smoke; timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -3 $OUT/smoke.log ;;
+prof) run prof; (cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/bench_under_rocprof.json 2> $GRAFT_REPO_ROOT/$OUT/prof.err); find $OUT/prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv; find $OUT/prof -name "*.db" -delete; find $OUT/prof -name "*kernel_trace.csv" -size +20M -delete; head -8 $OUT/kernel_stats.csv | cut -c1-160 ;;
+*) echo "unknown section $s" ;;
+esac
+done
+echo "=== done ($(date +%T))" | tee -a $OUT/log.txt

@@ -45,8 +45,12 @@ def bench_conv(B=64, dtype=torch.bfloat16, with_ref=True):
     dev = torch.device("cuda:0")
     rows = []
     tot = dict(fwd=0.0, dgrad=0.0, wgrad=0.0, ref_fwd=0.0, ref_bwd=0.0, flop=0.0)
+    only = os.environ.get("MB_ONLY", "")          # substring of the forward kernel name, e.g. "pp" or "256, 256"
     for (cin, cout, k, s, h, cnt) in V5L:
         p = 2 if k == 6 else k // 2
+        kname = ops.kernel_name("fwd", dtype, B, h, h, cin, cout, k, s, p)
+        if only and only not in kname and only not in ops.kernel_name("dgrad", dtype, B, h, h, cin, cout, k, s, p):
+            continue
         x = torch.randn(B, h, h, cin, device=dev).to(dtype)
         w = (torch.randn(cout, k, k, cin, device=dev) * 0.05).to(dtype)
         oh, ow = ops.conv_out_hw(h, h, k, s, p)
@@ -59,7 +63,7 @@ def bench_conv(B=64, dtype=torch.bfloat16, with_ref=True):
         t_f = timeit(lambda: ops.conv2d_fwd(x, w, s, p, out=y))
         t_d = timeit(lambda: ops.conv2d_dgrad(dy, wT, (h, h), s, p, out=dx)) if k != 6 else 0.0
         t_w = timeit(lambda: ops.conv2d_wgrad(x, dy, dw, k, s, p))
-        r = dict(cin=cin, cout=cout, k=k, s=s, h=h, count=cnt, gflop=flop / 1e9,
+        r = dict(cin=cin, cout=cout, k=k, s=s, h=h, count=cnt, gflop=flop / 1e9, fwd_kernel=kname,
                  fwd_ms=t_f * 1e3, dgrad_ms=t_d * 1e3, wgrad_ms=t_w * 1e3,
                  fwd_tf=flop / t_f / 1e12, dgrad_tf=(flop / t_d / 1e12 if t_d else 0), wgrad_tf=flop / t_w / 1e12)
         if with_ref:
