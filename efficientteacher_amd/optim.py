@@ -29,12 +29,37 @@ class FlatSGD(torch.optim.Optimizer):
         for g, r in zip(self.param_groups, self.flat.group_ranges()):
             g['range'] = r
             g.setdefault('initial_lr', lr)
+        self._model = model
         self.momentum_buf = torch.zeros_like(self.flat.params)
         self.first = True
+
+    # the momentum arena and the first-step flag live outside Optimizer.state: carry them through checkpoints
+    def state_dict(self):
+        sd = super().state_dict()
+        sd["flat_momentum"] = self.momentum_buf.detach().cpu().clone()
+        sd["flat_first"] = bool(self.first)
+        return sd
+
+    def load_state_dict(self, sd):
+        sd = dict(sd)
+        mom, first = sd.pop("flat_momentum", None), sd.pop("flat_first", None)
+        if mom is None:
+            raise ValueError("not a FlatSGD state_dict (no flat momentum arena)")
+        if mom.numel() != self.momentum_buf.numel():
+            raise ValueError("flat momentum arena of another model layout")
+        ranges = [g["range"] for g in self.param_groups]
+        super().load_state_dict(sd)
+        for g, r in zip(self.param_groups, ranges):        # 'range' is layout, not state
+            g["range"] = r
+        self.momentum_buf.copy_(mom.to(self.momentum_buf.device))
+        self.first = bool(first)
 
     @torch.no_grad()
     def step(self, closure=None, inv_scale=1.0):
         f = self.flat
+        if f is not self._model.flat_state():
+            raise RuntimeError("the model's arenas were rebuilt (model.to() / set_compute_dtype() / _apply) after this optimizer "
+                               "was created: it would update orphaned buffers -- build the optimizer after the last such call")
         # deferred weight-gradient launches must be in the arena (and their side stream joined) before it is read
         assert not ops.WGRAD_QUEUE.pending, "weight gradients still queued: backward() did not finish"
         ops.WGRAD_QUEUE.join()

@@ -60,13 +60,32 @@ class Trainer:
         return importlib.import_module(self.MODEL_MODULE).Model
 
     def build_model(self, cfg, device):
-        if cfg.weights:
-            raise NotImplementedError("checkpoint interchange is SURVEY.md 8(f-3), not built yet")
         self.model = self._model_class()(cfg).to(device)
         self.model.set_compute_dtype(self.amp_dtype)
+        ckpt = None
+        if str(cfg.weights).endswith('.pt'):       # trainer.py:127-144: intersect by name/shape, anchors excluded unless resuming
+            from ..utils.checkpoint import load_reference_checkpoint
+            ckpt = load_reference_checkpoint(cfg.weights, map_location="cpu")
+            msd = self.model.state_dict()
+            exclude = ['anchor'] if not cfg.resume else []
+            csd = {k: v for k, v in ckpt["model"].items() if k in msd and not any(x in k for x in exclude)
+                   and tuple(v.shape) == tuple(msd[k].shape)}
+            self.model.load_state_dict(csd, strict=False)      # marks the flat arenas changed (bf16 shadow, transposes)
+            LOGGER.info(f'Transferred {len(csd)}/{len(msd)} items from {cfg.weights}')
         for _, v in self.model.named_parameters():
             v.requires_grad = True
-        self.ema = ModelEMA(self.model)
+        self.ema = ModelEMA(self.model)                        # built AFTER the load: the teacher starts from the loaded weights
+        if ckpt is not None:
+            if ckpt.get("ema"):
+                esd = self.ema.ema.state_dict()
+                self.ema.ema.load_state_dict({k: v for k, v in ckpt["ema"].items() if k in esd and tuple(v.shape) == tuple(esd[k].shape)},
+                                             strict=False)
+            if ckpt.get("updates") is not None:
+                self.ema.updates = ckpt["updates"]
+            if ckpt.get("epoch") is not None:
+                self.start_epoch = ckpt["epoch"] + 1
+                self.epoch = self.start_epoch
+        self._ckpt = ckpt
 
     def build_optimizer(self, cfg):
         nbs = 64  # nominal batch size
@@ -83,9 +102,18 @@ class Trainer:
             self.lf = lambda x: ((1 - math.cos(x * math.pi / self.epochs)) / 2) * (cfg.hyp.lrf - 1) + 1
         self.scheduler = lr_scheduler.LambdaLR(self.optimizer, lr_lambda=self.lf)
         self.scheduler.last_epoch = self.epoch - 1
-        # warm-up length (trainer.py:372-376)
-        self.nw = max(round(self.warmup_epochs * self.nb), 1000)
-        self.nw = min(self.nw, (self.epochs - self.start_epoch) / 2 * self.nb)
+        ck = getattr(self, "_ckpt", None)
+        if ck is not None and ck.get("optimizer") is not None:   # trainer.py:249-251
+            try:
+                self.optimizer.load_state_dict(ck["optimizer"])
+            except (ValueError, KeyError, RuntimeError):
+                LOGGER.info("checkpoint optimizer state belongs to another optimizer type: starting it fresh")
+        # warm-up length (trainer.py:372-376): none at all when hyp.warmup_epochs == 0 (the default of configs/defaults.py)
+        if self.warmup_epochs > 0:
+            self.nw = max(round(self.warmup_epochs * self.nb), 1000)
+            self.nw = min(self.nw, (self.epochs - self.start_epoch) / 2 * self.nb)
+        else:
+            self.nw = -1
 
     def build_ddp_model(self, cfg, device):
         if self.cuda and self.RANK != -1:

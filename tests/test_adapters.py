@@ -1,0 +1,143 @@
+"""Row (b) of SURVEY.md section 8: the reference's OWN epoch loop (Trainer.before_epoch / train_in_epoch,
+trainer/trainer.py:358,406; SSODTrainer.train_in_epoch -> train_with_unlabeled, trainer/ssod_trainer.py:295,682) drives
+this package's hot path through ``efficientteacher_amd.trainer.adapters.hot_path_trainers()``.
+
+Needs the reference tree (build container only: it is imported live through oracle/ref_loader.py, nothing is copied);
+on the GPU box, where /root/reference does not exist, the module is skipped.  Kernels run in the SIMT emulator.
+The data loaders are replaced as SURVEY.md section 8(c) describes (lists of the reference's batch tuples)."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_loader
+from tests.conftest import ROOT
+
+pytestmark = pytest.mark.skipif(not ref_loader.available(), reason="reference tree not present (build container only)")
+SSOD_YAML = "configs/ssod/coco-standard/yolov5l_coco_ssod_10_percent.yaml"
+
+
+class _Loader(list):
+    num_workers = 0
+    sampler = None
+
+
+class _Dataset:
+    mosaic = True
+
+    def __init__(self, labels):
+        self.labels = labels
+        self.cls_ratio_gt = None
+        self.label_num_per_image = None
+
+    def __len__(self):
+        return 4
+
+
+def _batches(rng, n, B, S, unlabeled=False):
+    out = _Loader()
+    for _ in range(n):
+        imgs = torch.from_numpy(rng.integers(0, 256, (B, 3, S, S), dtype=np.uint8))
+        t = []
+        for b in range(B):
+            k = int(rng.integers(1, 4))
+            t.append(np.concatenate((np.full((k, 1), b), rng.integers(0, 80, (k, 1)), rng.uniform(0.3, 0.7, (k, 2)),
+                                     rng.uniform(0.1, 0.4, (k, 2))), 1))
+        targets = torch.from_numpy(np.concatenate(t, 0).astype(np.float32))
+        if not unlabeled:
+            out.append((imgs, targets, [f"img{b}.jpg" for b in range(B)], None))
+        else:
+            M = torch.zeros(B, 13, dtype=torch.float64)
+            for b in range(B):
+                M[b] = torch.tensor([b, 1, 0, 0, 0, 1, 0, 0, 0, 1, 1.0, 0, b % 2], dtype=torch.float64)
+            out.append((imgs, targets, [f"u{b}.jpg" for b in range(B)], None, imgs.clone(), M))
+    return out
+
+
+def _cfg(save_dir, ssod):
+    cfg = ref_loader.get_cfg(SSOD_YAML, ["Model.width_multiple", 0.125, "Model.depth_multiple", 0.33, "Dataset.batch_size", 2,
+                                         "Dataset.img_size", 64, "save_dir", save_dir, "noval", True, "nosave", True,
+                                         "epochs", 2, "SSOD.train_domain", bool(ssod), "device", "cpu", "Dataset.workers", 0,
+                                         "hyp.burn_epochs", 0])
+    cfg.freeze()
+    return cfg
+
+
+@pytest.fixture
+def ref_callbacks():
+    ref_loader.load()
+    from utils.callbacks import Callbacks
+    return Callbacks()
+
+
+def _mk(base, rng, ssod):
+    class T(base):
+        def build_dataloader(self, cfg, callbacks):          # no image files on disk
+            self.imgsz = cfg.Dataset.img_size
+            self.train_loader = _batches(rng, 2, 2, 64)
+            self.dataset = _Dataset([np.array([[3, .5, .5, .2, .2]], np.float32)] * 4)
+            self.nb = len(self.train_loader)
+            self.no_aug_epochs = cfg.hyp.no_aug_epochs
+            if ssod:
+                self.unlabeled_dataloader = _batches(rng, 2, 2, 64, unlabeled=True)
+                self.unlabeled_dataset = _Dataset([])
+                self.cls_ratio_gt = None
+                self.label_num_per_image = None
+    return T
+
+
+def test_reference_epoch_loop_drives_the_hot_path_supervised(emu, ref_callbacks):
+    from efficientteacher_amd.trainer.adapters import hot_path_trainers
+    from efficientteacher_amd.models.detector.yolo import Model as EtModel
+    from efficientteacher_amd.optim import FlatSGD
+    Trainer, _ = hot_path_trainers()
+    rng = np.random.default_rng(0)
+    with tempfile.TemporaryDirectory() as d:
+        t = _mk(Trainer, rng, False)(_cfg(d, False), torch.device("cpu"), ref_callbacks, -1, -1, 1)
+        assert isinstance(t.model, EtModel) and isinstance(t.optimizer, FlatSGD)
+        import trainer.trainer as ref_mod
+        assert isinstance(t, ref_mod.Trainer)                      # the reference's class: its loop, its loggers, its checkpoints
+        p0 = t.model.flat_state().params.clone()
+        t.last_opt_step = -1
+        t.plots = False                                            # the reference's plotting thread needs an older PIL
+        t.before_epoch()                                           # reference code: meters, warm-up length, first logging forward
+        assert t.nw == -1 or t.nw >= 0
+        t.train_in_epoch(ref_callbacks)                            # reference code: two iterations + scheduler.step()
+        assert torch.isfinite(t.model.flat_state().params).all()
+        assert not torch.equal(p0, t.model.flat_state().params)
+        assert len(t.meter.meters) >= 3 and all(np.isfinite(v) for v in t.meter.get_avg())
+        assert t.ema.updates >= 1
+
+
+def test_reference_epoch_loop_drives_the_hot_path_ssod(emu, ref_callbacks):
+    from efficientteacher_amd.trainer.adapters import hot_path_trainers
+    from efficientteacher_amd.models.detector.yolo_ssod import Model as EtModel
+    _, SSODTrainer = hot_path_trainers()
+    rng = np.random.default_rng(1)
+    with tempfile.TemporaryDirectory() as d:
+        t = _mk(SSODTrainer, rng, True)(_cfg(d, True), torch.device("cpu"), ref_callbacks, -1, -1, 1)
+        assert isinstance(t.model, EtModel)
+        import trainer.ssod_trainer as ref_mod
+        assert isinstance(t, ref_mod.SSODTrainer)
+        with torch.no_grad():            # a random-init teacher detects nothing: bump the objectness / class biases
+            for mi in t.model.head.m:
+                b = mi.bias.view(t.model.head.na, -1)
+                b[:, 4] += 6.0
+                b[:, 5:] += 3.5
+        t.model.flat_state().mark_weights_changed()
+        from efficientteacher_amd.utils.torch_utils import ModelEMA
+        t.ema = ModelEMA(t.model)
+        p0 = t.model.flat_state().params.clone()
+        e0 = t.ema.ema.flat_state().params.clone()
+        t.last_opt_step = -1
+        t.plots = False                                            # the reference's plotting thread needs an older PIL
+        t.before_epoch()
+        t.train_in_epoch(ref_callbacks)                            # -> the reference's train_with_unlabeled -> OUR train_instance
+        assert torch.isfinite(t.model.flat_state().params).all()
+        assert not torch.equal(p0, t.model.flat_state().params)
+        assert not torch.equal(e0, t.ema.ema.flat_state().params)   # the EMA teacher followed
+        names = set(t.meter.meters.keys())
+        assert {"box", "obj", "cls", "ss_box", "ss_obj", "ss_cls"} <= names, names
+        assert float(t.meter.meters["ss_obj"].avg) > 0             # pseudo labels reached the unsupervised loss
