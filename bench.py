@@ -169,6 +169,8 @@ def main():
     ap.add_argument("--per-rank", type=int, default=32, help="labeled (= unlabeled) images per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="run the teacher on the main stream (A/B)")
+    ap.add_argument("--graph", action="store_true", help="replay the step as one captured HIP graph (trainer/graph_step.py) instead of "
+                    "issuing every launch from Python (A/B: the 32+32 step is GPU-bound, both take ~64 ms)")
     ap.add_argument("--host-inputs", action="store_true", help="PCIe-inclusive variant: every step receives its three "
                     "uint8 image batches from pinned host memory (never the reported `value`; noted in DESIGN.md)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); 'gloo' lets two "
@@ -208,6 +210,8 @@ def main():
         return tp
     tr.teacher_pred_hook = hook
     tr.overlap_teacher = not a.no_overlap
+    if a.graph:
+        tr.use_graph = True
 
     ni = 2000               # past the warm-up ramp's first iterations, inside warm-up like early training
 
@@ -232,17 +236,20 @@ def main():
 
     # HIP-event timing of the conv launches (roofline leg) on a sample of the timed steps: two events per
     # launch are ~870 extra stream operations per step, ~3 % of the step if every step is instrumented
-    timed = set(range(0, a.steps, max(1, a.steps // 2)))
+    timed = {a.steps // 2} if a.steps > 2 else set(range(a.steps))
     sync()
     t0 = time.perf_counter()
     ar_rows = []
     ddp = tr.model if hasattr(tr.model, "collect_timing") else None
+    graph_default = tr.use_graph
     for i in range(a.steps):
         ops.TIMER = timer if i in timed else None
-        if ddp is not None:
+        tr.use_graph = graph_default and i not in timed      # HIP events cannot be recorded inside a replayed graph:
+        if ddp is not None:                                     # the instrumented step(s) of the timed region run eagerly
             ddp.timing = i in timed
         items = step(a.warmup + i)
     ops.TIMER = None
+    tr.use_graph = graph_default
     t_enq = time.perf_counter() - t0          # host time to enqueue the K steps (no device sync inside a step)
     sync()
     dt = time.perf_counter() - t0
@@ -303,7 +310,9 @@ def main():
                                                exposed_ms=ar_rows[-1][1], note="span: first chunk launch (during backward) -> "
                                                "last collective complete; exposed: compute stream waiting after backward")
                                           if ar_rows else None),
-                       "host_enqueue_ms_per_step": t_enq / a.steps * 1e3, "inputs": "host uint8 (PCIe inclusive)" if a.host_inputs else "resident in HBM"},
+                       "host_enqueue_ms_per_step": t_enq / a.steps * 1e3,
+                       "step_graph": dict(enabled=bool(graph_default and world == 1), replays=getattr(tr._graph, "replays", 0) if getattr(tr, "_graph", None) else 0,
+                                          eager_instrumented_steps=len(timed)), "inputs": "host uint8 (PCIe inclusive)" if a.host_inputs else "resident in HBM"},
             "roofline": roof,
         }
         if world == 1 and not a.no_cpu_baseline:

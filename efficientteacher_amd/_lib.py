@@ -31,9 +31,12 @@ SIGNATURES = {
     "et_ema_update": (c_int, [P, P, c_int64, c_float, c_float, P]),
     "et_sgd_nesterov": (c_int, [P, P, P, P, c_int64, c_float, c_float, c_float, c_int, c_float, P]),
     "et_cast_f32_to_bf16": (c_int, [P, P, c_int64, P]),
+    "et_ema_update_dev": (c_int, [P, P, c_int64, P, P]),
+    "et_sgd_nesterov_dev": (c_int, [P, P, P, P, c_int64, P, c_int, P]),
     "et_conv2d_stats_rows": (c_int, [c_int, c_int, c_int]),
     "et_conv2d_fwd": (c_int, [P, P, P, c_int] + [c_int] * 11 + [P, P, c_int, P, c_int, P, P, P]),
     "et_conv2d_dgrad": (c_int, [P, P, P, c_int] + [c_int] * 11 + [c_int, P, c_int, P, P]),
+    "et_conv2d_dgrad_bn": (c_int, [P, P, P, c_int] + [c_int] * 10 + [P, c_int, P, c_int, P, P, c_int, P, P, P]),
     "et_conv2d_wgrad": (c_int, [P, P, P, c_int] + [c_int] * 11 + [P, P]),
     "et_conv2d_wgrad_grouped": (c_int, [P, c_int, c_int] + [c_int] * 9 + [P, P]),
     "et_weight_transpose_all": (c_int, [P, P, c_int, P, c_int, ctypes.c_longlong, P]),
@@ -47,8 +50,11 @@ SIGNATURES = {
     "et_bn_act_fwd": (c_int, [P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, P, P, c_int, P]),
     "et_bn_act_bwd": (c_int, [P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, P, P, P, P, P, c_int, P, P, P, P,
                               c_size_t, P]),
+    "et_bn_act_bwd_from_partials": (c_int, [P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, P, P, P, P, P, c_int, P, P, P,
+                                            P, c_int, P, P]),
     "et_act_bwd": (c_int, [P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
     "et_pack_input": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "et_pack_input_u8": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_float, P]),
     "et_maxpool5_fwd": (c_int, [P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
     "et_maxpool5_bwd": (c_int, [P, c_int, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "et_upsample2x_fwd": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),

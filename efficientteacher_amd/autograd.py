@@ -10,6 +10,11 @@ from . import ops
 
 ACT_CODE = {"silu": ops.ACT_SILU, "relu": ops.ACT_RELU, "none": ops.ACT_NONE}
 
+# the reduce pass of BatchNorm backward inside the epilogue of the dgrad that produces its input gradient
+# (et_conv2d_dgrad_bn); ET_FUSE_BN_BWD=0 restores the separate reduce pass everywhere (A/B knob)
+import os as _os
+FUSE_BN_BWD = _os.environ.get("ET_FUSE_BN_BWD", "1") != "0"
+
 # set by parallel.FlatDataParallel: callable(ConvSlot) invoked right after a layer's wgrad has been
 # launched, so that the gradient all-reduce of finished arena chunks overlaps the rest of backward
 GRAD_READY_HOOK = None
@@ -39,10 +44,14 @@ class ConvBnActFn(Function):
     train mode, plus the Bottleneck shortcut (common.py:544)."""
 
     @staticmethod
-    def forward(ctx, x, residual, wparam, cs, bs, act, nbt, dst=None):
+    def forward(ctx, x, residual, wparam, cs, bs, act, nbt, dst=None, bn_in=None, bn_out=None):
         # wparam (the nn.Parameter) only ties the op into the autograd graph; its gradient is written
         # by the wgrad kernel directly into the flat arena, so backward returns None for it.
+        # bn_in: BnBwdSums of the block that produced x, passed ONLY when this conv is x's sole consumer (the caller knows
+        # the graph): this layer's dgrad then does that block's BatchNorm-backward reduce pass in its epilogue.
+        # bn_out: a one-element list that receives this block's BnBwdSums for the (sole) consumer of z.
         ctx.w_needs_grad = wparam.requires_grad
+        ctx.bn_in = bn_in if (bn_in is not None and cs.stride == 1 and residual is None) else None
         y, stats = ops.conv2d_fwd(x, cs.w_lp, cs.stride, cs.pad, want_stats=True)
         N, OH, OW, _ = y.shape
         scale, shift, mean, invstd = ops.bn_finalize(stats, N * OH * OW, bs.gamma, bs.beta, bs.eps, bs.momentum,
@@ -56,6 +65,10 @@ class ConvBnActFn(Function):
         ctx.cs, ctx.bs, ctx.act = cs, bs, act
         ctx.has_res = residual is not None
         ctx.x_needs_grad = x.requires_grad
+        ctx.bn_mine = None
+        if bn_out is not None and residual is None:
+            ctx.bn_mine = ops.BnBwdSums(y, scale, shift, act)
+            bn_out.append(ctx.bn_mine)
         ctx.save_for_backward(x, y, scale, shift, mean, invstd)
         return z
 
@@ -64,14 +77,15 @@ class ConvBnActFn(Function):
         x, y, scale, shift, mean, invstd = ctx.saved_tensors
         cs, bs = ctx.cs, ctx.bs
         dz = _dense_or_slice(dz)
-        dy = ops.bn_act_bwd(dz, y, bs.gamma, scale, shift, mean, invstd, ctx.act, bs.ggamma, bs.gbeta)
+        part = ctx.bn_mine.take(dz) if ctx.bn_mine is not None else None
+        dy = ops.bn_act_bwd(dz, y, bs.gamma, scale, shift, mean, invstd, ctx.act, bs.ggamma, bs.gbeta, partial=part)
         if ctx.w_needs_grad:
             _wgrad(x, dy, cs)
         dx = None
         if ctx.x_needs_grad:
             wT = cs.transposed()
-            dx = ops.conv2d_dgrad(dy, wT, (x.shape[1], x.shape[2]), cs.stride, cs.pad)
-        return dx, (dz if ctx.has_res else None), None, None, None, None, None, None
+            dx = ops.conv2d_dgrad(dy, wT, (x.shape[1], x.shape[2]), cs.stride, cs.pad, bn=ctx.bn_in)
+        return dx, (dz if ctx.has_res else None), None, None, None, None, None, None, None, None
 
 
 class BottleneckFn(Function):
@@ -80,8 +94,10 @@ class BottleneckFn(Function):
     the epilogue of cv1's dgrad (dx = dgrad(dy1) + dz) instead of a separate accumulation pass by autograd."""
 
     @staticmethod
-    def forward(ctx, x, w1, w2, cs1, bs1, cs2, bs2, act1, act2, nbt1, nbt2, dst=None):
+    def forward(ctx, x, w1, w2, cs1, bs1, cs2, bs2, act1, act2, nbt1, nbt2, dst=None, bn_in=None, bn_out=None):
+        # bn_in / bn_out: see ConvBnActFn (x's sole consumer is this node: both the cv1 path and the shortcut are inside it)
         ctx.w_needs_grad = w1.requires_grad or w2.requires_grad
+        ctx.bn_in = bn_in
         y1, st1 = ops.conv2d_fwd(x, cs1.w_lp, cs1.stride, cs1.pad, want_stats=True)
         N, H1, W1, _ = y1.shape
         a1 = ops.bn_finalize(st1, N * H1 * W1, bs1.gamma, bs1.beta, bs1.eps, bs1.momentum, bs1.rmean, bs1.rvar)
@@ -96,6 +112,10 @@ class BottleneckFn(Function):
         z = ops.bn_act_fwd(y2, a2[0], a2[1], act2, residual=x, out=out)
         ctx.meta = (cs1, bs1, cs2, bs2, act1, act2)
         ctx.x_needs_grad = x.requires_grad
+        ctx.bn_mine = None
+        if bn_out is not None:
+            ctx.bn_mine = ops.BnBwdSums(y2, a2[0], a2[1], act2)
+            bn_out.append(ctx.bn_mine)
         ctx.save_for_backward(x, y1, h, y2, *a1, *a2)
         return z
 
@@ -104,18 +124,23 @@ class BottleneckFn(Function):
         x, y1, h, y2, s1, b1, m1, i1, s2, b2, m2, i2 = ctx.saved_tensors
         cs1, bs1, cs2, bs2, act1, act2 = ctx.meta
         dz = _dense_or_slice(dz)
-        dy2 = ops.bn_act_bwd(dz, y2, bs2.gamma, s2, b2, m2, i2, act2, bs2.ggamma, bs2.gbeta)
+        part2 = ctx.bn_mine.take(dz) if ctx.bn_mine is not None else None
+        dy2 = ops.bn_act_bwd(dz, y2, bs2.gamma, s2, b2, m2, i2, act2, bs2.ggamma, bs2.gbeta, partial=part2)
         if ctx.w_needs_grad:
             _wgrad(h, dy2, cs2)
-        dh = ops.conv2d_dgrad(dy2, cs2.transposed(), (h.shape[1], h.shape[2]), cs2.stride, cs2.pad)
-        dy1 = ops.bn_act_bwd(dh, y1, bs1.gamma, s1, b1, m1, i1, act1, bs1.ggamma, bs1.gbeta)
+        # h = act(BN1(y1)) has exactly one consumer (cv2, inside this node): the reduce pass of BN1's backward rides
+        # the epilogue of cv2's dgrad
+        inner = ops.BnBwdSums(y1, s1, b1, act1) if FUSE_BN_BWD else None
+        dh = ops.conv2d_dgrad(dy2, cs2.transposed(), (h.shape[1], h.shape[2]), cs2.stride, cs2.pad, bn=inner)
+        dy1 = ops.bn_act_bwd(dh, y1, bs1.gamma, s1, b1, m1, i1, act1, bs1.ggamma, bs1.gbeta,
+                             partial=inner.take(dh) if inner is not None else None)
         if ctx.w_needs_grad:
             _wgrad(x, dy1, cs1)
         dx = None
         if ctx.x_needs_grad:
             dx = ops.conv2d_dgrad(dy1, cs1.transposed(), (x.shape[1], x.shape[2]), cs1.stride, cs1.pad,
-                                  residual=dz)
-        return (dx,) + (None,) * 11
+                                  residual=dz, bn=ctx.bn_in)
+        return (dx,) + (None,) * 13
 
 
 def c3_stem_fusable(cs1, bs1, cs2, bs2):
@@ -145,7 +170,8 @@ class C3StemFn(Function):
     concat [m(cv1(x)) | cv2(x)] that cv3 reads -- no copy."""
 
     @staticmethod
-    def forward(ctx, x, w1, w2, cs1, bs1, cs2, bs2, act, nbt1, nbt2, buf):
+    def forward(ctx, x, w1, w2, cs1, bs1, cs2, bs2, act, nbt1, nbt2, buf, bn_out=None):
+        # bn_out: receives the BnBwdSums of the cv1 half (t), whose sole consumer is the first bottleneck
         ctx.w_needs_grad = w1.requires_grad or w2.requires_grad
         c = cs1.cout
         wf = cs1.w_lp.as_strided((2 * c, 1, 1, cs1.cinp), (cs1.cinp, cs1.cinp, cs1.cinp, 1), cs1.w_lp.storage_offset())
@@ -160,6 +186,10 @@ class C3StemFn(Function):
         y2 = ops.bn_act_fwd(y[..., c:], aff[0][c:], aff[1][c:], act, out=buf[..., 2 * c:])
         ctx.meta = (cs1, bs1, cs2, bs2, act)
         ctx.x_needs_grad = x.requires_grad
+        ctx.bn_mine = None
+        if bn_out is not None:
+            ctx.bn_mine = ops.BnBwdSums(y[..., :c], aff[0][:c], aff[1][:c], act)
+            bn_out.append(ctx.bn_mine)
         ctx.save_for_backward(x, y, *aff)
         return t, y2
 
@@ -175,15 +205,17 @@ class C3StemFn(Function):
             if g is None:
                 dy[..., sl].zero_()
                 continue
-            ops.bn_act_bwd(_dense_or_slice(g), y[..., sl], bs.gamma, scale[sl], shift[sl], mean[sl], invstd[sl], act,
-                           bs.ggamma, bs.gbeta, out=dy[..., sl])
+            g = _dense_or_slice(g)
+            part = ctx.bn_mine.take(g) if (ctx.bn_mine is not None and sl.start == 0) else None
+            ops.bn_act_bwd(g, y[..., sl], bs.gamma, scale[sl], shift[sl], mean[sl], invstd[sl], act,
+                           bs.ggamma, bs.gbeta, out=dy[..., sl], partial=part)
         if ctx.w_needs_grad:
             _wgrad(x, dy, cs1, cs2)
         dx = None
         if ctx.x_needs_grad:
             wf = cs1.w_lp.as_strided((2 * c, 1, 1, cs1.cinp), (cs1.cinp, cs1.cinp, cs1.cinp, 1), cs1.w_lp.storage_offset())
             dx = ops.conv2d_dgrad(dy, ops.weight_transpose(wf), (x.shape[1], x.shape[2]), 1, 0)
-        return (dx,) + (None,) * 10
+        return (dx,) + (None,) * 11
 
 
 class _GradDst:

@@ -85,6 +85,15 @@ struct Epilogue {
     int ldr;
     float* stats;           // partial BN statistics [gridDim.x][2][Cout] or null
     int accumulate;         // out += result
+    // BatchNorm-BACKWARD statistics of the layer whose activation gradient this launch produces (dgrad only): with
+    // bn_y set, `stats` receives per-tile sums of  du = v * act'(y*bn_scale + bn_shift)  and  du * y  over the final
+    // values v (after residual / accumulate) instead of the forward sums -- the reduce pass of et_bn_act_bwd is then
+    // skipped for this tensor (its dz / y re-read, 4 B per element, becomes one y read inside this epilogue)
+    const void* bn_y;
+    int ld_bn;
+    const float* bn_scale;
+    const float* bn_shift;
+    int bn_act;
 };
 
 // Workgroup -> tile.  The launch is 1-D over ntm x ntn tiles.  Workgroups are dealt round-robin to the 8 XCDs
@@ -223,6 +232,15 @@ __device__ __forceinline__ void conv_epilogue_act(f32x16 (&acc)[BM / WM / 32][BN
     }
     const int srow = lane / CVN, scv = lane % CVN;  // this lane's (row, channel group) in the store phase
     const int co = n0 + wn * WCOLS + scv * 8;
+    // BN-backward statistics mode: this lane owns 8 channels in the store phase; per-channel affine in registers
+    const bool bnb = ep.bn_y != nullptr;
+    float bsc[8], bsh[8], bs1[8], bs2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { bsc[e] = 1.f; bsh[e] = 0.f; bs1[e] = 0.f; bs2[e] = 0.f; }
+    if (bnb && co + 8 <= g.Cout) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { bsc[e] = ep.bn_scale[co + e]; bsh[e] = ep.bn_shift[co + e]; }
+    }
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
@@ -277,8 +295,26 @@ __device__ __forceinline__ void conv_epilogue_act(f32x16 (&acc)[BM / WM / 32][BN
                             v[4] += __uint_as_float(rr.z << 16); v[5] += __uint_as_float(rr.z & 0xffff0000u);
                             v[6] += __uint_as_float(rr.w << 16); v[7] += __uint_as_float(rr.w & 0xffff0000u);
                         }
-                        *(u32x4*)yp = mk4(et_pack_bf2(v[0], v[1]), et_pack_bf2(v[2], v[3]), et_pack_bf2(v[4], v[5]),
-                                          et_pack_bf2(v[6], v[7]));
+                        const u32x4 packed = mk4(et_pack_bf2(v[0], v[1]), et_pack_bf2(v[2], v[3]), et_pack_bf2(v[4], v[5]),
+                                                 et_pack_bf2(v[6], v[7]));
+                        *(u32x4*)yp = packed;
+                        if (bnb) {
+                            // statistics of exactly what the apply pass will read back: the bf16-ROUNDED dz
+                            const u32x4 yy = *(const u32x4*)((const T*)ep.bn_y + pix * ep.ld_bn + co);
+                            const unsigned pw[4] = {packed.x, packed.y, packed.z, packed.w}, yw[4] = {yy.x, yy.y, yy.z, yy.w};
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                const float dz = __uint_as_float((e & 1) ? (pw[e >> 1] & 0xffff0000u) : (pw[e >> 1] << 16));
+                                const float yv = __uint_as_float((e & 1) ? (yw[e >> 1] & 0xffff0000u) : (yw[e >> 1] << 16));
+                                const float u = yv * bsc[e] + bsh[e];
+                                float gact = 1.f;
+                                if (ep.bn_act == ACT_SILU) { const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-u)); gact = sg * (1.0f + u * (1.0f - sg)); }
+                                else if (ep.bn_act == ACT_RELU) gact = u > 0.f ? 1.f : 0.f;
+                                const float du = dz * gact;
+                                bs1[e] += du;
+                                bs2[e] += du * yv;
+                            }
+                        }
                     } else {
                         if (ep.res) {
                             const float* rp = (const float*)ep.res + pix * ep.ldr + co;
@@ -291,6 +327,21 @@ __device__ __forceinline__ void conv_epilogue_act(f32x16 (&acc)[BM / WM / 32][BN
                         }
                         *(float4*)yp = make_float4(v[0], v[1], v[2], v[3]);
                         *(float4*)((float*)yp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                        if (bnb) {
+                            const float* bp = (const float*)ep.bn_y + pix * ep.ld_bn + co;
+                            const float4 y0 = *(const float4*)bp, y1 = *(const float4*)(bp + 4);
+                            const float yv8[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                const float u = yv8[e] * bsc[e] + bsh[e];
+                                float gact = 1.f;
+                                if (ep.bn_act == ACT_SILU) { const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-u)); gact = sg * (1.0f + u * (1.0f - sg)); }
+                                else if (ep.bn_act == ACT_RELU) gact = u > 0.f ? 1.f : 0.f;
+                                const float du = v[e] * gact;
+                                bs1[e] += du;
+                                bs2[e] += du * yv8[e];
+                            }
+                        }
                     }
                 } else {
                     for (int e = 0; e < 8 && co + e < g.Cout; ++e) {
@@ -305,6 +356,22 @@ __device__ __forceinline__ void conv_epilogue_act(f32x16 (&acc)[BM / WM / 32][BN
         __builtin_amdgcn_s_waitcnt(0xC07F);        // slab reads done before the next 32 rows overwrite it
         __builtin_amdgcn_wave_barrier();
     }
+    if (bnb) {
+        // lanes of a wave that share a channel group (same scv, different srow) are CVN apart: xor-reduce over the srow bits,
+        // then hand the 8 channel sums of lane scv to the [WM][BN][2] reduction the forward statistics use
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            for (int m = CVN; m < 64; m <<= 1) { bs1[e] += __shfl_xor(bs1[e], m); bs2[e] += __shfl_xor(bs2[e], m); }
+        float* red = (float*)lds_raw + WM * WN * L::SLAB;
+        if (lane < CVN) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int c = wn * WCOLS + scv * 8 + e;
+                red[(wm * BN + c) * 2 + 0] = bs1[e];
+                red[(wm * BN + c) * 2 + 1] = bs2[e];
+            }
+        }
+    }
     ET_TS(6);
     if (ep.stats) {
         // rows beyond M were zero-filled, so they add nothing.  Reduce lane halves, then the WM waves
@@ -314,7 +381,7 @@ __device__ __forceinline__ void conv_epilogue_act(f32x16 (&acc)[BM / WM / 32][BN
         for (int tn = 0; tn < TN; ++tn) {
             const float s = ssum[tn] + __shfl_xor(ssum[tn], 32);
             const float q = ssq[tn] + __shfl_xor(ssq[tn], 32);
-            if (hi == 0) {
+            if (hi == 0 && !bnb) {
                 const int c = wn * WCOLS + tn * 32 + l31;
                 red[(wm * BN + c) * 2 + 0] = s;
                 red[(wm * BN + c) * 2 + 1] = q;
@@ -1516,14 +1583,15 @@ extern "C" int et_conv2d_fwd(const void* x, const void* w, void* y, int dtype, i
     return 0;
 }
 
-extern "C" int et_conv2d_dgrad(const void* dy, const void* wT, void* dx, int dtype, int N, int IH, int IW, int Cin,
-                               int ldx, int Cout, int KH, int KW, int stride, int pad, int ldy, int accumulate,
-                               const void* residual, int ldr,
-                               const void* zero16, et_stream_t stream) {
+static int conv2d_dgrad_impl(const void* dy, const void* wT, void* dx, int dtype, int N, int IH, int IW, int Cin,
+                             int ldx, int Cout, int KH, int KW, int stride, int pad, int ldy, int accumulate,
+                             const void* residual, int ldr, const void* bn_y, int ld_bn, const float* bn_scale,
+                             const float* bn_shift, int bn_act, float* bn_stats, const void* zero16, et_stream_t stream) {
     // dx[n,iy,ix,ci] = sum_{ky,kx,co} dy[n,(iy+pad-ky)/s,(ix+pad-kx)/s,co] * wT[ci,ky,kx,co]
     if (!dy || !wT || !dx) return -1;
     if (KH * KW > CONV_MAX_TAPS || stride < 1 || stride > 2 || N <= 0) return -2;
     if (residual && stride != 1) return -2;        // the fused shortcut-gradient add is a stride-1 (Bottleneck) feature
+    if (bn_y && (stride != 1 || !bn_scale || !bn_shift || !bn_stats || Cin % 8)) return -2;   // one launch, whole channel groups
     const int OH = (IH + 2 * pad - KH) / stride + 1, OW = (IW + 2 * pad - KW) / stride + 1;
     const int vec = dtype == ET_F32 ? 4 : 8;
     for (int py = 0; py < stride; ++py)
@@ -1549,7 +1617,8 @@ extern "C" int et_conv2d_dgrad(const void* dy, const void* wT, void* dx, int dty
             // the "gathered" tensor of dgrad is dy (OH x OW x Cout), the written one is dx (IH x IW x Cin)
             int rc = fill_common(g, N, OH, OW, Cout, ldy, QH, QW, IH, IW, Cin, ldx, vec);
             if (rc) return rc;
-            Epilogue ep{nullptr, nullptr, ACT_NONE, residual, ldr, nullptr, accumulate};   // dx = dgrad (+ residual)
+            Epilogue ep{nullptr, nullptr, ACT_NONE, residual, ldr, bn_y ? bn_stats : nullptr, accumulate,
+                        bn_y, ld_bn, bn_scale, bn_shift, bn_act};   // dx = dgrad (+ residual) (+ BN-backward sums)
             if (t == 0) return -2;   // would need a zero fill; does not occur for k>=stride
             if (dtype == ET_F32) rc = launch_gemm<float>(dy, wT, dx, zero16, g, ep, (hipStream_t)stream);
             else if (dtype == ET_BF16) rc = launch_gemm<uint16_t>(dy, wT, dx, zero16, g, ep, (hipStream_t)stream);
@@ -1558,6 +1627,23 @@ extern "C" int et_conv2d_dgrad(const void* dy, const void* wT, void* dx, int dty
         }
     ET_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int et_conv2d_dgrad(const void* dy, const void* wT, void* dx, int dtype, int N, int IH, int IW, int Cin,
+                               int ldx, int Cout, int KH, int KW, int stride, int pad, int ldy, int accumulate,
+                               const void* residual, int ldr,
+                               const void* zero16, et_stream_t stream) {
+    return conv2d_dgrad_impl(dy, wT, dx, dtype, N, IH, IW, Cin, ldx, Cout, KH, KW, stride, pad, ldy, accumulate, residual, ldr,
+                             nullptr, 0, nullptr, nullptr, 0, nullptr, zero16, stream);
+}
+
+extern "C" int et_conv2d_dgrad_bn(const void* dy, const void* wT, void* dx, int dtype, int N, int IH, int IW, int Cin,
+                                  int ldx, int Cout, int KH, int KW, int pad, int ldy, const void* residual, int ldr,
+                                  const void* bn_y, int ld_bn, const float* bn_scale, const float* bn_shift, int bn_act,
+                                  float* bn_stats_partial, const void* zero16, et_stream_t stream) {
+    if (!bn_y) return -1;
+    return conv2d_dgrad_impl(dy, wT, dx, dtype, N, IH, IW, Cin, ldx, Cout, KH, KW, 1, pad, ldy, 0, residual, ldr, bn_y, ld_bn,
+                             bn_scale, bn_shift, bn_act, bn_stats_partial, zero16, stream);
 }
 
 struct WgradPlan { bool tr; int bm, bn; };

@@ -61,6 +61,7 @@ struct BnFwdFin {
 };
 struct BnBwdFin {
     float count; const float* gamma; const float* invstd; float* dgamma; float* dbeta; float* k0; float* k1; float* k2;
+    const float* mean;      // not null: the second total is sum(du * y) (conv-epilogue partials), converted here to sum(du * xhat)
 };
 
 __device__ __forceinline__ void bn_finalize_channel(const BnFwdFin& f, int c, double S, double Q) {
@@ -80,6 +81,7 @@ __device__ __forceinline__ void bn_finalize_channel(const BnFwdFin& f, int c, do
 }
 // dbeta += s1, dgamma += s2, coefficients of pass 2
 __device__ __forceinline__ void bn_finalize_channel(const BnBwdFin& f, int c, double S, double Q) {
+    if (f.mean) Q = (double)f.invstd[c] * (Q - (double)f.mean[c] * S);
     if (f.dbeta) f.dbeta[c] += (float)S;
     if (f.dgamma) f.dgamma[c] += (float)Q;
     f.k0[c] = f.gamma[c] * f.invstd[c];
@@ -411,7 +413,7 @@ extern "C" int et_bn_act_bwd(const void* dz, int lddz, const void* y, int ldy, v
         ET_ACT_LAUNCH(bn_act_bwd_reduce_kernel, uint16_t, act, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)dz, lddz,
                       (const uint16_t*)y, ldy, P, CV, scale, shift, save_mean, save_invstd, part);
     else return -2;
-    const BnBwdFin fin{(float)P, gamma, save_invstd, dgamma, dbeta, k0, k1, k2};
+    const BnBwdFin fin{(float)P, gamma, save_invstd, dgamma, dbeta, k0, k1, k2, nullptr};
     launch_rows_reduce_finalize(part, rows, C, tot, fin, (hipStream_t)stream);
     if (dtype == ET_F32)
         ET_ACT_LAUNCH(bn_act_bwd_apply_kernel, float, act, grid, dim3(256), 0, (hipStream_t)stream, (const float*)dz, lddz,
@@ -419,6 +421,35 @@ extern "C" int et_bn_act_bwd(const void* dz, int lddz, const void* y, int ldy, v
     else
         ET_ACT_LAUNCH(bn_act_bwd_apply_kernel, uint16_t, act, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)dz, lddz,
                       (const uint16_t*)y, ldy, (uint16_t*)dy, lddy, P, CV, scale, shift, save_mean, save_invstd, k0, k1, k2);
+    ET_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int et_bn_act_bwd_from_partials(const void* dz, int lddz, const void* y, int ldy, void* dy, int lddy, int dtype, int P,
+                                           int C, const float* gamma, const float* scale, const float* shift,
+                                           const float* save_mean, const float* save_invstd, int act, float* dgamma,
+                                           float* dbeta, double* totals, const float* partials, int partial_rows,
+                                           float* workspace /* 3*C floats */, et_stream_t stream) {
+    // the reduce pass has been done by the producer of dz (et_conv2d_dgrad_bn): partials (partial_rows, 2, C) hold per-tile
+    // sums of du and du*y.  Finalize (one small launch) + the apply pass only.
+    if (!dz || !y || !dy || !gamma || !scale || !shift || !save_mean || !save_invstd || !workspace || !totals || !partials) return -1;
+    const int vec = dtype == ET_F32 ? 4 : 8;
+    if (P <= 0 || C <= 0 || C > 2048 || C % vec || lddz % vec || ldy % vec || lddy % vec || partial_rows <= 0) return -2;
+    if (((uintptr_t)totals) & 7) return -3;
+    const int CV = C / vec;
+    float* k0 = workspace;
+    float* k1 = k0 + C;
+    float* k2 = k1 + C;
+    const BnBwdFin fin{(float)P, gamma, save_invstd, dgamma, dbeta, k0, k1, k2, save_mean};
+    launch_rows_reduce_finalize(partials, partial_rows, C, totals, fin, (hipStream_t)stream);
+    const dim3 grid(ew_blocks(P, CV, 16));
+    if (dtype == ET_F32)
+        ET_ACT_LAUNCH(bn_act_bwd_apply_kernel, float, act, grid, dim3(256), 0, (hipStream_t)stream, (const float*)dz, lddz,
+                      (const float*)y, ldy, (float*)dy, lddy, P, CV, scale, shift, save_mean, save_invstd, k0, k1, k2);
+    else if (dtype == ET_BF16)
+        ET_ACT_LAUNCH(bn_act_bwd_apply_kernel, uint16_t, act, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)dz, lddz,
+                      (const uint16_t*)y, ldy, (uint16_t*)dy, lddy, P, CV, scale, shift, save_mean, save_invstd, k0, k1, k2);
+    else return -2;
     ET_CHECK_LAUNCH();
     return 0;
 }

@@ -37,6 +37,65 @@ extern "C" int et_ema_update(float* ema, const float* model, int64_t n, float d,
     return 0;
 }
 
+// Hyper-parameters in DEVICE memory (et_*_dev entry points): a captured HIP graph of the training step must not bake
+// this step's lr / momentum / EMA decay into its kernel arguments -- warm-up, the lr schedule and ModelEMA's decay ramp
+// change them from step to step.  The host writes a few floats before each replay; the arithmetic is unchanged.
+__global__ __launch_bounds__(256) void ema_dev_kernel(float* __restrict__ v, const float* __restrict__ m, long long n,
+                                                      const float* __restrict__ d2) {
+    const float d = d2[0], omd = d2[1];
+    const long long i4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i4 + 3 < n) {
+        float4 a = *(float4*)(v + i4);
+        const float4 b = *(const float4*)(m + i4);
+        a.x = a.x * d; a.x = a.x + omd * b.x;
+        a.y = a.y * d; a.y = a.y + omd * b.y;
+        a.z = a.z * d; a.z = a.z + omd * b.z;
+        a.w = a.w * d; a.w = a.w + omd * b.w;
+        *(float4*)(v + i4) = a;
+    } else {
+        for (long long i = i4; i < n; ++i) { float a = v[i] * d; v[i] = a + omd * m[i]; }
+    }
+}
+
+extern "C" int et_ema_update_dev(float* ema, const float* model, int64_t n, const float* d_and_one_minus_d, et_stream_t stream) {
+    if (!ema || !model || !d_and_one_minus_d) return -1;
+    if (n < 0 || (((uintptr_t)ema | (uintptr_t)model) & 15)) return -2;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(ema_dev_kernel, dim3(et_cdiv(n, 1024)), dim3(256), 0, (hipStream_t)stream, ema, model, (long long)n,
+                       d_and_one_minus_d);
+    ET_CHECK_LAUNCH();
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void sgd_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+                                                      uint16_t* __restrict__ shadow, long long n, const float* __restrict__ hp,
+                                                      int first) {
+    const float lr = hp[0], mu = hp[1], wd = hp[2], inv_scale = hp[3];
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float gi = g[i] * inv_scale;
+    const float pi = p[i];
+    if (wd != 0.0f) gi = gi + wd * pi;
+    float b = first ? gi : (buf[i] * mu + gi);
+    buf[i] = b;
+    gi = gi + mu * b;
+    const float o = pi - lr * gi;
+    p[i] = o;
+    if (shadow) shadow[i] = et_f2bf(o);
+}
+
+extern "C" int et_sgd_nesterov_dev(float* p, const float* grad, float* momentum_buf, void* bf16_shadow, int64_t n,
+                                   const float* hp /* device: lr, momentum, weight_decay, inv_scale */, int first_step,
+                                   et_stream_t stream) {
+    if (!p || !grad || !momentum_buf || !hp) return -1;
+    if (n < 0) return -2;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(sgd_dev_kernel, dim3(et_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, p, grad, momentum_buf,
+                       (uint16_t*)bf16_shadow, (long long)n, hp, first_step);
+    ET_CHECK_LAUNCH();
+    return 0;
+}
+
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                   float* __restrict__ buf, uint16_t* __restrict__ shadow,
                                                   long long n, float lr, float mu, float wd, int first,

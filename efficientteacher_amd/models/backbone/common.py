@@ -10,6 +10,7 @@ import torch
 import torch.nn as nn
 
 from ... import ops
+from ... import autograd as _ag
 from ...autograd import BottleneckFn, C3StemFn, ConvBnActFn, JoinSlicesFn, SppfPoolFn, c3_stem_fusable
 
 
@@ -58,8 +59,10 @@ class Conv(nn.Module):
         self.bn = nn.BatchNorm2d(c2)
         self.act, self.act_name = get_activation(act=act)
 
-    def forward(self, x, residual=None, dst=None):
-        """dst = (buffer, channel offset): produce the output in place inside a wider NHWC buffer."""
+    def forward(self, x, residual=None, dst=None, bn_in=None, bn_out=None):
+        """dst = (buffer, channel offset): produce the output in place inside a wider NHWC buffer.
+        bn_in / bn_out: BatchNorm-backward hand-over between a block and the SOLE consumer of its output
+        (autograd.ConvBnActFn); only callers that know the graph pass them."""
         cs = getattr(self.conv, "_et_slot", None)
         if cs is None:
             raise RuntimeError("model state is not on the device arenas yet: move the Model to a GPU "
@@ -68,7 +71,7 @@ class Conv(nn.Module):
         act = _act_code(self.act)
         if self.bn.training:
             nbt = None if self._et_flat().bulk_nbt else self.bn.num_batches_tracked   # bulk: bumped once per forward
-            return ConvBnActFn.apply(x, residual, self.conv.weight, cs, bs, act, nbt, dst)
+            return ConvBnActFn.apply(x, residual, self.conv.weight, cs, bs, act, nbt, dst, bn_in, bn_out)
         # eval (EMA teacher): BatchNorm is an affine of the running statistics, folded into the conv epilogue
         flat = self._et_flat()
         o = bs.aff_off
@@ -92,7 +95,9 @@ class Bottleneck(nn.Module):
         self.cv2 = Conv(c_, c2, k[1], 1, g=g, act=act)
         self.add = shortcut and c1 == c2
 
-    def forward(self, x, dst=None):
+    def forward(self, x, dst=None, bn_in=None, bn_out=None):
+        """bn_in: the BatchNorm-backward hand-over of x's producer when this block is x's only consumer; bn_out: list
+        that receives this block's own hand-over for the only consumer of its output (C3.forward knows both)."""
         c1, c2 = self.cv1, self.cv2
         if (self.add and c1.bn.training and c2.bn.training and torch.is_grad_enabled() and c1.conv.stride[0] == 1
                 and getattr(c1.conv, "_et_slot", None) is not None):
@@ -101,8 +106,12 @@ class Bottleneck(nn.Module):
             return BottleneckFn.apply(x, c1.conv.weight, c2.conv.weight, c1.conv._et_slot, c1.bn._et_slot,
                                       c2.conv._et_slot, c2.bn._et_slot, _act_code(c1.act), _act_code(c2.act),
                                       None if bulk else c1.bn.num_batches_tracked,
-                                      None if bulk else c2.bn.num_batches_tracked, dst)
-        return self.cv2(self.cv1(x), residual=x if self.add else None, dst=dst)
+                                      None if bulk else c2.bn.num_batches_tracked, dst, bn_in, bn_out)
+        if self.add or not (c1.bn.training and torch.is_grad_enabled() and _ag.FUSE_BN_BWD):
+            return self.cv2(self.cv1(x), residual=x if self.add else None, dst=dst)
+        mid = []                                  # cv1's output has one consumer: cv2
+        h = self.cv1(x, bn_in=bn_in, bn_out=mid)
+        return self.cv2(h, dst=dst, bn_in=mid[0] if mid else None, bn_out=bn_out)
 
 
 class C3(nn.Module):
@@ -136,18 +145,26 @@ class C3(nn.Module):
             # train mode: cv1 | cv2 as one GEMM (C3StemFn); buf = [cv1(x) | m(cv1(x)) | cv2(x)]
             buf = torch.empty((N, H, W, 3 * c_), dtype=x.dtype, device=x.device)
             bulk = self.cv1._et_flat().bulk_nbt
-            t, y2 = C3StemFn.apply(x, self.cv1.conv.weight, self.cv2.conv.weight, c1s, self.cv1.bn._et_slot, c2s,
+            fuse = _ag.FUSE_BN_BWD
+            hand = [] if fuse else None       # BatchNorm-backward hand-over along the chain t -> m[0] -> m[1] -> ...: every link
+            t, y2 = C3StemFn.apply(x, self.cv1.conv.weight, self.cv2.conv.weight, c1s, self.cv1.bn._et_slot, c2s,   # has ONE consumer
                                    self.cv2.bn._et_slot, _act_code(self.cv1.act),
                                    None if bulk else self.cv1.bn.num_batches_tracked,
-                                   None if bulk else self.cv2.bn.num_batches_tracked, buf)
+                                   None if bulk else self.cv2.bn.num_batches_tracked, buf, hand)
             for i, b in enumerate(self.m):
-                t = b(t, dst=(buf, c_) if i == last else None)
+                nxt = [] if (fuse and i != last) else None
+                t = b(t, dst=(buf, c_) if i == last else None, bn_in=hand[0] if hand else None, bn_out=nxt)
+                hand = nxt
             return self.cv3(JoinSlicesFn.apply((buf[..., c_:],), t, y2))
         buf = torch.empty((N, H, W, 2 * c_), dtype=x.dtype, device=x.device)
         y2 = self.cv2(x, dst=(buf, c_))
-        t = self.cv1(x)
+        train = self.cv1.bn.training and torch.is_grad_enabled() and _ag.FUSE_BN_BWD and len(self.m) > 0
+        hand = [] if train else None
+        t = self.cv1(x, bn_out=hand)
         for i, b in enumerate(self.m):
-            t = b(t, dst=(buf, 0) if i == last else None)
+            nxt = [] if (train and i != last) else None
+            t = b(t, dst=(buf, 0) if i == last else None, bn_in=hand[0] if hand else None, bn_out=nxt)
+            hand = nxt
         if torch.is_grad_enabled() and (t.requires_grad or y2.requires_grad):
             cat = JoinSlicesFn.apply((buf,), t, y2)
         else:

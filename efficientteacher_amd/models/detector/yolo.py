@@ -149,7 +149,8 @@ class Model(nn.Module):
         flat.prepare_forward(self.training)
         if x.dim() != 4 or x.shape[1] > 8:
             raise ValueError("expected an NCHW image batch (B, 3, H, W)")
-        x8 = ops.pack_input(x, self._compute_dtype)
+        # uint8 batches (what the loaders deliver) are normalised inside the pack kernel: x / 255 (ssod_trainer.py:694-696)
+        x8 = ops.pack_input(x, self._compute_dtype, norm_scale=getattr(self, "input_norm_scale", 255.0))
         return self.neck(self.backbone(x8))
 
     def _forward_once(self, x, profile=False, visualize=False):

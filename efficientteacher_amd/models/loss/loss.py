@@ -83,11 +83,14 @@ class ComputeLoss:
                     cls_pw=self.cls_pw, obj_pw=self.obj_pw, box_w=float(self.box_w), obj_w=float(self.obj_w),
                     cls_w=float(self.cls_w))
 
-    def default_loss(self, p, targets):
+    def default_loss(self, p, targets, table=None):
+        """table: a ready (NT, 8) device table [img, cls, x, y, w, h, score, flags] (rows with flags 0 are padding) instead
+        of `targets` -- the fixed-capacity form the captured step graph replays (trainer/graph_step.py)."""
         dev = p[0].device
-        t = targets[:, :6].to(device=dev, dtype=torch.float32)
-        n = t.shape[0]
-        table = torch.cat((t, torch.zeros((n, 1), device=dev), torch.ones((n, 1), device=dev)), 1)
+        if table is None:
+            t = targets[:, :6].to(device=dev, dtype=torch.float32)
+            n = t.shape[0]
+            table = torch.cat((t, torch.zeros((n, 1), device=dev), torch.ones((n, 1), device=dev)), 1)
         hp = self._hp()
         hp["grad_dst"] = [getattr(pi, "_et_grad_dst", None) for pi in p]
         out = YoloLossFn.apply(table, hp, self._anchors_host, self.balance, *p)

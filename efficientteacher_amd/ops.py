@@ -140,11 +140,12 @@ class WgradQueue:
     the backward pass (autograd engine callback); ``on_done`` callbacks (gradient-ready hooks of the data-parallel
     wrapper) run right after the launch that covers their layer.  ET_WGRAD_GROUP=1 launches every layer at once.
 
-    Nothing in backward consumes a weight gradient, so on a GPU the grouped launches go to a second HIP stream
-    (ET_WGRAD_STREAM=0 keeps them on the launching stream): the MFMA-bound wgrad workgroups then fill the CUs the
-    critical path leaves idle -- the partially filled last residency round of every dgrad (YOLOv5's pixel counts are
-    25 * 2^k: 400 tiles on 256 CUs run as two rounds), the HBM-write burst of its epilogue, and the HBM-bound
-    BatchNorm backward passes.  Ordering: the side stream waits for the launching stream at every group launch (dy
+    Nothing in backward consumes a weight gradient, so on a GPU the grouped launches CAN go to a second HIP stream
+    (ET_WGRAD_STREAM=1): the MFMA-bound wgrad workgroups then fill the CUs the critical path leaves idle -- the partially
+    filled last residency round of every dgrad (YOLOv5's pixel counts are 25 * 2^k: 400 tiles on 256 CUs run as two
+    rounds), the HBM-write burst of its epilogue, and the HBM-bound BatchNorm backward passes.  Measured on the YOLOv5l
+    SSOD step (gpurun g3): 62.3 vs 62.8 ms per step -- the step is throughput-bound, the teacher stream already fills those
+    gaps -- so the default keeps the launches on the launching stream; the stream is kept for small-batch runs.  Ordering: the side stream waits for the launching stream at every group launch (dy
     and x are complete), the launching stream joins the side stream at the end of backward (before the optimizer /
     the final all-reduces); gradient-ready hooks run with the side stream current, so an RCCL all-reduce they start
     is ordered behind the wgrads it covers."""
@@ -157,7 +158,7 @@ class WgradQueue:
         self.last = {}
         self.tick = 0
         self._cb_armed = False
-        self.use_side = os.environ.get("ET_WGRAD_STREAM", "1") != "0"
+        self.use_side = os.environ.get("ET_WGRAD_STREAM", "0") == "1"
         self._side = {}              # device -> side stream
         self._dirty = set()          # devices whose side stream holds work the launching stream has not joined yet
 
@@ -280,8 +281,26 @@ def weight_transpose_all(w_arena, wT_arena, table, total):
                "et_weight_transpose_all")
 
 
-def conv2d_dgrad(dy, wT, in_hw, stride, pad, *, out=None, accumulate=False, residual=None):
-    """dx (N, IH, IW, Cin) from dy (N, OH, OW, Cout) and wT (Cin, KH, KW, Cout)."""
+class BnBwdSums:
+    """What the dgrad of a CONSUMER layer needs to run the reduce pass of its PRODUCER's BatchNorm backward in its own
+    epilogue (et_conv2d_dgrad_bn): the producer's raw conv output y, folded affine and activation -- and, after that
+    dgrad has run, the partial sums it left plus the identity of the tensor they belong to."""
+    __slots__ = ("y", "scale", "shift", "act", "partial", "dz_ptr")
+
+    def __init__(self, y, scale, shift, act):
+        self.y, self.scale, self.shift, self.act = y, scale, shift, act
+        self.partial, self.dz_ptr = None, None
+
+    def take(self, dz):
+        """the partial sums, if `dz` is exactly the tensor they were computed on (else None: fall back to the reduce pass)"""
+        p = self.partial if (self.partial is not None and dz.data_ptr() == self.dz_ptr) else None
+        self.partial, self.dz_ptr = None, None
+        return p
+
+
+def conv2d_dgrad(dy, wT, in_hw, stride, pad, *, out=None, accumulate=False, residual=None, bn=None):
+    """dx (N, IH, IW, Cin) from dy (N, OH, OW, Cout) and wT (Cin, KH, KW, Cout).  bn (a BnBwdSums): dx is the activation
+    gradient of a Conv block whose BatchNorm-backward reduce pass runs in this launch's epilogue (stride 1 only)."""
     N, OH, OW, Cout = dy.shape
     Cin, KH, KW, Cout2 = wT.shape
     assert Cout == Cout2 and wT.dtype == dy.dtype
@@ -290,6 +309,22 @@ def conv2d_dgrad(dy, wT, in_hw, stride, pad, *, out=None, accumulate=False, resi
     if out is None:
         assert not accumulate
         out = torch.empty((N, IH, IW, Cin), dtype=dy.dtype, device=dy.device)
+    if bn is not None and stride == 1 and not accumulate and bn.y.shape == out.shape and bn.y.dtype == out.dtype:
+        lib = _lib.load()
+        rows = lib.et_conv2d_stats_rows(N, IH, IW)
+        part = torch.empty((rows, 2, Cin), dtype=torch.float32, device=dy.device)
+        ev = TIMER.span(kernel_name("dgrad", dy.dtype, N, IH, IW, Cin, Cout, KH, stride, pad), 2.0 * N * OH * OW * Cout * Cin * KH * KW,
+                        nbytes=(dy.numel() + 2 * N * IH * IW * Cin + wT.numel()) * dy.element_size()) if TIMER else None
+        if ev:
+            ev[0].record()
+        _lib.check(lib.et_conv2d_dgrad_bn(_lib.ptr(dy), _lib.ptr(wT), _lib.ptr(out), et_dtype(dy), N, IH, IW, Cin, _nhwc(out), Cout,
+                                          KH, KW, pad, _nhwc(dy), _lib.ptr(residual), _nhwc(residual) if residual is not None else 0,
+                                          _lib.ptr(bn.y), _nhwc(bn.y), _lib.ptr(bn.scale), _lib.ptr(bn.shift), bn.act,
+                                          _lib.ptr(part), _lib.ptr(zero_page(dy.device)), _lib.stream(dy)), "et_conv2d_dgrad_bn")
+        if ev:
+            ev[1].record()
+        bn.partial, bn.dz_ptr = part, out.data_ptr()
+        return out
     tag = (kernel_name("dgrad", dy.dtype, N, IH, IW, Cin, Cout, KH, stride, pad) if stride == 1 else
            "conv_gemm (stride-2 dgrad parity classes)") if TIMER else None
     ev = TIMER.span(tag, 2.0 * N * OH * OW * Cout * Cin * KH * KW,
@@ -366,11 +401,20 @@ def bn_act_fwd(y, scale, shift, act, residual=None, out=None):
     return out
 
 
-def bn_act_bwd(dz, y, gamma, scale, shift, mean, invstd, act, dgamma, dbeta, out=None):
+def bn_act_bwd(dz, y, gamma, scale, shift, mean, invstd, act, dgamma, dbeta, out=None, partial=None):
+    """partial: (rows, 2, C) sums left by the dgrad that produced dz (BnBwdSums.take) -- the reduce pass is skipped"""
     N, H, W, C = y.shape
     lib = _lib.load()
     if out is None:
         out = torch.empty((N, H, W, C), dtype=y.dtype, device=y.device)
+    if partial is not None:
+        ws = torch.empty(3 * C, dtype=torch.float32, device=y.device)
+        _lib.check(lib.et_bn_act_bwd_from_partials(_lib.ptr(dz), _nhwc(dz), _lib.ptr(y), _nhwc(y), _lib.ptr(out), _nhwc(out),
+                                                   et_dtype(y), N * H * W, C, _lib.ptr(gamma), _lib.ptr(scale), _lib.ptr(shift),
+                                                   _lib.ptr(mean), _lib.ptr(invstd), act, _lib.ptr(dgamma), _lib.ptr(dbeta),
+                                                   _lib.ptr(bn_totals_scratch(y.device)), _lib.ptr(partial), partial.shape[0],
+                                                   _lib.ptr(ws), _lib.stream(y)), "et_bn_act_bwd_from_partials")
+        return out
     rows = lib.et_bn_reduce_rows(N * H * W, C, et_dtype(y))
     nws = rows * 2 * C + 3 * C
     ws = torch.empty(nws, dtype=torch.float32, device=y.device)
@@ -392,12 +436,18 @@ def act_bwd(dz, y, act, out=None):
 
 
 # ---- spatial ----------------------------------------------------------------------------------------
-def pack_input(x_nchw, dtype):
-    """(B,3,H,W) fp32 NCHW -> (B,H,W,8) NHWC of `dtype`, channels zero padded."""
+def pack_input(x_nchw, dtype, norm_scale=255.0):
+    """(B,3,H,W) NCHW -> (B,H,W,8) NHWC of `dtype`, channels zero padded.  fp32 input: values as they are (already
+    normalised by the caller); uint8 input (the loaders' batches): (float)x / norm_scale in the same pass."""
     x = x_nchw.contiguous()
+    B, C, H, W = x.shape
+    if x.dtype == torch.uint8:
+        y = torch.empty((B, H, W, 8), dtype=dtype, device=x.device)
+        _lib.check(_lib.load().et_pack_input_u8(_lib.ptr(x), _lib.ptr(y), et_dtype(y), B, C, H, W, float(norm_scale), _lib.stream(x)),
+                   "et_pack_input_u8")
+        return y
     if x.dtype != torch.float32:
         x = x.float()
-    B, C, H, W = x.shape
     y = torch.empty((B, H, W, 8), dtype=dtype, device=x.device)
     _lib.check(_lib.load().et_pack_input(_lib.ptr(x), _lib.ptr(y), et_dtype(y), B, C, H, W, _lib.stream(x)),
                "et_pack_input")
@@ -457,13 +507,27 @@ def pseudo_label_transform(dets, counts, M_s, width, height):
     return t9, valid
 
 
+_THR_CACHE = {}
+
+
+def _threshold_tensor(values, dev):
+    """per-class thresholds as a device fp64 tensor, cached by value: the trainer rewrites the lists only when LabelMatch
+    adapts them (ssod_trainer.py:322-323), and a host->device copy of a temporary cannot live inside a captured graph"""
+    key = (tuple(float(v) for v in values), dev)
+    t = _THR_CACHE.get(key)
+    if t is None:
+        if len(_THR_CACHE) > 64:
+            _THR_CACHE.clear()
+        t = _THR_CACHE[key] = torch.as_tensor(key[0], dtype=torch.float64).to(dev)
+    return t
+
+
 def select_targets(targets9, valid, thr_low, thr_high, nc, with_obj):
     """(N,9) fp64 pseudo labels (+ optional valid mask) -> (N,8) fp32 target table for et_yolo_loss."""
     N = targets9.shape[0]
     dev = targets9.device
     t9 = targets9.to(torch.float64).contiguous()
-    lo = torch.as_tensor(thr_low, dtype=torch.float64).to(dev)
-    hi = torch.as_tensor(thr_high, dtype=torch.float64).to(dev)
+    lo, hi = _threshold_tensor(thr_low, dev), _threshold_tensor(thr_high, dev)
     table = torch.empty((N, 8), dtype=torch.float32, device=dev)
     _lib.check(_lib.load().et_select_targets(_lib.ptr(t9), _lib.ptr(valid), N, _lib.ptr(lo), _lib.ptr(hi), nc,
                                              int(bool(with_obj)), _lib.ptr(table), _lib.stream(t9)),
@@ -542,6 +606,20 @@ def ema_update(ema_flat, model_flat, d):
     assert ema_flat.numel() == model_flat.numel() and ema_flat.dtype == torch.float32
     _lib.check(_lib.load().et_ema_update(_lib.ptr(ema_flat), _lib.ptr(model_flat), ema_flat.numel(), float(d),
                                          float(1. - d), _lib.stream(ema_flat)), "et_ema_update")
+
+
+def ema_update_dev(ema_flat, model_flat, d2):
+    """the same with d2 = device tensor [d, 1-d] (graph-replayable form)"""
+    assert ema_flat.numel() == model_flat.numel() and ema_flat.dtype == torch.float32 and d2.dtype == torch.float32
+    _lib.check(_lib.load().et_ema_update_dev(_lib.ptr(ema_flat), _lib.ptr(model_flat), ema_flat.numel(), _lib.ptr(d2),
+                                             _lib.stream(ema_flat)), "et_ema_update_dev")
+
+
+def sgd_nesterov_dev(p, g, buf, shadow, hp, first_step):
+    """hp: device tensor [lr, momentum, weight_decay, inv_scale] (graph-replayable form)"""
+    assert hp.dtype == torch.float32 and hp.numel() >= 4
+    _lib.check(_lib.load().et_sgd_nesterov_dev(_lib.ptr(p), _lib.ptr(g), _lib.ptr(buf), _lib.ptr(shadow), p.numel(), _lib.ptr(hp),
+                                               int(bool(first_step)), _lib.stream(p)), "et_sgd_nesterov_dev")
 
 
 def sgd_nesterov(p, g, buf, shadow, lr, momentum, weight_decay, first_step, inv_scale=1.0):

@@ -32,6 +32,9 @@ class FlatSGD(torch.optim.Optimizer):
         self._model = model
         self.momentum_buf = torch.zeros_like(self.flat.params)
         self.first = True
+        # graph-replayable form: per-group [lr, momentum, weight_decay, inv_scale] in device memory (trainer/graph_step.py)
+        self.hp_dev = None
+        self.capturing = False       # only a graph capture launches the device-hyper-parameter kernels
 
     # the momentum arena and the first-step flag live outside Optimizer.state: carry them through checkpoints
     def state_dict(self):
@@ -63,13 +66,24 @@ class FlatSGD(torch.optim.Optimizer):
         # deferred weight-gradient launches must be in the arena (and their side stream joined) before it is read
         assert not ops.WGRAD_QUEUE.pending, "weight gradients still queued: backward() did not finish"
         ops.WGRAD_QUEUE.join()
-        for g in self.param_groups:
+        for j, g in enumerate(self.param_groups):
             o, n = g['range']
             shadow = f.shadow if (f.shadow is not None and (o, n) == tuple(f.w_range)) else None
-            ops.sgd_nesterov(f.params[o:o + n], f.grads[o:o + n], self.momentum_buf[o:o + n], shadow,
-                             g['lr'], g['momentum'], g['weight_decay'], self.first, inv_scale)
+            if self.capturing and self.hp_dev is not None:
+                ops.sgd_nesterov_dev(f.params[o:o + n], f.grads[o:o + n], self.momentum_buf[o:o + n], shadow, self.hp_dev[j],
+                                     self.first)
+            else:
+                ops.sgd_nesterov(f.params[o:o + n], f.grads[o:o + n], self.momentum_buf[o:o + n], shadow,
+                                 g['lr'], g['momentum'], g['weight_decay'], self.first, inv_scale)
         self.first = False
         f.w_version += 1                 # the compute-precision shadow changed: transposed copies are stale
+
+    def hp_values(self, inv_scale=1.0):
+        """flat list [lr, momentum, weight_decay, inv_scale] per group: what step() would pass by value right now"""
+        out = []
+        for g in self.param_groups:
+            out += [float(g['lr']), float(g['momentum']), float(g['weight_decay']), float(inv_scale)]
+        return out
 
     def zero_grad(self, set_to_none=False):
         self.flat.zero_grad()

@@ -42,6 +42,17 @@ class SSODTrainer(Trainer):
         self.teacher_pred_hook = None      # optional callable(teacher_pred) -> teacher_pred (bench: synthetic scores)
         self.overlap_teacher = True        # teacher forward + pseudo labels on a second stream
         self._side = None
+        # the step as one captured HIP graph (trainer/graph_step.py), opt-in: ET_STEP_GRAPH=1 or use_graph=True.  Measured on
+        # MI355X (profiles/r02_graph_step_timing.txt): issuing the ~750 launches of an eager step takes the host 18-24 ms, a
+        # replay 3 ms, and both finish in 64-65 ms -- at 32+32 images the step is GPU-bound, so eager stays the default and the
+        # graph is for small per-GPU batches.  The first `graph_warmup` steps always run eagerly (first-step flags, allocator,
+        # lazily created streams).
+        import os
+        self.use_graph = os.environ.get("ET_STEP_GRAPH", "0") == "1"
+        self.graph_warmup = 3
+        self._eager_steps = 0
+        self._capturing = False
+        self._graph = None
 
     def _side_stream(self):
         if self._side is None:
@@ -65,6 +76,13 @@ class SSODTrainer(Trainer):
 
     def update_optimizer(self, loss, ni):
         loss.backward()
+        if self._capturing:                # graph capture: launches only; the host-side schedule runs before each replay
+            self.optimizer.step()
+            self.optimizer.zero_grad()
+            self.ema.update(self.model)
+            if self.semi_ema:
+                self.semi_ema.update(self.ema.ema)
+            return
         if isinstance(self.model, FlatDataParallel):
             self.model.reduce_gradients()
         self.accumulate = 1 if self.fixed_accumulate else max(round(64 / self.batch_size), 1)
@@ -89,6 +107,23 @@ class SSODTrainer(Trainer):
 
     def train_instance(self, imgs, targets, paths, unlabeled_imgs, unlabeled_imgs_ori, unlabeled_gt, unlabeled_M, ni,
                        pbar=None, callbacks=None):
+        """reference signature (ssod_trainer.py:587).  After a few eager steps the whole step is replayed as one HIP graph."""
+        if self.use_graph and self.cuda and self._eager_steps >= self.graph_warmup:
+            accumulate = 1 if self.fixed_accumulate else max(round(64 / self.batch_size), 1)
+            if ni <= self.nw and not self.fixed_accumulate:
+                import numpy as np
+                accumulate = max(1, np.interp(ni, [0, self.nw], [1, 64 / self.batch_size]).round())
+            if self._graph is None:
+                from .graph_step import StepGraph
+                self._graph = StepGraph(self)
+            if accumulate == 1 and self._graph.usable(imgs, targets):
+                return self._graph.run(imgs, targets, unlabeled_imgs, unlabeled_imgs_ori, unlabeled_M, ni)
+        self._eager_steps += 1
+        return self._train_instance_eager(imgs, targets, paths, unlabeled_imgs, unlabeled_imgs_ori, unlabeled_gt, unlabeled_M, ni,
+                                          pbar, callbacks)
+
+    def _train_instance_eager(self, imgs, targets, paths, unlabeled_imgs, unlabeled_imgs_ori, unlabeled_gt, unlabeled_M, ni,
+                              pbar=None, callbacks=None, sup_table=None):
         n_img = imgs.shape[0]
         height, width = unlabeled_imgs.shape[2], unlabeled_imgs.shape[3]
         # 1+2 teacher forward (ssod_trainer.py:595-599: EMA model, eval, no grad) and pseudo labels (:618).
@@ -114,7 +149,10 @@ class SSODTrainer(Trainer):
                 t.record_stream(cur)
         sup_pred, sup_feature, un_sup_pred, un_sup_feature = self.split_predict_and_feature(total_pred, total_feature, n_img)
         # 4 losses (:628-649); the zero-weighted domain losses (:631-636) contribute nothing
-        sup_loss, sup_loss_items = self.compute_loss(sup_pred, targets.to(self.device))
+        if sup_table is not None:                      # graph capture: the padded device-resident target table
+            sup_loss, sup_loss_items = self.compute_loss.default_loss(sup_pred, None, table=sup_table)
+        else:
+            sup_loss, sup_loss_items = self.compute_loss(sup_pred, targets.to(self.device))
         if self.cfg.SSOD.with_da_loss:                 # ssod_trainer.py:631-634
             d_loss = self.domain_loss(sup_feature)
             t_loss = self.target_loss(un_sup_feature)

@@ -42,20 +42,37 @@ def initialize_weights(model):
             m.inplace = True
 
 
-def _flat_ema_update(ema_model, model, d):
-    """v = v*d + (1-d)*m for every floating state tensor (parameters AND buffers)."""
+def _flat_ema_update(ema_model, model, d, d_dev=None):
+    """v = v*d + (1-d)*m for every floating state tensor (parameters AND buffers).  d_dev: device tensor [d, 1-d]
+    (graph-replayable launch, the host value `d` is then not used)."""
     src = de_parallel(model)
     fe, fm = ema_model.flat_state(), src.flat_state()
-    ops.ema_update(fe.params, fm.params, d)
-    ops.ema_update(fe.buffers, fm.buffers, d)
+    if d_dev is not None:
+        ops.ema_update_dev(fe.params, fm.params, d_dev)
+        ops.ema_update_dev(fe.buffers, fm.buffers, d_dev)
+    else:
+        ops.ema_update(fe.params, fm.params, d)
+        ops.ema_update(fe.buffers, fm.buffers, d)
     fe.mark_weights_changed()
 
 
 class _EMABase:
+    d_dev = None          # device [d, 1-d]: set by trainer/graph_step.py, update() then launches the replayable kernels
+    capturing = False     # inside a graph capture nothing executes: update() must not advance the host-side schedule
+
     def _make(self, model):
         self.ema = deepcopy(de_parallel(model)).eval()  # FP32 EMA
         for p in self.ema.parameters():
             p.requires_grad_(False)
+
+    def advance(self):
+        """host side of one update: bump the counters, return the decay this update uses"""
+        raise NotImplementedError
+
+    def update(self, model):
+        with torch.no_grad():
+            d = None if self.capturing else self.advance()
+            _flat_ema_update(self.ema, model, d, self.d_dev if self.capturing else None)
 
     def update_attr(self, model, include=(), exclude=('process_group', 'reducer')):
         copy_attr(self.ema, model, include, exclude)
@@ -69,10 +86,9 @@ class ModelEMA(_EMABase):
         self.updates = updates
         self.decay = lambda x: decay * (1 - math.exp(-x / 2000))
 
-    def update(self, model):
-        with torch.no_grad():
-            self.updates += 1
-            _flat_ema_update(self.ema, model, self.decay(self.updates))
+    def advance(self):
+        self.updates += 1
+        return self.decay(self.updates)
 
 
 class SemiSupModelEMA(_EMABase):
@@ -83,10 +99,9 @@ class SemiSupModelEMA(_EMABase):
         self.updates = updates
         self.decay = decay
 
-    def update(self, model):
-        with torch.no_grad():
-            self.updates += 1
-            _flat_ema_update(self.ema, model, self.decay)
+    def advance(self):
+        self.updates += 1
+        return self.decay
 
 
 class CosineEMA(_EMABase):
@@ -100,9 +115,8 @@ class CosineEMA(_EMABase):
         self.decay = decay_start
         self.updates = 0
 
-    def update(self, model):
-        with torch.no_grad():
-            _flat_ema_update(self.ema, model, self.decay)
+    def advance(self):
+        return self.decay
 
     def update_decay(self, cur_epoch):
         self.decay = self.decay_end - (self.decay_end - self.decay_start) * \

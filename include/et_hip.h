@@ -78,6 +78,12 @@ int et_sgd_nesterov(float* p, const float* grad, float* momentum_buf, void* bf16
                     float lr, float momentum, float weight_decay, int first_step, float inv_scale,
                     et_stream_t stream);
 int et_cast_f32_to_bf16(const float* src, void* dst, int64_t n, et_stream_t stream);
+/* The same two updates with their per-step scalars in DEVICE memory (d2 = {d, 1-d}; hp = {lr, momentum, weight_decay,
+ * inv_scale}): the form a captured HIP graph of the step replays -- warm-up (trainer.py:386-395), the lr schedule and
+ * ModelEMA's decay ramp (utils/torch_utils.py:324) change these every step, and kernel arguments are frozen at capture. */
+int et_ema_update_dev(float* ema, const float* model, int64_t n, const float* d_and_one_minus_d, et_stream_t stream);
+int et_sgd_nesterov_dev(float* p, const float* grad, float* momentum_buf, void* bf16_shadow, int64_t n, const float* hp,
+                        int first_step, et_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Convolution (the conv inside `Conv`, models/backbone/common.py:471-481; Detect.m,
@@ -107,6 +113,17 @@ int et_conv2d_dgrad(const void* dy, const void* wT, void* dx, int dtype, int N, 
                     int ldx, int Cout, int KH, int KW, int stride, int pad, int ldy, int accumulate,
                     const void* residual /* optional, stride 1 only: dx = dgrad + residual */, int ldr,
                     const void* zero16, et_stream_t stream);
+/* dgrad (stride 1) that ALSO does the reduce pass of the BatchNorm backward of the layer whose activation gradient it
+ * produces: dx = dgrad (+ residual) is the dz of a Conv block z = act(BN(y)); with that block's raw conv output
+ * bn_y (pixel stride ld_bn), its folded affine bn_scale / bn_shift (Cin values: the channels of dx) and activation,
+ * the epilogue accumulates per-tile partial sums of du = dz * act'(y*scale+shift) and du*y into
+ * bn_stats_partial (et_conv2d_stats_rows(N, IH, IW), 2, Cin) -- computed on the ROUNDED dz it stores, i.e. exactly the
+ * values et_bn_act_bwd_from_partials reads back.  Replaces bn_act_bwd's own reduce pass (a 4 B/element re-read of dz
+ * and y) by one y read here.  Reference math: torch.nn.BatchNorm2d backward as used by Conv (models/backbone/common.py:480). */
+int et_conv2d_dgrad_bn(const void* dy, const void* wT, void* dx, int dtype, int N, int IH, int IW, int Cin, int ldx, int Cout,
+                       int KH, int KW, int pad, int ldy, const void* residual, int ldr, const void* bn_y, int ld_bn,
+                       const float* bn_scale, const float* bn_shift, int bn_act, float* bn_stats_partial, const void* zero16,
+                       et_stream_t stream);
 int et_conv2d_wgrad(const void* x, const void* dy, float* dw, int dtype, int N, int IH, int IW, int Cin,
                     int ldx, int Cout, int KH, int KW, int stride, int pad, int ldy, const void* zero16,
                     et_stream_t stream);
@@ -164,6 +181,12 @@ int et_bn_act_bwd(const void* dz, int lddz, const void* y, int ldy, void* dy, in
                   const float* save_invstd, int act, float* dgamma, float* dbeta,
                   double* totals /* totals + tickets, zero in / zero out */, float* workspace, size_t ws_floats,
                   et_stream_t stream);
+/* et_bn_act_bwd without its reduce pass: `partials` (partial_rows, 2, C) are the per-tile sums of du and du*y that
+ * et_conv2d_dgrad_bn left when it produced dz.  workspace: 3*C floats.  totals as above (zero in / zero out). */
+int et_bn_act_bwd_from_partials(const void* dz, int lddz, const void* y, int ldy, void* dy, int lddy, int dtype, int P, int C,
+                                const float* gamma, const float* scale, const float* shift, const float* save_mean,
+                                const float* save_invstd, int act, float* dgamma, float* dbeta, double* totals,
+                                const float* partials, int partial_rows, float* workspace, et_stream_t stream);
 int et_act_bwd(const void* dz, int lddz, const void* y, int ldy, void* dy, int lddy, int dtype, int P, int C,
                int act, et_stream_t stream);
 
@@ -176,6 +199,10 @@ int et_act_bwd(const void* dz, int lddz, const void* y, int ldy, void* dy, int l
  *       bwd: dx = base + gather(dy) (base may be NULL).
  *   et_upsample2x_*: nn.Upsample(scale_factor=2, 'nearest') (models/neck/yolov5_neck.py:60,64).   */
 int et_pack_input(const float* x_nchw, void* y_nhwc8, int dtype, int B, int C, int H, int W, et_stream_t stream);
+/* the loader's uint8 batch directly: y = (float)x / norm_scale (IEEE division == torch `imgs.float() / 255.0`,
+ * trainer/trainer.py:411, trainer/ssod_trainer.py:694-696) packed to NHWC8 in one pass */
+int et_pack_input_u8(const uint8_t* x_nchw, void* y_nhwc8, int dtype, int B, int C, int H, int W, float norm_scale,
+                     et_stream_t stream);
 int et_maxpool5_fwd(const void* x, int ldx, void* y, int ldy, uint8_t* argmax, int dtype, int B, int H, int W, int C,
                     et_stream_t stream);
 int et_maxpool5_bwd(const void* dy, int lddy, const uint8_t* argmax, const void* base, int ldb, void* dx, int lddx,

@@ -260,3 +260,51 @@ def test_wgrad_grouped_eight_layers_256_tile(hip):
     ops.conv2d_wgrad_grouped(items, k, 1, 1)
     for (_, _, dw), ref in zip(items, refs):
         assert (dw.cpu() - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", [(2, 12, 12, 64, 40, 3), (2, 20, 20, 256, 256, 3), (3, 10, 10, 32, 128, 1)],
+                         ids=["128x64 tile", "256x256 tile", "1x1"])
+def test_dgrad_with_fused_bn_backward_sums(hip, case, dtype):
+    """et_conv2d_dgrad_bn + et_bn_act_bwd_from_partials == et_conv2d_dgrad + et_bn_act_bwd (the separate reduce pass),
+    with and without the shortcut-gradient residual; and both equal torch autograd of act(BN(y)) on the same tensors."""
+    from efficientteacher_amd import ops
+    N, H, W, Cin, Cout, k = case
+    p = k // 2
+    dy = _mk(hip, (N, H, W, Cout), dtype, 81)
+    w = (_mk(hip, (Cout, k, k, Cin), dtype, 82) * (1.0 / (k * k * Cout) ** 0.5)).to(dtype)
+    wT = ops.weight_transpose(w)
+    y = _mk(hip, (N, H, W, Cin), dtype, 83)                      # raw conv output of the PRODUCER block (channels = Cin here)
+    res = _mk(hip, (N, H, W, Cin), dtype, 84)
+    gamma = torch.rand(Cin, generator=torch.Generator().manual_seed(85)).add(0.5).to(hip.device)
+    beta = torch.randn(Cin, generator=torch.Generator().manual_seed(86)).to(hip.device)
+    yf = y.float().reshape(-1, Cin)
+    mean = yf.mean(0)
+    invstd = 1.0 / torch.sqrt(yf.var(0, unbiased=False) + 1e-3)
+    scale = gamma * invstd
+    shift = beta - mean * scale
+    for residual in (None, res):
+        for act in (ops.ACT_SILU, ops.ACT_NONE):
+            hand = ops.BnBwdSums(y, scale, shift, act)
+            dz_f = ops.conv2d_dgrad(dy, wT, (H, W), 1, p, residual=residual, bn=hand)
+            assert hand.partial is not None
+            dg_f, db_f = torch.zeros(Cin, device=hip.device), torch.zeros(Cin, device=hip.device)
+            out_f = ops.bn_act_bwd(dz_f, y, gamma, scale, shift, mean, invstd, act, dg_f, db_f, partial=hand.take(dz_f))
+            dz_u = ops.conv2d_dgrad(dy, wT, (H, W), 1, p, residual=residual)
+            dg_u, db_u = torch.zeros(Cin, device=hip.device), torch.zeros(Cin, device=hip.device)
+            out_u = ops.bn_act_bwd(dz_u, y, gamma, scale, shift, mean, invstd, act, dg_u, db_u)
+            assert torch.equal(dz_f, dz_u)                        # the extra epilogue work does not change what is stored
+            n = N * H * W
+            tol = (2e-4 if dtype == torch.float32 else 2e-2)
+            assert torch.allclose(db_f, db_u, rtol=1e-4, atol=tol * n ** 0.5)
+            assert torch.allclose(dg_f, dg_u, rtol=1e-3, atol=tol * n ** 0.5)
+            assert (out_f.float() - out_u.float()).abs().max().item() <= tol * max(1.0, out_u.float().abs().max().item())
+            # torch autograd reference on the stored dz
+            yr = y.detach().float().cpu().clone().requires_grad_(True)
+            g_r, b_r = gamma.cpu().clone().requires_grad_(True), beta.cpu().clone().requires_grad_(True)
+            u = torch.nn.functional.batch_norm(yr.permute(0, 3, 1, 2), None, None, g_r, b_r, True, 0.0, 1e-3)
+            z = torch.nn.functional.silu(u) if act == ops.ACT_SILU else u
+            z.backward(dz_f.float().cpu().permute(0, 3, 1, 2))
+            assert (out_f.float().cpu() - yr.grad).abs().max().item() <= 5 * tol * max(1.0, yr.grad.abs().max().item())
+            assert torch.allclose(dg_f.cpu(), g_r.grad, rtol=2e-2, atol=5 * tol * n ** 0.5)
+            assert torch.allclose(db_f.cpu(), b_r.grad, rtol=2e-2, atol=5 * tol * n ** 0.5)

@@ -93,3 +93,53 @@ def test_two_supervised_steps_match_plain_torch(hip):
         a, b, o = e_mine[k].cpu(), ema.state_dict()[k], sd[k]
         upd = (b - o).abs().max().item()
         assert (a - b).abs().max().item() <= 1e-3 * upd + 1e-6, k      # one fp32 ulp of the -4.9 biases is 4.8e-7
+
+
+def test_no_warmup_when_warmup_epochs_is_zero(hip):
+    """hyp.warmup_epochs == 0 (the default of configs/defaults.py): the reference sets nw = -1 (trainer.py:372-376), so
+    no iteration ever satisfies ni <= nw and lr / momentum of the three groups stay what the scheduler set."""
+    from efficientteacher_amd.configs import get_cfg
+    from efficientteacher_amd.trainer import Trainer
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(ROOT, YAML))
+    cfg.merge_from_list(["Model.width_multiple", 0.125, "Model.depth_multiple", 0.33, "Dataset.batch_size", 2,
+                         "hyp.warmup_epochs", 0])
+    cfg.freeze()
+    torch.manual_seed(0)
+    t = Trainer(cfg, hip.device, nb=1000)
+    assert t.nw == -1
+    before = [(g["lr"], g["momentum"]) for g in t.optimizer.param_groups]
+    rng = np.random.default_rng(6)
+    imgs = torch.from_numpy(rng.integers(0, 256, (2, 3, 64, 64), dtype=np.uint8))
+    targets = torch.tensor([[0, 3, .5, .5, .3, .4], [1, 17, .3, .6, .2, .2]])
+    t.train_step(imgs.to(hip.device), targets, 0)
+    assert [(g["lr"], g["momentum"]) for g in t.optimizer.param_groups] == before
+    assert before[0][0] == cfg.hyp.lr0 * t.lf(0) and before[0][1] == cfg.hyp.momentum
+
+
+def test_flat_sgd_state_dict_round_trip_and_orphan_guard(hip):
+    """the momentum arena travels through optimizer.state_dict() (a resumed run must not restart with zero momentum), and
+    an optimizer whose model rebuilt its arenas refuses to step instead of updating orphaned buffers"""
+    import pytest
+    from efficientteacher_amd.configs import get_cfg
+    from efficientteacher_amd.trainer import Trainer
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(ROOT, YAML))
+    cfg.merge_from_list(["Model.width_multiple", 0.125, "Model.depth_multiple", 0.33, "Dataset.batch_size", 2])
+    cfg.freeze()
+    torch.manual_seed(0)
+    t = Trainer(cfg, hip.device, nb=1000)
+    rng = np.random.default_rng(7)
+    imgs = torch.from_numpy(rng.integers(0, 256, (2, 3, 64, 64), dtype=np.uint8))
+    targets = torch.tensor([[0, 3, .5, .5, .3, .4], [1, 17, .3, .6, .2, .2]])
+    t.train_step(imgs.to(hip.device), targets, 5)
+    sd = t.optimizer.state_dict()
+    assert sd["flat_momentum"].abs().sum() > 0 and sd["flat_first"] is False
+    mom = t.optimizer.momentum_buf.clone()
+    t.build_optimizer(cfg)                               # a fresh optimizer (as after a restart) ...
+    assert t.optimizer.momentum_buf.abs().sum() == 0 and t.optimizer.first
+    t.optimizer.load_state_dict(sd)                      # ... resumes with the saved momentum
+    assert torch.equal(t.optimizer.momentum_buf, mom) and not t.optimizer.first
+    t.model.set_compute_dtype(torch.float32)             # rebuilds the arenas behind the optimizer's back
+    with pytest.raises(RuntimeError, match="rebuilt"):
+        t.optimizer.step()
