@@ -1,0 +1,253 @@
+// YOLOv8 anchor-free head (BASELINE.json configs[4]): inference decode of YoloV8Detect and the TaskAlignedAssigner.
+//
+//   v8_decode      reference models/head/yolov8_head.py:172-214 (eval branch): per anchor point the DFL expectation
+//                  softmax(reg[side, 0..reg_max]) . [0..reg_max] of the four sides, dist2bbox(..., 'xywh')
+//                  (models/module/nanodet_utils.py:92-103) around the cell centre (x + 0.5, y + 0.5), times the stride;
+//                  row = [cx, cy, w, h, 1, sigmoid(cls_0..nc-1)].  Reads the NHWC outputs of the two head branches in place.
+//   tal_*          reference models/assigner/tal_assigner.py:13-158 + select_candidates_in_gts / select_highest_overlaps /
+//                  iou_calculator (models/module/nanodet_utils.py:181-243): metric = score^alpha * IoU^beta inside the gt box,
+//                  top-k anchors per gt, an anchor claimed by several gts goes to the one with the highest IoU, targets
+//                  scaled by the normalised alignment metric.  Four launches, everything stays on the device:
+//                    tal_topk     one workgroup per (image, gt): metric of all anchors in LDS, k rounds of argmax
+//                    tal_resolve  one thread per (image, anchor): count claims, break multi-claims by IoU (first max)
+//                    tal_gtmax    one workgroup per (image, gt): max metric / max IoU over the anchors it finally owns
+//                    tal_emit     one thread per (image, anchor): labels, boxes, normalised one-hot scores, fg mask
+//                  Ties: torch.topk leaves the order of EQUAL values unspecified; here the smaller anchor index wins.  Equal
+//                  metrics only occur at exactly 0 (anchor inside the gt whose predicted box misses it), where the pick has
+//                  no effect on the loss (its target score is 0); tests compare on the anchors with a non-zero target.
+// Compiled with -ffp-contract=off (index decisions depend on fp32 results).
+#include "et_device.h"
+#include "../../include/et_hip.h"
+#include <math.h>
+
+template <typename T>
+__global__ __launch_bounds__(256) void v8_decode_kernel(const T* __restrict__ reg, int ld_reg, const T* __restrict__ cls, int ld_cls,
+                                                        int B, int H, int W, int reg_max, int nc, float stride, float cell_offset,
+                                                        float* __restrict__ out, long long A_total, long long a_offset) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;     // (b, y, x)
+    const long long total = (long long)B * H * W;
+    if (i >= total) return;
+    const int x = (int)(i % W), y = (int)((i / W) % H);
+    const long long b = i / ((long long)W * H);
+    const T* r = reg + i * ld_reg;
+    float d[4];
+    const int nb = reg_max + 1;
+    for (int s = 0; s < 4; ++s) {
+        float m = -INFINITY;
+        for (int k = 0; k < nb; ++k) m = fmaxf(m, et_elem<T>::ld(r[s * nb + k]));
+        float den = 0.f, num = 0.f;
+        for (int k = 0; k < nb; ++k) {
+            const float e = expf(et_elem<T>::ld(r[s * nb + k]) - m);
+            den += e;
+            num += e * (float)k;
+        }
+        d[s] = num / den;
+    }
+    const float ax = (float)x + cell_offset, ay = (float)y + cell_offset;
+    const float x1 = ax - d[0], y1 = ay - d[1], x2 = ax + d[2], y2 = ay + d[3];
+    float* o = out + (b * A_total + a_offset + (long long)y * W + x) * (5 + nc);
+    o[0] = (x1 + x2) / 2 * stride;
+    o[1] = (y1 + y2) / 2 * stride;
+    o[2] = (x2 - x1) * stride;
+    o[3] = (y2 - y1) * stride;
+    o[4] = 1.0f;
+    const T* c = cls + i * ld_cls;
+    for (int k = 0; k < nc; ++k) o[5 + k] = et_sigmoid(et_elem<T>::ld(c[k]));
+}
+
+extern "C" int et_v8_decode(const void* reg, int ld_reg, const void* cls, int ld_cls, int dtype, int B, int H, int W, int reg_max,
+                            int nc, float stride, float cell_offset, float* out, int64_t A_total, int64_t a_offset,
+                            et_stream_t stream) {
+    if (!reg || !cls || !out) return -1;
+    if (B <= 0 || H <= 0 || W <= 0 || reg_max < 0 || reg_max > 31 || nc <= 0) return -2;
+    const long long total = (long long)B * H * W;
+    const dim3 grid(et_cdiv(total, 256));
+    if (dtype == ET_F32)
+        hipLaunchKernelGGL((v8_decode_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)reg, ld_reg, (const float*)cls,
+                           ld_cls, B, H, W, reg_max, nc, stride, cell_offset, out, (long long)A_total, (long long)a_offset);
+    else if (dtype == ET_BF16)
+        hipLaunchKernelGGL((v8_decode_kernel<uint16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)reg, ld_reg,
+                           (const uint16_t*)cls, ld_cls, B, H, W, reg_max, nc, stride, cell_offset, out, (long long)A_total,
+                           (long long)a_offset);
+    else return -2;
+    ET_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---- TaskAlignedAssigner ----------------------------------------------------------------------------------------
+struct TalArgs {
+    const float* scores;   // (B, A, nc) sigmoid class scores
+    const float* boxes;    // (B, A, 4) predicted xyxy
+    const float* anc;      // (A, 2) anchor points
+    const float* glabel;   // (B, G)
+    const float* gbox;     // (B, G, 4) xyxy
+    const float* gmask;    // (B, G) 1 = real gt
+    int B, A, G, nc, topk;
+    float alpha, beta, eps;
+    unsigned char* pos;    // (B, G, A) workspace: 1 = anchor a is a top-k candidate of gt g inside its box
+    int* idx;              // (B, A) final gt index
+    int* fg;               // (B, A) final foreground flag
+    float* gmax;           // (B, G, 2) max metric / max IoU over the anchors the gt finally owns
+};
+
+// iou_calculator (nanodet_utils.py:181-200): box1 = gt, box2 = prediction
+__device__ __forceinline__ float tal_iou(const float* g, const float* p, float eps) {
+    const float x1 = fmaxf(g[0], p[0]), y1 = fmaxf(g[1], p[1]), x2 = fminf(g[2], p[2]), y2 = fminf(g[3], p[3]);
+    const float overlap = fmaxf(x2 - x1, 0.f) * fmaxf(y2 - y1, 0.f);
+    const float a1 = fmaxf(g[2] - g[0], 0.f) * fmaxf(g[3] - g[1], 0.f);
+    const float a2 = fmaxf(p[2] - p[0], 0.f) * fmaxf(p[3] - p[1], 0.f);
+    const float uni = a1 + a2 - overlap + eps;
+    return overlap / uni;
+}
+__device__ __forceinline__ float tal_metric(const TalArgs& t, int b, int g, int a, float* iou_out) {
+    const float* gb = t.gbox + ((size_t)b * t.G + g) * 4;
+    const float* pb = t.boxes + ((size_t)b * t.A + a) * 4;
+    int lab = (int)t.glabel[(size_t)b * t.G + g];
+    if (lab < 0) lab += t.nc;                                  // torch indexing with -1 (padded rows) wraps around
+    const float sc = t.scores[((size_t)b * t.A + a) * t.nc + lab];
+    const float iou = tal_iou(gb, pb, t.eps);
+    if (iou_out) *iou_out = iou;
+    return powf(sc, t.alpha) * powf(iou, t.beta);
+}
+__device__ __forceinline__ bool tal_in_gt(const TalArgs& t, int b, int g, int a) {
+    const float* gb = t.gbox + ((size_t)b * t.G + g) * 4;
+    const float ax = t.anc[2 * a], ay = t.anc[2 * a + 1];
+    const float m = fminf(fminf(ax - gb[0], ay - gb[1]), fminf(gb[2] - ax, gb[3] - ay));
+    return m > t.eps;
+}
+
+#define TAL_MAX_A 16384
+__global__ __launch_bounds__(256) void tal_topk_kernel(TalArgs t) {
+    __shared__ float met[TAL_MAX_A];
+    __shared__ float rv[256];
+    __shared__ int ri[256];
+    const int b = blockIdx.x / t.G, g = blockIdx.x % t.G;
+    unsigned char* pos = t.pos + ((size_t)b * t.G + g) * t.A;
+    for (int a = threadIdx.x; a < t.A; a += 256) {
+        pos[a] = 0;
+        const bool in = tal_in_gt(t, b, g, a);
+        met[a] = in ? tal_metric(t, b, g, a, nullptr) : 0.f;   // metric * mask_in_gts (tal_assigner.py:93)
+    }
+    __syncthreads();
+    if (t.gmask[(size_t)b * t.G + g] <= 0.f) return;           // padded gt: its k picks all collapse onto index 0 and are dropped (:139-142)
+    for (int k = 0; k < t.topk && k < t.A; ++k) {
+        float bv = -1.f;
+        int bi = 0x7fffffff;
+        for (int a = threadIdx.x; a < t.A; a += 256) {
+            const float v = met[a];
+            if (v > bv) { bv = v; bi = a; }                      // ascending scan: the smaller index wins ties
+        }
+        rv[threadIdx.x] = bv; ri[threadIdx.x] = bi;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (threadIdx.x < s) {
+                const float ov = rv[threadIdx.x + s];
+                const int oi = ri[threadIdx.x + s];
+                if (ov > rv[threadIdx.x] || (ov == rv[threadIdx.x] && oi < ri[threadIdx.x])) { rv[threadIdx.x] = ov; ri[threadIdx.x] = oi; }
+            }
+            __syncthreads();
+        }
+        const int win = ri[0];
+        if (threadIdx.x == 0) {
+            if (tal_in_gt(t, b, g, win)) pos[win] = 1;          // mask_topk * mask_in_gts * mask_gt
+            met[win] = -2.f;                                    // taken
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void tal_resolve_kernel(TalArgs t) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)t.B * t.A) return;
+    const int b = (int)(i / t.A), a = (int)(i % t.A);
+    int cnt = 0, first = 0;
+    for (int g = 0; g < t.G; ++g)
+        if (t.pos[((size_t)b * t.G + g) * t.A + a]) { if (!cnt) first = g; ++cnt; }
+    int idx = first;                                            // mask_pos.argmax(-2): first gt with a 1, or 0
+    if (cnt > 1) {                                              // select_highest_overlaps: argmax of the IoU over ALL gts
+        float best = -1.f;
+        for (int g = 0; g < t.G; ++g) {
+            float iou;
+            tal_metric(t, b, g, a, &iou);
+            if (iou > best) { best = iou; idx = g; }
+        }
+    }
+    t.idx[i] = idx;
+    t.fg[i] = cnt > 0 ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void tal_gtmax_kernel(TalArgs t) {
+    __shared__ float rm[256], ro[256];
+    const int b = blockIdx.x / t.G, g = blockIdx.x % t.G;
+    float bm = 0.f, bo = 0.f;                                   // align_metric * mask_pos and overlaps * mask_pos are >= 0
+    for (int a = threadIdx.x; a < t.A; a += 256) {
+        const size_t i = (size_t)b * t.A + a;
+        if (t.fg[i] && t.idx[i] == g) {
+            float iou;
+            const float m = tal_metric(t, b, g, a, &iou);
+            bm = fmaxf(bm, m); bo = fmaxf(bo, iou);
+        }
+    }
+    rm[threadIdx.x] = bm; ro[threadIdx.x] = bo;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) { rm[threadIdx.x] = fmaxf(rm[threadIdx.x], rm[threadIdx.x + s]); ro[threadIdx.x] = fmaxf(ro[threadIdx.x], ro[threadIdx.x + s]); }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { t.gmax[((size_t)b * t.G + g) * 2] = rm[0]; t.gmax[((size_t)b * t.G + g) * 2 + 1] = ro[0]; }
+}
+
+__global__ __launch_bounds__(256) void tal_emit_kernel(TalArgs t, long long* __restrict__ tlabel, float* __restrict__ tbox,
+                                                       float* __restrict__ tscore, unsigned char* __restrict__ fg_out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)t.B * t.A) return;
+    const int b = (int)(i / t.A), a = (int)(i % t.A);
+    const int g = t.idx[i], fg = t.fg[i];
+    long long lab = (long long)t.glabel[(size_t)b * t.G + g];
+    if (lab < 0) lab = 0;                                       // tal_assigner.py:153
+    tlabel[i] = lab;
+    const float* gb = t.gbox + ((size_t)b * t.G + g) * 4;
+    for (int k = 0; k < 4; ++k) tbox[i * 4 + k] = gb[k];
+    float norm = 0.f;
+    if (fg) {
+        const float m = tal_metric(t, b, g, a, nullptr);
+        norm = m * t.gmax[((size_t)b * t.G + g) * 2 + 1] / (t.gmax[((size_t)b * t.G + g) * 2] + t.eps);
+    }
+    float* ts = tscore + i * t.nc;
+    for (int k = 0; k < t.nc; ++k) ts[k] = (fg && k == (int)lab) ? norm : 0.f;
+    fg_out[i] = (unsigned char)fg;
+}
+
+extern "C" int et_tal_assign_workspace_bytes(int B, int A, int G, size_t* bytes) {
+    if (!bytes || B <= 0 || A <= 0 || G < 0) return -2;
+    *bytes = (size_t)B * (G > 0 ? G : 1) * A + 16 + (size_t)B * A * 8 + (size_t)B * (G > 0 ? G : 1) * 8 + 64;
+    return 0;
+}
+
+extern "C" int et_tal_assign(const float* pd_scores, const float* pd_bboxes, const float* anc_points, const float* gt_labels,
+                             const float* gt_bboxes, const float* mask_gt, int B, int A, int G, int nc, int topk, float alpha,
+                             float beta, float eps, int64_t* target_labels, float* target_bboxes, float* target_scores,
+                             uint8_t* fg_mask, void* workspace, size_t ws_bytes, et_stream_t stream) {
+    if (!pd_scores || !pd_bboxes || !anc_points || !target_labels || !target_bboxes || !target_scores || !fg_mask || !workspace) return -1;
+    if (B <= 0 || A <= 0 || A > TAL_MAX_A || G <= 0 || nc <= 0 || topk <= 0) return -2;
+    if (!gt_labels || !gt_bboxes || !mask_gt) return -1;
+    size_t need;
+    et_tal_assign_workspace_bytes(B, A, G, &need);
+    if (ws_bytes < need) return -3;
+    TalArgs t;
+    t.scores = pd_scores; t.boxes = pd_bboxes; t.anc = anc_points; t.glabel = gt_labels; t.gbox = gt_bboxes; t.gmask = mask_gt;
+    t.B = B; t.A = A; t.G = G; t.nc = nc; t.topk = topk; t.alpha = alpha; t.beta = beta; t.eps = eps;
+    char* w = (char*)workspace;
+    t.pos = (unsigned char*)w; w += (((size_t)B * G * A + 15) / 16) * 16;
+    t.idx = (int*)w; w += (size_t)B * A * 4;
+    t.fg = (int*)w; w += (size_t)B * A * 4;
+    t.gmax = (float*)w;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(tal_topk_kernel, dim3(B * G), dim3(256), 0, s, t);
+    hipLaunchKernelGGL(tal_resolve_kernel, dim3(et_cdiv((long long)B * A, 256)), dim3(256), 0, s, t);
+    hipLaunchKernelGGL(tal_gtmax_kernel, dim3(B * G), dim3(256), 0, s, t);
+    hipLaunchKernelGGL(tal_emit_kernel, dim3(et_cdiv((long long)B * A, 256)), dim3(256), 0, s, t, (long long*)target_labels, target_bboxes,
+                       target_scores, fg_mask);
+    ET_CHECK_LAUNCH();
+    return 0;
+}

@@ -172,6 +172,34 @@ class C3(nn.Module):
         return self.cv3(cat)
 
 
+class C2f(nn.Module):
+    # CSP Bottleneck with 2 convolutions (reference models/backbone/common.py:594-608): cv2(cat(split(cv1(x)), m_0, m_1, ...))
+    def __init__(self, c1, c2, n=1, shortcut=False, g=1, e=0.5, act=True):  # ch_in, ch_out, number, shortcut, groups, expansion
+        super().__init__()
+        self.c = int(c2 * e)  # hidden channels
+        if self.c % 8:
+            raise NotImplementedError("C2f hidden width must be a multiple of 8 channels (16-byte NHWC vectors)")
+        self.cv1 = Conv(c1, 2 * self.c, 1, 1, act=act)
+        self.cv2 = Conv((2 + n) * self.c, c2, 1, act=act)
+        self.m = nn.ModuleList(Bottleneck(self.c, self.c, shortcut, g, k=(3, 3), e=1.0, act=act) for _ in range(n))
+
+    def forward(self, x):
+        # every piece of the concat is produced in place in ONE buffer: cv1 fills [0, 2c), bottleneck i reads
+        # [(1+i)c, (2+i)c) and writes [(2+i)c, (3+i)c); cv2 reads the whole buffer (no split / cat copies)
+        N, H, W, _ = x.shape
+        c, n = self.c, len(self.m)
+        buf = torch.empty((N, H, W, (2 + n) * c), dtype=x.dtype, device=x.device)
+        y = self.cv1(x, dst=(buf, 0))
+        parts = [y]
+        t = y[..., c:]
+        for i, m in enumerate(self.m):
+            t = m(t, dst=(buf, (2 + i) * c))
+            parts.append(t)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in parts):
+            return self.cv2(JoinSlicesFn.apply((buf,), *parts))
+        return self.cv2(buf)
+
+
 class SPPF(nn.Module):
     # Spatial Pyramid Pooling - Fast (SPPF) layer
     def __init__(self, c1, c2, k=5, act=True):

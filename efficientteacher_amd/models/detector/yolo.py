@@ -54,6 +54,13 @@ class Model(nn.Module):
     # ---- reference surface -----------------------------------------------------------------------------------
     def check_head(self):
         m = self.head
+        from ..head.yolov8_head import YoloV8Detect
+        if isinstance(m, YoloV8Detect):              # reference yolo.py:77-81
+            m.inplace = self.inplace
+            self.stride = torch.Tensor(m.stride)
+            m.initialize_biases()
+            self.model_type = 'yolox'
+            return
         if not isinstance(m, Detect):
             raise NotImplementedError
         m.inplace = self.inplace

@@ -655,3 +655,39 @@ def scale_inplace(x, alpha, dev_scale=None):
     _lib.check(_lib.load().et_scale_inplace(_lib.ptr(x), et_dtype(x), x.numel(), float(alpha), _lib.ptr(dev_scale),
                                             _lib.stream(x)), "et_scale_inplace")
     return x
+
+
+# ---- YOLOv8 anchor-free head ---------------------------------------------------------------------------------
+def v8_decode(reg_nhwc, cls_nhwc, reg_max, nc, stride, cell_offset, out, a_offset):
+    """one level of YoloV8Detect's inference decode: writes out[:, a_offset : a_offset + H*W, :] (B, A_total, 5+nc) fp32"""
+    B, H, W, _ = reg_nhwc.shape
+    assert cls_nhwc.shape[:3] == (B, H, W) and out.is_contiguous() and out.dtype == torch.float32 and reg_nhwc.dtype == cls_nhwc.dtype
+    _lib.check(_lib.load().et_v8_decode(_lib.ptr(reg_nhwc), _nhwc(reg_nhwc), _lib.ptr(cls_nhwc), _nhwc(cls_nhwc), et_dtype(reg_nhwc),
+                                        B, H, W, int(reg_max), int(nc), float(stride), float(cell_offset), _lib.ptr(out), out.shape[1],
+                                        int(a_offset), _lib.stream(out)), "et_v8_decode")
+
+
+def tal_assign(pd_scores, pd_bboxes, anc_points, gt_labels, gt_bboxes, mask_gt, topk=13, alpha=1.0, beta=6.0, eps=1e-9):
+    """TaskAlignedAssigner.forward on the device: -> (target_labels (B,A) int64, target_bboxes (B,A,4), target_scores (B,A,nc),
+    fg_mask (B,A) bool)."""
+    import ctypes
+    B, A, nc = pd_scores.shape
+    G = gt_bboxes.shape[1]
+    dev = pd_scores.device
+    f = lambda t: t.to(torch.float32).contiguous()
+    tl = torch.empty((B, A), dtype=torch.int64, device=dev)
+    tb = torch.empty((B, A, 4), dtype=torch.float32, device=dev)
+    ts = torch.empty((B, A, nc), dtype=torch.float32, device=dev)
+    fg = torch.empty((B, A), dtype=torch.uint8, device=dev)
+    if G == 0:                                       # tal_assigner.py:52-57
+        return tl.fill_(nc), tb.zero_(), ts.zero_(), fg.zero_().bool()
+    lib = _lib.load()
+    n = ctypes.c_size_t()
+    _lib.check(lib.et_tal_assign_workspace_bytes(B, A, G, ctypes.byref(n)), "et_tal_assign_workspace_bytes")
+    ws = torch.empty(n.value, dtype=torch.uint8, device=dev)
+    ps, pb, ap = f(pd_scores), f(pd_bboxes), f(anc_points)
+    gl, gb, gm = f(gt_labels.reshape(B, G)), f(gt_bboxes), f(mask_gt.reshape(B, G))
+    _lib.check(lib.et_tal_assign(_lib.ptr(ps), _lib.ptr(pb), _lib.ptr(ap), _lib.ptr(gl), _lib.ptr(gb), _lib.ptr(gm), B, A, G, nc,
+                                 int(topk), float(alpha), float(beta), float(eps), _lib.ptr(tl), _lib.ptr(tb), _lib.ptr(ts),
+                                 _lib.ptr(fg), _lib.ptr(ws), n.value, _lib.stream(ps)), "et_tal_assign")
+    return tl, tb, ts, fg.bool()

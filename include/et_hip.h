@@ -274,6 +274,26 @@ int et_domain_focal(const void* feat, int ldf, int dtype, int64_t P, int label, 
 int et_scale_inplace(void* x, int dtype, int64_t n, float alpha, const float* dev_scale /*or NULL*/,
                      et_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * YOLOv8 anchor-free head (BASELINE.json configs[4]).
+ * et_v8_decode: inference branch of YoloV8Detect.forward (models/head/yolov8_head.py:172-214) for one level: DFL
+ *   expectation of the four sides, dist2bbox 'xywh' around the cell centre (x + cell_offset, y + cell_offset), * stride;
+ *   rows [cx, cy, w, h, 1, sigmoid(cls)] of out (B, A_total, 5 + nc) fp32 at anchor offset a_offset.  reg (B,H,W,>=4*(reg_max+1))
+ *   and cls (B,H,W,>=nc) are the NHWC outputs of the two head branches with pixel strides ld_reg / ld_cls.
+ * et_tal_assign: TaskAlignedAssigner.forward (models/assigner/tal_assigner.py:30-158; alpha 1, beta 6, top_k 13 in
+ *   ComputeTalLoss, models/loss/tal_loss.py:43).  pd_scores (B,A,nc) sigmoid scores, pd_bboxes (B,A,4) xyxy, anc_points (A,2),
+ *   gt_labels (B,G), gt_bboxes (B,G,4) xyxy, mask_gt (B,G), all fp32.  Outputs: target_labels (B,A) int64 (label of the
+ *   assigned gt; of gt 0 for background anchors, as the reference), target_bboxes (B,A,4), target_scores (B,A,nc)
+ *   (one-hot * normalised alignment metric), fg_mask (B,A) uint8.  Equal metrics: the smaller anchor index is taken first
+ *   (torch.topk leaves ties unspecified; they only occur at metric 0, where the target score is 0).  A <= 16384. */
+int et_v8_decode(const void* reg, int ld_reg, const void* cls, int ld_cls, int dtype, int B, int H, int W, int reg_max, int nc,
+                 float stride, float cell_offset, float* out, int64_t A_total, int64_t a_offset, et_stream_t stream);
+int et_tal_assign_workspace_bytes(int B, int A, int G, size_t* bytes /*host out*/);
+int et_tal_assign(const float* pd_scores, const float* pd_bboxes, const float* anc_points, const float* gt_labels,
+                  const float* gt_bboxes, const float* mask_gt, int B, int A, int G, int nc, int topk, float alpha, float beta,
+                  float eps, int64_t* target_labels, float* target_bboxes, float* target_scores, uint8_t* fg_mask,
+                  void* workspace, size_t ws_bytes, et_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -524,10 +524,78 @@ def case_ssod_step(cfg, model):
     save("ssod_step", **out)
 
 
+def case_v8():
+    """YOLOv8 anchor-free path from the LIVE reference: tiny-width model (C2f backbone + neck + decoupled
+    head) train / eval outputs, and TaskAlignedAssigner on synthetic predictions -- one case small, one at 8400 anchors
+    with crowded gts (anchors claimed by several gts, padded gt rows, metric-0 candidates)."""
+    from models.assigner.tal_assigner import TaskAlignedAssigner
+    from models.detector.yolo import Model
+    from . import v8
+    cfg = ref_loader.get_cfg("configs/sup/public/yolov8m_coco.yaml", ["Model.width_multiple", 0.125, "Model.depth_multiple", 0.33])
+    cfg.freeze()
+    torch.manual_seed(0)
+    m = Model(cfg)
+    with torch.no_grad():                      # non-trivial BN statistics / affine so that eval mode is a real test
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.running_mean.normal_(0, 0.1); mod.running_var.uniform_(0.5, 1.5)
+                mod.weight.uniform_(0.5, 1.5); mod.bias.normal_(0, 0.1)
+    o = v8.Model.from_cfg(cfg)
+    o.load_state_dict(m.state_dict(), strict=True)
+    rng = np.random.default_rng(11)
+    x = torch.from_numpy(rng.uniform(0, 1, (2, 3, 64, 64)).astype(np.float32))
+    out = {"w__" + k.replace(".", "__"): v.numpy() for k, v in m.state_dict().items()}
+    m.train(); o.train()
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    f, c, r = m(x)
+    m.load_state_dict(sd0); o.load_state_dict(sd0)            # the train forward moved the running statistics
+    f2, c2, r2 = o(x)
+    assert torch.equal(c, c2) and torch.equal(r, r2), "oracle v8 train forward differs from the reference"
+    o.load_state_dict(sd0)
+    m.eval(); o.eval()
+    z, _ = m(x)
+    z2, _ = o(x)
+    assert (z - z2).abs().max().item() < 2e-4
+    out.update(x=x.numpy(), train_cls=c.detach().numpy(), train_reg=r.detach().numpy(), eval_z=z.detach().numpy(),
+               feat_shapes=np.array([t.shape[-2:] for t in f]))
+    save("v8_model", **out)
+    # ---- assigner ----
+    asg = TaskAlignedAssigner(13, 80, 1.0, 6.0)
+    tal = {}
+    for name, (B, shapes, G, crowd) in dict(small=(2, [(8, 8), (4, 4), (2, 2)], 5, False), full=(2, [(80, 80), (40, 40), (20, 20)], 24, True)).items():
+        pts, _ = v8.anchor_points_train(shapes, (8, 16, 32))
+        A = pts.shape[0]
+        S = shapes[0][0] * 8
+        g = torch.Generator().manual_seed(5 + B)
+        ps = torch.rand(B, A, 80, generator=g) ** 3
+        ctr = pts.unsqueeze(0).expand(B, A, 2) + torch.randn(B, A, 2, generator=g) * 6
+        wh = torch.rand(B, A, 2, generator=g) * (S / 3) + 4
+        pb = torch.cat([ctr - wh / 2, ctr + wh / 2], -1)
+        gl = torch.randint(0, 80, (B, G, 1), generator=g).float()
+        lo, hi = (0.35, 0.65) if crowd else (0.2, 0.8)       # crowded: gts pile up in the middle -> multi-claims
+        gc = (torch.rand(B, G, 2, generator=g) * (hi - lo) + lo) * S
+        gwh = torch.rand(B, G, 2, generator=g) * (S / 3) + S / 16
+        gb = torch.cat([gc - gwh / 2, gc + gwh / 2], -1).clamp(0, S)
+        gb[-1, G - 2:] = 0; gl[-1, G - 2:] = -1              # padded rows as ComputeTalLoss.preprocess makes them
+        mg = (gb.sum(-1, keepdim=True) > 0).float()
+        tl, tb, ts, fg = asg(ps, pb, pts, gl, gb, mg)
+        mine = v8.tal_assign(ps, pb, pts, gl, gb, mg)
+        eff = ts.sum(-1) > 0
+        assert torch.equal(ts, mine[2]) and torch.equal(fg, mine[3]) and torch.equal(tl[eff], mine[0][eff]), name
+        print(f"   tal[{name}]: A={A} fg={int(fg.sum())} effective={int(eff.sum())} multi-claimed handled")
+        for k, v in dict(ps=ps, pb=pb, pts=pts, gl=gl, gb=gb, mg=mg, tl=tl, tb=tb, ts=ts, fg=fg).items():
+            tal[f"{name}__{k}"] = v.numpy()
+    save("v8_tal", **tal)
+
+
 def main():
     if not ref_loader.available():
         sys.exit("reference tree not present; golden vectors can only be generated in the build container")
     ref_loader.load()
+    if len(sys.argv) > 1 and sys.argv[1] == "v8":
+        print("== YOLOv8 path")
+        case_v8()
+        return
     torch.set_num_threads(4)
     print("nms ..."); case_nms()
     print("assigner / losses ..."); cfg, model = case_assigner_and_losses()
