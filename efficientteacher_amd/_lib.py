@@ -66,6 +66,7 @@ SIGNATURES = {
     "et_domain_focal": (c_int, [P, c_int, c_int, c_int64, c_int, c_float, P, c_int, P, P]),
     "et_scale_inplace": (c_int, [P, c_int, c_int64, c_float, P, P]),
     "et_v8_decode": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float, P, c_int64, c_int64, P]),
+    "et_tal_loss": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_float, P, P, P, P, P]),
     "et_tal_assign_workspace_bytes": (c_int, [c_int, c_int, c_int, ctypes.POINTER(c_size_t)]),
     "et_tal_assign": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_float, P, P, P, P, P, c_size_t, P]),
 }

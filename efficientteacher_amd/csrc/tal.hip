@@ -251,3 +251,151 @@ extern "C" int et_tal_assign(const float* pd_scores, const float* pd_bboxes, con
     ET_CHECK_LAUNCH();
     return 0;
 }
+
+
+// ---- ComputeTalLoss: forward + gradient in one pass per anchor ---------------------------------------------------------
+// reference models/loss/tal_loss.py:51-146 after the assigner (:95-102).  The two loss classes it imports
+// (models.loss.gfocal_loss.VarifocalLoss / BboxLoss) are absent from the reference tree; their definitions are the
+// written spec of oracle/v8.py::tal_loss (parity unpinned for this function, see there):
+//     loss_cls = sum BCEWithLogits(pred_scores, target_scores) / S                      S = max(sum target_scores, 1)
+//     loss_iou = sum_fg (1 - GIoU(pred_box, target_box)) * w / S                         w = sum_c target_scores[a, c]
+//     loss_dfl = sum_fg mean_side( CE(l, floor t) (ceil t - t) + CE(l, ceil t) (t - floor t) ) * w / S,  t = clip(dist, 0, reg_max - .01)
+//     loss     = w_class loss_cls + w_iou loss_iou + w_dfl loss_dfl
+// pred_box = anchor -/+ DFL expectation of the side logits (grid units).  One thread per (image, anchor) computes its terms and
+// writes d loss / d pred_scores, d loss / d pred_distri; S comes from tal_sum_kernel (device scalar, no host sync).
+struct TalLossArgs {
+    const float* ps;        // (B, A, nc) class logits
+    const float* pd;        // (B, A, 4*(reg_max+1)) DFL logits
+    const float* anc_s;     // (A, 2) anchor points in grid units
+    const float* stride;    // (A)
+    const float* tb;        // (B, A, 4) target boxes in PIXELS (assigner output)
+    const float* ts;        // (B, A, nc) target scores
+    const unsigned char* fg;
+    int B, A, nc, reg_max, iou_kind;
+    float w_class, w_iou, w_dfl;
+    float* gps;             // gradients, same shapes
+    float* gpd;
+    float* acc;             // [0] sum target scores  [1] cls  [2] iou  [3] dfl  (fp32 atomics)
+};
+
+__global__ __launch_bounds__(256) void tal_sum_kernel(const float* __restrict__ ts, long long n, float* __restrict__ acc) {
+    float s = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) s += ts[i];
+    s = et_wave_sum(s);
+    if ((threadIdx.x & 63) == 0) atomicAdd(acc, s);
+}
+
+__global__ __launch_bounds__(256) void tal_loss_kernel(TalLossArgs t) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    float l_cls = 0.f, l_iou = 0.f, l_dfl = 0.f;
+    if (i < (long long)t.B * t.A) {
+        const int a = (int)(i % t.A);
+        const float S = fmaxf(t.acc[0], 1.0f);
+        const float* x = t.ps + i * t.nc;
+        const float* y = t.ts + i * t.nc;
+        float* gx = t.gps + i * t.nc;
+        float w = 0.f;
+        for (int c = 0; c < t.nc; ++c) {
+            const float xv = x[c], yv = y[c];
+            // BCEWithLogits: max(x,0) - x*y + log(1 + exp(-|x|))
+            l_cls += fmaxf(xv, 0.f) - xv * yv + log1pf(expf(-fabsf(xv)));
+            gx[c] = t.w_class * (et_sigmoid(xv) - yv) / S;
+            w += yv;
+        }
+        const int nb = t.reg_max + 1;
+        const float* l = t.pd + i * 4 * nb;
+        float* gl = t.gpd + i * 4 * nb;
+        if (!t.fg[i]) {
+            for (int k = 0; k < 4 * nb; ++k) gl[k] = 0.f;
+        } else {
+            const float ax = t.anc_s[2 * a], ay = t.anc_s[2 * a + 1], st = t.stride[a];
+            float d[4], mx[4], den[4];
+            for (int s = 0; s < 4; ++s) {
+                float m = -INFINITY;
+                for (int k = 0; k < nb; ++k) m = fmaxf(m, l[s * nb + k]);
+                float dn = 0.f, nm = 0.f;
+                for (int k = 0; k < nb; ++k) { const float e = expf(l[s * nb + k] - m); dn += e; nm += e * (float)k; }
+                d[s] = nm / dn; mx[s] = m; den[s] = dn;
+            }
+            const float x1 = ax - d[0], y1 = ay - d[1], x2 = ax + d[2], y2 = ay + d[3];
+            const float X1 = t.tb[i * 4] / st, Y1 = t.tb[i * 4 + 1] / st, X2 = t.tb[i * 4 + 2] / st, Y2 = t.tb[i * 4 + 3] / st;
+            const float eps = 1e-7f;
+            const float w1 = x2 - x1, h1 = y2 - y1 + eps, w2 = X2 - X1, h2 = Y2 - Y1 + eps;
+            const float iw_ = fminf(x2, X2) - fmaxf(x1, X1), ih_ = fminf(y2, Y2) - fmaxf(y1, Y1);
+            const float iw = fmaxf(iw_, 0.f), ih = fmaxf(ih_, 0.f);
+            const float inter = iw * ih;
+            const float uni = w1 * h1 + w2 * h2 - inter + eps;
+            const float iou = inter / uni;
+            // d inter / d (x1, y1, x2, y2)
+            const float di[4] = {(iw_ > 0.f && x1 > X1) ? -ih : 0.f, (ih_ > 0.f && y1 > Y1) ? -iw : 0.f,
+                                 (iw_ > 0.f && x2 < X2) ? ih : 0.f, (ih_ > 0.f && y2 < Y2) ? iw : 0.f};
+            const float da[4] = {-h1, -w1, h1, w1};                 // d area1
+            float giou = iou, dg[4];
+            for (int k = 0; k < 4; ++k) {
+                const float du = da[k] - di[k];
+                dg[k] = (di[k] * uni - inter * du) / (uni * uni);
+            }
+            if (t.iou_kind == 1) {                                   // GIoU
+                const float cw = fmaxf(x2, X2) - fminf(x1, X1), ch = fmaxf(y2, Y2) - fminf(y1, Y1);
+                const float C = cw * ch + eps;
+                giou = iou - (C - uni) / C;
+                const float dc[4] = {(x1 < X1) ? -ch : 0.f, (y1 < Y1) ? -cw : 0.f, (x2 > X2) ? ch : 0.f, (y2 > Y2) ? cw : 0.f};
+                for (int k = 0; k < 4; ++k) {
+                    const float du = da[k] - di[k];
+                    dg[k] += (du * C - uni * dc[k]) / (C * C);
+                }
+            }
+            l_iou = (1.0f - giou) * w;
+            // box coordinate k depends on side k: x1 = ax - d0, y1 = ay - d1, x2 = ax + d2, y2 = ay + d3
+            const float sgn[4] = {-1.f, -1.f, 1.f, 1.f};
+            const float tdist[4] = {ax - X1, ay - Y1, X2 - ax, Y2 - ay};
+            for (int s = 0; s < 4; ++s) {
+                const float dL_dd = t.w_iou * (-dg[s]) * sgn[s] * w / S;          // d(w_iou * loss_iou) / d d_s
+                const float tt = fminf(fmaxf(tdist[s], 0.f), (float)t.reg_max - 0.01f);
+                const int tl = (int)tt, tr = tl + 1;
+                const float wl = (float)tr - tt, wr = tt - (float)tl;
+                const float lse = mx[s] + logf(den[s]);
+                l_dfl += ((lse - l[s * nb + tl]) * wl + (lse - l[s * nb + tr]) * wr) * 0.25f * w;
+                const float cd = t.w_dfl * 0.25f * w / S;
+                for (int k = 0; k < nb; ++k) {
+                    const float p = expf(l[s * nb + k] - mx[s]) / den[s];
+                    float gk = dL_dd * p * ((float)k - d[s]);                     // through the expectation
+                    gk += cd * (p - (k == tl ? wl : 0.f) - (k == tr ? wr : 0.f)); // DFL cross-entropy
+                    gl[s * nb + k] = gk;
+                }
+            }
+        }
+    }
+    l_cls = et_wave_sum(l_cls); l_iou = et_wave_sum(l_iou); l_dfl = et_wave_sum(l_dfl);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(t.acc + 1, l_cls); atomicAdd(t.acc + 2, l_iou); atomicAdd(t.acc + 3, l_dfl); }
+}
+
+__global__ void tal_loss_finalize_kernel(const float* __restrict__ acc, float w_class, float w_iou, float w_dfl, float* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const float S = fmaxf(acc[0], 1.0f);
+        out[0] = w_iou * acc[2] / S;
+        out[1] = w_dfl * acc[3] / S;
+        out[2] = w_class * acc[1] / S;
+        out[3] = out[0] + out[1] + out[2];
+    }
+}
+
+extern "C" int et_tal_loss(const float* pred_scores, const float* pred_distri, const float* anchor_points_s, const float* stride_tensor,
+                           const float* target_bboxes_px, const float* target_scores, const uint8_t* fg_mask, int B, int A, int nc,
+                           int reg_max, int iou_kind, float w_class, float w_iou, float w_dfl, float* grad_scores, float* grad_distri,
+                           float* acc_ws /* 4 floats, ZERO on entry */, float* out /* 4 floats */, et_stream_t stream) {
+    if (!pred_scores || !pred_distri || !anchor_points_s || !stride_tensor || !target_bboxes_px || !target_scores || !fg_mask ||
+        !grad_scores || !grad_distri || !acc_ws || !out) return -1;
+    if (B <= 0 || A <= 0 || nc <= 0 || reg_max < 1 || reg_max > 31 || (iou_kind != 0 && iou_kind != 1)) return -2;
+    TalLossArgs t;
+    t.ps = pred_scores; t.pd = pred_distri; t.anc_s = anchor_points_s; t.stride = stride_tensor; t.tb = target_bboxes_px;
+    t.ts = target_scores; t.fg = fg_mask; t.B = B; t.A = A; t.nc = nc; t.reg_max = reg_max; t.iou_kind = iou_kind;
+    t.w_class = w_class; t.w_iou = w_iou; t.w_dfl = w_dfl; t.gps = grad_scores; t.gpd = grad_distri; t.acc = acc_ws;
+    hipStream_t s = (hipStream_t)stream;
+    const long long n = (long long)B * A * nc;
+    hipLaunchKernelGGL(tal_sum_kernel, dim3((int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024)), dim3(256), 0, s, target_scores, n, acc_ws);
+    hipLaunchKernelGGL(tal_loss_kernel, dim3(et_cdiv((long long)B * A, 256)), dim3(256), 0, s, t);
+    hipLaunchKernelGGL(tal_loss_finalize_kernel, dim3(1), dim3(64), 0, s, acc_ws, w_class, w_iou, w_dfl, out);
+    ET_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,5 +1,6 @@
 from .loss import ComputeLoss, DomainLoss, TargetLoss  # noqa: F401
 from .ssod.ssod_loss import ComputeStudentMatchLoss  # noqa: F401
+from .tal_loss import ComputeTalLoss  # noqa: F401
 
 
 def build_ssod_loss(model, cfg):

@@ -691,3 +691,24 @@ def tal_assign(pd_scores, pd_bboxes, anc_points, gt_labels, gt_bboxes, mask_gt, 
                                  int(topk), float(alpha), float(beta), float(eps), _lib.ptr(tl), _lib.ptr(tb), _lib.ptr(ts),
                                  _lib.ptr(fg), _lib.ptr(ws), n.value, _lib.stream(ps)), "et_tal_assign")
     return tl, tb, ts, fg.bool()
+
+
+def tal_loss(pred_scores, pred_distri, anchor_points_s, stride_tensor, target_bboxes_px, target_scores, fg_mask, reg_max, iou_type,
+             w_class, w_iou, w_dfl):
+    """fused ComputeTalLoss terms + gradients (et_tal_loss): -> out (4,) [iou, dfl, cls, total] weighted, grad_scores, grad_distri"""
+    B, A, nc = pred_scores.shape
+    dev = pred_scores.device
+    kind = {"iou": 0, "giou": 1}.get(iou_type)
+    if kind is None:
+        raise NotImplementedError(f"Loss.iou_type {iou_type}: the fused TAL loss implements 'giou' (default) and 'iou'")
+    f = lambda t: t.to(torch.float32).contiguous()
+    ps, pd = f(pred_scores), f(pred_distri)
+    gs, gd = torch.empty_like(ps), torch.empty_like(pd)
+    acc = torch.zeros(4, dtype=torch.float32, device=dev)
+    out = torch.empty(4, dtype=torch.float32, device=dev)
+    fg8 = fg_mask.to(torch.uint8).contiguous()
+    _lib.check(_lib.load().et_tal_loss(_lib.ptr(ps), _lib.ptr(pd), _lib.ptr(f(anchor_points_s)), _lib.ptr(f(stride_tensor.reshape(-1))),
+                                       _lib.ptr(f(target_bboxes_px)), _lib.ptr(f(target_scores)), _lib.ptr(fg8), B, A, nc, int(reg_max),
+                                       kind, float(w_class), float(w_iou), float(w_dfl), _lib.ptr(gs), _lib.ptr(gd), _lib.ptr(acc),
+                                       _lib.ptr(out), _lib.stream(ps)), "et_tal_loss")
+    return out, gs, gd

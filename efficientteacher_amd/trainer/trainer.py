@@ -118,7 +118,11 @@ class Trainer:
     def build_ddp_model(self, cfg, device):
         if self.cuda and self.RANK != -1:
             self.model = FlatDataParallel(self.model)
-        self.compute_loss = ComputeLoss(self.model, cfg)
+        if cfg.Loss.type == 'ComputeTalLoss':          # YOLOv8 head (trainer.py:320-327 dispatches on cfg.Loss.type)
+            from ..models.loss import ComputeTalLoss
+            self.compute_loss = ComputeTalLoss(self.model, cfg)
+        else:
+            self.compute_loss = ComputeLoss(self.model, cfg)
 
     # ---- the step ------------------------------------------------------------------------------------------
     def _warmup(self, ni, accumulate_target):

@@ -288,6 +288,14 @@ int et_scale_inplace(void* x, int dtype, int64_t n, float alpha, const float* de
  *   (torch.topk leaves ties unspecified; they only occur at metric 0, where the target score is 0).  A <= 16384. */
 int et_v8_decode(const void* reg, int ld_reg, const void* cls, int ld_cls, int dtype, int B, int H, int W, int reg_max, int nc,
                  float stride, float cell_offset, float* out, int64_t A_total, int64_t a_offset, et_stream_t stream);
+/* et_tal_loss: ComputeTalLoss after the assigner (models/loss/tal_loss.py:104-128), forward + gradient: varifocal-free BCE class
+ *   term, GIoU (iou_kind 1) or IoU (0) box term and the DFL term, each normalised by max(sum target_scores, 1) and weighted;
+ *   out = [w_iou*loss_iou, w_dfl*loss_dfl, w_class*loss_cls, total]; grad_* = d total / d logits.  The reference's BboxLoss /
+ *   VarifocalLoss classes are absent from its tree: the spec is oracle/v8.py::tal_loss (parity unpinned, self-validated). */
+int et_tal_loss(const float* pred_scores, const float* pred_distri, const float* anchor_points_s, const float* stride_tensor,
+                const float* target_bboxes_px, const float* target_scores, const uint8_t* fg_mask, int B, int A, int nc, int reg_max,
+                int iou_kind, float w_class, float w_iou, float w_dfl, float* grad_scores, float* grad_distri,
+                float* acc_ws /* 4 floats, zero on entry */, float* out /* 4 floats */, et_stream_t stream);
 int et_tal_assign_workspace_bytes(int B, int A, int G, size_t* bytes /*host out*/);
 int et_tal_assign(const float* pd_scores, const float* pd_bboxes, const float* anc_points, const float* gt_labels,
                   const float* gt_bboxes, const float* mask_gt, int B, int A, int G, int nc, int topk, float alpha, float beta,
