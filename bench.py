@@ -215,13 +215,19 @@ def main():
 
     ni = 2000               # past the warm-up ramp's first iterations, inside warm-up like early training
 
-    host = None
-    if a.host_inputs:           # what a data loader hands over: uint8 NCHW batches in pinned host memory
-        host = [(t * 255).round().to(torch.uint8).cpu().pin_memory() for t in (imgs, u_str, u_ori)]
+    feed = None
+    if a.host_inputs:           # what a data loader hands over: uint8 NCHW batches in host memory, every step
+        from efficientteacher_amd.utils.prefetch import DevicePrefetcher
+        host = [(t * 255).round().to(torch.uint8).cpu() for t in (imgs, u_str, u_ori)]
+
+        def batches():
+            while True:
+                yield host
+        feed = DevicePrefetcher(batches(), device)      # copy stream, one step ahead; /255 happens in the pack kernel
 
     def step(i):
-        if host is not None:
-            im, us, uo = (h.to(device, non_blocking=True).float() / 255.0 for h in host)
+        if feed is not None:
+            im, us, uo = next(feed)
             return tr.train_instance(im, targets, None, us, uo, None, M_s, ni + i)
         return tr.train_instance(imgs, targets, None, u_str, u_ori, None, M_s, ni + i)
 

@@ -25,7 +25,8 @@ __global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict
 // uint8 NCHW batch as the data loaders deliver it (utils/datasets.py:1164, datasets_ssod.py:591) -> NHWC8 of the compute
 // dtype with the reference's `.float() / norm_scale` (trainer.py:411, ssod_trainer.py:694-696) folded in: 3 bytes read and
 // 16 written per pixel instead of a float conversion pass, a division pass and the fp32 pack (4+4+4+4+12+16 bytes).
-// v / scale is an IEEE division, bit-identical to torch's `x.float() / 255.0`.
+// v / scale is an IEEE division: bit-identical to torch's `x.float() / 255.0` on the CPU (the oracle); torch's GPU kernel
+// multiplies by the rounded reciprocal, which differs by at most 1 ulp.
 template <typename T>
 __global__ __launch_bounds__(256) void pack_input_u8_kernel(const uint8_t* __restrict__ x, T* __restrict__ y, int C, int HW,
                                                             long long total, float scale) {

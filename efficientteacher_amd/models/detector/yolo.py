@@ -81,6 +81,14 @@ class Model(nn.Module):
         # eval-mode forward already folds BatchNorm into the conv epilogue on the fly (et_bn_eval_affine)
         return self
 
+    def half(self):
+        """reference callers (val.py:212, trainer.py:475) switch to fp16 for inference / checkpoints; here the fp32 master
+        weights stay and the COMPUTE dtype becomes bf16 (the MFMA path; there are no fp16 kernels)"""
+        return self.set_compute_dtype(torch.bfloat16)
+
+    def float(self):
+        return self.set_compute_dtype(torch.float32)
+
     # ---- arenas -----------------------------------------------------------------------------------------------
     def flat_state(self):
         if self._flat is None:

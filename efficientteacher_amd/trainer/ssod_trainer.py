@@ -170,14 +170,16 @@ class SSODTrainer(Trainer):
 
     def train_with_unlabeled(self, labeled_batches, unlabeled_batches, start_ni=0):
         """ssod_trainer.py:682-697 for iterables of the reference's batch tuples
-        (imgs, targets, paths, shapes) and (imgs, targets, paths, shapes, imgs_ori, M_s)."""
+        (imgs, targets, paths, shapes) and (imgs, targets, paths, shapes, imgs_ori, M_s).  The uint8 image batches are
+        staged to the device one step ahead on a copy stream and normalised inside the input pack kernel
+        (utils/prefetch.py) instead of the reference's `.to(device).float() / 255.0` on the compute stream."""
+        from ..utils.prefetch import DevicePrefetcher
         self.optimizer.zero_grad()
-        labeled = iter(labeled_batches)
+        labeled = DevicePrefetcher(labeled_batches, self.device)
         out = None
-        for i, (t_imgs, t_gt, t_paths, _, t_imgs_ori, t_M) in enumerate(unlabeled_batches):
+        for i, (t_imgs, t_gt, t_paths, _, t_imgs_ori, t_M) in enumerate(DevicePrefetcher(unlabeled_batches, self.device)):
             imgs, targets, paths, _ = next(labeled)
-            imgs = imgs.to(self.device, non_blocking=True).float() / 255.0
-            t_imgs = t_imgs.to(self.device, non_blocking=True).float() / 255.0
-            t_imgs_ori = t_imgs_ori.to(self.device, non_blocking=True).float() / 255.0
+            if not self.cuda:                      # emulator / CPU tests: the plain conversion
+                imgs, t_imgs, t_imgs_ori = (x.float() / 255.0 if x.dtype == torch.uint8 else x for x in (imgs, t_imgs, t_imgs_ori))
             out = self.train_instance(imgs, targets, paths, t_imgs, t_imgs_ori, t_gt, t_M, start_ni + i)
         return out

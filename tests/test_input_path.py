@@ -1,0 +1,37 @@
+"""the loaders' uint8 batches go to the model as they are -- normalisation inside the input pack
+kernel (et_pack_input_u8), staging on a copy stream one step ahead (utils/prefetch.py)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.conftest import golden
+from tests.test_ssod_step import make_trainer
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_pack_input_uint8_equals_float_division(hip, dtype):
+    """(float)x / 255 in the kernel is bit-identical to the IEEE division `imgs.float() / 255.0` (what torch computes on the CPU --
+    the oracle's arithmetic; torch's GPU kernel multiplies by the rounded reciprocal instead, 1 ulp away) followed by the fp32 pack"""
+    from efficientteacher_amd import ops
+    rng = np.random.default_rng(1)
+    x = torch.from_numpy(rng.integers(0, 256, (2, 3, 20, 24), dtype=np.uint8))
+    a = ops.pack_input(hip.t(x), dtype)
+    b = ops.pack_input(hip.t(x.float() / 255.0), dtype)
+    assert a.shape == (2, 20, 24, 8) and torch.equal(a.cpu(), b.cpu())
+    assert (a[..., 3:] == 0).all()
+
+
+def test_train_with_unlabeled_on_loader_tuples(hip):
+    """the reference's batch tuples (uint8 images, labels, paths, shapes[, imgs_ori, M_s]) through train_with_unlabeled: the
+    losses of the first step equal a direct train_instance on the pre-normalised float tensors"""
+    g = golden("ssod_step")
+    u8 = lambda a: torch.from_numpy(np.round(a * 255).astype(np.uint8))
+    imgs, u_str, u_ori = u8(g["imgs"]), u8(g["u_str"]), u8(g["u_ori"])
+    targets, M_s = torch.from_numpy(g["targets"]), torch.from_numpy(g["M_s"])
+    cfg, t1 = make_trainer(hip)
+    out1 = t1.train_with_unlabeled([(imgs, targets, ["a", "b"], None)], [(u_str, None, ["c", "d"], None, u_ori, M_s)], start_ni=500)
+    cfg, t2 = make_trainer(hip)
+    f = lambda x: hip.t(x).float() / 255.0
+    out2 = t2.train_instance(f(imgs), hip.t(targets), None, f(u_str), f(u_ori), None, hip.t(M_s), 500)
+    for k in out2:
+        assert abs(float(out1[k]) - float(out2[k])) <= 1e-6 * max(1.0, abs(float(out2[k]))), k

@@ -21,6 +21,7 @@ bench_lock) run bench_lock; ET_CONV_PP=0 timeout 900 python bench.py --steps 20 
 bench_nostream) run bench_nostream; ET_WGRAD_STREAM=0 timeout 900 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_nostream.json 2> $OUT/bench_nostream.err; cut -c1-300 $OUT/bench_nostream.json ;;
 bench_nofuse) run bench_nofuse; ET_FUSE_BN_BWD=0 timeout 900 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_nofuse.json 2> $OUT/bench_nofuse.err; cut -c1-300 $OUT/bench_nofuse.json ;;
 bench_graph) run bench_graph; timeout 900 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --graph > $OUT/bench_graph.json 2> $OUT/bench_graph.err; cut -c1-300 $OUT/bench_graph.json ;;
+bench_host) run bench_host; timeout 900 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --host-inputs > $OUT/bench_host_inputs.json 2> $OUT/bench_host.err; cut -c1-300 $OUT/bench_host_inputs.json ;;
 bench_quick) run bench_quick; timeout 900 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_quick.json 2> $OUT/bench_quick.err; cut -c1-300 $OUT/bench_quick.json ;;
 smoke) run smoke; timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -3 $OUT/smoke.log ;;
 prof) run prof; (cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/bench_under_rocprof.json 2> $GRAFT_REPO_ROOT/$OUT/prof.err); find $OUT/prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv; find $OUT/prof -name "*kernel_trace.csv" | head -1 | xargs -I{} python tools/trace_streams.py {} > $OUT/trace_streams.txt 2>&1; cat $OUT/trace_streams.txt; find $OUT/prof -name "*.db" -delete; find $OUT/prof -name "*kernel_trace.csv" -size +20M -delete; head -8 $OUT/kernel_stats.csv | cut -c1-160 ;;
