@@ -184,6 +184,9 @@ class _SsodHotPath(_HotPath):
             raise NotImplementedError("SSOD.extra_teachers: extra teacher ensembles stay on the reference trainer")
         self._side = None
         self.teacher_pred_hook = None
+        # the captured-graph step (trainer/graph_step.py) needs this package's update_optimizer; under the reference's own
+        # update_optimizer (kept here on purpose) every step is issued eagerly
+        self.use_graph, self.graph_warmup, self._eager_steps, self._capturing, self._graph = False, 3, 0, False, None
         return ckpt
 
     # ---- ssod_trainer.py:258 ------------------------------------------------------------------------------------
