@@ -210,8 +210,8 @@ class _SsodHotPath(_HotPath):
     def train_instance(self, imgs, targets, paths, unlabeled_imgs, unlabeled_imgs_ori, unlabeled_gt, unlabeled_M, ni, pbar=None,
                        callbacks=None):
         from .ssod_trainer import SSODTrainer as _Core
-        items = _Core.train_instance(self, imgs, targets, paths, unlabeled_imgs, unlabeled_imgs_ori, unlabeled_gt, unlabeled_M,
-                                     ni, pbar, callbacks)
+        items = _Core._train_instance_eager(self, imgs, targets, paths, unlabeled_imgs, unlabeled_imgs_ori, unlabeled_gt, unlabeled_M,
+                                            ni, pbar, callbacks)
         if self.RANK in [-1, 0] and getattr(self, "meter", None) is not None:      # ssod_trainer.py:653-678 (the numbers it prints)
             self.meter.update(items)
             if pbar is not None and hasattr(pbar, "set_description"):
