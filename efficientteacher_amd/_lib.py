@@ -61,6 +61,8 @@ SIGNATURES = {
     "et_upsample2x_bwd": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "et_pseudo_label_transform": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P, P]),
     "et_yolo_loss": (c_int, [P, P]),
+    "et_ota_workspace_bytes": (c_int, [c_int, c_int, c_int, c_int, ctypes.POINTER(c_size_t)]),
+    "et_ota_assign": (c_int, [P, P, c_float, c_int, P, P, P]),
     "et_select_targets": (c_int, [P, P, c_int, P, P, c_int, c_int, P, P]),
     "et_scale_cast": (c_int, [P, P, c_int, c_int64, c_float, P, P]),
     "et_domain_focal": (c_int, [P, c_int, c_int, c_int64, c_int, c_float, P, c_int, P, P]),
@@ -89,7 +91,7 @@ class LossDesc(ctypes.Structure):
                 ("anchor_t", c_float), ("gr", c_float), ("cp", c_float), ("cn", c_float), ("cls_pw", c_float),
                 ("obj_pw", c_float), ("box_w", c_float), ("obj_w", c_float), ("cls_w", c_float),
                 ("pass_mask", c_int), ("ignore_obj", c_int), ("targets", P), ("acc_ws", P), ("out", P),
-                ("level", LossLevel * 4)]
+                ("ota_match", P), ("obj_channel", c_int), ("level", LossLevel * 4)]
 
 
 _dll = None

@@ -38,6 +38,8 @@ struct LossArgs {
     float anchor_t, gr, cp, cn, cls_pw, obj_pw, box_w, obj_w, cls_w;
     int pass_mask;         // bit p set: pass p enabled
     int ignore_obj;
+    int obj_ch;            // channel of the objectness logit: 4, or no-1 in the SimOTA half (loss.py:246)
+    const int* ota_match;  // NULL, or [nl][5*na*NT]: pass-0 slot -> index of the matched target, -1 = not a positive
     const float* tgt;      // [NT][8]: img, cls, x, y, w, h, score, flags(bit p = member of pass p)
     float* acc;            // [nl][16] accumulators, see ACC_* ; zeroed by the caller (et_yolo_loss does it)
 };
@@ -59,7 +61,7 @@ __device__ __forceinline__ float ld_logit(const void* p, int dtype, long long of
 }
 
 // candidate slot s of pass `pass` on this level -> assignment result
-__device__ __forceinline__ Slot eval_slot(const LossArgs& A, const LossLevel& L, int pass, int s) {
+__device__ __forceinline__ Slot eval_slot(const LossArgs& A, const LossLevel& L, int pass, int s, int level = 0) {
     Slot r;
     r.valid = false;
     const int k = s % A.NT;
@@ -91,6 +93,15 @@ __device__ __forceinline__ Slot eval_slot(const LossArgs& A, const LossLevel& L,
     r.tb[0] = gx - (float)gi; r.tb[1] = gy - (float)gj; r.tb[2] = gw; r.tb[3] = gh;
     r.score = t[6];
     r.seq = (unsigned)s + 1u + (pass == 1 ? (1u << 27) : 0u);
+    if (pass == 0 && A.ota_match) {
+        // SimOTA (ComputeLoss.ota_loss, loss.py:218-244): the slot keeps its cell and anchor, box and class come from the
+        // target the dynamic-k matching gave it: selected_tbox = ota_targets[:, 2:6] * gain ; selected_tbox[:, :2] -= grid
+        const int g = A.ota_match[(size_t)level * (5 * A.na * A.NT) + s];
+        if (g < 0) { r.valid = false; return r; }
+        const float* tg = A.tgt + (size_t)g * 8;
+        r.c = (int)tg[1];
+        r.tb[0] = tg[2] * nx - (float)gi; r.tb[1] = tg[3] * ny - (float)gj; r.tb[2] = tg[4] * nx; r.tb[3] = tg[5] * ny;
+    }
     return r;
 }
 
@@ -99,7 +110,7 @@ __global__ __launch_bounds__(256) void loss_count_kernel(LossArgs A, LossLevel L
     const int s = blockIdx.x * 256 + threadIdx.x;
     const int pass = blockIdx.y;
     int v = 0;
-    if (((A.pass_mask >> pass) & 1) && s < nslot) v = eval_slot(A, L, pass, s).valid ? 1 : 0;
+    if (((A.pass_mask >> pass) & 1) && s < nslot) v = eval_slot(A, L, pass, s, level).valid ? 1 : 0;
     v = et_wave_sum_i(v);
     if ((threadIdx.x & 63) == 0 && v) atomicAdd(A.acc + level * 16 + ACC_CNT0 + pass, (float)v);
 }
@@ -174,7 +185,7 @@ __global__ __launch_bounds__(256) void loss_pos_kernel(LossArgs A, LossLevel L, 
     int cls_c = 0;
     float cls_wgt = 0.f;
     if (((A.pass_mask >> pass) & 1) && s < nslot) {
-        const Slot r = eval_slot(A, L, pass, s);
+        const Slot r = eval_slot(A, L, pass, s, level);
         if (r.valid && r.b >= 0 && r.b < A.B) {
             const float npos = A.acc[level * 16 + ACC_CNT0 + pass];
             const long long off = r.b * L.sb + r.a * L.sa + r.gj * L.sy + r.gi * L.sx;
@@ -258,12 +269,12 @@ __global__ __launch_bounds__(256) void loss_obj_kernel(LossArgs A, LossLevel L, 
                 const int gj = (int)((i / L.nx) % L.ny);
                 const int a = (int)((i / ((long long)L.nx * L.ny)) % A.na);
                 const long long b = i / ((long long)L.nx * L.ny * A.na);
-                const long long off = b * L.sb + a * L.sa + gj * L.sy + gi * L.sx + 4;
+                const long long off = b * L.sb + a * L.sa + gj * L.sy + gi * L.sx + A.obj_ch;
                 const float x = ld_logit(L.p, A.dtype, off);
                 float g;
                 lsum = bce_logits(x, t, A.obj_pw, g);
                 const float n = fixed_n > 0.f ? fixed_n : A.acc[level * 16 + ACC_OBJN];
-                L.dp[off] = g * (A.obj_w * L.balance / n);
+                L.dp[off] += g * (A.obj_w * L.balance / n);   // += : in the SimOTA half this channel is also a class logit
             }
         }
     }
@@ -299,6 +310,326 @@ __global__ void loss_finalize_kernel(LossArgs A, float b0, float b1, float b2, f
     lbox *= A.box_w; lobj *= A.obj_w; lcls *= A.cls_w;
     out[0] = lbox; out[1] = lobj; out[2] = lcls;
     out[3] = (lbox + lobj + lcls) * (float)A.B;
+}
+
+// ---- SimOTA matching (YOLOAnchorAssigner.build_ota_targets, models/assigner/yolo_anchor_assigner.py:104-264) ------------
+// The reference loops over the images on the host; per image it gathers the candidates of find_3_positive (:266-317, the
+// same slots as build_targets), builds the (gt x candidate) IoU and cost matrices and runs dynamic-k matching with
+// torch.topk / .item() per gt.  Here, with no host round trip:
+//   ota_order    stable order of the targets by image (the reference's `targets[:, 0] == batch_idx` subsets) + image starts
+//   ota_cand     one thread per slot (level, offset, anchor, target): decoded box in pixels (:160-164), logits offset of
+//                its cell, sum over the classes of the t=0 BCE term of the pair-wise class cost (:196-205)
+//   ota_gt       one workgroup per gt: scans the slots of its image, every thread keeps its 13 largest IoUs and 13
+//                cheapest (cost, slot) in registers; the workgroup merges them, dynamic_k = max(1, int(sum of the top-13
+//                IoUs)) (:185-186) and marks the dynamic_k cheapest slots (:215-219)
+//   ota_resolve  one thread per slot: unmarked -> -1, marked once -> that gt, marked by several gts -> argmin of the cost
+//                over ALL gts of the image (:223-226)
+// Quirks kept from the reference: gt boxes are scaled by a literal 640 (:128 "TODO"), the "objectness" factor of the class
+// cost is the LAST channel of the prediction (p_obj_e2e = fg_pred[:, -1:], :157,199) -- with no = 5 + nc that is the logit
+// of class nc-1.  Ties (equal costs / IoUs): torch.topk and torch.min leave the pick unspecified; here the smaller slot
+// index (level-major, then reference candidate order) resp. the earlier gt wins.
+#define OTA_K 13
+
+struct OtaArgs {
+    LossArgs A;
+    LossLevel L[LOSS_MAXL];
+    float stride[LOSS_MAXL];
+    float img_size;
+    int topk;
+    int* order;        // [NT]   target indices grouped by image, input order inside an image; targets outside [0,B) last
+    int* istart;       // [B+1]
+    float* cbox;       // [nq][4] xyxy in pixels      nq = nl * 5 * na * NT
+    float* cs0;        // [nq]
+    long long* coff;   // [nq]   logits offset of the slot's cell
+    int* cimg;         // [nq]   image of the slot, -1 = not a candidate
+    int* cnt;          // [nq]
+    int* who;          // [nq]
+    int* match;        // [nq]   out
+};
+
+__device__ __forceinline__ int ota_key(const LossArgs& A, int k) {      // image of target k, or B for rows no image owns
+    const float* t = A.tgt + (size_t)k * 8;
+    const int b = (int)t[0];
+    return ((((int)t[7]) & 1) && t[0] == (float)b && b >= 0 && b < A.B) ? b : A.B;
+}
+
+__global__ __launch_bounds__(256) void ota_order_kernel(OtaArgs O) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    const LossArgs& A = O.A;
+    if (k < A.NT) {
+        const int key = ota_key(A, k);
+        int rank = 0;
+        for (int j = 0; j < A.NT; ++j) {
+            const int kj = ota_key(A, j);
+            rank += (kj < key || (kj == key && j < k)) ? 1 : 0;
+        }
+        O.order[rank] = k;
+    }
+    if (k <= A.B) {
+        int c = 0;
+        for (int j = 0; j < A.NT; ++j) c += ota_key(A, j) < k ? 1 : 0;
+        O.istart[k] = c;
+    }
+}
+
+__global__ __launch_bounds__(256) void ota_cand_kernel(OtaArgs O) {
+    const LossArgs& A = O.A;
+    const int nslot = 5 * A.na * A.NT;
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    const int level = blockIdx.y;
+    const LossLevel& L = O.L[level];
+    const size_t q = (size_t)level * nslot + s;
+    bool live = false;
+    long long off = 0;
+    if (s < nslot) {
+        const Slot r = eval_slot(A, L, 0, s);          // O.A.ota_match is NULL: the plain find_3_positive slot
+        live = r.valid && r.b >= 0 && r.b < A.B && ota_key(A, s % A.NT) == r.b;
+        O.cnt[q] = 0;
+        O.who[q] = -1;
+        O.cimg[q] = live ? r.b : -1;
+        if (live) {
+            off = r.b * L.sb + r.a * L.sa + r.gj * L.sy + r.gi * L.sx;
+            float sg[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sg[i] = 1.0f / (1.0f + expf(-ld_logit(L.p, A.dtype, off + i)));
+            const float st = O.stride[level];
+            const float px = (sg[0] * 2.f - 0.5f + (float)r.gi) * st, py = (sg[1] * 2.f - 0.5f + (float)r.gj) * st;
+            const float tw = sg[2] * 2, th = sg[3] * 2;
+            const float pw = tw * tw * L.anchors[r.a][0] * st, ph = th * th * L.anchors[r.a][1] * st;
+            float* cb = O.cbox + q * 4;
+            cb[0] = px - pw / 2; cb[1] = py - ph / 2; cb[2] = px + pw / 2; cb[3] = py + ph / 2;
+            O.coff[q] = off;
+        }
+    }
+    // class walk as in loss_pos_kernel: the wave spreads the nc logits of each live slot over its lanes
+    const int lane = threadIdx.x & 63;
+    unsigned long long m = __ballot(live);
+    float mine = 0.f;
+    while (m) {
+        const int src = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const unsigned lo = __shfl((unsigned)(off & 0xffffffffll), src);
+        const unsigned hi = __shfl((unsigned)((unsigned long long)off >> 32), src);
+        const long long off_s = (long long)(((unsigned long long)hi << 32) | lo);
+        const float se = 1.0f / (1.0f + expf(-ld_logit(L.p, A.dtype, off_s + A.no - 1)));
+        float acc = 0.f;
+        for (int c = lane; c < A.nc; c += 64) {
+            const float sc = 1.0f / (1.0f + expf(-ld_logit(L.p, A.dtype, off_s + 5 + c)));
+            const float y = sqrtf(sc * se);
+            float g_;
+            acc += bce_logits(logf(y / (1.0f - y)), 0.f, 1.f, g_);
+        }
+        acc = et_wave_sum(acc);
+        if (lane == src) mine = acc;
+    }
+    if (live) O.cs0[q] = mine;
+}
+
+// IoU (utils/metrics.py:252-274 box_iou) and cost (:183, :196-211) of gt (box gb, class gc) against slot q
+__device__ __forceinline__ float ota_pair(const OtaArgs& O, int level, size_t q, const float gb[4], int gc, float& iou) {
+    const float* cb = O.cbox + q * 4;
+    const float a1 = (gb[2] - gb[0]) * (gb[3] - gb[1]), a2 = (cb[2] - cb[0]) * (cb[3] - cb[1]);
+    const float iw = fmaxf(fminf(gb[2], cb[2]) - fmaxf(gb[0], cb[0]), 0.f);
+    const float ih = fmaxf(fminf(gb[3], cb[3]) - fmaxf(gb[1], cb[1]), 0.f);
+    const float inter = iw * ih;
+    iou = inter / (a1 + a2 - inter);
+    const LossLevel& L = O.L[level];
+    const long long off = O.coff[q];
+    const float sc = 1.0f / (1.0f + expf(-ld_logit(L.p, O.A.dtype, off + 5 + gc)));
+    const float se = 1.0f / (1.0f + expf(-ld_logit(L.p, O.A.dtype, off + O.A.no - 1)));
+    const float y = sqrtf(sc * se);
+    const float x = logf(y / (1.0f - y));
+    float g_;
+    const float cls = O.cs0[q] - bce_logits(x, 0.f, 1.f, g_) + bce_logits(x, 1.f, 1.f, g_);
+    float cost = cls + 3.0f * (-logf(iou + 1e-8f));
+    if (!(cost == cost)) cost = INFINITY;              // torch.topk orders NaN as the largest value
+    return cost;
+}
+
+__device__ __forceinline__ void ota_gt_box(const OtaArgs& O, int g, float gb[4], int& gc) {
+    const float* t = O.A.tgt + (size_t)g * 8;
+    const float x = t[2] * O.img_size, y = t[3] * O.img_size, w = t[4] * O.img_size, h = t[5] * O.img_size;   // :128
+    gb[0] = x - w / 2; gb[1] = y - h / 2; gb[2] = x + w / 2; gb[3] = y + h / 2;
+    gc = min(max((int)t[1], 0), O.A.nc - 1);
+}
+
+// slot index of candidate number ci of image range [r0, r1): level-major, then slot order (offset, anchor, target)
+__device__ __forceinline__ size_t ota_slot_of(const OtaArgs& O, int r0, int nimg, long long ci, int& level) {
+    const int per_level = 5 * O.A.na * nimg;
+    level = (int)(ci / per_level);
+    const int rem = (int)(ci % per_level);
+    const int oa = rem / nimg, j = rem % nimg;
+    const int k = O.order[r0 + j];
+    return (size_t)level * (5 * O.A.na * O.A.NT) + (size_t)oa * O.A.NT + k;
+}
+
+__global__ __launch_bounds__(256) void ota_gt_kernel(OtaArgs O) {
+    __shared__ float sh_i[256 * OTA_K];
+    __shared__ float sh_c[256 * OTA_K];
+    __shared__ int sh_q[256 * OTA_K];
+    __shared__ float rv[256];
+    __shared__ int ri[256];
+    __shared__ int rt[256];
+    const LossArgs& A = O.A;
+    const int g = O.order[blockIdx.x];
+    const int b = ota_key(A, g);
+    if (b >= A.B) return;
+    const int r0 = O.istart[b], nimg = O.istart[b + 1] - r0;
+    float gb[4];
+    int gc;
+    ota_gt_box(O, g, gb, gc);
+    float ti[OTA_K], tc[OTA_K];
+    int tq[OTA_K];
+#pragma unroll
+    for (int i = 0; i < OTA_K; ++i) { ti[i] = -1.f; tc[i] = INFINITY; tq[i] = 0x7fffffff; }
+    const long long ncand = (long long)A.nl * 5 * A.na * nimg;
+    const int tid = threadIdx.x;
+    for (long long ci = tid; ci < ncand; ci += 256) {
+        int level;
+        const size_t q = ota_slot_of(O, r0, nimg, ci, level);
+        if (O.cimg[q] != b) continue;
+        float iou;
+        float cost = ota_pair(O, level, q, gb, gc, iou);
+        int qi = (int)q;
+        float v = (iou == iou) ? iou : INFINITY;          // torch.topk: NaN sorts as the largest
+#pragma unroll
+        for (int i = 0; i < OTA_K; ++i) {
+            if (v > ti[i]) { const float x = ti[i]; ti[i] = v; v = x; }
+            if (cost < tc[i] || (cost == tc[i] && qi < tq[i])) {
+                const float x = tc[i]; const int y = tq[i];
+                tc[i] = cost; tq[i] = qi; cost = x; qi = y;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < OTA_K; ++i) { sh_i[tid * OTA_K + i] = ti[i]; sh_c[tid * OTA_K + i] = tc[i]; sh_q[tid * OTA_K + i] = tq[i]; }
+    __syncthreads();
+    // dynamic_k from the top-k IoUs of the whole workgroup
+    int ptr = 0;
+    float sum = 0.f;
+    const int K = min(O.topk, OTA_K);
+    for (int r = 0; r < K; ++r) {
+        rv[tid] = ptr < OTA_K ? sh_i[tid * OTA_K + ptr] : -1.f;
+        rt[tid] = tid;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if (tid < st && rv[tid + st] > rv[tid]) { rv[tid] = rv[tid + st]; rt[tid] = rt[tid + st]; }
+            __syncthreads();
+        }
+        const float best = rv[0];
+        const int wt = rt[0];
+        __syncthreads();
+        if (best < 0.f) break;                            // fewer than k candidates
+        sum += best;
+        if (tid == wt) ++ptr;
+    }
+    int dyn = (int)sum;                                    // .int() truncation; NaN/inf IoU sums are not meaningful in the reference either
+    if (!(sum == sum) || sum > 1e9f) dyn = K;
+    dyn = max(dyn, 1);
+    ptr = 0;
+    for (int r = 0; r < dyn; ++r) {
+        rv[tid] = ptr < OTA_K ? sh_c[tid * OTA_K + ptr] : INFINITY;
+        ri[tid] = ptr < OTA_K ? sh_q[tid * OTA_K + ptr] : 0x7fffffff;
+        rt[tid] = tid;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if (tid < st) {
+                const float ov = rv[tid + st];
+                const int oq = ri[tid + st];
+                if (ov < rv[tid] || (ov == rv[tid] && oq < ri[tid])) { rv[tid] = ov; ri[tid] = oq; rt[tid] = rt[tid + st]; }
+            }
+            __syncthreads();
+        }
+        const int wq = ri[0], wt = rt[0];
+        __syncthreads();
+        if (wq == 0x7fffffff) break;
+        if (tid == wt) {
+            ++ptr;
+            atomicAdd(O.cnt + wq, 1);
+            O.who[wq] = g;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void ota_resolve_kernel(OtaArgs O, long long nq) {
+    const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= nq) return;
+    const int b = O.cimg[q];
+    int res = -1;
+    if (b >= 0) {
+        const int c = O.cnt[q];
+        if (c == 1) res = O.who[q];
+        else if (c > 1) {
+            const int level = (int)(q / (5 * O.A.na * O.A.NT));
+            float best = INFINITY;
+            bool have = false;
+            for (int r = O.istart[b]; r < O.istart[b + 1]; ++r) {
+                const int g = O.order[r];
+                float gb[4], iou;
+                int gc;
+                ota_gt_box(O, g, gb, gc);
+                const float cost = ota_pair(O, level, (size_t)q, gb, gc, iou);
+                if (!have || cost < best) { best = cost; res = g; have = true; }
+            }
+        }
+    }
+    O.match[q] = res;
+}
+
+extern "C" int et_ota_workspace_bytes(int B, int na, int nl, int NT, size_t* bytes) {
+    if (!bytes) return -1;
+    if (B < 0 || na < 1 || nl < 1 || NT < 0) return -2;
+    const size_t nq = (size_t)nl * 5 * na * NT;
+    *bytes = sizeof(int) * (NT + B + 1 + 3 * nq) + sizeof(float) * 5 * nq + sizeof(long long) * nq + 64;
+    return 0;
+}
+
+extern "C" int et_ota_assign(const et_loss_desc* d, const float* strides, float img_size, int top_k, void* workspace, int* match,
+                             et_stream_t stream) {
+    if (!d || !d->targets || !strides || !workspace || !match) return -1;
+    if (d->nl < 1 || d->nl > LOSS_MAXL || d->na < 1 || d->na > 3 || d->nc < 1 || d->NT < 0 || top_k < 1 || top_k > OTA_K) return -2;
+    if (d->dtype != ET_F32 && d->dtype != ET_BF16) return -2;
+    const long long nq = (long long)d->nl * 5 * d->na * d->NT;
+    if (nq >= (1ll << 31)) return -2;
+    if (d->NT == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    OtaArgs O;
+    LossArgs& A = O.A;
+    A.dtype = d->dtype; A.B = d->B; A.na = d->na; A.nc = d->nc; A.no = d->nc + 5; A.NT = d->NT; A.nl = d->nl;
+    A.anchor_t = d->anchor_t; A.gr = d->gr; A.cp = d->cp; A.cn = d->cn; A.cls_pw = d->cls_pw; A.obj_pw = d->obj_pw;
+    A.box_w = d->box_w; A.obj_w = d->obj_w; A.cls_w = d->cls_w;
+    A.pass_mask = 1; A.ignore_obj = 0; A.obj_ch = 4; A.ota_match = nullptr;
+    A.tgt = d->targets; A.acc = nullptr;
+    for (int l = 0; l < LOSS_MAXL; ++l) {
+        LossLevel& L = O.L[l];
+        O.stride[l] = 0.f;
+        L.p = nullptr; L.dp = nullptr; L.tobj = nullptr; L.sb = L.sa = L.sy = L.sx = 0; L.ny = L.nx = 1; L.balance = 0.f;
+        for (int a = 0; a < 3; ++a) L.anchors[a][0] = L.anchors[a][1] = 1.f;
+        if (l >= d->nl) continue;
+        const et_loss_level* e = &d->level[l];
+        if (!e->p) return -1;
+        L.p = e->p; L.sb = e->sb; L.sa = e->sa; L.sy = e->sy; L.sx = e->sx; L.ny = e->ny; L.nx = e->nx;
+        for (int a = 0; a < d->na; ++a) { L.anchors[a][0] = e->anchors[2 * a]; L.anchors[a][1] = e->anchors[2 * a + 1]; }
+        O.stride[l] = strides[l];
+    }
+    O.img_size = img_size; O.topk = top_k;
+    char* w = (char*)workspace;
+    O.coff = (long long*)w;  w += sizeof(long long) * nq;
+    O.cbox = (float*)w;      w += sizeof(float) * 4 * nq;
+    O.cs0 = (float*)w;       w += sizeof(float) * nq;
+    O.cimg = (int*)w;        w += sizeof(int) * nq;
+    O.cnt = (int*)w;         w += sizeof(int) * nq;
+    O.who = (int*)w;         w += sizeof(int) * nq;
+    O.order = (int*)w;       w += sizeof(int) * d->NT;
+    O.istart = (int*)w;
+    O.match = match;
+    const int nslot = 5 * d->na * d->NT;
+    hipLaunchKernelGGL(ota_order_kernel, dim3((max(d->NT, d->B + 1) + 255) / 256), dim3(256), 0, s, O);
+    hipLaunchKernelGGL(ota_cand_kernel, dim3((nslot + 255) / 256, d->nl), dim3(256), 0, s, O);
+    hipLaunchKernelGGL(ota_gt_kernel, dim3(d->NT), dim3(256), 0, s, O);
+    hipLaunchKernelGGL(ota_resolve_kernel, dim3(et_cdiv(nq, 256)), dim3(256), 0, s, O, nq);
+    ET_CHECK_LAUNCH();
+    return 0;
 }
 
 // ---- pseudo-label -> target table (ComputeStudentMatchLoss.select_targets, ssod_loss.py:130-192) ----------
@@ -356,6 +687,8 @@ extern "C" int et_yolo_loss(const et_loss_desc* d, et_stream_t stream) {
     A.anchor_t = d->anchor_t; A.gr = d->gr; A.cp = d->cp; A.cn = d->cn; A.cls_pw = d->cls_pw; A.obj_pw = d->obj_pw;
     A.box_w = d->box_w; A.obj_w = d->obj_w; A.cls_w = d->cls_w;
     A.pass_mask = d->pass_mask; A.ignore_obj = d->ignore_obj;
+    A.ota_match = d->ota_match; A.obj_ch = d->obj_channel ? d->obj_channel : 4;
+    if (A.obj_ch < 4 || A.obj_ch >= A.no) return -2;
     A.tgt = d->targets; A.acc = d->acc_ws;
     if (A.dtype != ET_F32 && A.dtype != ET_BF16) return -2;
     (void)hipMemsetAsync(d->acc_ws, 0, sizeof(float) * 16 * LOSS_MAXL, s);

@@ -21,7 +21,19 @@ class YoloLossFn(torch.autograd.Function):
     def forward(ctx, table, hp, anchors_host, balance, *p):
         hp = dict(hp)
         ctx.grad_dst = hp.pop("grad_dst", None) or [None] * len(p)
-        out, dps = ops.yolo_loss(list(p), table, anchors_host, balance, **hp)
+        ota = hp.pop("ota", None)
+        if ota is None:
+            out, dps = ops.yolo_loss(list(p), table, anchors_host, balance, **hp)
+        else:
+            # ComputeLoss.ota_loss (loss.py:210-303): SimOTA-matched positives with the objectness read from the last
+            # channel (:246), then the plain anchor-based half (:251-292); the three sums are added BEFORE the weights,
+            # which is what adding the two weighted results amounts to.  Both halves accumulate into the same gradient.
+            pl = list(p)
+            match = ops.ota_assign(pl, table, anchors_host, ota["strides"], nc=hp["nc"], anchor_t=hp["anchor_t"],
+                                   top_k=ota["top_k"], img_size=ota["img_size"])
+            o1, dps = ops.yolo_loss(pl, table, anchors_host, balance, ota_match=match, obj_channel=hp["nc"] + 4, **hp)
+            o2, dps = ops.yolo_loss(pl, table, anchors_host, balance, dps=dps, **hp)
+            out = o1 + o2
         ctx.dps = dps
         ctx.meta = [(pi.shape, pi.stride(), pi.dtype) for pi in p]
         ctx.bs = p[0].shape[0]
@@ -56,8 +68,6 @@ class ComputeLoss:
             raise NotImplementedError("focal loss (Loss.fl_gamma > 0) is outside the hot path")
         if cfg.Loss.autobalance:
             raise NotImplementedError("Loss.autobalance needs a host sync per level; off in every shipped config")
-        if cfg.Loss.assigner_type == 'SimOTA':
-            raise NotImplementedError("SimOTA assignment is SURVEY.md 8(f-4), not built yet")
         self.cls_pw, self.obj_pw = float(cfg.Loss.cls_pw), float(cfg.Loss.obj_pw)
         self.cp, self.cn = smooth_BCE(eps=cfg.Loss.label_smoothing)
         det = _head_of(model)
@@ -75,7 +85,10 @@ class ComputeLoss:
             setattr(self, k, getattr(det, k))
         if self.num_keypoints > 0:
             raise NotImplementedError("keypoint losses are outside the hot path")
-        self.ota = False
+        # Loss.assigner_type == 'SimOTA' (loss.py:131-136, :306): dynamic-k matched positives on top of the anchor-based ones
+        self.ota = cfg.Loss.assigner_type == 'SimOTA'
+        self.top_k = int(cfg.Loss.top_k)
+        self._strides = [float(s) for s in det.stride]
         self._anchors_host = [[[float(v) for v in a] for a in lvl] for lvl in det.anchors.detach().cpu().tolist()]
 
     def _hp(self):
@@ -83,7 +96,7 @@ class ComputeLoss:
                     cls_pw=self.cls_pw, obj_pw=self.obj_pw, box_w=float(self.box_w), obj_w=float(self.obj_w),
                     cls_w=float(self.cls_w))
 
-    def default_loss(self, p, targets, table=None):
+    def default_loss(self, p, targets, table=None, ota=False):
         """table: a ready (NT, 8) device table [img, cls, x, y, w, h, score, flags] (rows with flags 0 are padding) instead
         of `targets` -- the fixed-capacity form the captured step graph replays (trainer/graph_step.py)."""
         dev = p[0].device
@@ -93,14 +106,22 @@ class ComputeLoss:
             table = torch.cat((t, torch.zeros((n, 1), device=dev), torch.ones((n, 1), device=dev)), 1)
         hp = self._hp()
         hp["grad_dst"] = [getattr(pi, "_et_grad_dst", None) for pi in p]
+        if ota:
+            if self.top_k > 13:
+                raise NotImplementedError("Loss.top_k > 13: the matching kernel keeps 13 candidates per thread")
+            # yolo_anchor_assigner.py:128 scales the targets by a literal 640 ("TODO" there); kept as is
+            hp["ota"] = dict(strides=self._strides, top_k=self.top_k, img_size=640.0)
         out = YoloLossFn.apply(table, hp, self._anchors_host, self.balance, *p)
         loss = out[3:4]
         det = out.detach()
         loss_dict = dict(box=det[0:1], obj=det[1:2], cls=det[2:3], loss=det[3:4])
         return loss, loss_dict
 
+    def ota_loss(self, p, targets, table=None):
+        return self.default_loss(p, targets, table=table, ota=True)
+
     def __call__(self, p, targets):
-        return self.default_loss(p, targets)
+        return self.ota_loss(p, targets) if self.ota else self.default_loss(p, targets)
 
 
 class _DomainFocal:

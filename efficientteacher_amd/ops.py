@@ -542,40 +542,82 @@ def _flat_span(p):
     return ((span + sx - 1) // sx) * sx if sx > 0 else span
 
 
+def _loss_desc(p, table, anchors_host, balance, hp, pass_mask, ignore_obj):
+    B, na = p[0].shape[0], p[0].shape[1]
+    nc = hp["nc"]
+    d = _lib.LossDesc()
+    d.dtype = et_dtype(p[0]); d.B = B; d.na = na; d.nc = nc; d.NT = int(table.shape[0]); d.nl = len(p)
+    for k in ("anchor_t", "gr", "cp", "cn", "cls_pw", "obj_pw", "box_w", "obj_w", "cls_w"):
+        setattr(d, k, hp[k])
+    d.pass_mask = pass_mask; d.ignore_obj = int(bool(ignore_obj))
+    d.ota_match = None; d.obj_channel = 0
+    for i, pi in enumerate(p):
+        assert pi.dim() == 5 and pi.stride(4) == 1 and pi.shape[4] == nc + 5 and pi.dtype == p[0].dtype
+        L = d.level[i]
+        L.p = _lib.ptr(pi)
+        L.sb, L.sa, L.sy, L.sx = pi.stride(0), pi.stride(1), pi.stride(2), pi.stride(3)
+        L.ny, L.nx = pi.shape[2], pi.shape[3]
+        for a in range(na):
+            L.anchors[2 * a] = float(anchors_host[i][a][0]); L.anchors[2 * a + 1] = float(anchors_host[i][a][1])
+        L.balance = float(balance[i])
+    return d
+
+
 def yolo_loss(p, table, anchors_host, balance, *, nc, anchor_t, gr, cp, cn, cls_pw, obj_pw, box_w, obj_w, cls_w,
-              pass_mask=1, ignore_obj=False):
+              pass_mask=1, ignore_obj=False, ota_match=None, obj_channel=0, dps=None):
     """Fused assignment + loss + gradient.  p: list of (B,na,ny,nx,no) logits views (channel stride 1).
-    Returns out (8,) fp32 [lbox, lobj, lcls, loss*bs, npos0..3] and the flat fp32 gradient buffers."""
+    Returns out (8,) fp32 [lbox, lobj, lcls, loss*bs, npos0..3] and the flat fp32 gradient buffers.
+    ota_match / obj_channel: the SimOTA half of ComputeLoss.ota_loss (positives from `ota_assign`, objectness on another
+    channel); dps: gradient buffers of an earlier call to accumulate into."""
+    import ctypes
     lib = _lib.load()
     dev = p[0].device
     B, na = p[0].shape[0], p[0].shape[1]
-    d = _lib.LossDesc()
-    d.dtype = et_dtype(p[0]); d.B = B; d.na = na; d.nc = nc; d.NT = int(table.shape[0]); d.nl = len(p)
-    d.anchor_t = anchor_t; d.gr = gr; d.cp = cp; d.cn = cn; d.cls_pw = cls_pw; d.obj_pw = obj_pw
-    d.box_w = box_w; d.obj_w = obj_w; d.cls_w = cls_w
-    d.pass_mask = pass_mask; d.ignore_obj = int(bool(ignore_obj))
     table = table.contiguous()
+    hp = dict(nc=nc, anchor_t=anchor_t, gr=gr, cp=cp, cn=cn, cls_pw=cls_pw, obj_pw=obj_pw, box_w=box_w, obj_w=obj_w, cls_w=cls_w)
+    d = _loss_desc(p, table, anchors_host, balance, hp, pass_mask, ignore_obj)
     acc = torch.empty(64, dtype=torch.float32, device=dev)
     out = torch.empty(8, dtype=torch.float32, device=dev)
     d.targets = _lib.ptr(table) if table.numel() else _lib.ptr(acc)
     d.acc_ws = _lib.ptr(acc); d.out = _lib.ptr(out)
-    keep, dps = [table, acc], []
+    if ota_match is not None:
+        assert ota_match.dtype == torch.int32 and ota_match.numel() == len(p) * 5 * na * table.shape[0]
+        d.ota_match = _lib.ptr(ota_match)
+    d.obj_channel = int(obj_channel)
+    keep, new_dps = [table, acc], []
     for i, pi in enumerate(p):
-        assert pi.dim() == 5 and pi.stride(4) == 1 and pi.shape[4] == nc + 5 and pi.dtype == p[0].dtype
         _, _, ny, nx, _ = pi.shape
-        dp = torch.zeros(_flat_span(pi), dtype=torch.float32, device=dev)
+        dp = dps[i] if dps is not None else torch.zeros(_flat_span(pi), dtype=torch.float32, device=dev)
+        assert dp.numel() == _flat_span(pi)
         tobj = torch.empty(B * na * ny * nx, dtype=torch.int64, device=dev)
         L = d.level[i]
-        L.p = _lib.ptr(pi); L.dp = _lib.ptr(dp); L.tobj_ws = _lib.ptr(tobj)
-        L.sb, L.sa, L.sy, L.sx = pi.stride(0), pi.stride(1), pi.stride(2), pi.stride(3)
-        L.ny, L.nx = ny, nx
-        for a in range(na):
-            L.anchors[2 * a] = float(anchors_host[i][a][0]); L.anchors[2 * a + 1] = float(anchors_host[i][a][1])
-        L.balance = float(balance[i])
-        dps.append(dp); keep.append(tobj)
-    import ctypes
+        L.dp = _lib.ptr(dp); L.tobj_ws = _lib.ptr(tobj)
+        new_dps.append(dp); keep.append(tobj)
     _lib.check(lib.et_yolo_loss(ctypes.byref(d), _lib.stream(p[0])), "et_yolo_loss")
-    return out, dps
+    return out, new_dps
+
+
+def ota_assign(p, table, anchors_host, strides, *, nc, anchor_t, top_k=13, img_size=640.0):
+    """SimOTA dynamic-k matching on the device (build_ota_targets, yolo_anchor_assigner.py:104-264).
+    Returns match (nl * 5*na*NT,) int32: matched row of `table` per candidate slot, -1 = not a positive."""
+    import ctypes
+    lib = _lib.load()
+    dev = p[0].device
+    B, na, nl, NT = p[0].shape[0], p[0].shape[1], len(p), int(table.shape[0])
+    table = table.contiguous()
+    hp = dict(nc=nc, anchor_t=anchor_t, gr=1.0, cp=1.0, cn=0.0, cls_pw=1.0, obj_pw=1.0, box_w=0.0, obj_w=0.0, cls_w=0.0)
+    d = _loss_desc(p, table, anchors_host, [0.0] * nl, hp, 1, False)
+    match = torch.full((nl * 5 * na * NT,), -1, dtype=torch.int32, device=dev)
+    if NT == 0:
+        return match
+    d.targets = _lib.ptr(table)
+    nbytes = ctypes.c_size_t(0)
+    _lib.check(lib.et_ota_workspace_bytes(B, na, nl, NT, ctypes.byref(nbytes)), "et_ota_workspace_bytes")
+    ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+    st = (ctypes.c_float * nl)(*[float(s) for s in strides])
+    _lib.check(lib.et_ota_assign(ctypes.byref(d), st, float(img_size), int(top_k), _lib.ptr(ws), _lib.ptr(match),
+                                 _lib.stream(p[0])), "et_ota_assign")
+    return match
 
 
 def scale_cast(src_flat, dtype, scale=1.0, dev_scale=None, out=None):

@@ -150,7 +150,8 @@ class SSODTrainer(Trainer):
         sup_pred, sup_feature, un_sup_pred, un_sup_feature = self.split_predict_and_feature(total_pred, total_feature, n_img)
         # 4 losses (:628-649); the zero-weighted domain losses (:631-636) contribute nothing
         if sup_table is not None:                      # graph capture: the padded device-resident target table
-            sup_loss, sup_loss_items = self.compute_loss.default_loss(sup_pred, None, table=sup_table)
+            fn = self.compute_loss.ota_loss if getattr(self.compute_loss, 'ota', False) else self.compute_loss.default_loss
+            sup_loss, sup_loss_items = fn(sup_pred, None, table=sup_table)
         else:
             sup_loss, sup_loss_items = self.compute_loss(sup_pred, targets.to(self.device))
         if self.cfg.SSOD.with_da_loss:                 # ssod_trainer.py:631-634

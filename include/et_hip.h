@@ -254,9 +254,20 @@ typedef struct {
     const float* targets;
     float* acc_ws;
     float* out;
+    const int* ota_match;   /* NULL, or the result of et_ota_assign: pass 0 takes its positives from it */
+    int obj_channel;        /* 0 = default (4); the SimOTA half of ComputeLoss.ota_loss reads objectness from no-1 */
     et_loss_level level[4];
 } et_loss_desc;
 int et_yolo_loss(const et_loss_desc* desc /*host*/, et_stream_t stream);
+/* SimOTA dynamic-k matching: YOLOAnchorAssigner.build_ota_targets (models/assigner/yolo_anchor_assigner.py:104-264) over the
+ * candidates of find_3_positive (:266-317), for the logits / targets / anchors of `desc` (dp, tobj_ws, acc_ws, out unused).
+ * strides[nl] = Detect.stride, img_size = the literal 640 of :128, top_k = Loss.top_k (<= 13).
+ * match[nl][5*na*NT] (device int32): index of the target matched to each candidate slot (slot order = reference candidate
+ * order: offset-major, anchor, target), -1 = not a positive.  Feed it to et_yolo_loss through desc->ota_match.
+ * Equal costs: the smaller slot index / the earlier target of the image wins (torch.topk / torch.min leave it open).     */
+int et_ota_workspace_bytes(int B, int na, int nl, int NT, size_t* bytes);
+int et_ota_assign(const et_loss_desc* desc /*host*/, const float* strides /*host, nl*/, float img_size, int top_k,
+                  void* workspace, int* match, et_stream_t stream);
 int et_select_targets(const double* targets9, const uint8_t* valid, int N, const double* thr_low,
                       const double* thr_high, int nc, int with_obj, float* table, et_stream_t stream);
 int et_scale_cast(const float* src, void* dst, int dtype, int64_t n, float scale,

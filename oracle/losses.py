@@ -176,3 +176,131 @@ def domain_loss(features, label):
     x = torch.cat([f.permute(0, 2, 3, 1).reshape(-1, 2) for f in features], 0)
     p = torch.softmax(x, dim=1)[:, label]
     return 0.5 * (-(1 - p) ** 2 * p.log()).mean()
+
+
+# ---- SimOTA (Loss.assigner_type == 'SimOTA') --------------------------------------------------------
+def box_iou_xyxy(b1, b2):
+    """utils/metrics.py:252-274: (N,4) x (M,4) -> (N,M), no epsilon."""
+    a1 = (b1[:, 2] - b1[:, 0]) * (b1[:, 3] - b1[:, 1])
+    a2 = (b2[:, 2] - b2[:, 0]) * (b2[:, 3] - b2[:, 1])
+    wh = (torch.min(b1[:, None, 2:], b2[:, 2:]) - torch.max(b1[:, None, :2], b2[:, :2])).clamp(0)
+    inter = wh[..., 0] * wh[..., 1]
+    return inter / (a1[:, None] + a2 - inter)
+
+
+def _xywh2xyxy(x):
+    return torch.stack((x[:, 0] - x[:, 2] / 2, x[:, 1] - x[:, 3] / 2, x[:, 0] + x[:, 2] / 2, x[:, 1] + x[:, 3] / 2), 1)
+
+
+def build_ota_targets(p, targets, anchors, strides, *, nc, anchor_t=4.0, top_k=13, img_size=640.0):
+    """YOLOAnchorAssigner.build_ota_targets (models/assigner/yolo_anchor_assigner.py:104-264) over the candidates of
+    find_3_positive (:266-317, the same rows as build_targets).  Returns per level a dict with b, a, gj, gi (int64), anch
+    (n,2), target (n,6: the matched target row) and slot (n: index of the candidate in the level's find_3_positive list) --
+    rows in the reference's order (image-major, then candidate order)."""
+    with torch.no_grad():
+        cand = _assign(p, anchors, targets, anchor_t)
+        nl = len(p)
+        out = [dict(b=[], a=[], gj=[], gi=[], anch=[], target=[], slot=[]) for _ in range(nl)]
+        for b in range(p[0].shape[0]):
+            sel = targets[:, 0] == b                                            # :123
+            tt = targets[sel]
+            if tt.shape[0] == 0:
+                continue
+            txyxy = _xywh2xyxy(tt[:, 2:6] * img_size)                           # :128-129 (the literal 640)
+            rows = []
+            for i, pi in enumerate(p):
+                r = cand[i]
+                idx = torch.nonzero(r["b"] == b).flatten()
+                fg = pi[r["b"][idx], r["a"][idx], r["gj"][idx], r["gi"][idx]].float()
+                grid = torch.stack((r["gi"][idx], r["gj"][idx]), 1).float()
+                pxy = (fg[:, :2].sigmoid() * 2. - 0.5 + grid) * strides[i]     # :160
+                pwh = (fg[:, 2:4].sigmoid() * 2) ** 2 * r["anch"][idx] * strides[i]
+                rows.append(dict(level=torch.full((idx.shape[0],), i), idx=idx, box=_xywh2xyxy(torch.cat((pxy, pwh), 1)),
+                                 cls=fg[:, 5:5 + nc], e2e=fg[:, -1:]))       # :155-157: p_obj_e2e is the LAST channel
+            level = torch.cat([r_["level"] for r_ in rows])
+            idx = torch.cat([r_["idx"] for r_ in rows])
+            box = torch.cat([r_["box"] for r_ in rows])
+            if box.shape[0] == 0:
+                continue
+            pcls = torch.cat([r_["cls"] for r_ in rows])
+            pe2e = torch.cat([r_["e2e"] for r_ in rows])
+            iou = box_iou_xyxy(txyxy, box)                                      # :181
+            iou_loss = -torch.log(iou + 1e-8)
+            topv, _ = torch.topk(iou, min(top_k, iou.shape[1]), dim=1)
+            dyn = torch.clamp(topv.sum(1).int(), min=1)                         # :186
+            onehot = F.one_hot(tt[:, 1].to(torch.int64), nc).float()            # (G, nc)
+            y = (pcls.sigmoid() * pe2e.sigmoid()).sqrt()                        # (M, nc)   :196-202
+            logit = torch.log(y / (1 - y))
+            cls_loss = F.binary_cross_entropy_with_logits(logit[None].expand(tt.shape[0], -1, -1),
+                                                          onehot[:, None, :].expand(-1, y.shape[0], -1),
+                                                          reduction="none").sum(-1)
+            cost = cls_loss + 3.0 * iou_loss                                    # :208-211
+            G, M = cost.shape
+            mark = torch.zeros((G, M), dtype=torch.bool)
+            order = torch.arange(M)
+            for g in range(G):                                                  # :215-219, ties: smaller candidate index
+                c = cost[g].clone()
+                c[torch.isnan(c)] = float("inf")
+                key = sorted(range(M), key=lambda j: (float(c[j]), j))
+                mark[g, key[:int(dyn[g])]] = True
+            n_per = mark.sum(0)
+            multi = n_per > 1
+            if multi.any():                                                     # :223-226
+                amin = torch.argmin(torch.where(torch.isnan(cost), torch.full_like(cost, float("inf")), cost)[:, multi], 0)
+                mark[:, multi] = False
+                mark[amin, order[multi]] = True
+            fg_mask = mark.any(0)
+            gt_of = mark[:, fg_mask].float().argmax(0)                          # :228
+            for i in range(nl):
+                m = (level[fg_mask] == i)
+                ci = idx[fg_mask][m]
+                r = cand[i]
+                o = out[i]
+                o["b"].append(r["b"][ci]); o["a"].append(r["a"][ci]); o["gj"].append(r["gj"][ci]); o["gi"].append(r["gi"][ci])
+                o["anch"].append(r["anch"][ci]); o["target"].append(tt[gt_of[m]]); o["slot"].append(ci)
+        res = []
+        for o in out:
+            cat = lambda k, shape, dt: torch.cat(o[k]) if o[k] else torch.zeros(shape, dtype=dt)
+            res.append(dict(b=cat("b", (0,), torch.int64), a=cat("a", (0,), torch.int64), gj=cat("gj", (0,), torch.int64),
+                            gi=cat("gi", (0,), torch.int64), anch=cat("anch", (0, 2), torch.float32),
+                            target=cat("target", (0, targets.shape[1]), torch.float32), slot=cat("slot", (0,), torch.int64)))
+        return res
+
+
+def ota_loss(p, targets, anchors, strides, *, nc=80, box_w=0.05, obj_w=1.0, cls_w=0.5, anchor_t=4.0,
+             balance=(4.0, 1.0, 0.4), gr=1.0, cp=1.0, cn=0.0, top_k=13, img_size=640.0):
+    """ComputeLoss.ota_loss (models/loss/loss.py:210-303): the SimOTA-matched half (objectness read from the LAST channel,
+    :246) plus the plain build_targets half (:251-292), summed before the weights."""
+    dev = p[0].device
+    lcls, lbox, lobj = (torch.zeros(1, device=dev) for _ in range(3))
+    ota = build_ota_targets(p, targets, anchors, strides, nc=nc, anchor_t=anchor_t, top_k=top_k, img_size=img_size)
+    for i, pi in enumerate(p):
+        r = ota[i]
+        tobj = torch.zeros_like(pi[..., 0])
+        if r["b"].shape[0]:
+            ny, nx = pi.shape[2], pi.shape[3]
+            gain = torch.tensor([nx, ny, nx, ny], dtype=torch.float32)
+            tbox = r["target"][:, 2:6] * gain                                   # :231
+            tbox[:, :2] -= torch.stack((r["gi"], r["gj"]), 1).float()           # :232
+            rr = dict(r, tbox=tbox, tcls=r["target"][:, 1].long())
+            lb, lc, iou = _box_cls_terms(pi, rr, nc, cp, cn)
+            lbox = lbox + lb
+            _scatter_last_wins(tobj, rr, (1.0 - gr) + gr * iou.detach().clamp(0))
+            if lc is not None:
+                lcls = lcls + lc
+        lobj = lobj + F.binary_cross_entropy_with_logits(pi[..., -1], tobj) * balance[i]      # :246
+    asg = _assign(p, anchors, targets, anchor_t)
+    for i, pi in enumerate(p):
+        r = asg[i]
+        tobj = torch.zeros_like(pi[..., 0])
+        if r["b"].shape[0]:
+            lb, lc, iou = _box_cls_terms(pi, r, nc, cp, cn)
+            lbox = lbox + lb
+            _scatter_last_wins(tobj, r, (1.0 - gr) + gr * iou.detach().clamp(0))
+            if lc is not None:
+                lcls = lcls + lc
+        lobj = lobj + F.binary_cross_entropy_with_logits(pi[..., 4], tobj) * balance[i]
+    lbox, lobj, lcls = lbox * box_w, lobj * obj_w, lcls * cls_w
+    bs = p[0].shape[0]
+    loss = lbox + lobj + lcls
+    return loss * bs, dict(box=lbox, obj=lobj, cls=lcls, loss=loss * bs)

@@ -10,7 +10,8 @@ Reference entry points exercised (file:line):
   utils/general.py:887 non_max_suppression_ssod, :994 non_max_suppression
   models/assigner/yolo_anchor_assigner.py:319 build_targets, :640 build_uc_targets_aug
   utils/metrics.py:207 bbox_iou(CIoU)
-  models/loss/loss.py:93 ComputeLoss, :376 TargetLoss, :398 DomainLoss
+  models/loss/loss.py:93 ComputeLoss (:138 default_loss, :210 ota_loss), :376 TargetLoss, :398 DomainLoss
+  models/assigner/yolo_anchor_assigner.py:104 build_ota_targets, :266 find_3_positive
   models/loss/ssod/ssod_loss.py:26 ComputeStudentMatchLoss
   utils/self_supervised_utils.py:194 FairPseudoLabel.create_pseudo_label_online_with_gt
   models/detector/yolo_ssod.py:44 Model (train + eval forward, backward)
@@ -588,6 +589,68 @@ def case_v8():
     save("v8_tal", **tal)
 
 
+def ota_inputs(seed=7, B=2, nc=6, shapes=((80, 80), (40, 40), (20, 20))):
+    """seeded inputs of the SimOTA case: regenerated (not stored) by tests/test_ota.py"""
+    rng = np.random.default_rng(seed)
+    t = synth_targets(rng, B, n_per=(3, 12))
+    t[:, 1] = rng.integers(0, nc, t.shape[0])
+    p = [rng.normal(0, 1.5, (B, 3, ny, nx, 5 + nc)).astype(np.float32) for ny, nx in shapes]
+    # make the predicted boxes of some cells plausible (random logits give IoUs near 0 and dynamic_k == 1 everywhere)
+    for pi in p:
+        pi[..., :4] *= 0.3
+    return t, p
+
+
+def case_ota():
+    """ComputeLoss with Loss.assigner_type == 'SimOTA' (models/loss/loss.py:210-303, yolo_anchor_assigner.py:104-317)."""
+    nc = 6
+    cfg = ref_loader.get_cfg(SSOD_YAML, TINY + ["Dataset.nc", nc, "Loss.assigner_type", "SimOTA"])
+    cfg.freeze()
+    from models.detector.yolo_ssod import Model
+    from models.loss.loss import ComputeLoss
+    torch.manual_seed(0)
+    model = Model(cfg)
+    closs = ComputeLoss(model, cfg)
+    assert closs.ota and closs.top_k == 13
+    anchors = model.head.anchors.clone()
+    strides = [float(s) for s in model.head.stride]
+    t, p = ota_inputs(nc=nc)
+    tt = torch.from_numpy(t)
+    pr = [torch.from_numpy(x).requires_grad_(True) for x in p]
+    loss, items = closs(pr, tt)
+    loss.backward()
+    bs, as_, gjs, gis, ota_t, anch = closs.ota_assigner([x.detach() for x in pr], tt)
+    kw = dict(nc=nc, box_w=closs.box_w, obj_w=closs.obj_w, cls_w=closs.cls_w, anchor_t=closs.anchor_t)
+    mine = o_loss.build_ota_targets([x.detach() for x in pr], tt, anchors, strides, nc=nc, anchor_t=closs.anchor_t)
+    out = dict(targets=t, anchors=anchors.numpy(), strides=np.array(strides), nc=np.int64(nc))
+    npos = 0
+    for i in range(3):
+        m = mine[i]
+        assert torch.equal(bs[i], m["b"]) and torch.equal(as_[i], m["a"]) and torch.equal(gjs[i], m["gj"]) \
+            and torch.equal(gis[i], m["gi"]) and torch.equal(ota_t[i], m["target"]) and torch.equal(anch[i], m["anch"]), i
+        npos += m["b"].shape[0]
+        for k in ("b", "a", "gj", "gi", "slot"):
+            out[f"l{i}_{k}"] = m[k].numpy()
+        out[f"l{i}_target"] = m["target"].numpy()
+    dyn_gt1 = sum(int((np.unique(mine[i]["target"].numpy(), axis=0, return_counts=True)[1] > 1).sum()) for i in range(3))
+    print(f"  SimOTA positives {npos}; target rows used more than once on a level: {dyn_gt1}")
+    po = [torch.from_numpy(x).requires_grad_(True) for x in p]
+    loss2, items2 = o_loss.ota_loss(po, tt, anchors, strides, **kw)
+    loss2.backward()
+    assert torch.allclose(loss, loss2, rtol=1e-6, atol=1e-7), (loss, loss2)
+    for a, b in zip(pr, po):
+        assert torch.allclose(a.grad, b.grad, rtol=1e-5, atol=1e-8)
+    out["loss"] = loss.detach().numpy()
+    out["items"] = np.array([items[k].item() for k in ("box", "obj", "cls")], np.float32)
+    out["weights"] = np.array([closs.box_w, closs.obj_w, closs.cls_w, closs.anchor_t], np.float64)
+    out["grad2"] = pr[2].grad.numpy()
+    for i in range(2):          # levels 0/1: the gradient rows of the SimOTA positives and per-channel sums
+        m = mine[i]
+        out[f"gradrows{i}"] = pr[i].grad[m["b"], m["a"], m["gj"], m["gi"]].numpy()
+        out[f"gradsum{i}"] = pr[i].grad.double().sum((0, 1, 2, 3)).numpy()
+    save("ota", **out)
+
+
 def main():
     if not ref_loader.available():
         sys.exit("reference tree not present; golden vectors can only be generated in the build container")
@@ -596,6 +659,10 @@ def main():
         print("== YOLOv8 path")
         case_v8()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "ota":
+        print("== SimOTA loss")
+        case_ota()
+        return
     torch.set_num_threads(4)
     print("nms ..."); case_nms()
     print("assigner / losses ..."); cfg, model = case_assigner_and_losses()
@@ -603,6 +670,7 @@ def main():
     print("model ..."); case_model(cfg, model)
     print("optimizer / EMA ..."); case_optim(model)
     print("ssod step (reference SSODTrainer.train_instance) ..."); case_ssod_step(cfg, model)
+    print("SimOTA loss ..."); case_ota()
     print("done")
 
 
