@@ -59,7 +59,8 @@ SIGNATURES = {
     "et_maxpool5_bwd": (c_int, [P, c_int, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "et_upsample2x_fwd": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "et_upsample2x_bwd": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
-    "et_pseudo_label_transform": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P, P]),
+    "et_pseudo_label_transform": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P]),
+    "et_score_log_append": (c_int, [P, P, c_int, c_int, P, P, P, c_int64, P]),
     "et_yolo_loss": (c_int, [P, P]),
     "et_ota_workspace_bytes": (c_int, [c_int, c_int, c_int, c_int, ctypes.POINTER(c_size_t)]),
     "et_ota_assign": (c_int, [P, P, c_float, c_int, P, P, P]),

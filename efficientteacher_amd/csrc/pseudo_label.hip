@@ -12,8 +12,8 @@
 
 __global__ __launch_bounds__(256) void pseudo_label_kernel(const float* __restrict__ dets, const int* __restrict__ counts,
                                                            const double* __restrict__ M_s, int B, int max_det,
-                                                           double width, double height, double* __restrict__ out,
-                                                           unsigned char* __restrict__ valid) {
+                                                           double width, double height, int clip01,
+                                                           double* __restrict__ out, unsigned char* __restrict__ valid) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= B * max_det) return;
     const int img = i / max_det, k = i - img * max_det;
@@ -56,9 +56,14 @@ __global__ __launch_bounds__(256) void pseudo_label_kernel(const float* __restri
             double ox = (nx1 + nx2) / 2, oy = (ny1 + ny2) / 2;                       // xyxy2xywh :223
             const double ow = nx2 - nx1, oh = ny2 - ny1;
             ox /= width; oy /= height;                                             // :224-225
+            double nw = ow / width, nh = oh / height;
+            if (clip01) {       // LabelMatch only (utils/labelmatch.py:333): xywh clipped to [0, 1] before the flips
+                ox = fmin(fmax(ox, 0.0), 1.0); oy = fmin(fmax(oy, 0.0), 1.0);
+                nw = fmin(fmax(nw, 0.0), 1.0); nh = fmin(fmax(nh, 0.0), 1.0);
+            }
             if (ud == 1) oy = 1 - oy;
             if (lr == 1) ox = 1 - ox;
-            res[1] = d[5]; res[2] = ox; res[3] = oy; res[4] = ow / width; res[5] = oh / height;
+            res[1] = d[5]; res[2] = ox; res[3] = oy; res[4] = nw; res[5] = nh;
             res[6] = d[4]; res[7] = d[6]; res[8] = d[7];
         }
     }
@@ -68,11 +73,49 @@ __global__ __launch_bounds__(256) void pseudo_label_kernel(const float* __restri
 }
 
 extern "C" int et_pseudo_label_transform(const float* dets, const int* counts, const double* M_s, int B, int max_det,
-                                         int width, int height, double* targets9, uint8_t* valid, et_stream_t stream) {
+                                         int width, int height, int clip01, double* targets9, uint8_t* valid, et_stream_t stream) {
     if (!dets || !counts || !M_s || !targets9 || !valid) return -1;
     if (B <= 0 || max_det <= 0) return -2;
     hipLaunchKernelGGL(pseudo_label_kernel, dim3((B * max_det + 255) / 256), dim3(256), 0, (hipStream_t)stream, dets, counts,
-                       M_s, B, max_det, (double)width, (double)height, targets9, valid);
+                       M_s, B, max_det, (double)width, (double)height, clip01, targets9, valid);
+    ET_CHECK_LAUNCH();
+    return 0;
+}
+
+// LabelMatch score bookkeeping (utils/labelmatch.py:279-287): the reference appends the confidence of EVERY detection the
+// NMS returned to a per-class python list on the host (score_list_epoch), read once per epoch by update_epoch_cls_thr.
+// Here the (class, confidence) pairs are appended to a device log through one atomic counter; the per-class lists are
+// formed at the end of the epoch, where only the sorted values matter, so the append order is free.  log_count keeps
+// counting past `cap` so that an overflow is visible to the host.
+__global__ __launch_bounds__(256) void score_log_kernel(const float* __restrict__ dets, const int* __restrict__ counts, int B,
+                                                        int max_det, float* __restrict__ conf_log, int* __restrict__ cls_log,
+                                                        unsigned long long* __restrict__ log_count, long long cap) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool live = i < B * max_det && (i % max_det) < counts[i / max_det];
+    const unsigned long long m = __ballot(live);
+    if (!m) return;
+    const int lane = threadIdx.x & 63;
+    unsigned long long base = 0;
+    const int leader = __ffsll((long long)m) - 1;
+    if (lane == leader) base = atomicAdd(log_count, (unsigned long long)__popcll(m));
+    const unsigned lo = __shfl((unsigned)(base & 0xffffffffull), leader), hi = __shfl((unsigned)(base >> 32), leader);
+    base = ((unsigned long long)hi << 32) | lo;
+    if (live) {
+        const long long pos = (long long)base + __popcll(m & ((1ull << lane) - 1ull));
+        if (pos < cap) {
+            const float* d = dets + (size_t)i * 8;
+            conf_log[pos] = d[4];
+            cls_log[pos] = (int)d[5];
+        }
+    }
+}
+
+extern "C" int et_score_log_append(const float* dets, const int* counts, int B, int max_det, float* conf_log, int* cls_log,
+                                   uint64_t* log_count, int64_t cap, et_stream_t stream) {
+    if (!dets || !counts || !conf_log || !cls_log || !log_count) return -1;
+    if (B <= 0 || max_det <= 0 || cap <= 0) return -2;
+    hipLaunchKernelGGL(score_log_kernel, dim3((B * max_det + 255) / 256), dim3(256), 0, (hipStream_t)stream, dets, counts, B,
+                       max_det, conf_log, cls_log, (unsigned long long*)log_count, (long long)cap);
     ET_CHECK_LAUNCH();
     return 0;
 }

@@ -494,17 +494,28 @@ def upsample2x_bwd(dy, out=None):
 
 
 # ---- pseudo labels / losses ---------------------------------------------------------------------------
-def pseudo_label_transform(dets, counts, M_s, width, height):
-    """dets (B,max_det,8) fp32, counts (B) int32, M_s (B,13) fp64 -> targets9 (B*max_det,9) fp64, valid uint8."""
+def pseudo_label_transform(dets, counts, M_s, width, height, clip01=False):
+    """dets (B,max_det,8) fp32, counts (B) int32, M_s (B,13) fp64 -> targets9 (B*max_det,9) fp64, valid uint8.
+    clip01: LabelMatch's extra clip of the normalised xywh (utils/labelmatch.py:333)."""
     B, max_det, _ = dets.shape
     dev = dets.device
     M_s = M_s.to(device=dev, dtype=torch.float64).contiguous()
     t9 = torch.empty((B * max_det, 9), dtype=torch.float64, device=dev)
     valid = torch.empty((B * max_det,), dtype=torch.uint8, device=dev)
     _lib.check(_lib.load().et_pseudo_label_transform(_lib.ptr(dets), _lib.ptr(counts), _lib.ptr(M_s), B, max_det,
-                                                     int(width), int(height), _lib.ptr(t9), _lib.ptr(valid),
-                                                     _lib.stream(dets)), "et_pseudo_label_transform")
+                                                     int(width), int(height), int(bool(clip01)), _lib.ptr(t9),
+                                                     _lib.ptr(valid), _lib.stream(dets)), "et_pseudo_label_transform")
     return t9, valid
+
+
+def score_log_append(dets, counts, conf_log, cls_log, log_count):
+    """append (conf, cls) of every NMS detection to the device log (LabelMatch, utils/labelmatch.py:279-287)"""
+    B, max_det, _ = dets.shape
+    assert conf_log.dtype == torch.float32 and cls_log.dtype == torch.int32 and log_count.dtype == torch.int64
+    assert conf_log.numel() == cls_log.numel()
+    _lib.check(_lib.load().et_score_log_append(_lib.ptr(dets), _lib.ptr(counts), B, max_det, _lib.ptr(conf_log),
+                                               _lib.ptr(cls_log), _lib.ptr(log_count), conf_log.numel(),
+                                               _lib.stream(dets)), "et_score_log_append")
 
 
 _THR_CACHE = {}

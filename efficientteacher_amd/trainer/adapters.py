@@ -199,8 +199,12 @@ class _SsodHotPath(_HotPath):
         self.target_loss = TargetLoss()
         if cfg.SSOD.pseudo_label_type == 'FairPseudoLabel':
             self.pseudo_label_creator = FairPseudoLabel(cfg)      # the device-resident one (the reference built its own at :68)
+        elif cfg.SSOD.pseudo_label_type == 'LabelMatch':          # ssod_trainer.py:70-71; after_epoch (:320-323) drives it unchanged
+            from ..utils.labelmatch import LabelMatch
+            self.pseudo_label_creator = LabelMatch(cfg, int(len(self.unlabeled_dataset) / self.WORLD_SIZE), self.label_num_per_image,
+                                                   cls_ratio_gt=self.cls_ratio_gt)
         else:
-            raise NotImplementedError("LabelMatch thresholds are SURVEY.md 8(f-4), not on the MI355X path yet")
+            raise NotImplementedError(f"SSOD.pseudo_label_type {cfg.SSOD.pseudo_label_type}")
 
     # ---- ssod_trainer.py:568 / :587 -----------------------------------------------------------------------------
     def split_predict_and_feature(self, total_pred, total_feature, n_img):

@@ -21,16 +21,33 @@ from .trainer import Trainer
 class SSODTrainer(Trainer):
     MODEL_MODULE = "efficientteacher_amd.models.detector.yolo_ssod"
 
-    def __init__(self, cfg, device, callbacks=None, LOCAL_RANK=-1, RANK=-1, WORLD_SIZE=1, nb=1000):
+    def __init__(self, cfg, device, callbacks=None, LOCAL_RANK=-1, RANK=-1, WORLD_SIZE=1, nb=1000, target_data_len=None,
+                 label_num_per_image=None, cls_ratio_gt=None):
+        """target_data_len / label_num_per_image / cls_ratio_gt: what the reference reads off its datasets for LabelMatch
+        (ssod_trainer.py:71, :226-227); this core has no data loaders, the caller passes them."""
         self.cfg = cfg
         self.set_env(cfg, device, LOCAL_RANK, RANK, WORLD_SIZE, callbacks, nb)
         self.build_model(cfg, device)
         self.build_optimizer(cfg)
         if cfg.SSOD.pseudo_label_type == 'FairPseudoLabel':
             self.pseudo_label_creator = FairPseudoLabel(cfg)
+        elif cfg.SSOD.pseudo_label_type == 'LabelMatch':
+            from ..utils.labelmatch import LabelMatch
+            if cls_ratio_gt is None:
+                raise ValueError("LabelMatch needs target_data_len, label_num_per_image and cls_ratio_gt (ssod_trainer.py:71)")
+            self.pseudo_label_creator = LabelMatch(cfg, int(target_data_len / WORLD_SIZE), label_num_per_image,
+                                                   cls_ratio_gt=cls_ratio_gt)
         else:
-            raise NotImplementedError("LabelMatch thresholds are SURVEY.md 8(f-4), not built yet")
+            raise NotImplementedError(f"SSOD.pseudo_label_type {cfg.SSOD.pseudo_label_type}")
         self.build_ddp_model(cfg, device)
+
+    def after_epoch(self, epoch=None):
+        """the LabelMatch part of ssod_trainer.py:319-323: re-estimate the per-class thresholds, hand them to the loss"""
+        epoch = self.epoch if epoch is None else epoch
+        if self.cfg.SSOD.pseudo_label_type == 'LabelMatch' and epoch >= self.cfg.SSOD.dynamic_thres_epoch:
+            self.pseudo_label_creator.update_epoch_cls_thr(epoch - self.start_epoch)
+            self.compute_un_sup_loss.ignore_thres_high = self.pseudo_label_creator.cls_thr_high
+            self.compute_un_sup_loss.ignore_thres_low = self.pseudo_label_creator.cls_thr_low
 
     def set_env(self, cfg, device, LOCAL_RANK, RANK, WORLD_SIZE, callbacks, nb=1000):
         super().set_env(cfg, device, LOCAL_RANK, RANK, WORLD_SIZE, callbacks, nb)
@@ -134,6 +151,8 @@ class SSODTrainer(Trainer):
         cur = torch.cuda.current_stream(self.device) if side is not None else None
         if side is not None:
             side.wait_stream(cur)
+        if self.cfg.SSOD.pseudo_label_type == 'LabelMatch':         # ssod_trainer.py:616-617
+            self.pseudo_label_creator.update(targets, n_img, unlabeled_imgs.shape[0])
         with torch.no_grad(), (torch.cuda.stream(side) if side is not None else _nullcontext()):
             (teacher_pred, _), _ = self.ema.ema(unlabeled_imgs_ori, augment=False)
             if self.teacher_pred_hook is not None:

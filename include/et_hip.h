@@ -218,7 +218,13 @@ int et_upsample2x_bwd(const void* dy, int lddy, void* dx, int lddx, int dtype, i
  * [img, cls, x, y, w, h, conf, obj_conf, cls_conf] stay PADDED, valid (B*max_det) uint8 marks
  * the surviving rows (the reference's row order == ascending padded index).                    */
 int et_pseudo_label_transform(const float* dets, const int* counts, const double* M_s, int B, int max_det,
-                              int width, int height, double* targets9, uint8_t* valid, et_stream_t stream);
+                              int width, int height, int clip01 /* LabelMatch: utils/labelmatch.py:333 */,
+                              double* targets9, uint8_t* valid, et_stream_t stream);
+/* LabelMatch's per-class score lists (utils/labelmatch.py:279-287, read by update_epoch_cls_thr :188-240): append the
+ * (confidence, class) of every NMS detection to a device log; *log_count (device, 64-bit) counts all appends, entries
+ * beyond `cap` are dropped (the host checks the counter at the end of the epoch).                                       */
+int et_score_log_append(const float* dets, const int* counts, int B, int max_det, float* conf_log, int* cls_log,
+                        uint64_t* log_count, int64_t cap, et_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Detection losses with fused anchor assignment, forward + gradient.  Replaces

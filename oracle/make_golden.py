@@ -14,6 +14,7 @@ Reference entry points exercised (file:line):
   models/assigner/yolo_anchor_assigner.py:104 build_ota_targets, :266 find_3_positive
   models/loss/ssod/ssod_loss.py:26 ComputeStudentMatchLoss
   utils/self_supervised_utils.py:194 FairPseudoLabel.create_pseudo_label_online_with_gt
+  utils/labelmatch.py:56 LabelMatch (:271 create_pseudo_label_online_with_gt, :188 update_epoch_cls_thr)
   models/detector/yolo_ssod.py:44 Model (train + eval forward, backward)
   utils/torch_utils.py:308 ModelEMA, :381 CosineEMA ; torch.optim.SGD as trainer.py:215
 """
@@ -651,6 +652,63 @@ def case_ota():
     save("ota", **out)
 
 
+def labelmatch_pred(rng, B, A, nc):
+    pred = synth_pred(rng, B, A, nc, obj_pow=2, cls_pow=6)
+    pred[..., 5:] = 0
+    hot = rng.integers(0, nc, (B, A))
+    np.put_along_axis(pred[..., 5:], hot[..., None], rng.uniform(0.3, 1, (B, A, 1)).astype(np.float32), 2)
+    return pred
+
+
+def case_labelmatch():
+    """utils/labelmatch.py: LabelMatch.create_pseudo_label_online_with_gt over two epochs of batches + update_epoch_cls_thr"""
+    import io
+    from contextlib import redirect_stdout
+    from utils.labelmatch import LabelMatch
+    from . import labelmatch as o_lm
+    nc = 5
+    cfg = ref_loader.get_cfg(SSOD_YAML, TINY + ["Dataset.nc", nc, "SSOD.pseudo_label_type", "LabelMatch",
+                                                "SSOD.resample_low_percent", 0.3, "SSOD.resample_high_percent", 0.1,
+                                                "Dataset.names", [str(i) for i in range(nc)]])
+    cfg.freeze()
+    rng = np.random.default_rng(33)
+    B, A, W, H = 3, 400, 640, 640
+    M_s = np.zeros((B, 13), np.float64)
+    for i in range(B):
+        s = [1.0, 0.7, 1.3][i]
+        M = np.array([[s, 0.03 * i, 40.0 * i - 30], [-0.02 * i, s, 25.0 * i - 10], [0, 0, 1]], np.float64)
+        M_s[i] = [i, *M.reshape(-1), s, i % 2, (i + 1) % 2]
+    imgs = torch.zeros(B, 3, H, W)
+    lm = LabelMatch(cfg, 100, 5, cls_ratio_gt=np.full(nc, 1.0 / nc))
+    mine = o_lm.LabelMatchState(nc, cfg.SSOD.ignore_thres_low, cfg.SSOD.ignore_thres_high, cfg.SSOD.resample_high_percent,
+                                cfg.SSOD.resample_low_percent)
+    out = dict(M_s=M_s, hw=np.array([H, W]), nc=np.int64(nc), seed=np.int64(33), BA=np.array([B, A]),
+               thr=np.array([cfg.SSOD.nms_conf_thres, cfg.SSOD.nms_iou_thres, cfg.SSOD.ignore_thres_low, cfg.SSOD.ignore_thres_high,
+                             cfg.SSOD.resample_low_percent, cfg.SSOD.resample_high_percent]))
+    step = 0
+    for epoch, nb in enumerate((3, 2)):
+        for _ in range(nb):
+            pred = labelmatch_pred(rng, B, A, nc)
+            with redirect_stdout(io.StringIO()):
+                ref_t, ref_inv = lm.create_pseudo_label_online_with_gt(torch.from_numpy(pred.copy()), imgs, torch.from_numpy(M_s),
+                                                                       imgs.clone())
+            mt, minv = mine.create_pseudo_label(pred, M_s, W, H, cfg.SSOD.nms_conf_thres, cfg.SSOD.nms_iou_thres)
+            assert ref_inv == minv and np.array_equal(ref_t.numpy(), mt), "LabelMatch pseudo-label pin failed"
+            out[f"targets{step}"] = mt
+            step += 1
+        for c in range(nc):
+            assert sorted(lm.score_list_epoch[c]) == sorted(mine.score_list_epoch[c])
+        with redirect_stdout(io.StringIO()):
+            lm.update_epoch_cls_thr(epoch)
+        mine.update_epoch_cls_thr(epoch)
+        assert list(lm.cls_thr_high) == list(mine.cls_thr_high) and list(lm.cls_thr_low) == list(mine.cls_thr_low), \
+            (lm.cls_thr_high, mine.cls_thr_high, lm.cls_thr_low, mine.cls_thr_low)
+        out[f"thr_high{epoch}"] = np.array(lm.cls_thr_high, np.float64)
+        out[f"thr_low{epoch}"] = np.array(lm.cls_thr_low, np.float64)
+        print(f"  epoch {epoch}: high {np.round(lm.cls_thr_high, 4)} low {np.round(lm.cls_thr_low, 4)}")
+    save("labelmatch", **out)
+
+
 def main():
     if not ref_loader.available():
         sys.exit("reference tree not present; golden vectors can only be generated in the build container")
@@ -658,6 +716,10 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "v8":
         print("== YOLOv8 path")
         case_v8()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "labelmatch":
+        print("== LabelMatch")
+        case_labelmatch()
         return
     if len(sys.argv) > 1 and sys.argv[1] == "ota":
         print("== SimOTA loss")
@@ -671,6 +733,7 @@ def main():
     print("optimizer / EMA ..."); case_optim(model)
     print("ssod step (reference SSODTrainer.train_instance) ..."); case_ssod_step(cfg, model)
     print("SimOTA loss ..."); case_ota()
+    print("LabelMatch ..."); case_labelmatch()
     print("done")
 
 

@@ -63,9 +63,10 @@ def transform_image_targets(t, M, s, width, height):
     return t
 
 
-def create_pseudo_label(dets, M_s, width, height):
+def create_pseudo_label(dets, M_s, width, height, clip01=False):
     """dets: NMS output list; M_s (B,13) fp64 [img, M00..M22, s, ud, lr].
-    Returns (targets (N',9) fp64 normalised, invalid_target_shape)."""
+    Returns (targets (N',9) fp64 normalised, invalid_target_shape).
+    clip01: LabelMatch's variant (utils/labelmatch.py:333) clips the normalised xywh to [0, 1] before the flips."""
     tnp = output_to_target_ssod(dets)
     out = []
     M_s = np.asarray(M_s, np.float64)
@@ -82,6 +83,8 @@ def create_pseudo_label(dets, M_s, width, height):
                 it[:, 2:6] = _nms.xyxy2xywh(it[:, 2:6])
                 it[:, [3, 5]] /= height
                 it[:, [2, 4]] /= width
+                if clip01:
+                    it[:, 2:6] = it[:, 2:6].clip(0, 1)
                 if ud == 1:
                     it[:, 3] = 1 - it[:, 3]
                 if lr == 1:
