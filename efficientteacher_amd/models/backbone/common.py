@@ -14,31 +14,27 @@ from ... import autograd as _ag
 from ...autograd import BottleneckFn, C3StemFn, ConvBnActFn, JoinSlicesFn, SppfPoolFn, c3_stem_fusable
 
 
+_ACTIVATIONS = {"silu": (nn.SiLU, None), "relu": (lambda: nn.ReLU(inplace=True), "relu")}
+
+
 def get_activation(act=True):
-    act_name = None
+    """(module, act_name) as the reference's helper returns (models/backbone/common.py:28).  Only the activations the fused
+    conv+BN+act kernels implement are constructible: SiLU (every shipped YOLOv5/v8 recipe), ReLU and none."""
     if isinstance(act, str):
-        if act == "silu":
-            m = nn.SiLU()
-        elif act == "relu":
-            m = nn.ReLU(inplace=True)
-            act_name = 'relu'
-        elif act == "hard_swish":
-            m = nn.Hardswish(inplace=True)
-            act_name = 'hard_swish'
-        elif act == "lrelu":
-            m = nn.LeakyReLU(0.1, inplace=True)
-            act_name = 'leaky_relu'
-        else:
-            raise AttributeError("Unsupported act type: {}".format(act))
-    else:
-        m = nn.SiLU() if act is True else (act if isinstance(act, nn.Module) else nn.Identity())
-    return m, act_name
+        if act not in _ACTIVATIONS:
+            raise AttributeError(f"activation '{act}' has no fused kernel (supported: {sorted(_ACTIVATIONS)})")
+        make, name = _ACTIVATIONS[act]
+        return make(), name
+    if isinstance(act, nn.Module):
+        return act, None
+    return (nn.SiLU() if act is True else nn.Identity()), None
 
 
-def autopad(k, p=None):  # kernel, padding
-    if p is None:
-        p = k // 2 if isinstance(k, int) else [x // 2 for x in k]
-    return p
+def autopad(k, p=None):
+    """'same' padding for an odd kernel unless a padding is given"""
+    if p is not None:
+        return p
+    return [x // 2 for x in k] if isinstance(k, (list, tuple)) else k // 2
 
 
 def _act_code(m):

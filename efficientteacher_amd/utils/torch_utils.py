@@ -23,23 +23,20 @@ def de_parallel(model):
 
 
 def copy_attr(a, b, include=(), exclude=()):
-    # Copy attributes from b to a, options to only include [...] and to exclude [...]
-    for k, v in b.__dict__.items():
-        if (len(include) and k not in include) or k.startswith('_') or k in exclude:
+    """public attributes of b -> a (all of them, or only `include`), minus `exclude`; ModelEMA.update_attr uses it"""
+    wanted = set(include)
+    for name, value in vars(b).items():
+        if name.startswith('_') or name in exclude or (wanted and name not in wanted):
             continue
-        else:
-            setattr(a, k, v)
+        setattr(a, name, value)
 
 
 def initialize_weights(model):
-    # reference utils/torch_utils.py:162-172
+    """the BatchNorm constants every reference model is built with (utils/torch_utils.py:162: eps 1e-3, momentum 0.03);
+    in-place activations are the fused kernels' business here, not a module flag"""
     for m in model.modules():
-        t = type(m)
-        if t is nn.BatchNorm2d:
-            m.eps = 1e-3
-            m.momentum = 0.03
-        elif t in [nn.Hardswish, nn.LeakyReLU, nn.ReLU, nn.ReLU6]:
-            m.inplace = True
+        if type(m) is nn.BatchNorm2d:
+            m.eps, m.momentum = 1e-3, 0.03
 
 
 def _flat_ema_update(ema_model, model, d, d_dev=None):
