@@ -173,6 +173,8 @@ def main():
                     "issuing every launch from Python (A/B: the 32+32 step is GPU-bound, both take ~64 ms)")
     ap.add_argument("--host-inputs", action="store_true", help="PCIe-inclusive variant: every step receives its three "
                     "uint8 image batches from pinned host memory (never the reported `value`; noted in DESIGN.md)")
+    ap.add_argument("--dump-launches", default=None, help="write (kernel, flops, bytes, ms) of every timed conv launch of the "
+                    "instrumented step to this JSON file (tools/quantization.py reads it)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); 'gloo' lets two "
                     "ranks share ONE GPU to exercise the N>1 code path where only a single GPU is available")
     a = ap.parse_args()
@@ -272,6 +274,10 @@ def main():
     if rank == 0:
         try:                 # the roofline leg must never cost the throughput line
             agg = timer.summary()
+            if a.dump_launches:
+                with open(a.dump_launches, "w") as f:
+                    json.dump([dict(kernel=t, flops=fl, launches=n, bytes=nb, ms=ea.elapsed_time(eb), shape=sh)
+                               for (t, fl, n, nb, ea, eb), sh in zip(timer.rows, timer.shapes)], f)
             dom = max((k for k in agg if k.startswith("conv_gemm") and "parity classes" not in k), key=lambda k: agg[k]["ms"])
             d = agg[dom]
             per_launch_flops = d["flops"] / d["launches"]

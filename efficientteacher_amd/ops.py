@@ -18,10 +18,12 @@ class KernelTimer:
 
     def __init__(self):
         self.rows = []          # (tag, flops, launches, algorithmic bytes, start_event, end_event)
+        self.shapes = []        # per row: (op, N, IH, IW, Cin, Cout, k, stride) or None
 
-    def span(self, tag, flops, launches=1, nbytes=0):
+    def span(self, tag, flops, launches=1, nbytes=0, shape=None):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         self.rows.append((tag, flops, launches, nbytes, a, b))
+        self.shapes.append(shape)
         return a, b
 
     def summary(self):
@@ -119,7 +121,8 @@ def conv2d_fwd(x, w, stride, pad, *, scale=None, bias=None, act=ACT_NONE, residu
         stats = torch.empty((rows, 2, Cout), dtype=torch.float32, device=x.device)
     ldr = _nhwc(residual) if residual is not None else 0
     ev = TIMER.span(kernel_name("fwd", x.dtype, N, IH, IW, Cin, Cout, KH, stride, pad), 2.0 * N * OH * OW * Cout * Cin * KH * KW,
-                    nbytes=(x.numel() + N * OH * OW * Cout + w.numel()) * x.element_size()) if TIMER else None
+                    nbytes=(x.numel() + N * OH * OW * Cout + w.numel()) * x.element_size(),
+                    shape=("fwd", N, IH, IW, Cin, Cout, KH, stride)) if TIMER else None
     if ev:
         ev[0].record()
     _lib.check(lib.et_conv2d_fwd(_lib.ptr(x), _lib.ptr(w), _lib.ptr(out), et_dtype(x), N, IH, IW, Cin, _nhwc(x),
@@ -314,7 +317,8 @@ def conv2d_dgrad(dy, wT, in_hw, stride, pad, *, out=None, accumulate=False, resi
         rows = lib.et_conv2d_stats_rows(N, IH, IW)
         part = torch.empty((rows, 2, Cin), dtype=torch.float32, device=dy.device)
         ev = TIMER.span(kernel_name("dgrad", dy.dtype, N, IH, IW, Cin, Cout, KH, stride, pad), 2.0 * N * OH * OW * Cout * Cin * KH * KW,
-                        nbytes=(dy.numel() + 2 * N * IH * IW * Cin + wT.numel()) * dy.element_size()) if TIMER else None
+                        nbytes=(dy.numel() + 2 * N * IH * IW * Cin + wT.numel()) * dy.element_size(),
+                        shape=("dgrad", N, IH, IW, Cin, Cout, KH, stride)) if TIMER else None
         if ev:
             ev[0].record()
         _lib.check(lib.et_conv2d_dgrad_bn(_lib.ptr(dy), _lib.ptr(wT), _lib.ptr(out), et_dtype(dy), N, IH, IW, Cin, _nhwc(out), Cout,
@@ -328,7 +332,8 @@ def conv2d_dgrad(dy, wT, in_hw, stride, pad, *, out=None, accumulate=False, resi
     tag = (kernel_name("dgrad", dy.dtype, N, IH, IW, Cin, Cout, KH, stride, pad) if stride == 1 else
            "conv_gemm (stride-2 dgrad parity classes)") if TIMER else None
     ev = TIMER.span(tag, 2.0 * N * OH * OW * Cout * Cin * KH * KW,
-                    stride * stride, nbytes=(dy.numel() + N * IH * IW * Cin + wT.numel()) * dy.element_size()) if TIMER else None
+                    stride * stride, nbytes=(dy.numel() + N * IH * IW * Cin + wT.numel()) * dy.element_size(),
+                    shape=("dgrad", N, IH, IW, Cin, Cout, KH, stride)) if TIMER else None
     if ev:
         ev[0].record()
     _lib.check(_lib.load().et_conv2d_dgrad(_lib.ptr(dy), _lib.ptr(wT), _lib.ptr(out), et_dtype(dy), N, IH, IW, Cin,
