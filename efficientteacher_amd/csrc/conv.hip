@@ -981,6 +981,174 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_pp_kernel(const uint16_t* __
 #undef ET_PPA
 }
 
+// ---- forward / dgrad gather-GEMM, 256x256 tile, FOUR waves of 128x128 (one wave per SIMD) ----------------------
+// The other route to a busy matrix pipe (MI355X_MICROARCH.md "one wave per SIMD (512-register kernel)"): instead of two
+// waves per SIMD covering each other's memory phases, ONE wave per SIMD with a 128x128 accumulator block (256 accumulator
+// registers) -- per 16-wide k-step it reads 8 fragments for 16 MFMAs (0.5 LDS reads per MFMA; the 128x64 wave tiles of
+// the 8-wave kernels need 1.0) and the whole workgroup issues 0.75 memory instructions per MFMA instead of 1.25, all of
+// which fit into the issue slots the 32-cycle MFMAs leave free.  With no second wave to hide behind, every latency is
+// covered by software pipelining inside the wave:
+//   * K-chunks are 32 wide (two k-steps, 32 MFMAs, ~1 k cycles) in a FOUR-deep LDS ring (4 x 32 KB): chunk c+3 is issued
+//     while chunk c is multiplied, its eight LDS-DMA pieces spread between the MFMAs of the first k-step;
+//   * the wait + barrier at the top of chunk c retire chunk c+1 (counted vmcnt: the pieces of c+2 stay in flight), so the
+//     fragments of chunk c+1's first k-step are fetched during chunk c's second k-step -- the barrier is never followed by
+//     a fragment read the matrix pipe has to wait for;
+//   * fragment sets alternate between two register sets (2 x 32 VGPRs).
+// WAR: buffer (c+3)%4 held chunk c-1, whose last fragment reads were consumed by MFMAs issued before this barrier.
+__global__ __launch_bounds__(256, 1) void conv_gemm_w4_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W,
+                                                              uint16_t* __restrict__ Y, const uint16_t* __restrict__ ZERO,
+                                                              GatherGeom g, Epilogue ep) {
+    constexpr int BM = 256, BN = 256, WM = 2, WN = 2, BKV = 4, NS = 4, VEC = 8, NT = 256;
+    constexpr int RPT = NT / BKV, RA = BM / RPT, RB = BN / RPT, PER = RA + RB;     // 64 rows per instruction, 4 + 4 pieces
+    constexpr int STAGE_VEC = (BM + BN) * BKV;                                      // 32 KB
+    constexpr int EPI_VEC = EpiLds<BM, BN, WM, WN>::VEC16;
+    constexpr int LDS_VEC = NS * STAGE_VEC > EPI_VEC ? NS * STAGE_VEC : EPI_VEC;
+    __shared__ __attribute__((aligned(16))) u32x4 lds_raw[LDS_VEC];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    int bx, by;
+    tile_of_block(g, bx, by);
+    const int m0 = bx * BM, n0 = by * BN;
+    const int lvec = tid & 3, lrow = tid >> 2;
+
+    int a_off[RA], a_iy[RA], a_ix[RA], a_lv[RA];
+    unsigned a_okm = 0u, b_okm = 0u;
+#pragma unroll
+    for (int j = 0; j < RA; ++j) {
+        const int rl = lrow + j * RPT;
+        const int p = m0 + rl;
+        const bool ok = p < g.M;
+        const uint32_t pp = ok ? p : 0;
+        const uint32_t t1 = fdiv(pp, g.dQW), qx = pp - t1 * g.QW;
+        const uint32_t n = fdiv(t1, g.dQH), qy = t1 - n * g.QH;
+        a_iy[j] = qy * g.isy;
+        a_ix[j] = qx * g.isx;
+        a_off[j] = ((n * g.IH + a_iy[j]) * g.IW + a_ix[j]) * g.ldx;
+        a_lv[j] = lvec ^ lds_swz<BKV>(rl);
+        a_okm |= ok ? (1u << j) : 0u;
+    }
+    int b_off[RB], b_lv[RB];
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+        const int rl = lrow + j * RPT;
+        const int co = n0 + rl;
+        const bool ok = co < g.Cout;
+        b_off[j] = (ok ? co : 0) * g.TT * g.Cin;
+        b_lv[j] = lvec ^ lds_swz<BKV>(rl);
+        b_okm |= ok ? (1u << j) : 0u;
+    }
+
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+    const int nchunks = g.KV / BKV;                // host: Cin % 32 == 0
+    int tap_u = 0, cv_u = 0;                       // cursor of the chunk being STAGED (wave-uniform, selects only: SGPRs)
+    int ti_cur = g.tapinfo[0];
+    int udy = 0, udx = 0, uwt = 0;
+#define ET_W4_DECODE()                                                   \
+    do {                                                                 \
+        udy = (int)(signed char)(ti_cur & 0xff);                         \
+        udx = (int)(signed char)((ti_cur >> 8) & 0xff);                  \
+        uwt = (ti_cur >> 16) & 0xff;                                     \
+    } while (0)
+#define ET_W4_ADVANCE()                                                  \
+    do {                                                                 \
+        const int t2_ = tap_u + 1, c2_ = cv_u + BKV;                     \
+        const bool wt_ = t2_ >= g.T, wc_ = c2_ >= g.CV;                  \
+        const int ta_ = wt_ ? 0 : t2_, ca_ = wt_ ? c2_ : cv_u;           \
+        const int cb_ = wc_ ? 0 : c2_, tb_ = wc_ ? t2_ : tap_u;          \
+        tap_u = g.tap_inner ? ta_ : tb_;                                 \
+        cv_u = g.tap_inner ? ca_ : cb_;                                  \
+        ti_cur = g.tapinfo[__builtin_amdgcn_readfirstlane(tap_u < g.T ? tap_u : 0)]; \
+    } while (0)
+    // one LDS-DMA piece (j < 4: A rows lrow + 64 j ; j >= 4: B rows) of the cursor's chunk into ring slot `dst`
+    auto piece = [&](u32x4* dst, int j) {
+        u32x4* const wbase = dst + wave * 64;
+        if (j < RA) {
+            const bool ok = (bool)((a_okm >> j) & 1u) & ((unsigned)(a_iy[j] + udy) < (unsigned)g.IH) &
+                            ((unsigned)(a_ix[j] + udx) < (unsigned)g.IW);
+            const uint16_t* src = ok ? X + (a_off[j] + (udy * g.IW + udx) * g.ldx + (cv_u + a_lv[j]) * VEC) : ZERO;
+            et_glds16(src, wbase + j * NT);
+        } else {
+            const int jb = j - RA;
+            const bool ok = (b_okm >> jb) & 1u;
+            const uint16_t* src = ok ? W + (b_off[jb] + uwt * g.Cin + (cv_u + b_lv[jb]) * VEC) : ZERO;
+            et_glds16(src, wbase + BM * BKV + jb * NT);
+        }
+    };
+    auto stage_all = [&](u32x4* dst) {
+        ET_W4_DECODE();
+#pragma unroll
+        for (int j = 0; j < PER; ++j) piece(dst, j);
+        ET_W4_ADVANCE();
+    };
+
+    const int l31 = lane & 31, gk = lane >> 5;
+    u32x4 af[2][4], bf[2][4];
+    auto fetch = [&](const u32x4* sm, int kk, int set) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int r = wm * 128 + t * 32 + l31;
+            af[set][t] = sm[r * BKV + ((kk * 2 + gk) ^ lds_swz<BKV>(r))];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int r = wn * 128 + t * 32 + l31;
+            bf[set][t] = sm[(BM + r) * BKV + ((kk * 2 + gk) ^ lds_swz<BKV>(r))];
+        }
+    };
+    auto mfma1 = [&](int set, int i) {
+        const int tm = i >> 2, tn = i & 3;
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[set][tm]),
+                                                               __builtin_bit_cast(bf16x8, bf[set][tn]), acc[tm][tn], 0, 0, 0);
+    };
+
+    // prologue: chunks 0, 1, 2 in flight; chunk 0 landed and its first fragments fetched
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < nchunks) stage_all(lds_raw + s * STAGE_VEC);
+    if (nchunks >= 3) et_wait_vmem_le<2 * PER>(); else if (nchunks == 2) et_wait_vmem_le<PER>(); else et_wait_vmem();
+    __builtin_amdgcn_s_barrier();
+    fetch(lds_raw, 0, 0);
+
+    int rd = 0;                                    // ring slot of chunk c
+    for (int c = 0; c < nchunks; ++c) {
+        const int rd1 = (rd + 1) & 3, wr = (rd + 3) & 3;
+        const bool more1 = c + 1 < nchunks, more3 = c + 3 < nchunks;
+        // chunk c+1 has landed (own pieces; then everybody's): only chunk c+2's pieces may still be in flight
+        if (c + 2 < nchunks) et_wait_vmem_le<PER>(); else et_wait_vmem();
+        __builtin_amdgcn_s_barrier();
+        const u32x4* const cur = lds_raw + rd * STAGE_VEC;
+        u32x4* const dst = lds_raw + wr * STAGE_VEC;
+        // ---- k-step 0: MFMAs on set 0; fetch k-step 1 of this chunk into set 1; issue chunk c+3
+        fetch(cur, 1, 1);
+        if (more3) ET_W4_DECODE();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            mfma1(0, i);
+            if ((i & 1) && more3) piece(dst, i >> 1);
+        }
+        if (more3) ET_W4_ADVANCE();
+        // ---- k-step 1: MFMAs on set 1; fetch k-step 0 of chunk c+1 into set 0
+        if (more1) fetch(lds_raw + rd1 * STAGE_VEC, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mfma1(1, i);
+        rd = rd1;
+    }
+    __syncthreads();                               // the epilogue reuses the ring as its staging area
+    conv_epilogue<uint16_t, BM, BN, WM, WN>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn);
+    __syncthreads();
+#undef ET_W4_DECODE
+#undef ET_W4_ADVANCE
+}
+
 // ---- wgrad ----------------------------------------------------------------------------------------
 struct WgradGeom {
     int N, IH, IW, Cin, ldx;     // X (gathered operand)
@@ -1433,7 +1601,7 @@ static int fill_common(GatherGeom& g, int N, int IH, int IW, int Cin, int ldx, i
 // ---- kernel selection ---------------------------------------------------------------------------------
 // ONE place decides which instantiation runs; et_conv2d_kernel_name() reports the same decision to the tests and
 // to bench.py's roofline tags (there is no second copy of this logic on the Python side).
-enum { GEMM_REG = 0, GEMM_GLDS = 1, GEMM_PP = 2 };
+enum { GEMM_REG = 0, GEMM_GLDS = 1, GEMM_PP = 2, GEMM_W4 = 3 };
 struct GemmPlan { int kind, BM, BN, WM, WN, BKV, NS; bool utap; };
 
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
@@ -1452,6 +1620,7 @@ static GemmPlan plan_gemm(const GatherGeom& g, int elem_bytes, bool have_zero_pa
     static const int ring_env = env_int("ET_CONV_RING", 0);
     static const int big = env_int("ET_CONV_BIG", 1);
     static const int use_pp = env_int("ET_CONV_PP", 1);
+    static const int use_w4 = env_int("ET_CONV_W4", 0);     // the 4-wave 128x128-per-wave tile instead of the ping-pong one
     const bool bf16 = elem_bytes == 2;
     const bool wide = g.Cout > 64 && !(narrow_k > 0 && g.T * g.Cin <= narrow_k);
     const bool glds = use_glds && have_zero_page;
@@ -1468,11 +1637,12 @@ static GemmPlan plan_gemm(const GatherGeom& g, int elem_bytes, bool have_zero_pa
         const long long blocks = (long long)((g.M + 255) / 256) * ((g.Cout + 255) / 256);
         const double rounds = (double)blocks / n_cu;
         const bool fills = (double)((blocks + n_cu - 1) / n_cu) / rounds <= 1.35;
-        if (g.TT > 1 || (g.T * g.Cin >= 512 && fills)) ring = use_pp ? 25680 : 25682;
+        if (g.TT > 1 || (g.T * g.Cin >= 512 && fills)) ring = use_w4 ? 25644 : (use_pp ? 25680 : 25682);
     }
     switch (ring) {
         case 25680: p = GemmPlan{GEMM_PP, 256, 256, 2, 4, 8, 2, true}; break;
         case 25682: p = GemmPlan{GEMM_GLDS, 256, 256, 2, 4, 8, 2, true}; break;
+        case 25644: p = GemmPlan{GEMM_W4, 256, 256, 2, 2, 4, 4, true}; break;
         case 25612: p = GemmPlan{GEMM_GLDS, 256, 128, 4, 2, 8, 2, true}; break;       // experiment
         case 12883: p.NS = 3; break;
         case 12843: p.BKV = 4; p.NS = 3; break;
@@ -1487,6 +1657,7 @@ static GemmPlan plan_gemm(const GatherGeom& g, int elem_bytes, bool have_zero_pa
 static void plan_name(const GemmPlan& p, int elem_bytes, char* buf, int n) {
     const char* t = elem_bytes == 2 ? "unsigned short" : "float";
     if (p.kind == GEMM_PP) snprintf(buf, n, "conv_gemm_pp_kernel");
+    else if (p.kind == GEMM_W4) snprintf(buf, n, "conv_gemm_w4_kernel");
     else if (p.kind == GEMM_GLDS) snprintf(buf, n, "conv_gemm_glds_kernel<%s, %d, %d, %d, %d, %d, %d, %s>", t, p.BM, p.BN, p.WM, p.WN, p.BKV, p.NS, p.utap ? "true" : "false");
     else snprintf(buf, n, "conv_gemm_kernel<%s, %d, %d, %d, %d, %d, %s>", t, p.BM, p.BN, p.WM, p.WN, p.BKV, p.utap ? "true" : "false");
 }
@@ -1510,6 +1681,13 @@ static int launch_gemm(const void* X, const void* W, void* Y, const void* zero16
     if (p.kind == GEMM_PP) {
         if constexpr (sizeof(T) == 2) {
             hipLaunchKernelGGL(conv_gemm_pp_kernel, grid, block, 0, s, (const uint16_t*)x, (const uint16_t*)w, (uint16_t*)y, (const uint16_t*)z, g, ep);
+            return 0;
+        }
+        return -2;
+    }
+    if (p.kind == GEMM_W4) {
+        if constexpr (sizeof(T) == 2) {
+            hipLaunchKernelGGL(conv_gemm_w4_kernel, grid, block, 0, s, (const uint16_t*)x, (const uint16_t*)w, (uint16_t*)y, (const uint16_t*)z, g, ep);
             return 0;
         }
         return -2;
@@ -1869,7 +2047,7 @@ extern "C" int et_conv2d_kernel_name(int op, int dtype, int N, int IH, int IW, i
 extern "C" int et_env_knobs(char* buf, int buflen) {
     // every ET_* tuning knob that is SET in this process's environment, as "NAME=value;..." (bench.py records it)
     static const char* names[] = {"ET_CONV_TAP_INNER", "ET_CONV_XCD", "ET_CONV_NARROW_K", "ET_CONV_NFAST", "ET_CONV_GLDS",
-                                  "ET_CONV_RING", "ET_CONV_BIG", "ET_CONV_PP", "ET_WGRAD_TR", "ET_WGRAD_BIG", "ET_WGRAD_BLOCKS",
+                                  "ET_CONV_RING", "ET_CONV_BIG", "ET_CONV_PP", "ET_CONV_W4", "ET_WGRAD_TR", "ET_WGRAD_BIG", "ET_WGRAD_BLOCKS",
                                   "ET_WGRAD_XCD", "ET_EW_VPT", "ET_WGRAD_GROUP", "ET_WGRAD_STALE", "ET_HIP_LIB"};
     if (!buf || buflen < 1) return -1;
     int off = 0;
