@@ -1013,8 +1013,10 @@ __global__ __launch_bounds__(256, 1) void conv_gemm_w4_kernel(const uint16_t* __
     const int m0 = bx * BM, n0 = by * BN;
     const int lvec = tid & 3, lrow = tid >> 2;
 
-    int a_off[RA], a_iy[RA], a_ix[RA], a_lv[RA];
-    unsigned a_okm = 0u, b_okm = 0u;
+    // per staged row: element offset with this lane's (swizzled) K-vector folded in, and a bit per tap "inside the image"
+    int a_off[RA];
+    unsigned a_tapok[RA];
+    unsigned b_okm = 0u;
 #pragma unroll
     for (int j = 0; j < RA; ++j) {
         const int rl = lrow + j * RPT;
@@ -1023,20 +1025,23 @@ __global__ __launch_bounds__(256, 1) void conv_gemm_w4_kernel(const uint16_t* __
         const uint32_t pp = ok ? p : 0;
         const uint32_t t1 = fdiv(pp, g.dQW), qx = pp - t1 * g.QW;
         const uint32_t n = fdiv(t1, g.dQH), qy = t1 - n * g.QH;
-        a_iy[j] = qy * g.isy;
-        a_ix[j] = qx * g.isx;
-        a_off[j] = ((n * g.IH + a_iy[j]) * g.IW + a_ix[j]) * g.ldx;
-        a_lv[j] = lvec ^ lds_swz<BKV>(rl);
-        a_okm |= ok ? (1u << j) : 0u;
+        const int iy = qy * g.isy, ix = qx * g.isx;
+        a_off[j] = ((n * g.IH + iy) * g.IW + ix) * g.ldx + (lvec ^ lds_swz<BKV>(rl)) * VEC;
+        unsigned m = 0u;
+        for (int t = 0; t < g.T; ++t) {
+            const int ti = g.tapinfo[t];
+            const int dy = (int)(signed char)(ti & 0xff), dx = (int)(signed char)((ti >> 8) & 0xff);
+            m |= (ok && (unsigned)(iy + dy) < (unsigned)g.IH && (unsigned)(ix + dx) < (unsigned)g.IW) ? (1u << t) : 0u;
+        }
+        a_tapok[j] = m;
     }
-    int b_off[RB], b_lv[RB];
+    int b_off[RB];
 #pragma unroll
     for (int j = 0; j < RB; ++j) {
         const int rl = lrow + j * RPT;
         const int co = n0 + rl;
         const bool ok = co < g.Cout;
-        b_off[j] = (ok ? co : 0) * g.TT * g.Cin;
-        b_lv[j] = lvec ^ lds_swz<BKV>(rl);
+        b_off[j] = (ok ? co : 0) * g.TT * g.Cin + (lvec ^ lds_swz<BKV>(rl)) * VEC;
         b_okm |= ok ? (1u << j) : 0u;
     }
 
@@ -1050,13 +1055,19 @@ __global__ __launch_bounds__(256, 1) void conv_gemm_w4_kernel(const uint16_t* __
 
     const int nchunks = g.KV / BKV;                // host: Cin % 32 == 0
     int tap_u = 0, cv_u = 0;                       // cursor of the chunk being STAGED (wave-uniform, selects only: SGPRs)
-    int ti_cur = g.tapinfo[0];
-    int udy = 0, udx = 0, uwt = 0;
+    // the tap table lives in ONE VGPR (lane t holds entry t) and is read with v_readlane: a scalar load inside the loop
+    // would share lgkmcnt with the fragment reads and, returning out of order, force every wait down to lgkmcnt(0)
+    const int v_tapinfo = g.tapinfo[lane < g.T ? lane : 0];
+    int ti_cur = __builtin_amdgcn_readlane(v_tapinfo, 0);
+    int s_aoff = 0, s_boff = 0, s_tap = 0;        // uniform parts of the staged chunk's source offsets, its tap number
+    unsigned s_live = ~0u;
 #define ET_W4_DECODE()                                                   \
     do {                                                                 \
-        udy = (int)(signed char)(ti_cur & 0xff);                         \
-        udx = (int)(signed char)((ti_cur >> 8) & 0xff);                  \
-        uwt = (ti_cur >> 16) & 0xff;                                     \
+        const int udy_ = (int)(signed char)(ti_cur & 0xff);              \
+        const int udx_ = (int)(signed char)((ti_cur >> 8) & 0xff);       \
+        s_aoff = (udy_ * g.IW + udx_) * g.ldx + cv_u * VEC;              \
+        s_boff = ((ti_cur >> 16) & 0xff) * g.Cin + cv_u * VEC;           \
+        s_tap = tap_u < g.T ? tap_u : 0;                                 \
     } while (0)
 #define ET_W4_ADVANCE()                                                  \
     do {                                                                 \
@@ -1066,20 +1077,19 @@ __global__ __launch_bounds__(256, 1) void conv_gemm_w4_kernel(const uint16_t* __
         const int cb_ = wc_ ? 0 : c2_, tb_ = wc_ ? t2_ : tap_u;          \
         tap_u = g.tap_inner ? ta_ : tb_;                                 \
         cv_u = g.tap_inner ? ca_ : cb_;                                  \
-        ti_cur = g.tapinfo[__builtin_amdgcn_readfirstlane(tap_u < g.T ? tap_u : 0)]; \
+        ti_cur = __builtin_amdgcn_readlane(v_tapinfo, tap_u < g.T ? tap_u : 0); \
     } while (0)
     // one LDS-DMA piece (j < 4: A rows lrow + 64 j ; j >= 4: B rows) of the cursor's chunk into ring slot `dst`
     auto piece = [&](u32x4* dst, int j) {
         u32x4* const wbase = dst + wave * 64;
         if (j < RA) {
-            const bool ok = (bool)((a_okm >> j) & 1u) & ((unsigned)(a_iy[j] + udy) < (unsigned)g.IH) &
-                            ((unsigned)(a_ix[j] + udx) < (unsigned)g.IW);
-            const uint16_t* src = ok ? X + (a_off[j] + (udy * g.IW + udx) * g.ldx + (cv_u + a_lv[j]) * VEC) : ZERO;
+            const bool ok = (a_tapok[j] >> s_tap) & s_live & 1u;
+            const uint16_t* src = ok ? X + (a_off[j] + s_aoff) : ZERO;
             et_glds16(src, wbase + j * NT);
         } else {
             const int jb = j - RA;
-            const bool ok = (b_okm >> jb) & 1u;
-            const uint16_t* src = ok ? W + (b_off[jb] + uwt * g.Cin + (cv_u + b_lv[jb]) * VEC) : ZERO;
+            const bool ok = (b_okm >> jb) & s_live & 1u;
+            const uint16_t* src = ok ? W + (b_off[jb] + s_boff) : ZERO;
             et_glds16(src, wbase + BM * BKV + jb * NT);
         }
     };
@@ -1112,36 +1122,49 @@ __global__ __launch_bounds__(256, 1) void conv_gemm_w4_kernel(const uint16_t* __
 
     // prologue: chunks 0, 1, 2 in flight; chunk 0 landed and its first fragments fetched
 #pragma unroll
-    for (int s = 0; s < NS - 1; ++s)
-        if (s < nchunks) stage_all(lds_raw + s * STAGE_VEC);
-    if (nchunks >= 3) et_wait_vmem_le<2 * PER>(); else if (nchunks == 2) et_wait_vmem_le<PER>(); else et_wait_vmem();
+    for (int s = 0; s < NS - 1; ++s) {
+        s_live = s < nchunks ? ~0u : 0u;
+        stage_all(lds_raw + s * STAGE_VEC);
+    }
+    et_wait_vmem_le<2 * PER>();
     __builtin_amdgcn_s_barrier();
     fetch(lds_raw, 0, 0);
 
     int rd = 0;                                    // ring slot of chunk c
     for (int c = 0; c < nchunks; ++c) {
         const int rd1 = (rd + 1) & 3, wr = (rd + 3) & 3;
-        const bool more1 = c + 1 < nchunks, more3 = c + 3 < nchunks;
+        // Past the end the loop keeps staging (dead pieces from the zero page into slots nobody reads) and fetching, so
+        // that every iteration is the same straight line and the counted wait below is always "all but the newest chunk".
+        s_live = c + 3 < nchunks ? ~0u : 0u;
         // chunk c+1 has landed (own pieces; then everybody's): only chunk c+2's pieces may still be in flight
-        if (c + 2 < nchunks) et_wait_vmem_le<PER>(); else et_wait_vmem();
+        et_wait_vmem_le<PER>();
         __builtin_amdgcn_s_barrier();
         const u32x4* const cur = lds_raw + rd * STAGE_VEC;
         u32x4* const dst = lds_raw + wr * STAGE_VEC;
         // ---- k-step 0: MFMAs on set 0; fetch k-step 1 of this chunk into set 1; issue chunk c+3
+        // (explicit lgkmcnt(0) BEFORE each fetch: the previous set was requested a whole k-step ago, so this costs nothing,
+        //  and it keeps at most 8 reads outstanding -- with 16 the 4-bit counter saturates and the compiler falls back to
+        //  lgkmcnt(0) right AFTER the new requests, i.e. in front of the MFMAs)
+        __builtin_amdgcn_s_waitcnt(0xC07F);
         fetch(cur, 1, 1);
-        if (more3) ET_W4_DECODE();
+        ET_W4_DECODE();
+        __builtin_amdgcn_sched_barrier(0);         // the reads stay up here, one k-step ahead of their use
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             mfma1(0, i);
-            if ((i & 1) && more3) piece(dst, i >> 1);
+            if (i & 1) { piece(dst, i >> 1); __builtin_amdgcn_sched_barrier(0); }
         }
-        if (more3) ET_W4_ADVANCE();
+        ET_W4_ADVANCE();
         // ---- k-step 1: MFMAs on set 1; fetch k-step 0 of chunk c+1 into set 0
-        if (more1) fetch(lds_raw + rd1 * STAGE_VEC, 0, 0);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        fetch(lds_raw + rd1 * STAGE_VEC, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 16; ++i) mfma1(1, i);
+        __builtin_amdgcn_sched_barrier(0);
         rd = rd1;
     }
+    et_wait_vmem();                                // the dead pieces too, before the ring is reused
     __syncthreads();                               // the epilogue reuses the ring as its staging area
     conv_epilogue<uint16_t, BM, BN, WM, WN>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn);
     __syncthreads();

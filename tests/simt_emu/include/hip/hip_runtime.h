@@ -223,6 +223,9 @@ template <typename T> static inline T __builtin_amdgcn_readfirstlane_emu(T v) {
     return emu::xlane(v, first);
 }
 #define __builtin_amdgcn_readfirstlane __builtin_amdgcn_readfirstlane_emu
+// v_readlane_b32: the value of `v` in lane `src_lane` (wave-uniform index)
+template <typename T> static inline T __builtin_amdgcn_readlane_emu(T v, int src_lane) { return emu::xlane(v, src_lane & 63); }
+#define __builtin_amdgcn_readlane __builtin_amdgcn_readlane_emu
 static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 static inline int __popc(unsigned x) { return __builtin_popcount(x); }
 static inline int __ffsll(unsigned long long x) { return __builtin_ffsll((long long)x); }
