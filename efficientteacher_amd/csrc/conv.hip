@@ -981,197 +981,6 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_pp_kernel(const uint16_t* __
 #undef ET_PPA
 }
 
-// ---- forward / dgrad gather-GEMM, 256x256 tile, FOUR waves of 128x128 (one wave per SIMD) ----------------------
-// The other route to a busy matrix pipe (MI355X_MICROARCH.md "one wave per SIMD (512-register kernel)"): instead of two
-// waves per SIMD covering each other's memory phases, ONE wave per SIMD with a 128x128 accumulator block (256 accumulator
-// registers) -- per 16-wide k-step it reads 8 fragments for 16 MFMAs (0.5 LDS reads per MFMA; the 128x64 wave tiles of
-// the 8-wave kernels need 1.0) and the whole workgroup issues 0.75 memory instructions per MFMA instead of 1.25, all of
-// which fit into the issue slots the 32-cycle MFMAs leave free.  With no second wave to hide behind, every latency is
-// covered by software pipelining inside the wave:
-//   * K-chunks are 32 wide (two k-steps, 32 MFMAs, ~1 k cycles) in a FOUR-deep LDS ring (4 x 32 KB): chunk c+3 is issued
-//     while chunk c is multiplied, its eight LDS-DMA pieces spread between the MFMAs of the first k-step;
-//   * the wait + barrier at the top of chunk c retire chunk c+1 (counted vmcnt: the pieces of c+2 stay in flight), so the
-//     fragments of chunk c+1's first k-step are fetched during chunk c's second k-step -- the barrier is never followed by
-//     a fragment read the matrix pipe has to wait for;
-//   * fragment sets alternate between two register sets (2 x 32 VGPRs).
-// WAR: buffer (c+3)%4 held chunk c-1, whose last fragment reads were consumed by MFMAs issued before this barrier.
-__global__ __launch_bounds__(256, 1) void conv_gemm_w4_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W,
-                                                              uint16_t* __restrict__ Y, const uint16_t* __restrict__ ZERO,
-                                                              GatherGeom g, Epilogue ep) {
-    constexpr int BM = 256, BN = 256, WM = 2, WN = 2, BKV = 4, NS = 4, VEC = 8, NT = 256;
-    constexpr int RPT = NT / BKV, RA = BM / RPT, RB = BN / RPT, PER = RA + RB;     // 64 rows per instruction, 4 + 4 pieces
-    constexpr int STAGE_VEC = (BM + BN) * BKV;                                      // 32 KB
-    constexpr int EPI_VEC = EpiLds<BM, BN, WM, WN>::VEC16;
-    constexpr int LDS_VEC = NS * STAGE_VEC > EPI_VEC ? NS * STAGE_VEC : EPI_VEC;
-    __shared__ __attribute__((aligned(16))) u32x4 lds_raw[LDS_VEC];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    int bx, by;
-    tile_of_block(g, bx, by);
-    const int m0 = bx * BM, n0 = by * BN;
-    const int lvec = tid & 3, lrow = tid >> 2;
-
-    // per staged row: element offset with this lane's (swizzled) K-vector folded in, and a bit per tap "inside the image"
-    int a_off[RA];
-    unsigned a_tapok[RA];
-    unsigned b_okm = 0u;
-#pragma unroll
-    for (int j = 0; j < RA; ++j) {
-        const int rl = lrow + j * RPT;
-        const int p = m0 + rl;
-        const bool ok = p < g.M;
-        const uint32_t pp = ok ? p : 0;
-        const uint32_t t1 = fdiv(pp, g.dQW), qx = pp - t1 * g.QW;
-        const uint32_t n = fdiv(t1, g.dQH), qy = t1 - n * g.QH;
-        const int iy = qy * g.isy, ix = qx * g.isx;
-        a_off[j] = ((n * g.IH + iy) * g.IW + ix) * g.ldx + (lvec ^ lds_swz<BKV>(rl)) * VEC;
-        unsigned m = 0u;
-        for (int t = 0; t < g.T; ++t) {
-            const int ti = g.tapinfo[t];
-            const int dy = (int)(signed char)(ti & 0xff), dx = (int)(signed char)((ti >> 8) & 0xff);
-            m |= (ok && (unsigned)(iy + dy) < (unsigned)g.IH && (unsigned)(ix + dx) < (unsigned)g.IW) ? (1u << t) : 0u;
-        }
-        a_tapok[j] = m;
-    }
-    int b_off[RB];
-#pragma unroll
-    for (int j = 0; j < RB; ++j) {
-        const int rl = lrow + j * RPT;
-        const int co = n0 + rl;
-        const bool ok = co < g.Cout;
-        b_off[j] = (ok ? co : 0) * g.TT * g.Cin + (lvec ^ lds_swz<BKV>(rl)) * VEC;
-        b_okm |= ok ? (1u << j) : 0u;
-    }
-
-    f32x16 acc[4][4];
-#pragma unroll
-    for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < 4; ++tn)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
-
-    const int nchunks = g.KV / BKV;                // host: Cin % 32 == 0
-    int tap_u = 0, cv_u = 0;                       // cursor of the chunk being STAGED (wave-uniform, selects only: SGPRs)
-    // the tap table lives in ONE VGPR (lane t holds entry t) and is read with v_readlane: a scalar load inside the loop
-    // would share lgkmcnt with the fragment reads and, returning out of order, force every wait down to lgkmcnt(0)
-    const int v_tapinfo = g.tapinfo[lane < g.T ? lane : 0];
-    int ti_cur = __builtin_amdgcn_readlane(v_tapinfo, 0);
-    int s_aoff = 0, s_boff = 0, s_tap = 0;        // uniform parts of the staged chunk's source offsets, its tap number
-    unsigned s_live = ~0u;
-#define ET_W4_DECODE()                                                   \
-    do {                                                                 \
-        const int udy_ = (int)(signed char)(ti_cur & 0xff);              \
-        const int udx_ = (int)(signed char)((ti_cur >> 8) & 0xff);       \
-        s_aoff = (udy_ * g.IW + udx_) * g.ldx + cv_u * VEC;              \
-        s_boff = ((ti_cur >> 16) & 0xff) * g.Cin + cv_u * VEC;           \
-        s_tap = tap_u < g.T ? tap_u : 0;                                 \
-    } while (0)
-#define ET_W4_ADVANCE()                                                  \
-    do {                                                                 \
-        const int t2_ = tap_u + 1, c2_ = cv_u + BKV;                     \
-        const bool wt_ = t2_ >= g.T, wc_ = c2_ >= g.CV;                  \
-        const int ta_ = wt_ ? 0 : t2_, ca_ = wt_ ? c2_ : cv_u;           \
-        const int cb_ = wc_ ? 0 : c2_, tb_ = wc_ ? t2_ : tap_u;          \
-        tap_u = g.tap_inner ? ta_ : tb_;                                 \
-        cv_u = g.tap_inner ? ca_ : cb_;                                  \
-        ti_cur = __builtin_amdgcn_readlane(v_tapinfo, tap_u < g.T ? tap_u : 0); \
-    } while (0)
-    // one LDS-DMA piece (j < 4: A rows lrow + 64 j ; j >= 4: B rows) of the cursor's chunk into ring slot `dst`
-    auto piece = [&](u32x4* dst, int j) {
-        u32x4* const wbase = dst + wave * 64;
-        if (j < RA) {
-            const bool ok = (a_tapok[j] >> s_tap) & s_live & 1u;
-            const uint16_t* src = ok ? X + (a_off[j] + s_aoff) : ZERO;
-            et_glds16(src, wbase + j * NT);
-        } else {
-            const int jb = j - RA;
-            const bool ok = (b_okm >> jb) & s_live & 1u;
-            const uint16_t* src = ok ? W + (b_off[jb] + s_boff) : ZERO;
-            et_glds16(src, wbase + BM * BKV + jb * NT);
-        }
-    };
-    auto stage_all = [&](u32x4* dst) {
-        ET_W4_DECODE();
-#pragma unroll
-        for (int j = 0; j < PER; ++j) piece(dst, j);
-        ET_W4_ADVANCE();
-    };
-
-    const int l31 = lane & 31, gk = lane >> 5;
-    u32x4 af[2][4], bf[2][4];
-    auto fetch = [&](const u32x4* sm, int kk, int set) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int r = wm * 128 + t * 32 + l31;
-            af[set][t] = sm[r * BKV + ((kk * 2 + gk) ^ lds_swz<BKV>(r))];
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int r = wn * 128 + t * 32 + l31;
-            bf[set][t] = sm[(BM + r) * BKV + ((kk * 2 + gk) ^ lds_swz<BKV>(r))];
-        }
-    };
-    auto mfma1 = [&](int set, int i) {
-        const int tm = i >> 2, tn = i & 3;
-        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[set][tm]),
-                                                               __builtin_bit_cast(bf16x8, bf[set][tn]), acc[tm][tn], 0, 0, 0);
-    };
-
-    // prologue: chunks 0, 1, 2 in flight; chunk 0 landed and its first fragments fetched
-#pragma unroll
-    for (int s = 0; s < NS - 1; ++s) {
-        s_live = s < nchunks ? ~0u : 0u;
-        stage_all(lds_raw + s * STAGE_VEC);
-    }
-    et_wait_vmem_le<2 * PER>();
-    __builtin_amdgcn_s_barrier();
-    fetch(lds_raw, 0, 0);
-
-    int rd = 0;                                    // ring slot of chunk c
-    for (int c = 0; c < nchunks; ++c) {
-        const int rd1 = (rd + 1) & 3, wr = (rd + 3) & 3;
-        // Past the end the loop keeps staging (dead pieces from the zero page into slots nobody reads) and fetching, so
-        // that every iteration is the same straight line and the counted wait below is always "all but the newest chunk".
-        s_live = c + 3 < nchunks ? ~0u : 0u;
-        // chunk c+1 has landed (own pieces; then everybody's): only chunk c+2's pieces may still be in flight
-        et_wait_vmem_le<PER>();
-        __builtin_amdgcn_s_barrier();
-        const u32x4* const cur = lds_raw + rd * STAGE_VEC;
-        u32x4* const dst = lds_raw + wr * STAGE_VEC;
-        // ---- k-step 0: MFMAs on set 0; fetch k-step 1 of this chunk into set 1; issue chunk c+3
-        // (explicit lgkmcnt(0) BEFORE each fetch: the previous set was requested a whole k-step ago, so this costs nothing,
-        //  and it keeps at most 8 reads outstanding -- with 16 the 4-bit counter saturates and the compiler falls back to
-        //  lgkmcnt(0) right AFTER the new requests, i.e. in front of the MFMAs)
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        fetch(cur, 1, 1);
-        ET_W4_DECODE();
-        __builtin_amdgcn_sched_barrier(0);         // the reads stay up here, one k-step ahead of their use
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            mfma1(0, i);
-            if (i & 1) { piece(dst, i >> 1); __builtin_amdgcn_sched_barrier(0); }
-        }
-        ET_W4_ADVANCE();
-        // ---- k-step 1: MFMAs on set 1; fetch k-step 0 of chunk c+1 into set 0
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        fetch(lds_raw + rd1 * STAGE_VEC, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) mfma1(1, i);
-        __builtin_amdgcn_sched_barrier(0);
-        rd = rd1;
-    }
-    et_wait_vmem();                                // the dead pieces too, before the ring is reused
-    __syncthreads();                               // the epilogue reuses the ring as its staging area
-    conv_epilogue<uint16_t, BM, BN, WM, WN>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn);
-    __syncthreads();
-#undef ET_W4_DECODE
-#undef ET_W4_ADVANCE
-}
-
 // ---- wgrad ----------------------------------------------------------------------------------------
 struct WgradGeom {
     int N, IH, IW, Cin, ldx;     // X (gathered operand)
@@ -1624,7 +1433,7 @@ static int fill_common(GatherGeom& g, int N, int IH, int IW, int Cin, int ldx, i
 // ---- kernel selection ---------------------------------------------------------------------------------
 // ONE place decides which instantiation runs; et_conv2d_kernel_name() reports the same decision to the tests and
 // to bench.py's roofline tags (there is no second copy of this logic on the Python side).
-enum { GEMM_REG = 0, GEMM_GLDS = 1, GEMM_PP = 2, GEMM_W4 = 3 };
+enum { GEMM_REG = 0, GEMM_GLDS = 1, GEMM_PP = 2 };
 struct GemmPlan { int kind, BM, BN, WM, WN, BKV, NS; bool utap; };
 
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
@@ -1643,7 +1452,6 @@ static GemmPlan plan_gemm(const GatherGeom& g, int elem_bytes, bool have_zero_pa
     static const int ring_env = env_int("ET_CONV_RING", 0);
     static const int big = env_int("ET_CONV_BIG", 1);
     static const int use_pp = env_int("ET_CONV_PP", 1);
-    static const int use_w4 = env_int("ET_CONV_W4", 0);     // the 4-wave 128x128-per-wave tile instead of the ping-pong one
     const bool bf16 = elem_bytes == 2;
     const bool wide = g.Cout > 64 && !(narrow_k > 0 && g.T * g.Cin <= narrow_k);
     const bool glds = use_glds && have_zero_page;
@@ -1660,12 +1468,11 @@ static GemmPlan plan_gemm(const GatherGeom& g, int elem_bytes, bool have_zero_pa
         const long long blocks = (long long)((g.M + 255) / 256) * ((g.Cout + 255) / 256);
         const double rounds = (double)blocks / n_cu;
         const bool fills = (double)((blocks + n_cu - 1) / n_cu) / rounds <= 1.35;
-        if (g.TT > 1 || (g.T * g.Cin >= 512 && fills)) ring = use_w4 ? 25644 : (use_pp ? 25680 : 25682);
+        if (g.TT > 1 || (g.T * g.Cin >= 512 && fills)) ring = use_pp ? 25680 : 25682;
     }
     switch (ring) {
         case 25680: p = GemmPlan{GEMM_PP, 256, 256, 2, 4, 8, 2, true}; break;
         case 25682: p = GemmPlan{GEMM_GLDS, 256, 256, 2, 4, 8, 2, true}; break;
-        case 25644: p = GemmPlan{GEMM_W4, 256, 256, 2, 2, 4, 4, true}; break;
         case 25612: p = GemmPlan{GEMM_GLDS, 256, 128, 4, 2, 8, 2, true}; break;       // experiment
         case 12883: p.NS = 3; break;
         case 12843: p.BKV = 4; p.NS = 3; break;
@@ -1680,7 +1487,6 @@ static GemmPlan plan_gemm(const GatherGeom& g, int elem_bytes, bool have_zero_pa
 static void plan_name(const GemmPlan& p, int elem_bytes, char* buf, int n) {
     const char* t = elem_bytes == 2 ? "unsigned short" : "float";
     if (p.kind == GEMM_PP) snprintf(buf, n, "conv_gemm_pp_kernel");
-    else if (p.kind == GEMM_W4) snprintf(buf, n, "conv_gemm_w4_kernel");
     else if (p.kind == GEMM_GLDS) snprintf(buf, n, "conv_gemm_glds_kernel<%s, %d, %d, %d, %d, %d, %d, %s>", t, p.BM, p.BN, p.WM, p.WN, p.BKV, p.NS, p.utap ? "true" : "false");
     else snprintf(buf, n, "conv_gemm_kernel<%s, %d, %d, %d, %d, %d, %s>", t, p.BM, p.BN, p.WM, p.WN, p.BKV, p.utap ? "true" : "false");
 }
@@ -1704,13 +1510,6 @@ static int launch_gemm(const void* X, const void* W, void* Y, const void* zero16
     if (p.kind == GEMM_PP) {
         if constexpr (sizeof(T) == 2) {
             hipLaunchKernelGGL(conv_gemm_pp_kernel, grid, block, 0, s, (const uint16_t*)x, (const uint16_t*)w, (uint16_t*)y, (const uint16_t*)z, g, ep);
-            return 0;
-        }
-        return -2;
-    }
-    if (p.kind == GEMM_W4) {
-        if constexpr (sizeof(T) == 2) {
-            hipLaunchKernelGGL(conv_gemm_w4_kernel, grid, block, 0, s, (const uint16_t*)x, (const uint16_t*)w, (uint16_t*)y, (const uint16_t*)z, g, ep);
             return 0;
         }
         return -2;
@@ -2070,7 +1869,7 @@ extern "C" int et_conv2d_kernel_name(int op, int dtype, int N, int IH, int IW, i
 extern "C" int et_env_knobs(char* buf, int buflen) {
     // every ET_* tuning knob that is SET in this process's environment, as "NAME=value;..." (bench.py records it)
     static const char* names[] = {"ET_CONV_TAP_INNER", "ET_CONV_XCD", "ET_CONV_NARROW_K", "ET_CONV_NFAST", "ET_CONV_GLDS",
-                                  "ET_CONV_RING", "ET_CONV_BIG", "ET_CONV_PP", "ET_CONV_W4", "ET_WGRAD_TR", "ET_WGRAD_BIG", "ET_WGRAD_BLOCKS",
+                                  "ET_CONV_RING", "ET_CONV_BIG", "ET_CONV_PP", "ET_WGRAD_TR", "ET_WGRAD_BIG", "ET_WGRAD_BLOCKS",
                                   "ET_WGRAD_XCD", "ET_EW_VPT", "ET_WGRAD_GROUP", "ET_WGRAD_STALE", "ET_HIP_LIB"};
     if (!buf || buflen < 1) return -1;
     int off = 0;

@@ -190,13 +190,9 @@ def test_lds_dma_pipelines_under_adversarial_schedules(emu, dma_late, seed):
 
 
 def _check_instantiation(hip, case, kf, kd, kw):
-    import os
     from efficientteacher_amd import ops
     N, H, W, Cin, Cout, k, s, p = case
     dt = torch.bfloat16
-    if os.environ.get("ET_CONV_W4") == "1":      # the knob swaps the 4-wave tile in wherever the ping-pong tile is the default
-        sub = lambda n: n.replace("conv_gemm_pp_kernel", "conv_gemm_w4_kernel") if n else n
-        kf, kd = sub(kf), [sub(n) for n in kd] if kd else kd
     assert ops.kernel_name("fwd", dt, N, H, W, Cin, Cout, k, s, p) == kf
     x = _mk(hip, (N, H, W, Cin), dt, 41)
     w = (_mk(hip, (Cout, k, k, Cin), dt, 42) * (1.0 / (k * k * Cin) ** 0.5)).to(dt)

@@ -13,9 +13,6 @@ conv_tests) run conv_tests; timeout 900 python -m pytest tests/test_conv.py -x -
 all_tests) run all_tests; timeout 2400 python -m pytest tests -x -q -m gpu > $OUT/pytest_gpu.log 2>&1; tail -5 $OUT/pytest_gpu.log ;;
 mb_pp) run mb_pp; MB_REF=0 MB_ONLY=${MB_ONLY:-pp} timeout 600 python tools/microbench.py conv > $OUT/mb_pp1.log 2>&1; tail -1 $OUT/mb_pp1.log ;;
 mb_lock) run mb_lock; ET_CONV_PP=0 MB_REF=0 MB_ONLY=${MB_ONLY:-"256, 256"} timeout 600 python tools/microbench.py conv > $OUT/mb_pp0.log 2>&1; tail -1 $OUT/mb_pp0.log ;;
-mb_w4) run mb_w4; ET_CONV_W4=1 MB_REF=0 MB_ONLY=w4 timeout 600 python tools/microbench.py conv > $OUT/mb_w4.log 2>&1; tail -1 $OUT/mb_w4.log ;;
-w4_tests) run w4_tests; ET_CONV_W4=1 timeout 900 python -m pytest tests/test_conv.py -x -q -m gpu > $OUT/pytest_conv_w4.log 2>&1; tail -3 $OUT/pytest_conv_w4.log ;;
-bench_w4) run bench_w4; ET_CONV_W4=1 timeout 900 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_w4.json 2> $OUT/bench_w4.err; cut -c1-300 $OUT/bench_w4.json ;;
 mb_all) run mb_all; MB_REF=0 timeout 900 python tools/microbench.py conv > $OUT/mb_all.log 2>&1; tail -1 $OUT/mb_all.log ;;
 mb_bn) run mb_bn; timeout 600 python tools/microbench.py bn > $OUT/mb_bn.log 2>&1; tail -1 $OUT/mb_bn.log ;;
 host) run host; timeout 600 python tools/host_bound.py > $OUT/host_bound.log 2>&1; tail -1 $OUT/host_bound.log ;;
