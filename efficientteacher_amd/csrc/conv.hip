@@ -981,6 +981,227 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_pp_kernel(const uint16_t* __
 #undef ET_PPA
 }
 
+// ---- the stem: 6x6 stride-2 pad-2 convolution of the packed image (8 channels, 3 used) ----------------------------
+// (YoloV5BackBone.stage1, models/backbone/yolov5_backbone.py:36: Conv(3, 64, 6, 2, 2)).  As a gather-GEMM this layer is the
+// worst case of the generic kernels: K = 36 taps x 8 channels, so every 16-byte LDS-DMA piece is its own (tap, pixel)
+// gather and each input pixel travels L2 -> LDS nine times (measured 0.79 ms at B=64 against an HBM floor of 0.25 ms).
+// Here one workgroup computes a 4 x 64 block of output pixels from ONE staged input patch (12 x 132 pixels, 25 KB: each
+// input pixel is staged 1.5 times instead of 9) and reads its MFMA operands out of that patch with constant offsets:
+//   * the patch keeps the image's pixel order (a patch row is one contiguous 2.1 KB run of the packed image: every staging
+//     instruction of a wave is a coalesced 1 KB read); output column c, tap column kx reads patch column 2c + kx, and since
+//     taps 2ks / 2ks+1 of a k-step are horizontal neighbours of one kernel row, the lane's K-half (lane >> 5) is simply one
+//     more slot.  The stride-2 fragment reads are 2-way bank conflicts on 36 reads per tile -- irrelevant next to staging
+//     (a de-interleaved patch, conflict-free but staged in 32-byte strides, measured 0.57 ms against this layout's figure
+//     in profiles/);
+//   * the whole weight matrix (64 x 288 bf16) sits in LDS for the lifetime of the (persistent) workgroup, row pitch 37
+//     slots (odd: conflict-free b128 reads);
+//   * operands are SWAPPED (weights = MFMA A, pixels = MFMA B): a lane then owns one output pixel and 4 consecutive
+//     channels per accumulator quad, so the result is stored straight from registers in 8-byte pieces -- no LDS
+//     transposition; BN statistics are accumulated per lane over all tiles of the workgroup and reduced once at the end.
+// HBM-bound by construction: 57 KB of traffic and 72 MFMAs per wave per tile.
+#define STEM_TR 4
+#define STEM_TC 64
+#define STEM_PH 12                      // patch rows = 2 * TR + 4
+#define STEM_PITCH 132                  // patch columns = 2 * TC + 4
+#define STEM_PSLOTS (7 * 256)           // 12 * 132 = 1584 slots, rounded up to whole staging instructions
+#define STEM_WPITCH 37
+#define STEM_WSLOTS (10 * 256)          // 64 * 37 = 2368 slots, rounded up
+
+struct StemArgs {
+    const uint16_t* x; const uint16_t* w; uint16_t* y; const uint16_t* zero;
+    int N, IH, IW, ldx, OH, OW, ldy, Cout;
+    int trn, tcn, ntiles;               // tile grid per image: rows, cols; total tiles
+    const float* scale; const float* bias; int act;
+    float* stats; int stat_rows;        // [stat_rows][2][Cout] or null
+};
+
+template <int ACT>
+__global__ __launch_bounds__(256, 2) void conv_stem_kernel(StemArgs a) {
+    __shared__ __attribute__((aligned(16))) u32x4 wl[STEM_WSLOTS];
+    __shared__ __attribute__((aligned(16))) u32x4 pl[STEM_PSLOTS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    // ---- weights -> LDS once (pitch 37; channels >= Cout and the pad slot read the zero page)
+#pragma unroll
+    for (int i = 0; i < STEM_WSLOTS / 256; ++i) {
+        const int slot = i * 256 + tid;
+        const int ch = slot / STEM_WPITCH, tap = slot - ch * STEM_WPITCH;
+        const bool ok = ch < a.Cout && tap < 36;
+        et_glds16(ok ? a.w + ((size_t)ch * 36 + tap) * 8 : a.zero, wl + i * 256 + wave * 64);
+    }
+    // ---- this thread's patch slots: (row, column) offsets inside a patch, constant over tiles
+    int s_dy[STEM_PSLOTS / 256], s_dx[STEM_PSLOTS / 256];
+#pragma unroll
+    for (int i = 0; i < STEM_PSLOTS / 256; ++i) {
+        const int slot = i * 256 + tid;
+        const int prow = slot / STEM_PITCH;
+        s_dy[i] = prow < STEM_PH ? prow : -100000;          // fails every bounds check below
+        s_dx[i] = slot - prow * STEM_PITCH;
+    }
+    float ssum[2][16], ssq[2][16];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { ssum[cb][r] = 0.f; ssq[cb][r] = 0.f; }
+
+    const u32x4* const wbase = wl + l31 * STEM_WPITCH + hi;                          // + cb * 32 * 37 + 2 * ks
+    const u32x4* const pbase = pl + (2 * wave) * STEM_PITCH + 2 * l31 + hi;          // + pb * 64 + (ks/3) * PITCH + 2 * (ks%3)
+
+    auto stage_patch = [&](int tile) {
+        const int tc = tile % a.tcn, t2 = tile / a.tcn;
+        const int tr = t2 % a.trn, n = t2 / a.trn;
+        const int iy0 = 2 * tr * STEM_TR - 2, ix0 = 2 * tc * STEM_TC - 2;
+#pragma unroll
+        for (int i = 0; i < STEM_PSLOTS / 256; ++i) {
+            const int iy = iy0 + s_dy[i], ix = ix0 + s_dx[i];
+            const bool ok = (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
+            const uint16_t* src = ok ? a.x + (((size_t)n * a.IH + iy) * a.IW + ix) * a.ldx : a.zero;
+            et_glds16(src, pl + i * 256 + wave * 64);
+        }
+    };
+    if ((int)blockIdx.x < a.ntiles) stage_patch(blockIdx.x);
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        const int tc = tile % a.tcn, t2 = tile / a.tcn;
+        const int tr = t2 % a.trn, n = t2 / a.trn;
+        const int oy0 = tr * STEM_TR, ox0 = tc * STEM_TC;
+        et_wait_vmem();
+        __syncthreads();
+        // ---- 18 k-steps (two taps of one kernel row each): 2 channel blocks x 2 pixel blocks of 32x32x16 MFMAs
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[cb][pb][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 18; ++ks) {
+            u32x4 wf[2], pf[2];
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) wf[cb] = wbase[cb * 32 * STEM_WPITCH + 2 * ks];
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb) pf[pb] = pbase[pb * 64 + (ks / 3) * STEM_PITCH + 2 * (ks % 3)];
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int pb = 0; pb < 2; ++pb)
+                    acc[cb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[cb]),
+                                                                          __builtin_bit_cast(bf16x8, pf[pb]), acc[cb][pb], 0, 0, 0);
+        }
+        // every wave is done with the patch: the next tile's patch streams in behind this tile's epilogue
+        __syncthreads();
+        if (tile + (int)gridDim.x < a.ntiles) stage_patch(tile + gridDim.x);
+        // ---- epilogue straight from registers: lane = pixel (l31 of block pb), register r = channel 8*(r>>2) + 4*hi + (r&3).
+        // The two lanes of a pixel (hi = 0 / 1) each hold 4 of every 8 consecutive channels: they trade quads so that each
+        // ends up with 8 whole channel octets -- 8 stores of 16 bytes per lane instead of 16 of 8 (the store tail of a
+        // row-per-lane epilogue is issue-bound: MI355X_MICROARCH.md, "attention epilogue store tail")
+        const int oy = oy0 + wave;
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) {
+            const int ox = ox0 + pb * 32 + l31;
+            const bool pok = oy < a.OH && ox < a.OW;
+            uint16_t* const yp = a.y + (((size_t)n * a.OH + oy) * a.OW + ox) * a.ldy;
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                if (pok) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { const float raw = acc[cb][pb][r]; ssum[cb][r] += raw; ssq[cb][r] += raw * raw; }
+                }
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    // octets j0 = 2m (kept by the hi = 0 lane) and j1 = 2m + 1 (kept by the hi = 1 lane)
+                    float lo4[4], hi4[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float q0 = acc[cb][pb][8 * m + e], q1 = acc[cb][pb][8 * m + 4 + e];
+                        const float t = __shfl_xor(hi ? q0 : q1, 32);
+                        lo4[e] = hi ? t : q0;        // channels oct*8 + e
+                        hi4[e] = hi ? q1 : t;        // channels oct*8 + 4 + e
+                    }
+                    const int ch = cb * 32 + 8 * (2 * m + hi);
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float u = e < 4 ? lo4[e] : hi4[e - 4];
+                        if (a.scale) u = u * a.scale[ch + e];
+                        if (a.bias) u = u + a.bias[ch + e];
+                        if constexpr (ACT == ACT_SILU) u = u * __builtin_amdgcn_rcpf(1.0f + __expf(-u));
+                        else if constexpr (ACT == ACT_RELU) u = fmaxf(u, 0.f);
+                        v[e] = u;
+                    }
+                    if (pok && ch < a.Cout)
+                        *(u32x4*)(yp + ch) = mk4(et_pack_bf2(v[0], v[1]), et_pack_bf2(v[2], v[3]), et_pack_bf2(v[4], v[5]), et_pack_bf2(v[6], v[7]));
+                }
+            }
+        }
+    }
+    // ---- BN statistics: per-lane sums over this workgroup's pixels -> one partial row per workgroup, zeros elsewhere
+    if (a.stats) {
+        float* const red = (float*)wl;        // [4 waves][2][64]; the weights are no longer needed
+        __syncthreads();
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float s1 = ssum[cb][r], s2 = ssq[cb][r];
+#pragma unroll
+                for (int m = 1; m < 32; m <<= 1) { s1 += __shfl_xor(s1, m); s2 += __shfl_xor(s2, m); }
+                if (l31 == 0) {
+                    const int ch = cb * 32 + 8 * (r >> 2) + 4 * hi + (r & 3);
+                    red[(wave * 2 + 0) * 64 + ch] = s1;
+                    red[(wave * 2 + 1) * 64 + ch] = s2;
+                }
+            }
+        __syncthreads();
+        if (tid < 128) {
+            const int which = tid >> 6, ch = tid & 63;
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) t += red[(w * 2 + which) * 64 + ch];
+            if (ch < a.Cout) {
+                // the consumer sums ALL stat_rows partial rows: this workgroup owns rows blockIdx.x, + gridDim.x, ...
+                for (int row = blockIdx.x; row < a.stat_rows; row += gridDim.x)
+                    a.stats[((size_t)row * 2 + which) * a.Cout + ch] = row == (int)blockIdx.x ? t : 0.f;
+            }
+        }
+    }
+}
+
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+static int device_cus() {
+    static const int n_cu = [] { hipDeviceProp_t p; int d = 0; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; }();
+    return n_cu;
+}
+
+// shape gate + launch; returns 1 if the stem kernel took the problem
+static int try_launch_stem(const void* x, const void* w, void* y, int dtype, int N, int IH, int IW, int Cin, int ldx, int Cout,
+                           int KH, int KW, int stride, int pad, int ldy, const float* scale, const float* bias, int act,
+                           const void* residual, float* stats, const void* zero16, hipStream_t s, bool launch) {
+    static const int use_stem = env_int("ET_CONV_STEM", 1);
+    if (!use_stem || dtype != ET_BF16 || KH != 6 || KW != 6 || stride != 2 || pad != 2 || Cin != 8 || Cout > 64 || Cout % 8 ||
+        residual || !zero16)
+        return 0;
+    if (!launch) return 1;
+    StemArgs a;
+    a.x = (const uint16_t*)x; a.w = (const uint16_t*)w; a.y = (uint16_t*)y; a.zero = (const uint16_t*)zero16;
+    a.N = N; a.IH = IH; a.IW = IW; a.ldx = ldx; a.Cout = Cout; a.ldy = ldy;
+    a.OH = (IH + 2 * pad - KH) / stride + 1; a.OW = (IW + 2 * pad - KW) / stride + 1;
+    a.trn = (a.OH + STEM_TR - 1) / STEM_TR; a.tcn = (a.OW + STEM_TC - 1) / STEM_TC;
+    a.ntiles = N * a.trn * a.tcn;
+    a.scale = scale; a.bias = bias; a.act = act; a.stats = stats;
+    a.stat_rows = (N * a.OH * a.OW + 127) / 128;
+    int grid = env_int("ET_CONV_STEM_WGS", 2 * device_cus());      // read per launch: tests shrink it to exercise the tile loop
+    if (grid < 1) grid = 1;
+    if (grid > a.ntiles) grid = a.ntiles;
+    if (stats && grid > a.stat_rows) grid = a.stat_rows;
+    if (act == ACT_SILU) hipLaunchKernelGGL((conv_stem_kernel<ACT_SILU>), dim3(grid), dim3(256), 0, s, a);
+    else if (act == ACT_RELU) hipLaunchKernelGGL((conv_stem_kernel<ACT_RELU>), dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((conv_stem_kernel<ACT_NONE>), dim3(grid), dim3(256), 0, s, a);
+    return 1;
+}
+
 // ---- wgrad ----------------------------------------------------------------------------------------
 struct WgradGeom {
     int N, IH, IW, Cin, ldx;     // X (gathered operand)
@@ -1436,12 +1657,6 @@ static int fill_common(GatherGeom& g, int N, int IH, int IW, int Cin, int ldx, i
 enum { GEMM_REG = 0, GEMM_GLDS = 1, GEMM_PP = 2 };
 struct GemmPlan { int kind, BM, BN, WM, WN, BKV, NS; bool utap; };
 
-static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
-static int device_cus() {
-    static const int n_cu = [] { hipDeviceProp_t p; int d = 0; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; }();
-    return n_cu;
-}
-
 static GemmPlan plan_gemm(const GatherGeom& g, int elem_bytes, bool have_zero_page) {
     // tuning knobs, read once.  ET_CONV_NARROW_K=<K>: GEMMs with K <= K elements use the 128x64 tile (smaller
     // register/LDS footprint: 3 workgroups per CU for the HBM-bound short-K 1x1 layers).  ET_CONV_GLDS=0: VGPR staging.
@@ -1561,6 +1776,11 @@ extern "C" int et_conv2d_fwd(const void* x, const void* w, void* y, int dtype, i
                              const void* zero16, et_stream_t stream) {
     if (!x || !w || !y) return -1;
     if (KH * KW > CONV_MAX_TAPS || stride < 1 || N <= 0 || Cout <= 0) return -2;
+    if (try_launch_stem(x, w, y, dtype, N, IH, IW, Cin, ldx, Cout, KH, KW, stride, pad, ldy, scale, bias, act, residual,
+                        stats_partial, zero16, (hipStream_t)stream, true)) {
+        ET_CHECK_LAUNCH();
+        return 0;
+    }
     GatherGeom g;
     const int OH = (IH + 2 * pad - KH) / stride + 1, OW = (IW + 2 * pad - KW) / stride + 1;
     g.T = g.TT = KH * KW;
@@ -1846,6 +2066,11 @@ extern "C" int et_conv2d_kernel_name(int op, int dtype, int N, int IH, int IW, i
     }
     GatherGeom g;
     if (op == 0) {
+        if (try_launch_stem(nullptr, nullptr, nullptr, dtype, N, IH, IW, Cin, Cin, Cout, KH, KW, stride, pad, Cout, nullptr, nullptr, 0,
+                            nullptr, nullptr, have_zero_page ? (const void*)buf : nullptr, nullptr, false)) {
+            snprintf(buf, buflen, "conv_stem_kernel");       // rocprofv3: "void conv_stem_kernel<ACT>(StemArgs)"
+            return 0;
+        }
         g.T = g.TT = KH * KW;
         if (Cin % vec) return -2;
         g.Cin = Cin; g.Cout = Cout; g.CV = Cin / vec; g.KV = g.T * g.CV; g.M = N * OH * OW;
@@ -1869,7 +2094,7 @@ extern "C" int et_conv2d_kernel_name(int op, int dtype, int N, int IH, int IW, i
 extern "C" int et_env_knobs(char* buf, int buflen) {
     // every ET_* tuning knob that is SET in this process's environment, as "NAME=value;..." (bench.py records it)
     static const char* names[] = {"ET_CONV_TAP_INNER", "ET_CONV_XCD", "ET_CONV_NARROW_K", "ET_CONV_NFAST", "ET_CONV_GLDS",
-                                  "ET_CONV_RING", "ET_CONV_BIG", "ET_CONV_PP", "ET_WGRAD_TR", "ET_WGRAD_BIG", "ET_WGRAD_BLOCKS",
+                                  "ET_CONV_RING", "ET_CONV_BIG", "ET_CONV_PP", "ET_CONV_STEM", "ET_WGRAD_TR", "ET_WGRAD_BIG", "ET_WGRAD_BLOCKS",
                                   "ET_WGRAD_XCD", "ET_EW_VPT", "ET_WGRAD_GROUP", "ET_WGRAD_STALE", "ET_HIP_LIB"};
     if (!buf || buflen < 1) return -1;
     int off = 0;

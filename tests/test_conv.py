@@ -164,7 +164,7 @@ SELECT = [
      "conv_wgrad_tr_kernel<128, 256, 2, 4>"),
     ((2, 12, 12, 64, 64, 1, 1, 0), GLDS + "128, 64, 2, 2, 4, 3, true>", [GLDS + "128, 64, 2, 2, 4, 3, true>"],
      "conv_wgrad_tr_kernel<64, 64, 2, 2>"),
-    ((1, 16, 16, 8, 32, 6, 2, 2), GLDS + "128, 64, 2, 2, 4, 2, false>", None, None),          # the stem (no dgrad in the net)
+    ((1, 16, 16, 8, 32, 6, 2, 2), "conv_stem_kernel", None, None),                            # the stem (no dgrad in the net)
     ((1, 5, 5, 64, 264, 3, 1, 1), "conv_gemm_pp_kernel", [GLDS + "128, 64, 2, 2, 4, 2, false>"],
      "conv_wgrad_tr_kernel<256, 256, 2, 4>"),                                                  # ragged M and Cout on the 256^2 tiles
     ((3, 14, 14, 192, 320, 3, 1, 1), "conv_gemm_pp_kernel", [GLDS + "128, 128, 2, 2, 8, 2, true>"], "conv_wgrad_tr_kernel<256, 256, 2, 4>"),
@@ -187,6 +187,12 @@ def test_lds_dma_pipelines_under_adversarial_schedules(emu, dma_late, seed):
     emu.configure(dma_late, seed)
     for case, kf, kd, kw in (SELECT[0], SELECT[4], SELECT[8]):
         _check_instantiation(emu, case, kf, kd, kw)
+    import os
+    os.environ["ET_CONV_STEM_WGS"] = "2"          # 6 tiles on 2 persistent workgroups: the single patch buffer is re-staged
+    try:
+        _stem_case(emu, 1, 20, 300, 48)
+    finally:
+        del os.environ["ET_CONV_STEM_WGS"]
 
 
 def _check_instantiation(hip, case, kf, kd, kw):
@@ -308,3 +314,40 @@ def test_dgrad_with_fused_bn_backward_sums(hip, case, dtype):
             assert (out_f.float().cpu() - yr.grad).abs().max().item() <= 5 * tol * max(1.0, yr.grad.abs().max().item())
             assert torch.allclose(dg_f.cpu(), g_r.grad, rtol=2e-2, atol=5 * tol * n ** 0.5)
             assert torch.allclose(db_f.cpu(), b_r.grad, rtol=2e-2, atol=5 * tol * n ** 0.5)
+
+
+@pytest.mark.parametrize("N,H,W,Cout", [(1, 16, 16, 32), (2, 36, 40, 64), (1, 20, 300, 48), (3, 8, 132, 64)])
+def test_stem_kernel(hip, N, H, W, Cout):
+    """the dedicated 6x6 s2 p2 kernel of the packed image (conv_stem_kernel): ragged tile grids in both directions, channel
+    counts below 64, raw output + BN statistics (student) and folded scale/bias + SiLU into a channel slice (teacher)"""
+    _stem_case(hip, N, H, W, Cout)
+
+
+def _stem_case(hip, N, H, W, Cout):
+    from efficientteacher_amd import ops
+    dt = torch.bfloat16
+    assert ops.kernel_name("fwd", dt, N, H, W, 8, Cout, 6, 2, 2) == "conv_stem_kernel"
+    x = _mk(hip, (N, H, W, 8), dt, 141)
+    x[..., 3:] = 0                                   # the packed image: 3 real channels
+    w = (_mk(hip, (Cout, 6, 6, 8), dt, 142) * (1.0 / (36 * 3) ** 0.5)).to(dt)
+    OH, OW = ops.conv_out_hw(H, W, 6, 2, 2)
+    ref = _ref_conv(x, w, 2, 2)
+    y, stats = ops.conv2d_fwd(x, w, 2, 2, want_stats=True)
+    tol = 2e-2 * max(1.0, ref.abs().max().item())
+    assert (y.float().cpu() - ref).abs().max().item() <= tol
+    flat = ref.reshape(-1, Cout)
+    st = stats.sum(0).cpu()
+    assert torch.allclose(st[0], flat.sum(0), rtol=1e-3, atol=2e-2 * flat.shape[0] ** 0.5 * 4)
+    assert torch.allclose(st[1], (flat ** 2).sum(0), rtol=2e-2, atol=1e-3)
+    sc = _mk(hip, (Cout,), torch.float32, 143).abs() + 0.5
+    bi = _mk(hip, (Cout,), torch.float32, 144)
+    wide = torch.zeros((N, OH, OW, Cout + 16), dtype=dt, device=hip.device)
+    ops.conv2d_fwd(x, w, 2, 2, scale=sc, bias=bi, act=ops.ACT_SILU, out=wide[..., 8:8 + Cout])
+    ref2 = F.silu(ref * sc.cpu() + bi.cpu())
+    assert (wide[..., 8:8 + Cout].float().cpu() - ref2).abs().max().item() <= 3e-2 * max(1.0, ref2.abs().max().item())
+    assert (wide[..., :8] == 0).all() and (wide[..., 8 + Cout:] == 0).all()
+    # the generic kernel on the same problem (ET_CONV_STEM is read once per process, so compare through the residual form,
+    # which the stem kernel declines)
+    zero = torch.zeros((N, OH, OW, Cout), dtype=dt, device=hip.device)
+    y2, _ = ops.conv2d_fwd(x, w, 2, 2, residual=zero, want_stats=True)
+    assert (y2.float() - y.float()).abs().max().item() <= 1e-2 * max(1.0, ref.abs().max().item())

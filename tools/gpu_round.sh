@@ -13,6 +13,8 @@ conv_tests) run conv_tests; timeout 900 python -m pytest tests/test_conv.py -x -
 all_tests) run all_tests; timeout 2400 python -m pytest tests -x -q -m gpu > $OUT/pytest_gpu.log 2>&1; tail -5 $OUT/pytest_gpu.log ;;
 mb_pp) run mb_pp; MB_REF=0 MB_ONLY=${MB_ONLY:-pp} timeout 600 python tools/microbench.py conv > $OUT/mb_pp1.log 2>&1; tail -1 $OUT/mb_pp1.log ;;
 mb_lock) run mb_lock; ET_CONV_PP=0 MB_REF=0 MB_ONLY=${MB_ONLY:-"256, 256"} timeout 600 python tools/microbench.py conv > $OUT/mb_pp0.log 2>&1; tail -1 $OUT/mb_pp0.log ;;
+mb_stem) run mb_stem; MB_REF=0 MB_ONLY=stem timeout 600 python tools/microbench.py conv > $OUT/mb_stem.log 2>&1; grep -v "^$" $OUT/mb_stem.log | tail -3 | cut -c1-400; ET_CONV_STEM=0 MB_REF=0 MB_ONLY="4, 2, false" timeout 600 python tools/microbench.py conv > $OUT/mb_stem_off.log 2>&1; grep -v "^$" $OUT/mb_stem_off.log | tail -3 | cut -c1-400 ;;
+bench_nostem) run bench_nostem; ET_CONV_STEM=0 timeout 900 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_nostem.json 2> $OUT/bench_nostem.err; cut -c1-300 $OUT/bench_nostem.json ;;
 mb_all) run mb_all; MB_REF=0 timeout 900 python tools/microbench.py conv > $OUT/mb_all.log 2>&1; tail -1 $OUT/mb_all.log ;;
 mb_bn) run mb_bn; timeout 600 python tools/microbench.py bn > $OUT/mb_bn.log 2>&1; tail -1 $OUT/mb_bn.log ;;
 host) run host; timeout 600 python tools/host_bound.py > $OUT/host_bound.log 2>&1; tail -1 $OUT/host_bound.log ;;
