@@ -276,6 +276,8 @@ def test_dgrad_with_fused_bn_backward_sums(hip, case, dtype):
     with and without the shortcut-gradient residual; and both equal torch autograd of act(BN(y)) on the same tensors."""
     from efficientteacher_amd import ops
     N, H, W, Cin, Cout, k = case
+    if hip.emulated and Cin >= 256:      # one ragged 256-row tile pair is enough for the CPU tier (the GPU tier runs the full case)
+        N, H, W = 1, 17, 17
     p = k // 2
     dy = _mk(hip, (N, H, W, Cout), dtype, 81)
     w = (_mk(hip, (Cout, k, k, Cin), dtype, 82) * (1.0 / (k * k * Cout) ** 0.5)).to(dtype)
