@@ -1683,7 +1683,11 @@ static GemmPlan plan_gemm(const GatherGeom& g, int elem_bytes, bool have_zero_pa
         const long long blocks = (long long)((g.M + 255) / 256) * ((g.Cout + 255) / 256);
         const double rounds = (double)blocks / n_cu;
         const bool fills = (double)((blocks + n_cu - 1) / n_cu) / rounds <= 1.35;
-        if (g.TT > 1 || (g.T * g.Cin >= 512 && fills)) ring = use_pp ? 25680 : 25682;
+        // a grid that leaves most CUs without a 256x256 tile (the teacher's 32-image 20x20 layers: 100 tiles) is better
+        // served by four times as many 128x128 tiles at two workgroups per CU (ET_CONV_BIG_MINFILL, percent of the CUs)
+        static const int minfill = env_int("ET_CONV_BIG_MINFILL", 0);
+        const bool enough = blocks * 100 >= (long long)minfill * n_cu;
+        if (enough && (g.TT > 1 || (g.T * g.Cin >= 512 && fills))) ring = use_pp ? 25680 : 25682;
     }
     switch (ring) {
         case 25680: p = GemmPlan{GEMM_PP, 256, 256, 2, 4, 8, 2, true}; break;
@@ -2094,7 +2098,7 @@ extern "C" int et_conv2d_kernel_name(int op, int dtype, int N, int IH, int IW, i
 extern "C" int et_env_knobs(char* buf, int buflen) {
     // every ET_* tuning knob that is SET in this process's environment, as "NAME=value;..." (bench.py records it)
     static const char* names[] = {"ET_CONV_TAP_INNER", "ET_CONV_XCD", "ET_CONV_NARROW_K", "ET_CONV_NFAST", "ET_CONV_GLDS",
-                                  "ET_CONV_RING", "ET_CONV_BIG", "ET_CONV_PP", "ET_CONV_STEM", "ET_WGRAD_TR", "ET_WGRAD_BIG", "ET_WGRAD_BLOCKS",
+                                  "ET_CONV_RING", "ET_CONV_BIG", "ET_CONV_BIG_MINFILL", "ET_CONV_PP", "ET_CONV_STEM", "ET_WGRAD_TR", "ET_WGRAD_BIG", "ET_WGRAD_BLOCKS",
                                   "ET_WGRAD_XCD", "ET_EW_VPT", "ET_WGRAD_GROUP", "ET_WGRAD_STALE", "ET_HIP_LIB"};
     if (!buf || buflen < 1) return -1;
     int off = 0;

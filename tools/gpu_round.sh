@@ -15,6 +15,13 @@ mb_pp) run mb_pp; MB_REF=0 MB_ONLY=${MB_ONLY:-pp} timeout 600 python tools/micro
 mb_lock) run mb_lock; ET_CONV_PP=0 MB_REF=0 MB_ONLY=${MB_ONLY:-"256, 256"} timeout 600 python tools/microbench.py conv > $OUT/mb_pp0.log 2>&1; tail -1 $OUT/mb_pp0.log ;;
 mb_stem) run mb_stem; MB_REF=0 MB_ONLY=stem timeout 600 python tools/microbench.py conv > $OUT/mb_stem.log 2>&1; grep -v "^$" $OUT/mb_stem.log | tail -3 | cut -c1-400; ET_CONV_STEM=0 MB_REF=0 MB_ONLY="4, 2, false" timeout 600 python tools/microbench.py conv > $OUT/mb_stem_off.log 2>&1; grep -v "^$" $OUT/mb_stem_off.log | tail -3 | cut -c1-400 ;;
 bench_nostem) run bench_nostem; ET_CONV_STEM=0 timeout 900 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_nostem.json 2> $OUT/bench_nostem.err; cut -c1-300 $OUT/bench_nostem.json ;;
+mb_fill) run mb_fill; for F in 0 45 80; do echo "MINFILL $F" >> $OUT/mb_fill.log; ET_CONV_BIG_MINFILL=$F MB_B=32 MB_REF=0 timeout 600 python tools/microbench.py conv 2>&1 | grep -E '"k": 3|"k": 1' | python -c "
+import sys,json
+for l in sys.stdin:
+    d=json.loads(l)
+    if d['h']<=40 and d['cout']>=256: print(d['cin'],d['cout'],d['k'],d['s'],d['h'],d['fwd_kernel'][:32],round(d['fwd_ms']*1e3,1),round(d['dgrad_ms']*1e3,1))
+" >> $OUT/mb_fill.log; done; cat $OUT/mb_fill.log ;;
+bench_fill) run bench_fill; for F in 45 80; do ET_CONV_BIG_MINFILL=$F timeout 900 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_fill$F.json 2> $OUT/bench_fill$F.err; cut -c1-200 $OUT/bench_fill$F.json; done ;;
 mb_all) run mb_all; MB_REF=0 timeout 900 python tools/microbench.py conv > $OUT/mb_all.log 2>&1; tail -1 $OUT/mb_all.log ;;
 mb_bn) run mb_bn; timeout 600 python tools/microbench.py bn > $OUT/mb_bn.log 2>&1; tail -1 $OUT/mb_bn.log ;;
 host) run host; timeout 600 python tools/host_bound.py > $OUT/host_bound.log 2>&1; tail -1 $OUT/host_bound.log ;;
