@@ -270,6 +270,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     loss_ok = all(math.isfinite(float(v)) for v in items.values())
+    # outside the timed region: what issuing ONE step costs the host when the HIP queue is empty at its start (inside the
+    # timed loop the host runs ahead until the queue is full and then advances at the GPU's pace, so t_enq ~ dt there)
+    enq_empty = []
+    for j in range(3):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        step(a.warmup + a.steps + j)
+        enq_empty.append((time.perf_counter() - t1) * 1e3)
+    torch.cuda.synchronize()
 
     if rank == 0:
         try:                 # the roofline leg must never cost the throughput line
@@ -323,6 +332,10 @@ def main():
                                                "last collective complete; exposed: compute stream waiting after backward")
                                           if ar_rows else None),
                        "host_enqueue_ms_per_step": t_enq / a.steps * 1e3,
+                       "host_enqueue_ms_empty_queue": sorted(enq_empty)[1],
+                       "host_enqueue_note": "per_step is measured inside the timed loop, where the host blocks on the full HIP "
+                                            "queue (back-pressure: it tracks the GPU step time); empty_queue is the median host time "
+                                            "to issue one step after a device synchronise, i.e. the real launch cost",
                        "step_graph": dict(enabled=bool(graph_default and world == 1), replays=getattr(tr._graph, "replays", 0) if getattr(tr, "_graph", None) else 0,
                                           eager_instrumented_steps=len(timed)), "inputs": "host uint8 (PCIe inclusive)" if a.host_inputs else "resident in HBM"},
             "roofline": roof,

@@ -162,8 +162,8 @@ class Model(nn.Module):
     def _features(self, x):
         flat = self.flat_state()
         flat.prepare_forward(self.training)
-        if x.dim() != 4 or x.shape[1] > 8:
-            raise ValueError("expected an NCHW image batch (B, 3, H, W)")
+        if not all(t.dim() == 4 and t.shape[1] <= 8 for t in (x if isinstance(x, (list, tuple)) else (x,))):
+            raise ValueError("expected an NCHW image batch (B, 3, H, W), or a list of such batches of one shape")
         # uint8 batches (what the loaders deliver) are normalised inside the pack kernel: x / 255 (ssod_trainer.py:694-696)
         x8 = ops.pack_input(x, self._compute_dtype, norm_scale=getattr(self, "input_norm_scale", 255.0))
         return self.neck(self.backbone(x8))

@@ -441,19 +441,31 @@ def act_bwd(dz, y, act, out=None):
 
 
 # ---- spatial ----------------------------------------------------------------------------------------
-def pack_input(x_nchw, dtype, norm_scale=255.0):
+def pack_input(x_nchw, dtype, norm_scale=255.0, out=None):
     """(B,3,H,W) NCHW -> (B,H,W,8) NHWC of `dtype`, channels zero padded.  fp32 input: values as they are (already
     normalised by the caller); uint8 input (the loaders' batches): (float)x / norm_scale in the same pass."""
+    if isinstance(x_nchw, (list, tuple)):
+        # several batches of one shape (the labelled and the unlabelled images of an SSOD step): packed into consecutive
+        # ranges of ONE buffer -- the reference's torch.cat of the two batches (ssod_trainer.py:623) without the copy
+        parts = list(x_nchw)
+        _, C, H, W = parts[0].shape
+        assert all(p.shape[1:] == parts[0].shape[1:] and p.device == parts[0].device for p in parts)
+        y = torch.empty((sum(p.shape[0] for p in parts), H, W, 8), dtype=dtype, device=parts[0].device)
+        b0 = 0
+        for p in parts:
+            pack_input(p, dtype, norm_scale, out=y[b0:b0 + p.shape[0]])
+            b0 += p.shape[0]
+        return y
     x = x_nchw.contiguous()
     B, C, H, W = x.shape
+    y = out if out is not None else torch.empty((B, H, W, 8), dtype=dtype, device=x.device)
+    assert y.shape == (B, H, W, 8) and y.is_contiguous() and y.dtype == dtype
     if x.dtype == torch.uint8:
-        y = torch.empty((B, H, W, 8), dtype=dtype, device=x.device)
         _lib.check(_lib.load().et_pack_input_u8(_lib.ptr(x), _lib.ptr(y), et_dtype(y), B, C, H, W, float(norm_scale), _lib.stream(x)),
                    "et_pack_input_u8")
         return y
     if x.dtype != torch.float32:
         x = x.float()
-    y = torch.empty((B, H, W, 8), dtype=dtype, device=x.device)
     _lib.check(_lib.load().et_pack_input(_lib.ptr(x), _lib.ptr(y), et_dtype(y), B, C, H, W, _lib.stream(x)),
                "et_pack_input")
     return y

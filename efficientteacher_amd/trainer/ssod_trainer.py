@@ -160,7 +160,9 @@ class SSODTrainer(Trainer):
             t9, valid = self.pseudo_label_creator.create_pseudo_label_padded(teacher_pred, unlabeled_M, width, height)
             has_targets = valid.any().float()        # == not invalid_target_shape, as a device flag
         # 3 student forward on the concatenated batch (:623-627)
-        total_imgs = torch.cat([imgs, unlabeled_imgs], 0)
+        # the reference concatenates the two batches (:623); here they are packed into one NHWC buffer directly
+        same = imgs.shape[1:] == unlabeled_imgs.shape[1:] and imgs.dtype == unlabeled_imgs.dtype
+        total_imgs = [imgs, unlabeled_imgs] if same else torch.cat([imgs, unlabeled_imgs.to(imgs.dtype)], 0)
         total_pred, total_feature = self.model(total_imgs)
         if side is not None:
             cur.wait_stream(side)
