@@ -362,10 +362,16 @@ class SppfPoolFn(Function):
     """cat([x, m(x), m(m(x)), m(m(m(x)))], C)   -- SPPF.forward (common.py:702-708), m = MaxPool2d(5,1,2)."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, holder=None):
+        """holder = (cat,): x was PRODUCED IN PLACE as the first channel slice of the 4C-wide buffer (SPPF.forward passes
+        cv1 that slot), so nothing is copied"""
         N, H, W, C = x.shape
-        cat = torch.empty((N, H, W, 4 * C), dtype=x.dtype, device=x.device)
-        cat[..., :C].copy_(x)
+        if holder is not None:
+            cat = holder[0]
+            assert cat.shape == (N, H, W, 4 * C) and x.data_ptr() == cat.data_ptr() and x.stride() == cat[..., :C].stride()
+        else:
+            cat = torch.empty((N, H, W, 4 * C), dtype=x.dtype, device=x.device)
+            cat[..., :C].copy_(x)
         idx = []
         for i in range(3):
             _, ix = ops.maxpool5_fwd(cat[..., i * C:(i + 1) * C], out=cat[..., (i + 1) * C:(i + 2) * C])
@@ -381,7 +387,7 @@ class SppfPoolFn(Function):
         dcat = _dense_or_slice(dcat)
         d2 = ops.maxpool5_bwd(dcat[..., 3 * C:], i3, base=dcat[..., 2 * C:3 * C])
         d1 = ops.maxpool5_bwd(d2, i2, base=dcat[..., C:2 * C])
-        return ops.maxpool5_bwd(d1, i1, base=dcat[..., :C])
+        return ops.maxpool5_bwd(d1, i1, base=dcat[..., :C]), None
 
 
 class UpsampleCatFn(Function):

@@ -216,7 +216,13 @@ class SPPF(nn.Module):
         self.m = nn.MaxPool2d(kernel_size=k, stride=1, padding=k // 2)
 
     def forward(self, x):
-        return self.cv2(SppfPoolFn.apply(self.cv1(x)))
+        # cv1 writes its output straight into the first quarter of the concat buffer the three poolings fill
+        cs = getattr(self.cv1.conv, "_et_slot", None)
+        if cs is None or cs.coutp != self.cv1.conv.out_channels:
+            return self.cv2(SppfPoolFn.apply(self.cv1(x)))
+        N, H, W, _ = x.shape
+        cat = torch.empty((N, H, W, 4 * cs.coutp), dtype=x.dtype, device=x.device)
+        return self.cv2(SppfPoolFn.apply(self.cv1(x, dst=(cat, 0)), (cat,)))
 
 
 class Concat(nn.Module):
