@@ -353,3 +353,27 @@ def _stem_case(hip, N, H, W, Cout):
     zero = torch.zeros((N, OH, OW, Cout), dtype=dt, device=hip.device)
     y2, _ = ops.conv2d_fwd(x, w, 2, 2, residual=zero, want_stats=True)
     assert (y2.float() - y.float()).abs().max().item() <= 1e-2 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.gpu
+def test_stem_kernel_full_size():
+    """the bench's own stem problem (640x640, 64 channels, many persistent tiles per workgroup) against the generic
+    gather-GEMM on the same tensors, element-wise, plus the BN statistics"""
+    from efficientteacher_amd import _lib, ops
+    _lib._use_library_for_tests(None, False)
+    dev = torch.device("cuda:0")
+    dt = torch.bfloat16
+    N, H, W, Cout = 16, 640, 640, 64
+    g = torch.Generator().manual_seed(7)
+    x = torch.zeros((N, H, W, 8), dtype=dt, device=dev)
+    x[..., :3] = torch.rand((N, H, W, 3), generator=g).to(dev).to(dt)
+    w = (torch.randn((Cout, 6, 6, 8), generator=g) * 0.1).to(dev).to(dt)
+    assert ops.kernel_name("fwd", dt, N, H, W, 8, Cout, 6, 2, 2) == "conv_stem_kernel"
+    y, st = ops.conv2d_fwd(x, w, 2, 2, want_stats=True)
+    zero = torch.zeros_like(y)
+    y2, st2 = ops.conv2d_fwd(x, w, 2, 2, residual=zero, want_stats=True)          # the stem kernel declines residuals
+    assert (y.float() - y2.float()).abs().max().item() <= 2e-2 * y2.float().abs().max().item()
+    a, b = st.double().sum(0), st2.double().sum(0)
+    assert torch.allclose(a, b, rtol=1e-4, atol=1e-2)
+    ref = y2.float().reshape(-1, Cout)
+    assert torch.allclose(a[0], ref.double().sum(0), rtol=2e-3, atol=1.0)
