@@ -1659,10 +1659,12 @@ struct GemmPlan { int kind, BM, BN, WM, WN, BKV, NS; bool utap; };
 
 static GemmPlan plan_gemm(const GatherGeom& g, int elem_bytes, bool have_zero_page) {
     // tuning knobs, read once.  ET_CONV_NARROW_K=<K>: GEMMs with K <= K elements use the 128x64 tile (smaller
-    // register/LDS footprint: 3 workgroups per CU for the HBM-bound short-K 1x1 layers).  ET_CONV_GLDS=0: VGPR staging.
+    // register/LDS footprint: 3 workgroups per CU for the HBM-bound short-K 1x1 layers); default 128 -- at K = 256 the
+    // 128-wide tile re-reads the activations half as often and measured 150 -> 124 us on 256->256 @80x80, B=64
+    // (profiles/r02_microbench_narrow_k.log).  ET_CONV_GLDS=0: VGPR staging.
     // ET_CONV_RING=<rows><kvec><depth> forces one LDS-DMA instantiation.  ET_CONV_BIG=0: no 256x256 tiles.
     // ET_CONV_PP=0: the lockstep 256x256 kernel instead of the ping-pong one.
-    static const int narrow_k = env_int("ET_CONV_NARROW_K", 256);
+    static const int narrow_k = env_int("ET_CONV_NARROW_K", 128);
     static const int use_glds = env_int("ET_CONV_GLDS", 1);
     static const int ring_env = env_int("ET_CONV_RING", 0);
     static const int big = env_int("ET_CONV_BIG", 1);

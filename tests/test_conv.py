@@ -152,7 +152,7 @@ SELECT = [
     # N, H, W, Cin, Cout, k, s, p, fwd kernel, dgrad kernels (per parity class), wgrad kernel
     ((2, 20, 20, 256, 256, 3, 1, 1), "conv_gemm_pp_kernel", ["conv_gemm_pp_kernel"], "conv_wgrad_tr_kernel<256, 256, 2, 4>"),
     ((2, 20, 20, 128, 256, 3, 2, 1), "conv_gemm_pp_kernel",
-     [GLDS + "128, 64, 2, 2, 4, 3, true>", GLDS + "128, 128, 2, 2, 8, 2, true>", GLDS + "128, 128, 2, 2, 8, 2, true>",
+     [GLDS + "128, 128, 2, 2, 4, 3, true>", GLDS + "128, 128, 2, 2, 8, 2, true>", GLDS + "128, 128, 2, 2, 8, 2, true>",
       GLDS + "128, 128, 2, 2, 8, 2, true>"], "conv_wgrad_tr_kernel<256, 256, 2, 4>"),
     ((2, 20, 20, 512, 512, 1, 1, 0), GLDS + "128, 128, 2, 2, 8, 2, true>", [GLDS + "128, 128, 2, 2, 8, 2, true>"],
      "conv_wgrad_tr_kernel<128, 128, 2, 2>"),
