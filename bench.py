@@ -174,7 +174,7 @@ def main():
     ap.add_argument("--host-inputs", action="store_true", help="PCIe-inclusive variant: every step receives its three "
                     "uint8 image batches from pinned host memory (never the reported `value`; noted in DESIGN.md)")
     ap.add_argument("--dump-launches", default=None, help="write (kernel, flops, bytes, ms) of every timed conv launch of the "
-                    "instrumented step to this JSON file (tools/quantization.py reads it)")
+                    "instrumented step to this JSON file (tools/launch_table.py prints it)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); 'gloo' lets two "
                     "ranks share ONE GPU to exercise the N>1 code path where only a single GPU is available")
     a = ap.parse_args()
