@@ -279,6 +279,19 @@ def main():
         step(a.warmup + a.steps + j)
         enq_empty.append((time.perf_counter() - t1) * 1e3)
     torch.cuda.synchronize()
+    # also outside the timed region: ONE instrumented step with the teacher on the main stream (no kernel shares the GPU with
+    # the timed one): the same launches' durations without the inflation the overlapped teacher stream causes
+    solo = None
+    try:
+        t_solo = ops.KernelTimer()
+        keep_overlap = tr.overlap_teacher
+        tr.overlap_teacher, ops.TIMER, tr.use_graph = False, t_solo, False
+        step(a.warmup + a.steps + 3)
+        ops.TIMER, tr.overlap_teacher, tr.use_graph = None, keep_overlap, graph_default
+        torch.cuda.synchronize()
+        solo = t_solo.summary()
+    except Exception:
+        ops.TIMER = None
 
     if rank == 0:
         try:                 # the roofline leg must never cost the throughput line
@@ -310,6 +323,13 @@ def main():
                         avg_launch_us=per_launch_s * 1e6, algorithmic_gflop_per_launch=per_launch_flops / 1e9,
                         all_conv_kernels=dict(ms_per_step=conv_ms, tflops=conv_fl / (conv_ms * 1e-3) / 1e12,
                                               algorithmic_tflop_per_step=conv_fl / 1e12))
+            if solo and dom in solo:
+                sd = solo[dom]
+                roof["same_kernel_teacher_not_overlapped"] = dict(
+                    avg_launch_us=sd["ms"] * 1e3 / sd["launches"], frac=sd["flops"] / (sd["ms"] * 1e-3) / PEAK_BF16,
+                    all_conv_ms=sum(v["ms"] for v in solo.values()),
+                    note="one extra step outside the timed region with the teacher forward on the main stream: in the timed "
+                         "region the teacher's launches share the GPU with the student's and lengthen them")
         except Exception as e:
             roof = dict(bound="mfma", kernel=None, achieved=None, peak=PEAK_BF16 / 1e12, unit="TFLOP/s", frac=None,
                         traffic=None, error=f"{type(e).__name__}: {e}")
