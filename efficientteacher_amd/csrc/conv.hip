@@ -981,168 +981,6 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_pp_kernel(const uint16_t* __
 #undef ET_PPA
 }
 
-// ---- 3x3 stride-1 gather-GEMM with the three horizontal taps sharing ONE staged activation tile ("dx reuse") -----------
-// In the generic kernels every tap of a 3x3 layer stages its own 128-row activation tile, although the tiles of taps
-// (dy,-1), (dy,0), (dy,+1) are the SAME pixels shifted by one row of the tile: pixel p + dy*W + dx.  Here a group of three
-// chunks (one dy, one 64-channel slice) stages the rows p0-1 .. p0+128 ONCE (130 rows of a 160-row slot) and the MFMA
-// fragments of tap dx are read at row offset dx+1; lanes whose pixel sits on the left / right image edge get zeros for
-// dx = -1 / +1 (in the flattened pixel order their neighbour is the end of the previous / start of the next image row).
-// Per chunk the workgroup then issues 4 + 5/3 instead of 4 + 4 LDS-DMA instructions per thread and moves a third less
-// L2 -> LDS traffic -- the issue cost of those instructions is what bounds the 128-row kernels.
-// 128 x BN tile (BN = 128 or 64), four waves of 64 x BN/2, 64-channel chunks, A and B double buffered separately.
-// Requirements (checked on the host, else the generic kernel runs): 9 taps in groups of three with equal dy and
-// dx in {-1,0,1}, stride 1, output lattice == input lattice, Cin % 64 == 0, tap-inner chunk order.
-template <int BN>
-__global__ __launch_bounds__(256, 2) void conv_gemm_dxr_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W,
-                                                               uint16_t* __restrict__ Y, const uint16_t* __restrict__ ZERO,
-                                                               GatherGeom g, Epilogue ep) {
-    constexpr int BM = 128, WM = 2, WN = 2, BKV = 8, VEC = 8, NT = 256;
-    constexpr int TM = 2, TN = BN / WN / 32;
-    constexpr int AROWS = 160;                     // 130 used: 5 staging instructions of 32 rows
-    constexpr int A_VEC = AROWS * BKV, B_VEC = BN * BKV;
-    constexpr int RB = BN / 32;
-    constexpr int EPI_VEC = EpiLds<BM, BN, WM, WN>::VEC16;
-    constexpr int RING_VEC = 2 * A_VEC + 2 * B_VEC;
-    constexpr int LDS_VEC = RING_VEC > EPI_VEC ? RING_VEC : EPI_VEC;
-    __shared__ __attribute__((aligned(16))) u32x4 lds_raw[LDS_VEC];
-    u32x4* const lds_a = lds_raw;                  // [2][A_VEC]
-    u32x4* const lds_b = lds_raw + 2 * A_VEC;      // [2][B_VEC]
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    int bx, by;
-    tile_of_block(g, bx, by);
-    const int m0 = bx * BM, n0 = by * BN;
-    const int lvec = tid & 7, lrow = tid >> 3;     // 32 rows x 8 K-vectors per staging instruction
-
-    // staged A rows: slot row r = lrow + 32 j holds the pixel c = m0 - 1 + r shifted by dy image rows
-    int a_off[5], a_y[5];
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        const int r = lrow + 32 * j;
-        const int c = m0 - 1 + r;
-        const bool ok = r < BM + 2 && c >= 0 && c < g.M;
-        const uint32_t cc = ok ? c : 0;
-        const uint32_t t1 = fdiv(cc, g.dQW), x = cc - t1 * g.QW;
-        const uint32_t n = fdiv(t1, g.dQH), y = t1 - n * g.QH;
-        a_off[j] = ((n * g.IH + y) * g.IW + x) * g.ldx + (lvec ^ lds_swz<BKV>(r)) * VEC;
-        a_y[j] = ok ? (int)y : -100000;
-    }
-    int b_off[RB];
-    unsigned b_okm = 0u;
-#pragma unroll
-    for (int j = 0; j < RB; ++j) {
-        const int r = lrow + 32 * j;
-        const int co = n0 + r;
-        const bool ok = co < g.Cout;
-        b_off[j] = (ok ? co : 0) * g.TT * g.Cin + (lvec ^ lds_swz<BKV>(r)) * VEC;
-        b_okm |= ok ? (1u << j) : 0u;
-    }
-    // fragment side: is this lane's pixel (row tile tm) on the left / right edge of its image row?
-    const int l31 = lane & 31, gk = lane >> 5;
-    bool edge_l[TM], edge_r[TM];
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-        const int p = m0 + wm * 64 + tm * 32 + l31;
-        const uint32_t pp = p < g.M ? p : 0;
-        const uint32_t x = pp - fdiv(pp, g.dQW) * g.QW;
-        edge_l[tm] = x == 0;
-        edge_r[tm] = x == (uint32_t)(g.QW - 1);
-    }
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
-
-    const int nchunks = g.KV / BKV;                // taps inner: chunk = (channel slice cv, tap t)
-    auto stage_a = [&](u32x4* dst, int tap, int cv) {       // the group's shared tile: dy of `tap`, dx ignored
-        int dy, dx, wt;
-        tap_lookup_uniform(g, tap, dy, dx, wt);
-        const int doff = dy * g.IW * g.ldx + cv * VEC;
-#pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            const bool ok = (unsigned)(a_y[j] + dy) < (unsigned)g.IH;
-            et_glds16(ok ? X + (a_off[j] + doff) : ZERO, dst + j * NT + wave * 64);
-        }
-    };
-    auto stage_b = [&](u32x4* dst, int tap, int cv) {
-        int dy, dx, wt;
-        tap_lookup_uniform(g, tap, dy, dx, wt);
-        const int woff = wt * g.Cin + cv * VEC;
-#pragma unroll
-        for (int j = 0; j < RB; ++j) {
-            const bool ok = (b_okm >> j) & 1u;
-            et_glds16(ok ? W + (b_off[j] + woff) : ZERO, dst + j * NT + wave * 64);
-        }
-    };
-    auto mma = [&](const u32x4* sa, const u32x4* sb, int dx) {
-        const bool ml = dx < 0, mr = dx > 0;                 // wave-uniform
-#pragma unroll
-        for (int kk = 0; kk < BKV / 2; ++kk) {
-            u32x4 af[TM], bf[TN];
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm) {
-                const int r = wm * 64 + tm * 32 + l31 + dx + 1;
-                af[tm] = sa[r * BKV + ((kk * 2 + gk) ^ lds_swz<BKV>(r))];
-                if ((ml && edge_l[tm]) || (mr && edge_r[tm])) af[tm] = mk4(0u, 0u, 0u, 0u);
-            }
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn) {
-                const int r = wn * (BN / WN) + tn * 32 + l31;
-                bf[tn] = sb[r * BKV + ((kk * 2 + gk) ^ lds_swz<BKV>(r))];
-            }
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn)
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[tm]),
-                                                                          __builtin_bit_cast(bf16x8, bf[tn]), acc[tm][tn], 0, 0, 0);
-        }
-    };
-
-    int tap_s = 0, cv_s = 0;                       // cursor of the chunk being staged
-    stage_a(lds_a, 0, 0);
-    stage_b(lds_b, 0, 0);
-    if (++tap_s >= g.T) { tap_s = 0; cv_s += BKV; }
-    int tap_c = 0;                                 // tap of the chunk being multiplied
-    for (int c = 0; c < nchunks; ++c) {
-        et_wait_vmem();
-        __syncthreads();                           // chunk c is in LDS; every wave has finished chunk c-1
-        const int grp = c / 3;
-        if (c + 1 < nchunks) {
-            if (tap_s % 3 == 0) stage_a(lds_a + ((grp + 1) & 1) * A_VEC, tap_s, cv_s);     // chunk c+1 opens a new group
-            stage_b(lds_b + ((c + 1) & 1) * B_VEC, tap_s, cv_s);
-            if (++tap_s >= g.T) { tap_s = 0; cv_s += BKV; }
-        }
-        int dy, dx, wt;
-        tap_lookup_uniform(g, tap_c, dy, dx, wt);
-        mma(lds_a + (grp & 1) * A_VEC, lds_b + (c & 1) * B_VEC, dx);
-        if (++tap_c >= g.T) tap_c = 0;
-    }
-    __syncthreads();                               // the epilogue reuses the rings as its staging area
-    conv_epilogue<uint16_t, BM, BN, WM, WN>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn);
-    __syncthreads();
-}
-
-// host gate of the kernel above
-static bool dxr_eligible(const GatherGeom& g) {
-    if (g.T != 9 || g.TT != 9 || g.isy != 1 || g.isx != 1 || g.QH != g.IH || g.QW != g.IW || g.CV % 8 || !g.tap_inner) return false;
-    for (int t = 0; t < 9; t += 3) {
-        unsigned seen = 0;
-        for (int i = 0; i < 3; ++i) {
-            if (g.dy[t + i] != g.dy[t] || g.dx[t + i] < -1 || g.dx[t + i] > 1) return false;
-            seen |= 1u << (g.dx[t + i] + 1);
-        }
-        if (seen != 7u) return false;
-    }
-    return g.QW >= 2;
-}
-
 // ---- the stem: 6x6 stride-2 pad-2 convolution of the packed image (8 channels, 3 used) ----------------------------
 // (YoloV5BackBone.stage1, models/backbone/yolov5_backbone.py:36: Conv(3, 64, 6, 2, 2)).  As a gather-GEMM this layer is the
 // worst case of the generic kernels: K = 36 taps x 8 channels, so every 16-byte LDS-DMA piece is its own (tap, pixel)
@@ -1816,7 +1654,7 @@ static int fill_common(GatherGeom& g, int N, int IH, int IW, int Cin, int ldx, i
 // ---- kernel selection ---------------------------------------------------------------------------------
 // ONE place decides which instantiation runs; et_conv2d_kernel_name() reports the same decision to the tests and
 // to bench.py's roofline tags (there is no second copy of this logic on the Python side).
-enum { GEMM_REG = 0, GEMM_GLDS = 1, GEMM_PP = 2, GEMM_DXR = 3 };
+enum { GEMM_REG = 0, GEMM_GLDS = 1, GEMM_PP = 2 };
 struct GemmPlan { int kind, BM, BN, WM, WN, BKV, NS; bool utap; };
 
 static GemmPlan plan_gemm(const GatherGeom& g, int elem_bytes, bool have_zero_page) {
@@ -1863,8 +1701,6 @@ static GemmPlan plan_gemm(const GatherGeom& g, int elem_bytes, bool have_zero_pa
         case 25683: p.BM = 256; p.NS = 3; break;
         default: break;
     }
-    static const int use_dxr = env_int("ET_CONV_DXR", 1);
-    if (use_dxr && !ring_env && p.kind == GEMM_GLDS && p.BM == 128 && p.BKV == 8 && p.NS == 2 && dxr_eligible(g)) p.kind = GEMM_DXR;
     return p;
 }
 
@@ -1872,7 +1708,6 @@ static GemmPlan plan_gemm(const GatherGeom& g, int elem_bytes, bool have_zero_pa
 static void plan_name(const GemmPlan& p, int elem_bytes, char* buf, int n) {
     const char* t = elem_bytes == 2 ? "unsigned short" : "float";
     if (p.kind == GEMM_PP) snprintf(buf, n, "conv_gemm_pp_kernel");
-    else if (p.kind == GEMM_DXR) snprintf(buf, n, "conv_gemm_dxr_kernel<%d>", p.BN);
     else if (p.kind == GEMM_GLDS) snprintf(buf, n, "conv_gemm_glds_kernel<%s, %d, %d, %d, %d, %d, %d, %s>", t, p.BM, p.BN, p.WM, p.WN, p.BKV, p.NS, p.utap ? "true" : "false");
     else snprintf(buf, n, "conv_gemm_kernel<%s, %d, %d, %d, %d, %d, %s>", t, p.BM, p.BN, p.WM, p.WN, p.BKV, p.utap ? "true" : "false");
 }
@@ -1896,14 +1731,6 @@ static int launch_gemm(const void* X, const void* W, void* Y, const void* zero16
     if (p.kind == GEMM_PP) {
         if constexpr (sizeof(T) == 2) {
             hipLaunchKernelGGL(conv_gemm_pp_kernel, grid, block, 0, s, (const uint16_t*)x, (const uint16_t*)w, (uint16_t*)y, (const uint16_t*)z, g, ep);
-            return 0;
-        }
-        return -2;
-    }
-    if (p.kind == GEMM_DXR) {
-        if constexpr (sizeof(T) == 2) {
-            if (p.BN == 128) hipLaunchKernelGGL((conv_gemm_dxr_kernel<128>), grid, block, 0, s, (const uint16_t*)x, (const uint16_t*)w, (uint16_t*)y, (const uint16_t*)z, g, ep);
-            else hipLaunchKernelGGL((conv_gemm_dxr_kernel<64>), grid, block, 0, s, (const uint16_t*)x, (const uint16_t*)w, (uint16_t*)y, (const uint16_t*)z, g, ep);
             return 0;
         }
         return -2;
@@ -2250,31 +2077,21 @@ extern "C" int et_conv2d_kernel_name(int op, int dtype, int N, int IH, int IW, i
             snprintf(buf, buflen, "conv_stem_kernel");       // rocprofv3: "void conv_stem_kernel<ACT>(StemArgs)"
             return 0;
         }
-        // the same geometry et_conv2d_fwd builds (the plan looks at taps, strides and lattices)
         g.T = g.TT = KH * KW;
-        for (int ky = 0; ky < KH; ++ky)
-            for (int kx = 0; kx < KW; ++kx) { g.dy[ky * KW + kx] = (signed char)(ky - pad); g.dx[ky * KW + kx] = (signed char)(kx - pad); }
-        g.isy = g.isx = stride;
-        if (fill_common(g, N, IH, IW, Cin, Cin, OH, OW, OH, OW, Cout, Cout, vec)) return -2;
+        if (Cin % vec) return -2;
+        g.Cin = Cin; g.Cout = Cout; g.CV = Cin / vec; g.KV = g.T * g.CV; g.M = N * OH * OW;
     } else if (op == 1) {
-        // ... and conv2d_dgrad_impl for one output-parity class
         if (stride > 2 || Cout % vec) return -2;
         const int py = parity_class / stride, px = parity_class % stride;
         if (py >= stride) return -2;
         int t = 0;
         for (int ky = 0; ky < KH; ++ky) {
             if ((py + pad - ky) % stride) continue;
-            for (int kx = 0; kx < KW; ++kx) {
-                if ((px + pad - kx) % stride) continue;
-                g.dy[t] = (signed char)((py + pad - ky) / stride);
-                g.dx[t] = (signed char)((px + pad - kx) / stride);
-                ++t;
-            }
+            for (int kx = 0; kx < KW; ++kx) if (!((px + pad - kx) % stride)) ++t;
         }
         g.T = t; g.TT = KH * KW;
-        g.isy = g.isx = 1;
         const int QH = (IH - py + stride - 1) / stride, QW = (IW - px + stride - 1) / stride;
-        if (fill_common(g, N, OH, OW, Cout, Cout, QH, QW, IH, IW, Cin, Cin, vec)) return -2;
+        g.Cin = Cout; g.Cout = Cin; g.CV = Cout / vec; g.KV = g.T * g.CV; g.M = N * QH * QW;
     } else return -2;
     plan_name(plan_gemm(g, eb, have_zero_page != 0), eb, buf, buflen);
     return 0;
@@ -2283,7 +2100,7 @@ extern "C" int et_conv2d_kernel_name(int op, int dtype, int N, int IH, int IW, i
 extern "C" int et_env_knobs(char* buf, int buflen) {
     // every ET_* tuning knob that is SET in this process's environment, as "NAME=value;..." (bench.py records it)
     static const char* names[] = {"ET_CONV_TAP_INNER", "ET_CONV_XCD", "ET_CONV_NARROW_K", "ET_CONV_NFAST", "ET_CONV_GLDS",
-                                  "ET_CONV_RING", "ET_CONV_BIG", "ET_CONV_BIG_MINFILL", "ET_CONV_PP", "ET_CONV_DXR", "ET_CONV_STEM", "ET_WGRAD_TR", "ET_WGRAD_BIG", "ET_WGRAD_BLOCKS",
+                                  "ET_CONV_RING", "ET_CONV_BIG", "ET_CONV_BIG_MINFILL", "ET_CONV_PP", "ET_CONV_STEM", "ET_WGRAD_TR", "ET_WGRAD_BIG", "ET_WGRAD_BLOCKS",
                                   "ET_WGRAD_XCD", "ET_EW_VPT", "ET_WGRAD_GROUP", "ET_WGRAD_STALE", "ET_HIP_LIB"};
     if (!buf || buflen < 1) return -1;
     int off = 0;

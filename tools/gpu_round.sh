@@ -22,13 +22,6 @@ for l in sys.stdin:
     if d['h']<=40 and d['cout']>=256: print(d['cin'],d['cout'],d['k'],d['s'],d['h'],d['fwd_kernel'][:32],round(d['fwd_ms']*1e3,1),round(d['dgrad_ms']*1e3,1))
 " >> $OUT/mb_fill.log; done; cat $OUT/mb_fill.log ;;
 bench_fill) run bench_fill; for F in 45 80; do ET_CONV_BIG_MINFILL=$F timeout 900 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_fill$F.json 2> $OUT/bench_fill$F.err; cut -c1-200 $OUT/bench_fill$F.json; done ;;
-mb_dxr) run mb_dxr; for D in 1 0; do echo "DXR $D" >> $OUT/mb_dxr.log; ET_CONV_DXR=$D MB_REF=0 timeout 600 python tools/microbench.py conv 2>&1 | grep '"k": 3' | python -c "
-import sys,json
-for l in sys.stdin:
-    d=json.loads(l)
-    if d['s']==1 and d['cout']<=128: print(d['cin'],d['cout'],d['h'],'x%d'%d['count'],d['fwd_kernel'][:40],round(d['fwd_ms']*1e3,1),round(d['dgrad_ms']*1e3,1),round(d['fwd_tf']))
-" >> $OUT/mb_dxr.log; done; cat $OUT/mb_dxr.log ;;
-bench_nodxr) run bench_nodxr; ET_CONV_DXR=0 timeout 900 python bench.py --steps 24 --warmup 6 --no-cpu-baseline > $OUT/bench_nodxr.json 2> $OUT/bench_nodxr.err; cut -c1-200 $OUT/bench_nodxr.json ;;
 mb_all) run mb_all; MB_REF=0 timeout 900 python tools/microbench.py conv > $OUT/mb_all.log 2>&1; tail -1 $OUT/mb_all.log ;;
 mb_bn) run mb_bn; timeout 600 python tools/microbench.py bn > $OUT/mb_bn.log 2>&1; tail -1 $OUT/mb_bn.log ;;
 host) run host; timeout 600 python tools/host_bound.py > $OUT/host_bound.log 2>&1; tail -1 $OUT/host_bound.log ;;
