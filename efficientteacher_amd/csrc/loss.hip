@@ -38,6 +38,7 @@ struct LossArgs {
     float anchor_t, gr, cp, cn, cls_pw, obj_pw, box_w, obj_w, cls_w;
     int pass_mask;         // bit p set: pass p enabled
     int ignore_obj;
+    float fl_gamma;        // > 0: FocalLoss(BCE, gamma, alpha 0.25) around the class and objectness terms (loss.py:37-62, :112-114)
     int obj_ch;            // channel of the objectness logit: 4, or no-1 in the SimOTA half (loss.py:246)
     const int* ota_match;  // NULL, or [nl][5*na*NT]: pass-0 slot -> index of the matched target, -1 = not a positive
     const float* tgt;      // [NT][8]: img, cls, x, y, w, h, score, flags(bit p = member of pass p)
@@ -122,6 +123,22 @@ __device__ __forceinline__ float bce_logits(float x, float t, float pw, float& g
     const float sg = 1.0f / (1.0f + expf(-x));
     grad = (1.0f - t) + lw * (sg - 1.0f);
     return (1.0f - t) * x + lw * sp;
+}
+
+// FocalLoss wrapper of the reference (loss.py:46-62, TF formulation): bce * alpha_t * (1 - p_t)^gamma, alpha 0.25.
+__device__ __forceinline__ float focal_bce_logits(float x, float t, float pw, float gamma, float& grad) {
+    float gb;
+    const float b = bce_logits(x, t, pw, gb);
+    if (!(gamma > 0.f)) { grad = gb; return b; }
+    const float p = 1.0f / (1.0f + expf(-x));
+    const float pt = t * p + (1.0f - t) * (1.0f - p);
+    const float af = t * 0.25f + (1.0f - t) * 0.75f;
+    const float om = 1.0f - pt;
+    const float mf = powf(om, gamma);
+    // d mf / dx = -gamma (1 - p_t)^(gamma-1) * d p_t / dx ,  d p_t / dx = (2t - 1) p (1 - p)
+    const float dmf = om > 0.f ? -gamma * powf(om, gamma - 1.0f) * (2.0f * t - 1.0f) * p * (1.0f - p) : 0.f;
+    grad = af * (gb * mf + b * dmf);
+    return b * af * mf;
 }
 
 __device__ __forceinline__ float min_grad_a(float a, float b) { return a < b ? 1.f : (a == b ? 0.5f : 0.f); }
@@ -241,7 +258,7 @@ __global__ __launch_bounds__(256) void loss_pos_kernel(LossArgs A, LossLevel L, 
             for (int c = lane; c < A.nc; c += 64) {
                 const float x = ld_logit(L.p, A.dtype, off_s + 5 + c);
                 float gr_;
-                cls_sum += bce_logits(x, c == c_s ? A.cp : A.cn, A.cls_pw, gr_);
+                cls_sum += focal_bce_logits(x, c == c_s ? A.cp : A.cn, A.cls_pw, A.fl_gamma, gr_);
                 atomicAdd(L.dp + off_s + 5 + c, wgt_s * gr_);
             }
         }
@@ -272,7 +289,7 @@ __global__ __launch_bounds__(256) void loss_obj_kernel(LossArgs A, LossLevel L, 
                 const long long off = b * L.sb + a * L.sa + gj * L.sy + gi * L.sx + A.obj_ch;
                 const float x = ld_logit(L.p, A.dtype, off);
                 float g;
-                lsum = bce_logits(x, t, A.obj_pw, g);
+                lsum = focal_bce_logits(x, t, A.obj_pw, A.fl_gamma, g);
                 const float n = fixed_n > 0.f ? fixed_n : A.acc[level * 16 + ACC_OBJN];
                 L.dp[off] += g * (A.obj_w * L.balance / n);   // += : in the SimOTA half this channel is also a class logit
             }
@@ -598,7 +615,7 @@ extern "C" int et_ota_assign(const et_loss_desc* d, const float* strides, float 
     A.dtype = d->dtype; A.B = d->B; A.na = d->na; A.nc = d->nc; A.no = d->nc + 5; A.NT = d->NT; A.nl = d->nl;
     A.anchor_t = d->anchor_t; A.gr = d->gr; A.cp = d->cp; A.cn = d->cn; A.cls_pw = d->cls_pw; A.obj_pw = d->obj_pw;
     A.box_w = d->box_w; A.obj_w = d->obj_w; A.cls_w = d->cls_w;
-    A.pass_mask = 1; A.ignore_obj = 0; A.obj_ch = 4; A.ota_match = nullptr;
+    A.pass_mask = 1; A.ignore_obj = 0; A.obj_ch = 4; A.ota_match = nullptr; A.fl_gamma = 0.f;
     A.tgt = d->targets; A.acc = nullptr;
     for (int l = 0; l < LOSS_MAXL; ++l) {
         LossLevel& L = O.L[l];
@@ -688,6 +705,7 @@ extern "C" int et_yolo_loss(const et_loss_desc* d, et_stream_t stream) {
     A.box_w = d->box_w; A.obj_w = d->obj_w; A.cls_w = d->cls_w;
     A.pass_mask = d->pass_mask; A.ignore_obj = d->ignore_obj;
     A.ota_match = d->ota_match; A.obj_ch = d->obj_channel ? d->obj_channel : 4;
+    A.fl_gamma = d->fl_gamma;
     if (A.obj_ch < 4 || A.obj_ch >= A.no) return -2;
     A.tgt = d->targets; A.acc = d->acc_ws;
     if (A.dtype != ET_F32 && A.dtype != ET_BF16) return -2;

@@ -64,8 +64,7 @@ class ComputeLoss:
     # Compute losses (reference models/loss/loss.py:93)
     def __init__(self, model, cfg):
         self.sort_obj_iou = False
-        if cfg.Loss.fl_gamma > 0:
-            raise NotImplementedError("focal loss (Loss.fl_gamma > 0) is outside the hot path")
+        self.fl_gamma = float(cfg.Loss.fl_gamma)      # > 0: FocalLoss around BCEcls / BCEobj (reference loss.py:112-114)
         if cfg.Loss.autobalance:
             raise NotImplementedError("Loss.autobalance needs a host sync per level; off in every shipped config")
         self.cls_pw, self.obj_pw = float(cfg.Loss.cls_pw), float(cfg.Loss.obj_pw)
@@ -94,7 +93,7 @@ class ComputeLoss:
     def _hp(self):
         return dict(nc=self.nc, anchor_t=float(self.anchor_t), gr=float(self.gr), cp=float(self.cp), cn=float(self.cn),
                     cls_pw=self.cls_pw, obj_pw=self.obj_pw, box_w=float(self.box_w), obj_w=float(self.obj_w),
-                    cls_w=float(self.cls_w))
+                    cls_w=float(self.cls_w), fl_gamma=self.fl_gamma)
 
     def default_loss(self, p, targets, table=None, ota=False):
         """table: a ready (NT, 8) device table [img, cls, x, y, w, h, score, flags] (rows with flags 0 are padding) instead

@@ -578,7 +578,7 @@ def _loss_desc(p, table, anchors_host, balance, hp, pass_mask, ignore_obj):
     for k in ("anchor_t", "gr", "cp", "cn", "cls_pw", "obj_pw", "box_w", "obj_w", "cls_w"):
         setattr(d, k, hp[k])
     d.pass_mask = pass_mask; d.ignore_obj = int(bool(ignore_obj))
-    d.ota_match = None; d.obj_channel = 0
+    d.ota_match = None; d.obj_channel = 0; d.fl_gamma = float(hp.get("fl_gamma", 0.0))
     for i, pi in enumerate(p):
         assert pi.dim() == 5 and pi.stride(4) == 1 and pi.shape[4] == nc + 5 and pi.dtype == p[0].dtype
         L = d.level[i]
@@ -592,7 +592,7 @@ def _loss_desc(p, table, anchors_host, balance, hp, pass_mask, ignore_obj):
 
 
 def yolo_loss(p, table, anchors_host, balance, *, nc, anchor_t, gr, cp, cn, cls_pw, obj_pw, box_w, obj_w, cls_w,
-              pass_mask=1, ignore_obj=False, ota_match=None, obj_channel=0, dps=None):
+              pass_mask=1, ignore_obj=False, ota_match=None, obj_channel=0, dps=None, fl_gamma=0.0):
     """Fused assignment + loss + gradient.  p: list of (B,na,ny,nx,no) logits views (channel stride 1).
     Returns out (8,) fp32 [lbox, lobj, lcls, loss*bs, npos0..3] and the flat fp32 gradient buffers.
     ota_match / obj_channel: the SimOTA half of ComputeLoss.ota_loss (positives from `ota_assign`, objectness on another
@@ -602,7 +602,8 @@ def yolo_loss(p, table, anchors_host, balance, *, nc, anchor_t, gr, cp, cn, cls_
     dev = p[0].device
     B, na = p[0].shape[0], p[0].shape[1]
     table = table.contiguous()
-    hp = dict(nc=nc, anchor_t=anchor_t, gr=gr, cp=cp, cn=cn, cls_pw=cls_pw, obj_pw=obj_pw, box_w=box_w, obj_w=obj_w, cls_w=cls_w)
+    hp = dict(nc=nc, anchor_t=anchor_t, gr=gr, cp=cp, cn=cn, cls_pw=cls_pw, obj_pw=obj_pw, box_w=box_w, obj_w=obj_w, cls_w=cls_w,
+              fl_gamma=fl_gamma)
     d = _loss_desc(p, table, anchors_host, balance, hp, pass_mask, ignore_obj)
     acc = torch.empty(64, dtype=torch.float32, device=dev)
     out = torch.empty(8, dtype=torch.float32, device=dev)

@@ -262,6 +262,7 @@ typedef struct {
     float* out;
     const int* ota_match;   /* NULL, or the result of et_ota_assign: pass 0 takes its positives from it */
     int obj_channel;        /* 0 = default (4); the SimOTA half of ComputeLoss.ota_loss reads objectness from no-1 */
+    float fl_gamma;         /* > 0: FocalLoss(gamma, alpha 0.25) around the class / objectness BCE (loss.py:37-62, :112-114) */
     et_loss_level level[4];
 } et_loss_desc;
 int et_yolo_loss(const et_loss_desc* desc /*host*/, et_stream_t stream);

@@ -62,7 +62,7 @@ def _scatter_last_wins(tobj, r, vals):
         tf[flat[k]] = vals[k]
 
 
-def _box_cls_terms(pi, r, nc, cp, cn, want_box=True, want_cls=True):
+def _box_cls_terms(pi, r, nc, cp, cn, want_box=True, want_cls=True, fl_gamma=0.0):
     ps = pi[r["b"], r["a"], r["gj"], r["gi"]]
     lbox = lcls = None
     iou = None
@@ -74,12 +74,21 @@ def _box_cls_terms(pi, r, nc, cp, cn, want_box=True, want_cls=True):
     if want_cls and nc > 1:
         t = torch.full_like(ps[:, 5:], cn)
         t[torch.arange(ps.shape[0]), r["tcls"]] = cp
-        lcls = F.binary_cross_entropy_with_logits(ps[:, 5:], t)
+        lcls = focal_bce(ps[:, 5:], t, fl_gamma) if fl_gamma > 0 else F.binary_cross_entropy_with_logits(ps[:, 5:], t)
     return lbox, lcls, iou
 
 
+def focal_bce(pred, true, gamma, alpha=0.25):
+    """FocalLoss(nn.BCEWithLogitsLoss(), gamma) with mean reduction (models/loss/loss.py:37-62)"""
+    loss = F.binary_cross_entropy_with_logits(pred, true, reduction="none")
+    prob = torch.sigmoid(pred)
+    p_t = true * prob + (1 - true) * (1 - prob)
+    loss = loss * (true * alpha + (1 - true) * (1 - alpha)) * (1.0 - p_t) ** gamma
+    return loss.mean()
+
+
 def compute_loss(p, targets, anchors, *, nc=80, box_w=0.05, obj_w=1.0, cls_w=0.5,
-                 anchor_t=4.0, balance=(4.0, 1.0, 0.4), gr=1.0, cp=1.0, cn=0.0):
+                 anchor_t=4.0, balance=(4.0, 1.0, 0.4), gr=1.0, cp=1.0, cn=0.0, fl_gamma=0.0):
     """loss.py:138-208.  p: list of (B,na,ny,nx,5+nc); targets (n,6).
     Returns (loss*bs [1], dict(box,obj,cls,loss))."""
     dev = p[0].device
@@ -89,12 +98,13 @@ def compute_loss(p, targets, anchors, *, nc=80, box_w=0.05, obj_w=1.0, cls_w=0.5
         r = asg[i]
         tobj = torch.zeros_like(pi[..., 0])
         if r["b"].shape[0]:
-            lb, lc, iou = _box_cls_terms(pi, r, nc, cp, cn)
+            lb, lc, iou = _box_cls_terms(pi, r, nc, cp, cn, fl_gamma=fl_gamma)
             lbox = lbox + lb
             _scatter_last_wins(tobj, r, (1.0 - gr) + gr * iou.detach().clamp(0))
             if lc is not None:
                 lcls = lcls + lc
-        lobj = lobj + F.binary_cross_entropy_with_logits(pi[..., 4], tobj) * balance[i]
+        lobj = lobj + (focal_bce(pi[..., 4], tobj, fl_gamma) if fl_gamma > 0 else
+                       F.binary_cross_entropy_with_logits(pi[..., 4], tobj)) * balance[i]
     lbox, lobj, lcls = lbox * box_w, lobj * obj_w, lcls * cls_w
     bs = p[0].shape[0]
     loss = lbox + lobj + lcls

@@ -709,6 +709,37 @@ def case_labelmatch():
     save("labelmatch", **out)
 
 
+def case_focal():
+    """ComputeLoss with Loss.fl_gamma = 1.5 (FocalLoss around BCEcls / BCEobj, models/loss/loss.py:37-62, :112-114) on the inputs
+    of tests/golden/compute_loss.npz"""
+    g = np.load(os.path.join(OUT, "compute_loss.npz"))
+    cfg = ref_loader.get_cfg(SSOD_YAML, TINY + ["Loss.fl_gamma", 1.5, "Loss.label_smoothing", 0.1])
+    cfg.freeze()
+    from models.detector.yolo_ssod import Model
+    from models.loss.loss import ComputeLoss
+    torch.manual_seed(0)
+    model = Model(cfg)
+    closs = ComputeLoss(model, cfg)
+    anchors = torch.from_numpy(g["anchors"])
+    assert torch.equal(model.head.anchors, anchors)
+    t = torch.from_numpy(g["targets"])
+    pr = [torch.from_numpy(g[f"p{i}"]).requires_grad_(True) for i in range(3)]
+    loss, items = closs(pr, t)
+    loss.backward()
+    po = [torch.from_numpy(g[f"p{i}"]).requires_grad_(True) for i in range(3)]
+    loss2, _ = o_loss.compute_loss(po, t, anchors, nc=80, box_w=closs.box_w, obj_w=closs.obj_w, cls_w=closs.cls_w,
+                                   anchor_t=closs.anchor_t, cp=closs.cp, cn=closs.cn, fl_gamma=1.5)
+    loss2.backward()
+    assert torch.allclose(loss, loss2, rtol=1e-6, atol=1e-7), (loss, loss2)
+    for a, b in zip(pr, po):
+        assert torch.allclose(a.grad, b.grad, rtol=1e-5, atol=1e-9)
+    out = dict(loss=loss.detach().numpy(), items=np.array([items[k].item() for k in ("box", "obj", "cls")], np.float32),
+               hp=np.array([1.5, 0.1, closs.cp, closs.cn], np.float64))
+    for i in range(3):
+        out[f"grad{i}"] = pr[i].grad.numpy()
+    save("focal_loss", **out)
+
+
 def main():
     if not ref_loader.available():
         sys.exit("reference tree not present; golden vectors can only be generated in the build container")
@@ -716,6 +747,10 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "v8":
         print("== YOLOv8 path")
         case_v8()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "focal":
+        print("== focal loss")
+        case_focal()
         return
     if len(sys.argv) > 1 and sys.argv[1] == "labelmatch":
         print("== LabelMatch")
@@ -734,6 +769,7 @@ def main():
     print("ssod step (reference SSODTrainer.train_instance) ..."); case_ssod_step(cfg, model)
     print("SimOTA loss ..."); case_ota()
     print("LabelMatch ..."); case_labelmatch()
+    print("focal loss ..."); case_focal()
     print("done")
 
 

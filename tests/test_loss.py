@@ -139,3 +139,23 @@ def test_domain_and_target_loss_golden(hip):
         got = feats[i].grad[..., :2].cpu()
         assert (got - ref).abs().max().item() <= 1e-5 * ref.abs().max().item() + 1e-9
         assert (feats[i].grad[..., 2:] == 0).all()
+
+
+def test_focal_compute_loss_golden(hip):
+    """Loss.fl_gamma = 1.5, label smoothing 0.1: FocalLoss around the class and objectness BCE (reference loss.py:37-62),
+    fused value + gradient against the reference run (tests/golden/focal_loss.npz, `python -m oracle.make_golden focal`)"""
+    from efficientteacher_amd.models.loss import ComputeLoss
+    g, gi = golden("focal_loss"), golden("compute_loss")
+    cfg = _cfg()
+    cfg.merge_from_list(["Loss.fl_gamma", float(g["hp"][0]), "Loss.label_smoothing", float(g["hp"][1])])
+    closs = ComputeLoss(_fake_model(gi["anchors"], hip.device), cfg)
+    assert closs.fl_gamma == 1.5 and abs(closs.cp - g["hp"][2]) < 1e-12 and abs(closs.cn - g["hp"][3]) < 1e-12
+    p = [hip.t(gi[f"p{i}"]).requires_grad_(True) for i in range(3)]
+    loss, items = closs(p, hip.t(gi["targets"]))
+    ref = float(g["loss"][0])
+    assert abs(loss.item() - ref) <= 1e-4 * abs(ref), (loss.item(), ref)
+    assert np.allclose([items[k].item() for k in ("box", "obj", "cls")], g["items"], rtol=1e-4, atol=1e-7)
+    loss.backward()
+    for i in range(3):
+        r = g[f"grad{i}"]
+        assert np.abs(p[i].grad.cpu().numpy() - r).max() <= 1e-4 * np.abs(r).max() + 1e-8, i
