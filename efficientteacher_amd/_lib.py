@@ -92,7 +92,7 @@ class LossDesc(ctypes.Structure):
                 ("anchor_t", c_float), ("gr", c_float), ("cp", c_float), ("cn", c_float), ("cls_pw", c_float),
                 ("obj_pw", c_float), ("box_w", c_float), ("obj_w", c_float), ("cls_w", c_float),
                 ("pass_mask", c_int), ("ignore_obj", c_int), ("targets", P), ("acc_ws", P), ("out", P),
-                ("ota_match", P), ("obj_channel", c_int), ("fl_gamma", c_float), ("level", LossLevel * 4)]
+                ("ota_match", P), ("obj_channel", c_int), ("balance_dev", P), ("autobalance_ssi", c_int), ("fl_gamma", c_float), ("level", LossLevel * 4)]
 
 
 _dll = None

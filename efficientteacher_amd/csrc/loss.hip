@@ -38,6 +38,8 @@ struct LossArgs {
     float anchor_t, gr, cp, cn, cls_pw, obj_pw, box_w, obj_w, cls_w;
     int pass_mask;         // bit p set: pass p enabled
     int ignore_obj;
+    float* balance_dev;    // NULL, or [nl] objectness balance weights in device memory (Loss.autobalance: they change every step)
+    int ssi;               // autobalance: index of the stride-16 level the weights are renormalised by; -1 = fixed weights
     float fl_gamma;        // > 0: FocalLoss(BCE, gamma, alpha 0.25) around the class and objectness terms (loss.py:37-62, :112-114)
     int obj_ch;            // channel of the objectness logit: 4, or no-1 in the SimOTA half (loss.py:246)
     const int* ota_match;  // NULL, or [nl][5*na*NT]: pass-0 slot -> index of the matched target, -1 = not a positive
@@ -291,7 +293,8 @@ __global__ __launch_bounds__(256) void loss_obj_kernel(LossArgs A, LossLevel L, 
                 float g;
                 lsum = focal_bce_logits(x, t, A.obj_pw, A.fl_gamma, g);
                 const float n = fixed_n > 0.f ? fixed_n : A.acc[level * 16 + ACC_OBJN];
-                L.dp[off] += g * (A.obj_w * L.balance / n);   // += : in the SimOTA half this channel is also a class logit
+                const float bal = A.balance_dev ? A.balance_dev[level] : L.balance;
+                L.dp[off] += g * (A.obj_w * bal / n);   // += : in the SimOTA half this channel is also a class logit
             }
         }
     }
@@ -322,7 +325,14 @@ __global__ void loss_finalize_kernel(LossArgs A, float b0, float b1, float b2, f
             }
         }
         const float nobj = A.ignore_obj ? a[ACC_OBJN] : (float)ncell[l];
-        lobj += (a[ACC_OBJ] / nobj) * bal[l];
+        const float obji = a[ACC_OBJ] / nobj;
+        lobj += obji * (A.balance_dev ? A.balance_dev[l] : bal[l]);
+        // Loss.autobalance (loss.py:193-194): balance[l] = balance[l] * 0.9999 + 0.0001 / obji, AFTER its use above
+        if (A.balance_dev && A.ssi >= 0) A.balance_dev[l] = A.balance_dev[l] * 0.9999f + 0.0001f / obji;
+    }
+    if (A.balance_dev && A.ssi >= 0) {                  // loss.py:196-197
+        const float ref = A.balance_dev[A.ssi];
+        for (int l = 0; l < A.nl; ++l) A.balance_dev[l] = A.balance_dev[l] / ref;
     }
     lbox *= A.box_w; lobj *= A.obj_w; lcls *= A.cls_w;
     out[0] = lbox; out[1] = lobj; out[2] = lcls;
@@ -615,7 +625,7 @@ extern "C" int et_ota_assign(const et_loss_desc* d, const float* strides, float 
     A.dtype = d->dtype; A.B = d->B; A.na = d->na; A.nc = d->nc; A.no = d->nc + 5; A.NT = d->NT; A.nl = d->nl;
     A.anchor_t = d->anchor_t; A.gr = d->gr; A.cp = d->cp; A.cn = d->cn; A.cls_pw = d->cls_pw; A.obj_pw = d->obj_pw;
     A.box_w = d->box_w; A.obj_w = d->obj_w; A.cls_w = d->cls_w;
-    A.pass_mask = 1; A.ignore_obj = 0; A.obj_ch = 4; A.ota_match = nullptr; A.fl_gamma = 0.f;
+    A.pass_mask = 1; A.ignore_obj = 0; A.obj_ch = 4; A.ota_match = nullptr; A.fl_gamma = 0.f; A.balance_dev = nullptr; A.ssi = -1;
     A.tgt = d->targets; A.acc = nullptr;
     for (int l = 0; l < LOSS_MAXL; ++l) {
         LossLevel& L = O.L[l];
@@ -706,6 +716,8 @@ extern "C" int et_yolo_loss(const et_loss_desc* d, et_stream_t stream) {
     A.pass_mask = d->pass_mask; A.ignore_obj = d->ignore_obj;
     A.ota_match = d->ota_match; A.obj_ch = d->obj_channel ? d->obj_channel : 4;
     A.fl_gamma = d->fl_gamma;
+    A.balance_dev = d->balance_dev; A.ssi = d->balance_dev ? d->autobalance_ssi : -1;
+    if (A.balance_dev && A.ssi >= A.nl) return -2;
     if (A.obj_ch < 4 || A.obj_ch >= A.no) return -2;
     A.tgt = d->targets; A.acc = d->acc_ws;
     if (A.dtype != ET_F32 && A.dtype != ET_BF16) return -2;

@@ -65,14 +65,17 @@ class ComputeLoss:
     def __init__(self, model, cfg):
         self.sort_obj_iou = False
         self.fl_gamma = float(cfg.Loss.fl_gamma)      # > 0: FocalLoss around BCEcls / BCEobj (reference loss.py:112-114)
-        if cfg.Loss.autobalance:
-            raise NotImplementedError("Loss.autobalance needs a host sync per level; off in every shipped config")
         self.cls_pw, self.obj_pw = float(cfg.Loss.cls_pw), float(cfg.Loss.obj_pw)
         self.cp, self.cn = smooth_BCE(eps=cfg.Loss.label_smoothing)
         det = _head_of(model)
         self.balance = {3: [4.0, 1.0, 0.4]}.get(det.nl, [4.0, 1.0, 0.25, 0.06, .02])
-        self.ssi = 0
-        self.gr, self.autobalance = 1.0, False
+        # Loss.autobalance (reference loss.py:118, :193-197): the balance weights follow 1 / (objectness loss of the level) and
+        # are renormalised by the stride-16 level after every call -- kept in device memory and updated by the loss kernel
+        # itself (the reference reads obji.item() per level on the host)
+        self.autobalance = bool(cfg.Loss.autobalance)
+        self.ssi = [float(s) for s in det.stride].index(16.0) if self.autobalance else 0
+        self._balance_dev = None
+        self.gr = 1.0
         nl = det.nl
         nc = 1 if cfg.single_cls else cfg.Dataset.nc
         self.box_w = cfg.Loss.box * 3.0 / nl
@@ -110,6 +113,12 @@ class ComputeLoss:
                 raise NotImplementedError("Loss.top_k > 13: the matching kernel keeps 13 candidates per thread")
             # yolo_anchor_assigner.py:128 scales the targets by a literal 640 ("TODO" there); kept as is
             hp["ota"] = dict(strides=self._strides, top_k=self.top_k, img_size=640.0)
+        if self.autobalance:
+            if ota:
+                raise NotImplementedError("Loss.autobalance with SimOTA: the reference updates the weights inside the first half only")
+            if self._balance_dev is None or self._balance_dev.device != dev:
+                self._balance_dev = torch.tensor(self.balance, dtype=torch.float32, device=dev)
+            hp["balance_dev"], hp["ssi"] = self._balance_dev, self.ssi
         out = YoloLossFn.apply(table, hp, self._anchors_host, self.balance, *p)
         loss = out[3:4]
         det = out.detach()

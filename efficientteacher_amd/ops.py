@@ -579,6 +579,7 @@ def _loss_desc(p, table, anchors_host, balance, hp, pass_mask, ignore_obj):
         setattr(d, k, hp[k])
     d.pass_mask = pass_mask; d.ignore_obj = int(bool(ignore_obj))
     d.ota_match = None; d.obj_channel = 0; d.fl_gamma = float(hp.get("fl_gamma", 0.0))
+    d.balance_dev = None; d.autobalance_ssi = -1
     for i, pi in enumerate(p):
         assert pi.dim() == 5 and pi.stride(4) == 1 and pi.shape[4] == nc + 5 and pi.dtype == p[0].dtype
         L = d.level[i]
@@ -592,7 +593,7 @@ def _loss_desc(p, table, anchors_host, balance, hp, pass_mask, ignore_obj):
 
 
 def yolo_loss(p, table, anchors_host, balance, *, nc, anchor_t, gr, cp, cn, cls_pw, obj_pw, box_w, obj_w, cls_w,
-              pass_mask=1, ignore_obj=False, ota_match=None, obj_channel=0, dps=None, fl_gamma=0.0):
+              pass_mask=1, ignore_obj=False, ota_match=None, obj_channel=0, dps=None, fl_gamma=0.0, balance_dev=None, ssi=-1):
     """Fused assignment + loss + gradient.  p: list of (B,na,ny,nx,no) logits views (channel stride 1).
     Returns out (8,) fp32 [lbox, lobj, lcls, loss*bs, npos0..3] and the flat fp32 gradient buffers.
     ota_match / obj_channel: the SimOTA half of ComputeLoss.ota_loss (positives from `ota_assign`, objectness on another
@@ -613,6 +614,9 @@ def yolo_loss(p, table, anchors_host, balance, *, nc, anchor_t, gr, cp, cn, cls_
         assert ota_match.dtype == torch.int32 and ota_match.numel() == len(p) * 5 * na * table.shape[0]
         d.ota_match = _lib.ptr(ota_match)
     d.obj_channel = int(obj_channel)
+    if balance_dev is not None:          # Loss.autobalance: the weights live (and are updated) on the device
+        assert balance_dev.dtype == torch.float32 and balance_dev.numel() >= len(p) and balance_dev.device == dev
+        d.balance_dev = _lib.ptr(balance_dev); d.autobalance_ssi = int(ssi)
     keep, new_dps = [table, acc], []
     for i, pi in enumerate(p):
         _, _, ny, nx, _ = pi.shape

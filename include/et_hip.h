@@ -262,6 +262,8 @@ typedef struct {
     float* out;
     const int* ota_match;   /* NULL, or the result of et_ota_assign: pass 0 takes its positives from it */
     int obj_channel;        /* 0 = default (4); the SimOTA half of ComputeLoss.ota_loss reads objectness from no-1 */
+    float* balance_dev;     /* NULL (level[].balance is used), or device [nl] objectness balance weights ... */
+    int autobalance_ssi;    /* ... updated after use as Loss.autobalance does (loss.py:193-197): index of the stride-16 level, -1 = leave them */
     float fl_gamma;         /* > 0: FocalLoss(gamma, alpha 0.25) around the class / objectness BCE (loss.py:37-62, :112-114) */
     et_loss_level level[4];
 } et_loss_desc;

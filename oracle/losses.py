@@ -88,7 +88,12 @@ def focal_bce(pred, true, gamma, alpha=0.25):
 
 
 def compute_loss(p, targets, anchors, *, nc=80, box_w=0.05, obj_w=1.0, cls_w=0.5,
-                 anchor_t=4.0, balance=(4.0, 1.0, 0.4), gr=1.0, cp=1.0, cn=0.0, fl_gamma=0.0):
+                 anchor_t=4.0, balance=(4.0, 1.0, 0.4), gr=1.0, cp=1.0, cn=0.0, fl_gamma=0.0, autobalance_ssi=None):
+    """... autobalance_ssi: Loss.autobalance (loss.py:193-197) -- `balance` must then be a LIST, updated in place"""
+    return _compute_loss(p, targets, anchors, nc, box_w, obj_w, cls_w, anchor_t, balance, gr, cp, cn, fl_gamma, autobalance_ssi)
+
+
+def _compute_loss(p, targets, anchors, nc, box_w, obj_w, cls_w, anchor_t, balance, gr, cp, cn, fl_gamma, autobalance_ssi):
     """loss.py:138-208.  p: list of (B,na,ny,nx,5+nc); targets (n,6).
     Returns (loss*bs [1], dict(box,obj,cls,loss))."""
     dev = p[0].device
@@ -103,8 +108,14 @@ def compute_loss(p, targets, anchors, *, nc=80, box_w=0.05, obj_w=1.0, cls_w=0.5
             _scatter_last_wins(tobj, r, (1.0 - gr) + gr * iou.detach().clamp(0))
             if lc is not None:
                 lcls = lcls + lc
-        lobj = lobj + (focal_bce(pi[..., 4], tobj, fl_gamma) if fl_gamma > 0 else
-                       F.binary_cross_entropy_with_logits(pi[..., 4], tobj)) * balance[i]
+        obji = (focal_bce(pi[..., 4], tobj, fl_gamma) if fl_gamma > 0 else
+                F.binary_cross_entropy_with_logits(pi[..., 4], tobj))
+        lobj = lobj + obji * balance[i]
+        if autobalance_ssi is not None:
+            balance[i] = balance[i] * 0.9999 + 0.0001 / obji.detach().item()
+    if autobalance_ssi is not None:
+        ref = balance[autobalance_ssi]
+        balance[:] = [x / ref for x in balance]
     lbox, lobj, lcls = lbox * box_w, lobj * obj_w, lcls * cls_w
     bs = p[0].shape[0]
     loss = lbox + lobj + lcls

@@ -740,6 +740,38 @@ def case_focal():
     save("focal_loss", **out)
 
 
+def case_autobalance():
+    """ComputeLoss with Loss.autobalance (models/loss/loss.py:118, :193-197): three consecutive calls, the balance weights evolve"""
+    g = np.load(os.path.join(OUT, "compute_loss.npz"))
+    cfg = ref_loader.get_cfg(SSOD_YAML, TINY + ["Loss.autobalance", True])
+    cfg.freeze()
+    from models.detector.yolo_ssod import Model
+    from models.loss.loss import ComputeLoss
+    torch.manual_seed(0)
+    model = Model(cfg)
+    closs = ComputeLoss(model, cfg)
+    assert closs.autobalance and closs.ssi == 1
+    anchors = torch.from_numpy(g["anchors"])
+    t = torch.from_numpy(g["targets"])
+    bal = [4.0, 1.0, 0.4]
+    out = {}
+    for k in range(3):
+        sc = 1.0 + 0.25 * k
+        pr = [(torch.from_numpy(g[f"p{i}"]) * sc).requires_grad_(True) for i in range(3)]
+        loss, items = closs(pr, t)
+        loss.backward()
+        po = [(torch.from_numpy(g[f"p{i}"]) * sc).requires_grad_(True) for i in range(3)]
+        loss2, _ = o_loss.compute_loss(po, t, anchors, nc=80, box_w=closs.box_w, obj_w=closs.obj_w, cls_w=closs.cls_w,
+                                       anchor_t=closs.anchor_t, balance=bal, autobalance_ssi=1)
+        loss2.backward()
+        assert torch.allclose(loss, loss2, rtol=1e-6, atol=1e-7), (k, loss, loss2)
+        assert np.allclose(closs.balance, bal, rtol=1e-6), (closs.balance, bal)
+        out[f"loss{k}"] = loss.detach().numpy()
+        out[f"balance{k}"] = np.array(closs.balance, np.float64)
+        out[f"grad{k}"] = pr[0].grad.numpy()[..., 4].copy()             # objectness-channel gradient of level 0 carries balance[0]
+    save("autobalance", **out)
+
+
 def main():
     if not ref_loader.available():
         sys.exit("reference tree not present; golden vectors can only be generated in the build container")
@@ -747,6 +779,10 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "v8":
         print("== YOLOv8 path")
         case_v8()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "autobalance":
+        print("== autobalance")
+        case_autobalance()
         return
     if len(sys.argv) > 1 and sys.argv[1] == "focal":
         print("== focal loss")
@@ -770,6 +806,7 @@ def main():
     print("SimOTA loss ..."); case_ota()
     print("LabelMatch ..."); case_labelmatch()
     print("focal loss ..."); case_focal()
+    print("autobalance ..."); case_autobalance()
     print("done")
 
 

@@ -159,3 +159,24 @@ def test_focal_compute_loss_golden(hip):
     for i in range(3):
         r = g[f"grad{i}"]
         assert np.abs(p[i].grad.cpu().numpy() - r).max() <= 1e-4 * np.abs(r).max() + 1e-8, i
+
+
+def test_autobalance_golden(hip):
+    """Loss.autobalance: three consecutive calls; the objectness balance weights are updated on the device after every call
+    exactly as the reference updates its python list (loss.py:193-197) -- losses, weights and the level-0 objectness gradient"""
+    from efficientteacher_amd.models.loss import ComputeLoss
+    g, gi = golden("autobalance"), golden("compute_loss")
+    cfg = _cfg()
+    cfg.merge_from_list(["Loss.autobalance", True])
+    closs = ComputeLoss(_fake_model(gi["anchors"], hip.device), cfg)
+    assert closs.autobalance and closs.ssi == 1
+    t = hip.t(gi["targets"])
+    for k in range(3):
+        p = [(hip.t(gi[f"p{i}"]) * (1.0 + 0.25 * k)).requires_grad_(True) for i in range(3)]
+        loss, _ = closs(p, t)
+        loss.backward()
+        ref = float(g[f"loss{k}"][0])
+        assert abs(loss.item() - ref) <= 1e-4 * abs(ref), (k, loss.item(), ref)
+        assert np.allclose(closs._balance_dev.cpu().numpy(), g[f"balance{k}"], rtol=1e-5), k
+        r = g[f"grad{k}"]
+        assert np.abs(p[0].grad[..., 4].cpu().numpy() - r).max() <= 1e-4 * np.abs(r).max() + 1e-9, k
