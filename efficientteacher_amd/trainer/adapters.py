@@ -157,9 +157,14 @@ class _HotPath:
                 inner.class_weights = labels_to_class_weights(self.dataset.labels, self.nc).to(device) * self.nc
             except ImportError:
                 pass
-        if cfg.Loss.type != 'ComputeLoss':
-            raise NotImplementedError(f"Loss.type {cfg.Loss.type}: only the YOLOv5 anchor loss is on the MI355X path")
-        self.compute_loss = ComputeLoss(self.model, cfg)
+        if cfg.Loss.type == 'ComputeTalLoss':          # the YOLOv8 recipes (trainer.py:320-327 dispatches on cfg.Loss.type)
+            from ..models.loss import ComputeTalLoss
+            self.compute_loss = ComputeTalLoss(self.model, cfg)
+        elif cfg.Loss.type == 'ComputeLoss':
+            self.compute_loss = ComputeLoss(self.model, cfg)
+        else:
+            raise NotImplementedError(f"Loss.type {cfg.Loss.type}: the YOLOv5 anchor loss and the YOLOv8 TAL loss are on the "
+                                      "MI355X path; other heads keep the reference trainer")
         self.detect = inner.head
 
 

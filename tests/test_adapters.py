@@ -173,3 +173,27 @@ def test_reference_epoch_loop_with_labelmatch(emu, ref_callbacks):
         t.compute_un_sup_loss.ignore_thres_high = lm.cls_thr_high   # :321-322
         t.compute_un_sup_loss.ignore_thres_low = lm.cls_thr_low
         assert len(lm.cls_thr_low) == cfg.Dataset.nc and max(lm.cls_thr_low) > cfg.SSOD.ignore_thres_low
+
+
+def test_reference_epoch_loop_drives_the_v8_path(emu, ref_callbacks):
+    """configs/sup/public/yolov8m_coco.yaml (C2f / DFL head / TAL loss) under the reference's own Trainer loop: the reference
+    cannot build its ComputeTalLoss (its gfocal_loss module is missing), the adapter's build_ddp_model supplies this package's"""
+    from efficientteacher_amd.trainer.adapters import hot_path_trainers
+    from efficientteacher_amd.models.loss import ComputeTalLoss
+    Trainer, _ = hot_path_trainers()
+    rng = np.random.default_rng(3)
+    with tempfile.TemporaryDirectory() as d:
+        cfg = ref_loader.get_cfg("configs/sup/public/yolov8m_coco.yaml",
+                                 ["Model.width_multiple", 0.125, "Model.depth_multiple", 0.33, "Dataset.batch_size", 2,
+                                  "Dataset.img_size", 64, "save_dir", d, "noval", True, "nosave", True, "epochs", 2, "device", "cpu",
+                                  "Dataset.workers", 0])
+        cfg.freeze()
+        t = _mk(Trainer, rng, False)(cfg, torch.device("cpu"), ref_callbacks, -1, -1, 1)
+        assert isinstance(t.compute_loss, ComputeTalLoss)
+        p0 = t.model.flat_state().params.clone()
+        t.last_opt_step = -1
+        t.plots = False
+        t.before_epoch()
+        t.train_in_epoch(ref_callbacks)
+        assert torch.isfinite(t.model.flat_state().params).all() and not torch.equal(p0, t.model.flat_state().params)
+        assert all(np.isfinite(v) for v in t.meter.get_avg())
