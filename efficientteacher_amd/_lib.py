@@ -29,6 +29,7 @@ SIGNATURES = {
     "et_detect_decode": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int64,
                                  P, c_float, P, c_int64, c_int64, P]),
     "et_ema_update": (c_int, [P, P, c_int64, c_float, c_float, P]),
+    "et_adamw": (c_int, [P, P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int, c_float, P]),
     "et_sgd_nesterov": (c_int, [P, P, P, P, c_int64, c_float, c_float, c_float, c_int, c_float, P]),
     "et_cast_f32_to_bf16": (c_int, [P, P, c_int64, P]),
     "et_ema_update_dev": (c_int, [P, P, c_int64, P, P]),

@@ -8,6 +8,7 @@
 //          the updated weights for the MFMA kernels, all in the same pass.
 // Compiled with -ffp-contract=off.
 #include "et_device.h"
+#include <math.h>
 #include "../../include/et_hip.h"
 
 __global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ v, const float* __restrict__ m, long long n,
@@ -121,6 +122,42 @@ extern "C" int et_sgd_nesterov(float* p, const float* grad, float* momentum_buf,
     if (n == 0) return 0;
     hipLaunchKernelGGL(sgd_kernel, dim3(et_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, p, grad, momentum_buf,
                        (uint16_t*)bf16_shadow, (long long)n, lr, momentum, weight_decay, first_step, inv_scale);
+    ET_CHECK_LAUNCH();
+    return 0;
+}
+
+// AdamW (torch.optim.AdamW as built at trainer/trainer.py:212 when cfg.adam: betas = (hyp.momentum, 0.999), eps 1e-8, decoupled
+// weight decay), same operation order as torch's single-tensor implementation:
+//   p *= 1 - lr * wd ; m = lerp(m, g, 1 - b1) ; v = v * b2 + (1 - b2) g^2 ; p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)
+// bc1 = 1 - b1^t, bc2 = 1 - b2^t are computed on the host in double and passed as floats (step_size, 1/sqrt(bc2)).
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, uint16_t* __restrict__ shadow, long long n, float lr_wd,
+                                                    float b1, float b2, float step_size, float inv_sqrt_bc2, float eps,
+                                                    float inv_scale) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i] * inv_scale;
+    float pi = p[i];
+    pi = pi * (1.0f - lr_wd);
+    float mi = m[i];
+    mi = mi + (gi - mi) * (1.0f - b1);
+    float vi = v[i] * b2;
+    vi = vi + (1.0f - b2) * gi * gi;
+    const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+    pi = pi - step_size * (mi / denom);
+    p[i] = pi; m[i] = mi; v[i] = vi;
+    if (shadow) shadow[i] = et_f2bf(pi);
+}
+
+extern "C" int et_adamw(float* p, const float* grad, float* exp_avg, float* exp_avg_sq, void* bf16_shadow, int64_t n, float lr,
+                        float beta1, float beta2, float eps, float weight_decay, int step, float inv_scale, et_stream_t stream) {
+    if (!p || !grad || !exp_avg || !exp_avg_sq) return -1;
+    if (n < 0 || step < 1) return -2;
+    if (n == 0) return 0;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(adamw_kernel, dim3(et_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, p, grad, exp_avg, exp_avg_sq,
+                       (uint16_t*)bf16_shadow, (long long)n, lr * weight_decay, beta1, beta2, (float)((double)lr / bc1),
+                       (float)(1.0 / sqrt(bc2)), eps, inv_scale);
     ET_CHECK_LAUNCH();
     return 0;
 }

@@ -697,6 +697,12 @@ def sgd_nesterov_dev(p, g, buf, shadow, hp, first_step):
                                                int(bool(first_step)), _lib.stream(p)), "et_sgd_nesterov_dev")
 
 
+def adamw(p, g, exp_avg, exp_avg_sq, shadow, lr, beta1, beta2, eps, weight_decay, step, inv_scale=1.0):
+    _lib.check(_lib.load().et_adamw(_lib.ptr(p), _lib.ptr(g), _lib.ptr(exp_avg), _lib.ptr(exp_avg_sq), _lib.ptr(shadow), p.numel(),
+                                    float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step),
+                                    float(inv_scale), _lib.stream(p)), "et_adamw")
+
+
 def sgd_nesterov(p, g, buf, shadow, lr, momentum, weight_decay, first_step, inv_scale=1.0):
     _lib.check(_lib.load().et_sgd_nesterov(_lib.ptr(p), _lib.ptr(g), _lib.ptr(buf), _lib.ptr(shadow), p.numel(),
                                            float(lr), float(momentum), float(weight_decay), int(bool(first_step)),

@@ -87,3 +87,67 @@ class FlatSGD(torch.optim.Optimizer):
 
     def zero_grad(self, set_to_none=False):
         self.flat.zero_grad()
+
+
+class FlatAdamW(torch.optim.Optimizer):
+    """torch.optim.AdamW over the flat arena, as the reference builds it when ``cfg.adam`` (trainer/trainer.py:212):
+    ``AdamW(g_b, lr=lr0, betas=(momentum, 0.999))`` + the decayed-weights group + the BN-weight group.  Kept quirk: AdamW's
+    default weight_decay 0.01 therefore applies to the bias and BN-weight groups too (the reference never overrides it)."""
+
+    def __init__(self, model, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, default_weight_decay=1e-2):
+        import torch.nn as nn
+        self.flat = model.flat_state()
+        g_bnw, g_w, g_b = [], [], []
+        for v in model.modules():
+            if hasattr(v, 'bias') and isinstance(v.bias, nn.Parameter):
+                g_b.append(v.bias)
+            if isinstance(v, nn.BatchNorm2d):
+                g_bnw.append(v.weight)
+            elif hasattr(v, 'weight') and isinstance(v.weight, nn.Parameter):
+                g_w.append(v.weight)
+        groups = [dict(params=g_b), dict(params=g_w, weight_decay=weight_decay), dict(params=g_bnw)]
+        super().__init__(groups, dict(lr=lr, betas=betas, eps=eps, weight_decay=default_weight_decay))
+        for g, r in zip(self.param_groups, self.flat.group_ranges()):
+            g['range'] = r
+            g.setdefault('initial_lr', lr)
+        self._model = model
+        self.exp_avg = torch.zeros_like(self.flat.params)
+        self.exp_avg_sq = torch.zeros_like(self.flat.params)
+        self.steps = 0
+
+    def state_dict(self):
+        sd = super().state_dict()
+        sd["flat_exp_avg"] = self.exp_avg.detach().cpu().clone()
+        sd["flat_exp_avg_sq"] = self.exp_avg_sq.detach().cpu().clone()
+        sd["flat_steps"] = int(self.steps)
+        return sd
+
+    def load_state_dict(self, sd):
+        sd = dict(sd)
+        m, v, n = sd.pop("flat_exp_avg", None), sd.pop("flat_exp_avg_sq", None), sd.pop("flat_steps", None)
+        if m is None or v is None or m.numel() != self.exp_avg.numel():
+            raise ValueError("not a FlatAdamW state_dict of this model layout")
+        ranges = [g["range"] for g in self.param_groups]
+        super().load_state_dict(sd)
+        for g, r in zip(self.param_groups, ranges):
+            g["range"] = r
+        self.exp_avg.copy_(m.to(self.exp_avg.device)); self.exp_avg_sq.copy_(v.to(self.exp_avg_sq.device))
+        self.steps = int(n)
+
+    @torch.no_grad()
+    def step(self, closure=None, inv_scale=1.0):
+        f = self.flat
+        if f is not self._model.flat_state():
+            raise RuntimeError("the model's arenas were rebuilt after this optimizer was created")
+        assert not ops.WGRAD_QUEUE.pending, "weight gradients still queued: backward() did not finish"
+        ops.WGRAD_QUEUE.join()
+        self.steps += 1
+        for g in self.param_groups:
+            o, n = g['range']
+            shadow = f.shadow if (f.shadow is not None and (o, n) == tuple(f.w_range)) else None
+            ops.adamw(f.params[o:o + n], f.grads[o:o + n], self.exp_avg[o:o + n], self.exp_avg_sq[o:o + n], shadow, g['lr'],
+                      g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'], self.steps, inv_scale)
+        f.w_version += 1
+
+    def zero_grad(self, set_to_none=False):
+        self.flat.zero_grad()

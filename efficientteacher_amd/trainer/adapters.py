@@ -119,13 +119,16 @@ class _HotPath:
     def build_optimizer(self, cfg, optinit=True, weight_masks=None, ckpt=None):
         from torch.optim import lr_scheduler
         from ..optim import FlatSGD
-        if cfg.adam or cfg.Model.RepOpt:
-            raise NotImplementedError("the MI355X path implements SGD(nesterov) (every SSOD recipe); AdamW / RepOptimizer "
-                                      "stay on the reference trainer")
+        if cfg.Model.RepOpt:
+            raise NotImplementedError("RepOptimizer (YOLOv6 re-parameterised training) stays on the reference trainer")
         nbs = 64
         self.accumulate = max(round(nbs / self.batch_size), 1)
         weight_decay = cfg.hyp.weight_decay * self.batch_size * self.accumulate / nbs
-        self.optimizer = FlatSGD(self.model, lr=cfg.hyp.lr0, momentum=cfg.hyp.momentum, nesterov=True, weight_decay=weight_decay)
+        if cfg.adam:
+            from ..optim import FlatAdamW
+            self.optimizer = FlatAdamW(self.model, lr=cfg.hyp.lr0, betas=(cfg.hyp.momentum, 0.999), weight_decay=weight_decay)
+        else:
+            self.optimizer = FlatSGD(self.model, lr=cfg.hyp.lr0, momentum=cfg.hyp.momentum, nesterov=True, weight_decay=weight_decay)
         if cfg.linear_lr:
             self.lf = lambda x: (1 - x / (self.epochs - 1)) * (1.0 - cfg.hyp.lrf) + cfg.hyp.lrf
         else:

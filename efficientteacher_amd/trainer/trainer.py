@@ -91,10 +91,12 @@ class Trainer:
         nbs = 64  # nominal batch size
         self.accumulate = max(round(nbs / self.batch_size), 1)
         weight_decay = cfg.hyp.weight_decay * self.batch_size * self.accumulate / nbs
-        if cfg.adam:
-            raise NotImplementedError("AdamW is outside the hot path (every SSOD recipe uses SGD)")
-        self.optimizer = FlatSGD(self.model, lr=cfg.hyp.lr0, momentum=cfg.hyp.momentum, nesterov=True,
-                                 weight_decay=weight_decay)
+        if cfg.adam:                                   # trainer.py:210-212
+            from ..optim import FlatAdamW
+            self.optimizer = FlatAdamW(self.model, lr=cfg.hyp.lr0, betas=(cfg.hyp.momentum, 0.999), weight_decay=weight_decay)
+        else:
+            self.optimizer = FlatSGD(self.model, lr=cfg.hyp.lr0, momentum=cfg.hyp.momentum, nesterov=True,
+                                     weight_decay=weight_decay)
         if cfg.linear_lr:
             self.lf = lambda x: (1 - x / (self.epochs - 1)) * (1.0 - cfg.hyp.lrf) + cfg.hyp.lrf
         else:

@@ -74,6 +74,10 @@ int et_detect_decode(const void* raw, int dtype, int B, int na, int ny, int nx, 
  *      GradScaler 1/scale (trainer.py:399-400) folded in and an optional bf16 shadow copy of the
  *      updated values (bf16_shadow may be NULL).  Pointers must be 16-byte aligned for EMA.      */
 int et_ema_update(float* ema, const float* model, int64_t n, float d, float one_minus_d, et_stream_t stream);
+/* AdamW over a flat arena: torch.optim.AdamW(betas=(hyp.momentum, 0.999)) as built at trainer/trainer.py:212 when cfg.adam
+ * (decoupled weight decay, eps 1e-8); `step` = 1-based update count (bias corrections are formed on the host in double).   */
+int et_adamw(float* p, const float* grad, float* exp_avg, float* exp_avg_sq, void* bf16_shadow, int64_t n, float lr,
+             float beta1, float beta2, float eps, float weight_decay, int step, float inv_scale, et_stream_t stream);
 int et_sgd_nesterov(float* p, const float* grad, float* momentum_buf, void* bf16_shadow, int64_t n,
                     float lr, float momentum, float weight_decay, int first_step, float inv_scale,
                     et_stream_t stream);

@@ -54,3 +54,42 @@ def test_ema_teacher_is_independent_copy(hip):
     with torch.no_grad():
         (z, _), _ = ema.ema(hip.t(g["x"]))
     assert np.abs(z.cpu().numpy() - g["eval_z"]).max() <= 1e-4 * np.abs(g["eval_z"]).max()
+
+
+def test_adamw_matches_torch(hip):
+    """FlatAdamW (cfg.adam, reference trainer.py:210-217) against torch.optim.AdamW with the reference's three groups on the
+    same parameters and gradients: three steps, incl. the default 0.01 decay the reference leaves on biases / BN weights"""
+    from efficientteacher_amd.optim import FlatAdamW
+    cfg, model, _ = build(hip, torch.bfloat16)
+    model.train()
+    opt = FlatAdamW(model, lr=0.01, betas=(0.937, 0.999), weight_decay=5e-4)
+    import torch.nn as nn
+    g_bnw, g_w, g_b = [], [], []
+    clones = {}
+    for v in model.modules():
+        for name, grp in (("bias", g_b), ("weight", g_bnw if isinstance(v, nn.BatchNorm2d) else g_w)):
+            p = getattr(v, name, None)
+            if isinstance(p, nn.Parameter):
+                c = p.detach().cpu().clone().requires_grad_(True)
+                clones[id(p)] = c
+                grp.append(c)
+    ref = torch.optim.AdamW(g_b, lr=0.01, betas=(0.937, 0.999))
+    ref.add_param_group({'params': g_w, 'weight_decay': 5e-4})
+    ref.add_param_group({'params': g_bnw})
+    gen = torch.Generator().manual_seed(5)
+    params = list(model.parameters())
+    for step in range(3):
+        opt.zero_grad()
+        for p in params:
+            gr = torch.randn(p.shape, generator=gen) * 0.1
+            p.grad.copy_(gr.to(hip.device))
+            clones[id(p)].grad = gr.clone()
+        opt.step()
+        ref.step()
+    worst = max(((p.detach().cpu() - clones[id(p)].detach()).abs().max() / (clones[id(p)].detach().abs().max() + 1e-6)).item()
+                for p in params)
+    assert worst <= 2e-6, worst
+    sd = opt.state_dict()
+    opt2 = FlatAdamW(model, lr=0.01, betas=(0.937, 0.999), weight_decay=5e-4)
+    opt2.load_state_dict(sd)
+    assert opt2.steps == 3 and torch.equal(opt2.exp_avg, opt.exp_avg)
