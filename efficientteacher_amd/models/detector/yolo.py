@@ -143,6 +143,10 @@ class Model(nn.Module):
         new.rebuild_flat()
         return new
 
+    def __reduce_ex__(self, protocol):
+        from ...utils.checkpoint import reduce_model
+        return reduce_model(self, protocol)
+
     def load_state_dict(self, *a, **k):
         r = super().load_state_dict(*a, **k)
         if self._flat is not None:

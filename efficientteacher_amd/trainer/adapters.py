@@ -214,6 +214,27 @@ class _SsodHotPath(_HotPath):
         else:
             raise NotImplementedError(f"SSOD.pseudo_label_type {cfg.SSOD.pseudo_label_type}")
 
+    # ---- ssod_trainer.py:295 ------------------------------------------------------------------------------------
+    def train_in_epoch(self, callbacks):
+        """the reference's dispatch between burn-in and SSOD epochs, restated because at the first SSOD epoch it constructs
+        the semi-supervised EMA from ITS module's CosineEMA / SemiSupModelEMA (per-tensor deepcopy classes that know nothing
+        of the flat arenas and the bf16 shadow); everything it calls is inherited"""
+        if self.epoch < self.cfg.hyp.burn_epochs:
+            if self.cfg.SSOD.with_da_loss:
+                self.train_without_unlabeled_da(callbacks)
+            else:
+                self.train_without_unlabeled(callbacks)
+            if self.RANK in [-1, 0]:
+                print('burn_in_epoch: {}, cur_epoch: {}'.format(self.cfg.hyp.burn_epochs, self.epoch))
+            return
+        if self.epoch == self.cfg.hyp.burn_epochs:             # :305-317 (its state_dict loop there has no effect)
+            if self.cosine_ema:
+                self.semi_ema = CosineEMA(self.ema.ema, decay_start=self.cfg.SSOD.ema_rate,
+                                          total_epoch=self.epochs - self.cfg.hyp.burn_epochs)
+            else:
+                self.semi_ema = SemiSupModelEMA(self.ema.ema, self.cfg.SSOD.ema_rate)
+        self.train_with_unlabeled(callbacks)
+
     # ---- ssod_trainer.py:568 / :587 -----------------------------------------------------------------------------
     def split_predict_and_feature(self, total_pred, total_feature, n_img):
         from .ssod_trainer import SSODTrainer as _Core

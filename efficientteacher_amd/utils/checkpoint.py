@@ -13,6 +13,7 @@ buffer names of this package's models are identical to the reference's, so inter
   state_dicts (same keys) and ``'format': 'state_dict'`` marks the difference.
 """
 import copy
+import importlib
 
 import torch
 
@@ -60,3 +61,49 @@ def save_checkpoint(path, model, ema=None, optimizer=None, epoch=-1, best_fitnes
         ckpt["format"] = "state_dict"
     torch.save(ckpt, path)
     return ckpt
+
+
+# ---- pickling this package's models (what the reference's own save code does: torch.save({'model': deepcopy(model).half()})) ----
+def _reference_model_class(et_model):
+    """the reference's Model class of the same module path (models.detector.yolo / yolo_ssod), if its tree is importable"""
+    name = type(et_model).__module__.replace("efficientteacher_amd.", "", 1)
+    try:
+        mod = importlib.import_module(name)
+    except ImportError:
+        return None
+    cls = getattr(mod, "Model", None)
+    if cls is None or cls.__module__.startswith("efficientteacher_amd"):
+        return None
+    return cls
+
+
+def _rebuild_et_model(module_name, cfg, state_dict, half):
+    m = importlib.import_module(module_name).Model(cfg)
+    m.load_state_dict({k: v.float() if v.is_floating_point() else v for k, v in state_dict.items()}, strict=True)
+    m._compute_dtype = torch.bfloat16 if half else torch.float32
+    return m
+
+
+def reduce_model(m, protocol):
+    """``Model.__reduce_ex__``: the arenas, slots and weak references of a live model are not state -- its state_dict is.
+    Where the reference tree is importable (a reference ``train.py`` running the adapters) the pickle is that of the
+    REFERENCE's own Model carrying these weights, fp16 after ``.half()`` as the reference stores them: the files its
+    ``after_epoch`` writes (trainer.py:475-481, ssod_trainer.py:391-407) stay loadable by the reference alone.  Elsewhere the
+    pickle rebuilds this package's Model from (cfg, state_dict)."""
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    half = m._compute_dtype == torch.bfloat16
+    Ref = _reference_model_class(m)
+    if Ref is not None:
+        ref = Ref(m.cfg)
+        ref.load_state_dict(sd, strict=True)
+        for k in ("nc", "names", "hyp", "class_weights", "yaml"):
+            if hasattr(m, k):
+                setattr(ref, k, getattr(m, k))
+        if half:
+            ref.half()
+        # pickle refuses __newobj__ of another class for this object; a stdlib callable applied to the reference module keeps
+        # the stream free of names from this package
+        return copy.copy, (ref,)
+    if half:
+        sd = {k: v.half() if v.is_floating_point() else v for k, v in sd.items()}
+    return _rebuild_et_model, (type(m).__module__, m.cfg, sd, half)

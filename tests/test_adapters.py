@@ -57,10 +57,10 @@ def _batches(rng, n, B, S, unlabeled=False):
 
 
 def _cfg(save_dir, ssod, extra=()):
-    cfg = ref_loader.get_cfg(SSOD_YAML, list(extra) + ["Model.width_multiple", 0.125, "Model.depth_multiple", 0.33, "Dataset.batch_size", 2,
+    cfg = ref_loader.get_cfg(SSOD_YAML, ["Model.width_multiple", 0.125, "Model.depth_multiple", 0.33, "Dataset.batch_size", 2,
                                          "Dataset.img_size", 64, "save_dir", save_dir, "noval", True, "nosave", True,
                                          "epochs", 2, "SSOD.train_domain", bool(ssod), "device", "cpu", "Dataset.workers", 0,
-                                         "hyp.burn_epochs", 0])
+                                         "hyp.burn_epochs", 0] + list(extra))
     cfg.freeze()
     return cfg
 
@@ -197,3 +197,66 @@ def test_reference_epoch_loop_drives_the_v8_path(emu, ref_callbacks):
         t.train_in_epoch(ref_callbacks)
         assert torch.isfinite(t.model.flat_state().params).all() and not torch.equal(p0, t.model.flat_state().params)
         assert all(np.isfinite(v) for v in t.meter.get_avg())
+
+
+def test_burn_in_epoch_then_ssod_epoch(emu, ref_callbacks):
+    """hyp.burn_epochs = 1 (the 1 / 2 / 5 % COCO recipes burn in for 220 epochs): epoch 0 runs the reference's supervised
+    train_without_unlabeled over the hot path, epoch 1 creates the semi-supervised EMA -- THIS package's arena-aware class, not
+    the reference's per-tensor one -- and runs the SSOD step"""
+    from efficientteacher_amd.trainer.adapters import hot_path_trainers
+    from efficientteacher_amd.utils.torch_utils import CosineEMA as EtCosineEMA, ModelEMA
+    _, SSODTrainer = hot_path_trainers()
+    rng = np.random.default_rng(4)
+    with tempfile.TemporaryDirectory() as d:
+        t = _mk(SSODTrainer, rng, True)(_cfg(d, True, ["hyp.burn_epochs", 1]), torch.device("cpu"), ref_callbacks, -1, -1, 1)
+        assert t.semi_ema is None
+        with torch.no_grad():
+            for mi in t.model.head.m:
+                b = mi.bias.view(t.model.head.na, -1)
+                b[:, 4] += 6.0
+                b[:, 5:] += 3.5
+        t.model.flat_state().mark_weights_changed()
+        t.ema = ModelEMA(t.model)
+        t.last_opt_step = -1
+        t.plots = False
+        t.epoch = 0
+        t.before_epoch()
+        p0 = t.model.flat_state().params.clone()
+        t.train_in_epoch(ref_callbacks)                   # burn-in: supervised only
+        assert t.semi_ema is None and not torch.equal(p0, t.model.flat_state().params)
+        assert "ss_obj" not in t.meter.meters or float(t.meter.meters["ss_obj"].avg) == 0
+        t.epoch = 1
+        t.before_epoch()
+        t.train_in_epoch(ref_callbacks)                   # first SSOD epoch
+        assert isinstance(t.semi_ema, EtCosineEMA)
+        assert float(t.meter.meters["ss_obj"].avg) > 0
+        assert torch.isfinite(t.model.flat_state().params).all()
+
+
+def test_reference_after_epoch_saves_a_reference_checkpoint_and_resumes(emu, ref_callbacks):
+    """the reference's own after_epoch (ssod_trainer.py:319-411) pickles `deepcopy(model).half()`: with the hot-path model in
+    place the file must still be a REFERENCE checkpoint (its Model class, fp16 tensors, optimizer state), and a new trainer
+    built with cfg.weights = last.pt starts from those weights"""
+    from efficientteacher_amd.trainer.adapters import hot_path_trainers
+    _, SSODTrainer = hot_path_trainers()
+    rng = np.random.default_rng(6)
+    with tempfile.TemporaryDirectory() as d:
+        t = _mk(SSODTrainer, rng, True)(_cfg(d, True, ["nosave", False]), torch.device("cpu"), ref_callbacks, -1, -1, 1)
+        t.last_opt_step = -1
+        t.plots = False
+        t.before_epoch()
+        t.train_in_epoch(ref_callbacks)
+        t.results, t.best_fitness, t.lr = (0, 0, 0, 0, 0, 0, 0), 0.0, [0.0, 0.0, 0.0]
+        t.after_epoch(ref_callbacks, None)                       # noval: bookkeeping + checkpoint files only
+        ck = torch.load(str(t.last), map_location="cpu", weights_only=False)
+        assert type(ck["model"]).__module__ == "models.detector.yolo_ssod" and type(ck["ema"]).__module__ == "models.detector.yolo_ssod"
+        assert next(ck["model"].parameters()).dtype == torch.float16
+        assert "flat_momentum" in ck["optimizer"] and ck["epoch"] == 0
+        msd = {k: v.detach().cpu() for k, v in t.model.state_dict().items()}
+        for k, v in ck["model"].float().state_dict().items():
+            if v.is_floating_point():
+                assert (v - msd[k].float()).abs().max() <= 1e-3 * max(1.0, msd[k].abs().max().item()), k
+        # a fresh trainer picks the file up through cfg.weights (trainer.py:127-144 semantics)
+        t2 = _mk(SSODTrainer, rng, True)(_cfg(d, True, ["weights", str(t.last)]), torch.device("cpu"), ref_callbacks, -1, -1, 1)
+        k = "backbone.stage1.conv.weight"
+        assert (t2.model.state_dict()[k].cpu() - ck["model"].state_dict()[k]).abs().max() == 0

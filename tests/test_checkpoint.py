@@ -82,3 +82,20 @@ def test_interchange_with_the_reference_format(tmp_path):
     for k, v in mine.state_dict().items():
         if v.is_floating_point():
             assert torch.allclose(v.half().float(), csd[k], rtol=0, atol=0), k
+
+
+def test_model_pickles_without_the_reference(hip, monkeypatch):
+    """torch.save(model) where no reference tree is importable: the pickle carries (cfg, state_dict) and rebuilds this
+    package's Model; with .half() the tensors are stored fp16 as the reference's checkpoints are"""
+    import io
+    from efficientteacher_amd.utils import checkpoint as ck
+    from tests.test_model import build
+    monkeypatch.setattr(ck, "_reference_model_class", lambda m: None)
+    cfg, model, _ = build(hip, torch.float32)
+    buf = io.BytesIO()
+    torch.save({"model": model}, buf)
+    buf.seek(0)
+    m2 = torch.load(buf, map_location="cpu", weights_only=False)["model"]
+    assert type(m2) is type(model)
+    for k, v in model.state_dict().items():
+        assert torch.equal(v.cpu(), m2.state_dict()[k]), k
