@@ -260,3 +260,47 @@ def test_reference_after_epoch_saves_a_reference_checkpoint_and_resumes(emu, ref
         t2 = _mk(SSODTrainer, rng, True)(_cfg(d, True, ["weights", str(t.last)]), torch.device("cpu"), ref_callbacks, -1, -1, 1)
         k = "backbone.stage1.conv.weight"
         assert (t2.model.state_dict()[k].cpu() - ck["model"].state_dict()[k]).abs().max() == 0
+
+
+def test_reference_val_run_over_the_hot_path_model(emu, ref_callbacks):
+    """the reference's own val.run (val.py:149-400: its loop, its NMS, its metrics) fed with the hot-path model, against the
+    same call on the reference's Model carrying the same weights (obtained by pickling: utils/checkpoint.reduce_model): the
+    metric tuples agree.  (The loss entries are 0 on both sides: `if outputs is not list` at val.py:305 is always true, so the
+    reference never reaches its compute_loss call.)"""
+    import io
+    from copy import deepcopy
+    from pathlib import Path
+    import val as ref_val
+    from models.loss.loss import ComputeLoss as RefComputeLoss
+    from efficientteacher_amd.trainer.adapters import hot_path_trainers
+    _, SSODTrainer = hot_path_trainers()
+    rng = np.random.default_rng(8)
+    with tempfile.TemporaryDirectory() as d:
+        cfg = _cfg(d, True)
+        t = _mk(SSODTrainer, rng, True)(cfg, torch.device("cpu"), ref_callbacks, -1, -1, 1)
+        with torch.no_grad():
+            for mi in t.model.head.m:
+                b = mi.bias.view(t.model.head.na, -1)
+                b[:, 4] += 4.0
+                b[:, 5:] += 2.0
+        t.model.flat_state().mark_weights_changed()
+        loader = []
+        for bi in range(2):
+            imgs = torch.from_numpy(rng.integers(0, 256, (2, 3, 64, 64), dtype=np.uint8))
+            tg = torch.tensor([[0, 3, .5, .5, .3, .3], [1, 7, .4, .6, .2, .5]], dtype=torch.float32)
+            loader.append((imgs, tg, [f"a{bi}.jpg", f"b{bi}.jpg"], [((64, 64), ((1.0, 1.0), (0.0, 0.0)))] * 2))
+        data = {'nc': 80, 'names': cfg.Dataset.names, 'val': 'x'}
+
+        def run(model, closs):
+            return ref_val.run(data, batch_size=2, imgsz=64, model=model, conf_thres=0.001, single_cls=False,
+                               dataloader=[(a.clone(), b.clone(), c, s) for a, b, c, s in loader], save_dir=Path(d), plots=False,
+                               callbacks=ref_callbacks, compute_loss=closs, num_points=0, val_ssod=True, val_kp=False)[0]
+        mine = run(deepcopy(t.model), t.compute_loss)
+        buf = io.BytesIO()
+        torch.save(t.model, buf)
+        buf.seek(0)
+        ref_model = torch.load(buf, map_location="cpu", weights_only=False).float()
+        assert type(ref_model).__module__ == "models.detector.yolo_ssod"
+        ref = run(ref_model, RefComputeLoss(ref_model, cfg))
+        assert np.allclose(mine[:4], ref[:4], atol=1e-6), (mine, ref)
+        assert np.allclose(mine[4:], ref[4:], rtol=2e-4, atol=1e-6), (mine, ref)
