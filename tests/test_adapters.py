@@ -284,11 +284,26 @@ def test_reference_val_run_over_the_hot_path_model(emu, ref_callbacks):
                 b[:, 4] += 4.0
                 b[:, 5:] += 2.0
         t.model.flat_state().mark_weights_changed()
+        buf = io.BytesIO()
+        torch.save(t.model, buf)
+        buf.seek(0)
+        ref_model = torch.load(buf, map_location="cpu", weights_only=False).float()
+        assert type(ref_model).__module__ == "models.detector.yolo_ssod"
+        # labels = a few of the reference model's own confident detections, so that precision / recall / mAP are not all zero
+        from utils.general import non_max_suppression as ref_nms, xyxy2xywh
         loader = []
+        ref_model.eval()
         for bi in range(2):
             imgs = torch.from_numpy(rng.integers(0, 256, (2, 3, 64, 64), dtype=np.uint8))
-            tg = torch.tensor([[0, 3, .5, .5, .3, .3], [1, 7, .4, .6, .2, .5]], dtype=torch.float32)
+            with torch.no_grad():
+                z = ref_model(imgs.float() / 255.0)[0][0]
+            rows = []
+            for i, det in enumerate(ref_nms(z, 0.005, 0.45, max_det=3)):
+                for *xyxy, conf, c in det.tolist():
+                    rows.append([i, c, *(xyxy2xywh(torch.tensor([xyxy])) / 64.0)[0].tolist()])
+            tg = torch.tensor(rows, dtype=torch.float32).reshape(-1, 6)
             loader.append((imgs, tg, [f"a{bi}.jpg", f"b{bi}.jpg"], [((64, 64), ((1.0, 1.0), (0.0, 0.0)))] * 2))
+        assert sum(x[1].shape[0] for x in loader) >= 4
         data = {'nc': 80, 'names': cfg.Dataset.names, 'val': 'x'}
 
         def run(model, closs):
@@ -296,11 +311,7 @@ def test_reference_val_run_over_the_hot_path_model(emu, ref_callbacks):
                                dataloader=[(a.clone(), b.clone(), c, s) for a, b, c, s in loader], save_dir=Path(d), plots=False,
                                callbacks=ref_callbacks, compute_loss=closs, num_points=0, val_ssod=True, val_kp=False)[0]
         mine = run(deepcopy(t.model), t.compute_loss)
-        buf = io.BytesIO()
-        torch.save(t.model, buf)
-        buf.seek(0)
-        ref_model = torch.load(buf, map_location="cpu", weights_only=False).float()
-        assert type(ref_model).__module__ == "models.detector.yolo_ssod"
         ref = run(ref_model, RefComputeLoss(ref_model, cfg))
-        assert np.allclose(mine[:4], ref[:4], atol=1e-6), (mine, ref)
+        assert ref[2] > 0.5, ref                                   # mAP@.5 of a model scored against its own detections
+        assert np.allclose(mine[:4], ref[:4], atol=2e-3), (mine, ref)
         assert np.allclose(mine[4:], ref[4:], rtol=2e-4, atol=1e-6), (mine, ref)
