@@ -69,7 +69,9 @@ def _cfg(save_dir, ssod, extra=()):
 def ref_callbacks():
     ref_loader.load()
     from utils.callbacks import Callbacks
-    return Callbacks()
+    cb = Callbacks()
+    cb._callbacks = {k: [] for k in cb._callbacks}     # the hook table is a CLASS attribute there: drop other tests' loggers
+    return cb
 
 
 def _mk(base, rng, ssod):
