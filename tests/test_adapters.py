@@ -58,7 +58,7 @@ def _batches(rng, n, B, S, unlabeled=False):
 
 def _cfg(save_dir, ssod, extra=()):
     cfg = ref_loader.get_cfg(SSOD_YAML, ["Model.width_multiple", 0.125, "Model.depth_multiple", 0.33, "Dataset.batch_size", 2,
-                                         "Dataset.img_size", 64, "save_dir", save_dir, "noval", True, "nosave", True,
+                                         "Dataset.img_size", 32, "save_dir", save_dir, "noval", True, "nosave", True,
                                          "epochs", 2, "SSOD.train_domain", bool(ssod), "device", "cpu", "Dataset.workers", 0,
                                          "hyp.burn_epochs", 0] + list(extra))
     cfg.freeze()
@@ -78,12 +78,12 @@ def _mk(base, rng, ssod):
     class T(base):
         def build_dataloader(self, cfg, callbacks):          # no image files on disk
             self.imgsz = cfg.Dataset.img_size
-            self.train_loader = _batches(rng, 2, 2, 64)
+            self.train_loader = _batches(rng, 2, 2, cfg.Dataset.img_size)
             self.dataset = _Dataset([np.array([[3, .5, .5, .2, .2]], np.float32)] * 4)
             self.nb = len(self.train_loader)
             self.no_aug_epochs = cfg.hyp.no_aug_epochs
             if ssod:
-                self.unlabeled_dataloader = _batches(rng, 2, 2, 64, unlabeled=True)
+                self.unlabeled_dataloader = _batches(rng, 2, 2, cfg.Dataset.img_size, unlabeled=True)
                 self.unlabeled_dataset = _Dataset([])
                 self.cls_ratio_gt = np.full(cfg.Dataset.nc, 1.0 / cfg.Dataset.nc)
                 self.label_num_per_image = 2
@@ -187,7 +187,7 @@ def test_reference_epoch_loop_drives_the_v8_path(emu, ref_callbacks):
     with tempfile.TemporaryDirectory() as d:
         cfg = ref_loader.get_cfg("configs/sup/public/yolov8m_coco.yaml",
                                  ["Model.width_multiple", 0.125, "Model.depth_multiple", 0.33, "Dataset.batch_size", 2,
-                                  "Dataset.img_size", 64, "save_dir", d, "noval", True, "nosave", True, "epochs", 2, "device", "cpu",
+                                  "Dataset.img_size", 32, "save_dir", d, "noval", True, "nosave", True, "epochs", 2, "device", "cpu",
                                   "Dataset.workers", 0])
         cfg.freeze()
         t = _mk(Trainer, rng, False)(cfg, torch.device("cpu"), ref_callbacks, -1, -1, 1)
