@@ -62,8 +62,11 @@ class LabelMatch:
         self.pse_count += pse_n
         if labels is None or labels.numel() == 0:
             return
-        h = torch.bincount(labels[:, 1].to(torch.int64).clamp_(0, self.nc - 1), minlength=self.nc)
-        self._cls_hist = h if self._cls_hist is None else self._cls_hist + h
+        idx = labels[:, 1].to(torch.int64).clamp_(0, self.nc - 1)
+        if self._cls_hist is None or self._cls_hist.device != idx.device:
+            self._cls_hist = torch.zeros(self.nc, dtype=torch.float32, device=idx.device)
+        # index_add_, not bincount: bincount sizes its output from the data (a device->host synchronisation per step)
+        self._cls_hist.index_add_(0, idx, torch.ones(idx.shape[0], dtype=torch.float32, device=idx.device))
 
     def create_pseudo_label_padded(self, out, M_s, width, height, max_det=300):
         """out (B, A, 5+nc) teacher predictions -> (targets9 (B*max_det, 9) fp64, valid (B*max_det) uint8)."""
