@@ -15,7 +15,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
 # exact-rounding files: integer/index decisions depend on fp32 results, so no FMA contraction
-EXACT = {"nms.hip", "loss.hip", "pseudo_label.hip", "detect.hip", "optim.hip", "tal.hip"}
+EXACT = {"nms.hip", "loss.hip", "pseudo_label.hip", "detect.hip", "optim.hip", "tal.hip", "augment.hip"}
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
           "-I", os.path.join(ROOT, "include")]
 

@@ -525,6 +525,19 @@ def pseudo_label_transform(dets, counts, M_s, width, height, clip01=False):
     return t9, valid
 
 
+def strong_view_u8(weak, minv, lut, cutouts, flags, border_value=114):
+    """weak (B,3,H,W) uint8 -> strong view (B,3,H,W) uint8: warp + colour LUTs + cutouts + flips in one pass (csrc/augment.hip)"""
+    B, C, H, W = weak.shape
+    assert weak.dtype == torch.uint8 and C == 3 and weak.is_contiguous()
+    assert minv.dtype == torch.float64 and minv.shape == (B, 6) and flags.dtype == torch.int32 and flags.shape == (B, 3)
+    assert cutouts.dtype == torch.int32 and cutouts.shape == (B, 32, 7) and (lut is None or (lut.dtype == torch.uint8 and lut.shape == (B, 3, 256)))
+    out = torch.empty_like(weak)
+    _lib.check(_lib.load().et_strong_view_u8(_lib.ptr(weak), _lib.ptr(out), B, H, W, _lib.ptr(minv.contiguous()),
+                                             _lib.ptr(lut.contiguous()) if lut is not None else None, _lib.ptr(cutouts.contiguous()),
+                                             _lib.ptr(flags.contiguous()), int(border_value), _lib.stream(weak)), "et_strong_view_u8")
+    return out
+
+
 def score_log_append(dets, counts, conf_log, cls_log, log_count):
     """append (conf, cls) of every NMS detection to the device log (LabelMatch, utils/labelmatch.py:279-287)"""
     B, max_det, _ = dets.shape

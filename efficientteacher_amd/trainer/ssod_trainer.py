@@ -70,6 +70,7 @@ class SSODTrainer(Trainer):
         self._eager_steps = 0
         self._capturing = False
         self._graph = None
+        self._strong_view = None           # utils/augment.StrongViewGenerator, created on first use (weak-view-only batches)
 
     def _side_stream(self):
         if self._side is None:
@@ -201,6 +202,11 @@ class SSODTrainer(Trainer):
         out = None
         for i, (t_imgs, t_gt, t_paths, _, t_imgs_ori, t_M) in enumerate(DevicePrefetcher(unlabeled_batches, self.device)):
             imgs, targets, paths, _ = next(labeled)
+            if t_imgs is None:                     # loader delivered the weak view only: strong view + M_s on the device
+                if self._strong_view is None:
+                    from ..utils.augment import StrongViewGenerator
+                    self._strong_view = StrongViewGenerator(self.cfg.hyp)
+                t_imgs, t_M = self._strong_view(t_imgs_ori)
             if not self.cuda:                      # emulator / CPU tests: the plain conversion
                 imgs, t_imgs, t_imgs_ori = (x.float() / 255.0 if x.dtype == torch.uint8 else x for x in (imgs, t_imgs, t_imgs_ori))
             out = self.train_instance(imgs, targets, paths, t_imgs, t_imgs_ori, t_gt, t_M, start_ni + i)

@@ -215,6 +215,17 @@ int et_upsample2x_fwd(const void* x, int ldx, void* y, int ldy, int dtype, int B
 int et_upsample2x_bwd(const void* dy, int lddy, void* dx, int lddx, int dtype, int B, int H, int W, int C, et_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Strong view of an unlabeled batch from its weak view: the per-pixel work of the reference's data-loader
+ * workers -- cv2.warpAffine(M[:2], borderValue 114) of random_perspective_with_M (utils/datasets_ssod.py:902-945),
+ * augment_hsv's LUTs between BGR2HSV / HSV2BGR (utils/augmentations.py:48-61), cutout rectangles (:382-398), flipud / fliplr
+ * (datasets_ssod.py:552-563) -- fused, one thread per output pixel.  weak / strong: (B,3,H,W) uint8 RGB planes;
+ * minv [B][6] fp64: dst->src affine map (OpenCV's inverse of M[:2]); lut [B][3][256] uint8 (hue, sat, val) or NULL;
+ * cutouts [B][32][7] int32 (x0,y0,x1,y1 half open, r,g,b); flags [B][3] int32 (n_cutouts, flipud, fliplr).
+ * PARITY UNPINNED (cv2 absent from the build image): restates OpenCV's published 8-bit algorithms, see csrc/augment.hip.   */
+int et_strong_view_u8(const uint8_t* weak, uint8_t* strong, int B, int H, int W, const double* minv, const uint8_t* lut,
+                      const int* cutouts, const int* flags, int border_value, et_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Online pseudo labels.  Replaces FairPseudoLabel.create_pseudo_label_online_with_gt
  * (utils/self_supervised_utils.py:194-245) after the NMS: per detection xyxy->xywh (fp32),
  * then in fp64 the affine warp by M_s (B,13) [img, M00..M22, s, ud, lr], clip, box_candidates

@@ -10,7 +10,7 @@ CSRC = os.path.join(ROOT, "efficientteacher_amd", "csrc")
 OUT = os.path.join(HERE, "_build")
 LIB = os.path.join(OUT, "libet_emu.so")
 CXX = os.environ.get("ET_EMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")
-EXACT = {"nms.hip", "loss.hip", "pseudo_label.hip", "detect.hip", "optim.hip", "tal.hip"}
+EXACT = {"nms.hip", "loss.hip", "pseudo_label.hip", "detect.hip", "optim.hip", "tal.hip", "augment.hip"}
 FLAGS = ["-x", "c++", "-std=c++17", "-O2", "-fPIC", "-g0", "-Wno-unused-function", "-Wno-unknown-attributes",
          "-Wno-unused-value", "-fno-strict-aliasing",
          "-I", os.path.join(HERE, "include"), "-I", os.path.join(ROOT, "include")]

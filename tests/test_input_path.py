@@ -35,3 +35,16 @@ def test_train_with_unlabeled_on_loader_tuples(hip):
     out2 = t2.train_instance(f(imgs), hip.t(targets), None, f(u_str), f(u_ori), None, hip.t(M_s), 500)
     for k in out2:
         assert abs(float(out1[k]) - float(out2[k])) <= 1e-6 * max(1.0, abs(float(out2[k]))), k
+
+
+def test_train_with_unlabeled_generates_the_strong_view(hip):
+    """an unlabeled batch that carries the weak view only (imgs = None, M_s = None): the strong view and its M_s rows come from
+    utils/augment.StrongViewGenerator on the device, and the step runs on them"""
+    g = golden("ssod_step")
+    u8 = lambda a: torch.from_numpy(np.round(a * 255).astype(np.uint8))
+    imgs, u_ori = u8(g["imgs"]), u8(g["u_ori"])
+    targets = torch.from_numpy(g["targets"])
+    cfg, t = make_trainer(hip)
+    out = t.train_with_unlabeled([(imgs, targets, ["a", "b"], None)], [(None, None, ["c", "d"], None, u_ori, None)], start_ni=500)
+    assert t._strong_view is not None
+    assert all(np.isfinite(float(v)) for v in out.values()) and {"ss_box", "ss_obj", "ss_cls"} <= set(out)
