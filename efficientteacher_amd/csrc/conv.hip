@@ -861,27 +861,24 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_pp_kernel(const uint16_t* __
 #else
 #define ET_PPA(n) 0
 #endif
-    auto stage_a = [&](int i, int buf) {
-        u32x4* const wbase = lds_raw + (2 * i + buf) * HALF_VEC + wave * 64;
-        const int doff = (udy * g.IW + udx) * g.ldx + (cv_u + lv) * VEC;
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
+    // one LDS-DMA piece (jj = 0 / 1: rows 0-63 / 64-127 of the half-tile) of half-tile kind k (0 A0, 1 A1, 2 B0, 3 B1)
+    auto stage_piece = [&](int k, int buf, int jj) {
+        u32x4* const wbase = lds_raw + (2 * k + buf) * HALF_VEC + wave * 64;
+        if (k < 2) {
+            const int i = k;
+            const int doff = (udy * g.IW + udx) * g.ldx + (cv_u + lv) * VEC;
             const bool ok = (bool)((a_okm >> (i * 2 + jj)) & 1u) & ((unsigned)(a_iy[i][jj] + udy) < (unsigned)g.IH) &
                             ((unsigned)(a_ix[i][jj] + udx) < (unsigned)g.IW) & !ET_PPA(22);
-            const uint16_t* src = ok ? X + (a_off[i][jj] + doff) : ZERO;
-            et_glds16(src, wbase + jj * 512);
-        }
-    };
-    auto stage_b = [&](int j, int buf) {
-        u32x4* const wbase = lds_raw + (2 * (2 + j) + buf) * HALF_VEC + wave * 64;
-        const int woff = uwt * g.Cin + (cv_u + lv) * VEC;
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
+            et_glds16(ok ? X + (a_off[i][jj] + doff) : ZERO, wbase + jj * 512);
+        } else {
+            const int j = k - 2;
+            const int woff = uwt * g.Cin + (cv_u + lv) * VEC;
             const bool ok = ((b_okm >> (j * 2 + jj)) & 1u) & !ET_PPA(22);
-            const uint16_t* src = ok ? W + (b_off[j][jj] + woff) : ZERO;
-            et_glds16(src, wbase + jj * 512);
+            et_glds16(ok ? W + (b_off[j][jj] + woff) : ZERO, wbase + jj * 512);
         }
     };
+    auto stage_a = [&](int i, int buf) { stage_piece(i, buf, 0); stage_piece(i, buf, 1); };
+    auto stage_b = [&](int j, int buf) { stage_piece(2 + j, buf, 0); stage_piece(2 + j, buf, 1); };
 
     const int l31 = lane & 31, gk = lane >> 5;
     u32x4 af[2][4], bf[4];                         // A fragments of one half (2 row tiles x 4 k-steps), B of one half
@@ -902,16 +899,29 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_pp_kernel(const uint16_t* __
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) bf[kk] = sm[r * BKV + ((kk * 2 + gk) ^ lds_swz<BKV>(r))];
     };
-    auto mfma8 = [&](int i, int j) {
+    // 8 MFMAs of one phase; `sk >= 0`: the two LDS-DMA pieces of half-tile kind sk (next chunk, buffer sb) are issued BETWEEN
+    // them (after the 2nd and the 5th), where an LDS-DMA instruction costs ~60 cycles of issue instead of the 100-185 it costs in
+    // a load section that is also issuing a dozen ds_reads (MI355X_MICROARCH.md "LDS-DMA piece ... issue cost")
+    auto mfma8 = [&](int i, int j, int sk, int sb) {
         if (ET_PPA(24)) { for (int t = 0; t < 2; ++t) for (int kk = 0; kk < 4; ++kk) { asm volatile("" :: "v"(af[t][kk]), "v"(bf[kk])); } return; }
         if (!ET_PPA(27)) __builtin_amdgcn_s_setprio(1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < 2; ++t) {
                 acc[2 * i + t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[t][kk]),
                                                                            __builtin_bit_cast(bf16x8, bf[kk]), acc[2 * i + t][j], 0, 0, 0);
+                const int n = kk * 2 + t;
+                // placement experiments (ET_ABLATE 31 / 32 / 33): pieces after MFMA (0,1) / second piece only, the first stays in the
+                // load section / (3,6); default (1,4)
+                const int p0 = ET_PPA(31) ? 0 : ET_PPA(33) ? 3 : ET_PPA(32) ? -1 : 1, p1 = ET_PPA(31) ? 1 : ET_PPA(33) ? 6 : ET_PPA(32) ? 3 : 4;
+                if (sk >= 0 && (n == p0 || n == p1) && !ET_PPA(21)) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    stage_piece(sk, sb, n == p0 ? 0 : 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(0);
     };
@@ -933,31 +943,60 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_pp_kernel(const uint16_t* __
         constexpr bool LAST = decltype(last_tag)::value;
         const int nb = buf ^ 1;
         if constexpr (!LAST) ET_PP_DECODE();
-        // ---- ph0: (A0, B0)
+        if (ET_PPA(29) | ET_PPA(34)) {
+            // ---- r02 first version: the half-tile of a phase is issued in its LOAD section (34: BEFORE the fragment reads)
+            constexpr bool F = ET_PPA(34);
+            if constexpr (!LAST && F) ET_PP_STAGE(stage_a(0, nb));
+            load_a(0, buf); load_b(0, buf);
+            if constexpr (!LAST && !F) ET_PP_STAGE(stage_a(0, nb));
+            if constexpr (LAST) ET_PP_WAIT(2); else ET_PP_WAIT(4);     // B1 of this chunk has landed
+            ET_PP_BAR(); mfma8(0, 0, -1, 0); ET_PP_BAR();
+            if constexpr (!LAST && F) ET_PP_STAGE(stage_b(0, nb));
+            load_b(1, buf);
+            if constexpr (!LAST && !F) ET_PP_STAGE(stage_b(0, nb));
+            if constexpr (LAST) ET_PP_WAIT(0); else ET_PP_WAIT(4);     // A1 of this chunk has landed
+            ET_PP_BAR(); mfma8(0, 1, -1, 0); ET_PP_BAR();
+            if constexpr (!LAST && F) ET_PP_STAGE(stage_b(1, nb));
+            load_a(1, buf);
+            if constexpr (!LAST && !F) ET_PP_STAGE(stage_b(1, nb));
+            ET_PP_BAR(); mfma8(1, 1, -1, 0); ET_PP_BAR();
+            if constexpr (!LAST && F) ET_PP_STAGE(stage_a(1, nb));
+            load_b(0, buf);
+            if constexpr (!LAST) { if constexpr (!F) ET_PP_STAGE(stage_a(1, nb)); ET_PP_ADVANCE(); ET_PP_WAIT(4); }   // A0, B0 of the next chunk
+            ET_PP_BAR(); mfma8(1, 0, -1, 0); ET_PP_BAR();
+            return;
+        }
+        // The half-tile of a phase is issued inside its MFMA section, i.e. AFTER that phase's wait: every counted wait sees
+        // two pieces fewer in flight than in the first version (vmcnt 2 where it was 4; the tail chunk is unchanged).
+        // ---- ph0: (A0, B0); issues A0 of the next chunk
         load_a(0, buf); load_b(0, buf);
-        if constexpr (!LAST) ET_PP_STAGE(stage_a(0, nb));
-        if constexpr (LAST) ET_PP_WAIT(2); else ET_PP_WAIT(4);     // B1 of this chunk has landed
+        if (ET_PPA(32)) { if constexpr (!LAST) stage_piece(0, nb, 0); if constexpr (LAST) ET_PP_WAIT(2); else ET_PP_WAIT(3); }
+        else ET_PP_WAIT(2);                                            // B1 of this chunk has landed (A1 may be in flight)
         ET_PP_BAR();
-        mfma8(0, 0);
+        mfma8(0, 0, LAST ? -1 : 0, nb);
         ET_PP_BAR();
-        // ---- ph1: (A0, B1)
+        // ---- ph1: (A0, B1); issues B0'.  (Fetching B1 one phase early, during ph0's MFMAs, is a race: the OTHER wave group is one
+        // barrier behind and retires its pieces of B1 only at its own ph0 wait -- tried, and the emulator's plain schedule
+        // caught it; fetching B0 early for ph3 is legal but measured no gain, 5.58 vs 5.58 ms over the model's layers)
         load_b(1, buf);
-        if constexpr (!LAST) ET_PP_STAGE(stage_b(0, nb));
-        if constexpr (LAST) ET_PP_WAIT(0); else ET_PP_WAIT(4);     // A1 of this chunk has landed
+        if (ET_PPA(32)) { if constexpr (!LAST) stage_piece(2, nb, 0); if constexpr (LAST) ET_PP_WAIT(0); else ET_PP_WAIT(3); }
+        else if constexpr (LAST) ET_PP_WAIT(0); else ET_PP_WAIT(2);    // A1 of this chunk has landed (A0' may be in flight)
         ET_PP_BAR();
-        mfma8(0, 1);
+        mfma8(0, 1, LAST ? -1 : 2, nb);
         ET_PP_BAR();
-        // ---- ph2: (A1, B1)
+        // ---- ph2: (A1, B1); issues B1'
         load_a(1, buf);
-        if constexpr (!LAST) ET_PP_STAGE(stage_b(1, nb));
+        if (ET_PPA(32)) { if constexpr (!LAST) stage_piece(3, nb, 0); }
         ET_PP_BAR();
-        mfma8(1, 1);
+        mfma8(1, 1, LAST ? -1 : 3, nb);
         ET_PP_BAR();
-        // ---- ph3: (A1, B0)
+        // ---- ph3: (A1, B0); issues A1', then the cursor moves on
         load_b(0, buf);
-        if constexpr (!LAST) { ET_PP_STAGE(stage_a(1, nb)); ET_PP_ADVANCE(); ET_PP_WAIT(4); }   // A0, B0 of the next chunk
+        if (ET_PPA(32)) { if constexpr (!LAST) { stage_piece(1, nb, 0); ET_PP_WAIT(3); } }
+        else if constexpr (!LAST) ET_PP_WAIT(2);                       // A0', B0' have landed (B1' may be in flight)
         ET_PP_BAR();
-        mfma8(1, 0);
+        mfma8(1, 0, LAST ? -1 : 1, nb);
+        if constexpr (!LAST) ET_PP_ADVANCE();
         ET_PP_BAR();
     };
     int buf = 0;
