@@ -139,9 +139,10 @@ extern "C" int et_debug_read(unsigned long long* host, int n) {
 #endif
 
 // ---- one K-chunk of MFMAs from LDS --------------------------------------------------------------
-template <typename T, int BM, int BN, int WM, int WN, int BKV>
+struct NoBetween { __device__ __forceinline__ void operator()(int) const {} };
+template <typename T, int BM, int BN, int WM, int WN, int BKV, typename BETWEEN = NoBetween>
 __device__ __forceinline__ void mma_chunk(const u32x4* __restrict__ sm, f32x16 (&acc)[BM / WM / 32][BN / WN / 32],
-                                          int wm, int wn, int lane) {
+                                          int wm, int wn, int lane, BETWEEN between = BETWEEN()) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     const int l31 = lane & 31, g = lane >> 5;
     // Software-pipelined over the k-steps: the fragments of step kk+1 are requested BEFORE the MFMAs of step
@@ -188,6 +189,7 @@ __device__ __forceinline__ void mma_chunk(const u32x4* __restrict__ sm, f32x16 (
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(af[cur][tm].w), __uint_as_float(bf[cur][tn].w), acc[tm][tn], 0, 0, 0);
                 }
             }
+        between(kk);
     }
 }
 
@@ -651,12 +653,14 @@ __global__ __launch_bounds__(64 * WM * WN, (NS == 3 && BKV == 4 && BM == 128) ? 
     int tap_u = 0, cv_u = 0;
 
     // issue the LDS-DMA of one K-chunk into `dst` (all NT threads, RA + RB instructions each)
-    auto stage = [&](u32x4* dst, int chunk, int tap_c, int cv_c) {
+    // pieces [q0, q1) of the chunk's PER = RA + RB LDS-DMA instructions per thread (A rows first)
+    auto stage_range = [&](u32x4* dst, int chunk, int tap_c, int cv_c, int q0, int q1) {
         u32x4* const wbase = dst + wave * 64;              // wave-uniform: lanes land at wbase[j*NT + lane]
         int udy = 0, udx = 0, uwt = 0;
         if constexpr (UTAP) tap_lookup_uniform(g, tap_c, udy, udx, uwt);   // once per chunk, before the burst
 #pragma unroll
         for (int j = 0; j < RA; ++j) {
+            if (j < q0 || j >= q1) continue;
             int dy = udy, dx = udx, cv;
             bool kok = true;
             if constexpr (UTAP) {
@@ -680,6 +684,7 @@ __global__ __launch_bounds__(64 * WM * WN, (NS == 3 && BKV == 4 && BM == 128) ? 
         }
 #pragma unroll
         for (int j = 0; j < RB; ++j) {
+            if (RA + j < q0 || RA + j >= q1) continue;
             int wt = uwt, cv;
             bool kok = true;
             if constexpr (UTAP) {
@@ -701,6 +706,7 @@ __global__ __launch_bounds__(64 * WM * WN, (NS == 3 && BKV == 4 && BM == 128) ? 
             et_glds16(src, wbase + BM * BKV + j * NT);
         }
     };
+    auto stage = [&](u32x4* dst, int chunk, int tap_c, int cv_c) { stage_range(dst, chunk, tap_c, cv_c, 0, PER); };
 #define ET_ADVANCE_CURSOR()                                              \
     if constexpr (UTAP) {                                                \
         if (g.tap_inner) {                                               \
@@ -733,11 +739,24 @@ __global__ __launch_bounds__(64 * WM * WN, (NS == 3 && BKV == 4 && BM == 128) ? 
         // barrier must be the bare s_barrier: __syncthreads() carries a fence that waits vmcnt(0), i.e. drains
         // the very LDS-DMA the ring keeps in flight
         if constexpr (NS > 2) __builtin_amdgcn_s_barrier(); else __syncthreads();
+#if defined(ET_ABLATE) && (ET_ABLATE == 40)
+        // experiment: the next chunk's pieces issued BETWEEN the k-steps of this chunk's MFMAs instead of in one burst before them
+        {
+            const bool more = c + NS - 1 < nchunks;
+            u32x4* const dstp = lds_raw + wr * STAGE_VEC;
+            const int cn = c + NS - 1, tu = tap_u, cu = cv_u;
+            constexpr int KS = BKV / 2, PPK = (PER + KS - 1) / KS;
+            auto between = [&](int kk) { if (more) stage_range(dstp, cn, tu, cu, kk * PPK, min((kk + 1) * PPK, PER)); };
+            mma_chunk<T, BM, BN, WM, WN, BKV>(lds_raw + rd * STAGE_VEC, acc, wm, wn, lane, between);
+            if (more) { ET_ADVANCE_CURSOR(); }
+        }
+#else
 #if !defined(ET_ABLATE) || (ET_ABLATE != 2)
         if (c + NS - 1 < nchunks) { stage(lds_raw + wr * STAGE_VEC, c + NS - 1, tap_u, cv_u); ET_ADVANCE_CURSOR(); }
 #endif
 #if !defined(ET_ABLATE) || (ET_ABLATE != 1)
         mma_chunk<T, BM, BN, WM, WN, BKV>(lds_raw + rd * STAGE_VEC, acc, wm, wn, lane);
+#endif
 #endif
         rd = rd + 1 == NS ? 0 : rd + 1;
         wr = wr + 1 == NS ? 0 : wr + 1;
