@@ -152,3 +152,33 @@ def test_split_batch_fallback_paths(hip):
     ((a * 1.5).sum() + (b * -1.0).sum()).backward()           # both halves, ordinary torch gradients
     ref = torch.full_like(p, 1.5); ref[3:] = -1.0
     assert torch.equal(p.grad, ref)
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 96, 160), (1, 160, 32)])
+def test_rectangular_inputs_match_the_oracle(hip, B, H, W):
+    """val.py feeds rectangular letter-boxed batches (multiples of the 32-pixel stride): eval outputs and a train-mode
+    forward / backward against the oracle model with the same weights, fp32 mode.  Exercises ragged tile grids in the stem,
+    odd pyramid sizes (5 x 1 at stride 32) and the upsample / concat paths off the square case."""
+    from oracle import model as o_model
+    cfg, model, g = build(hip, torch.float32)
+    ref = o_model.Model.from_cfg(cfg)
+    ref.load_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()}, strict=True)
+    rng = np.random.default_rng(B * 1000 + H)
+    x = rng.uniform(0, 1, (B, 3, H, W)).astype(np.float32)
+    model.eval(); ref.eval()
+    with torch.no_grad():
+        (z, _), _ = model(hip.t(x))
+        zr = ref(torch.from_numpy(x))[0][0]
+    assert z.shape == zr.shape
+    assert (z.cpu() - zr).abs().max().item() <= 1e-4 * max(1.0, zr.abs().max().item())
+    model.train(); ref.train()
+    out, _ = model(hip.t(x))
+    outr = ref(torch.from_numpy(x))[0]
+    loss = sum((o.float() ** 2).mean() for o in out)
+    lossr = sum((o ** 2).mean() for o in outr)
+    assert abs(loss.item() - lossr.item()) <= 1e-4 * abs(lossr.item())
+    model.zero_grad(); loss.backward(); lossr.backward()
+    for k in ("backbone.stage1.conv.weight", "neck.C2.cv3.conv.weight", "head.m.2.bias"):
+        a = dict(model.named_parameters())[k].grad.cpu()
+        b = dict(ref.named_parameters())[k].grad
+        assert (a - b).abs().max().item() <= 2e-3 * max(b.abs().max().item(), 1e-6), k
