@@ -38,6 +38,7 @@ struct FastDiv {
 };
 static FastDiv make_fastdiv(uint32_t d) {
     FastDiv f;
+    if (d == 0) d = 1;           // degenerate geometry (empty lattice): such launches are skipped, but never divide by zero here
     f.d = d;
     uint32_t s = 0;
     while ((1ull << s) < d) ++s;
@@ -1867,6 +1868,21 @@ extern "C" int et_conv2d_fwd(const void* x, const void* w, void* y, int dtype, i
     return 0;
 }
 
+// dx pixels of an output-parity class that no tap reaches (1x1 stride-2: three of the four classes): their gradient is zero
+template <typename T>
+__global__ __launch_bounds__(256) void zero_lattice_kernel(T* __restrict__ dx, int N, int IH, int IW, int ldx, int Cin, int QH, int QW,
+                                                           int stride, int py, int px) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)N * QH * QW * Cin;
+    if (i >= total) return;
+    const int c = (int)(i % Cin);
+    long long q = i / Cin;
+    const int qx = (int)(q % QW); q /= QW;
+    const int qy = (int)(q % QH);
+    const int n = (int)(q / QH);
+    dx[(((long long)n * IH + qy * stride + py) * IW + qx * stride + px) * ldx + c] = T(0);
+}
+
 static int conv2d_dgrad_impl(const void* dy, const void* wT, void* dx, int dtype, int N, int IH, int IW, int Cin,
                              int ldx, int Cout, int KH, int KW, int stride, int pad, int ldy, int accumulate,
                              const void* residual, int ldr, const void* bn_y, int ld_bn, const float* bn_scale,
@@ -1898,12 +1914,20 @@ static int conv2d_dgrad_impl(const void* dy, const void* wT, void* dx, int dtype
             for (int q = 0; q < t; ++q) g.tapinfo[q] = (g.dy[q] & 0xff) | ((g.dx[q] & 0xff) << 8) | ((int)g.wt[q] << 16);
             g.isy = g.isx = 1; g.osy = g.osx = stride; g.ooy = py; g.oox = px;
             const int QH = (IH - py + stride - 1) / stride, QW = (IW - px + stride - 1) / stride;
+            if (QH <= 0 || QW <= 0) continue;      // a 1-pixel-high / -wide input has no pixel in this parity class
             // the "gathered" tensor of dgrad is dy (OH x OW x Cout), the written one is dx (IH x IW x Cin)
             int rc = fill_common(g, N, OH, OW, Cout, ldy, QH, QW, IH, IW, Cin, ldx, vec);
             if (rc) return rc;
             Epilogue ep{nullptr, nullptr, ACT_NONE, residual, ldr, bn_y ? bn_stats : nullptr, accumulate,
                         bn_y, ld_bn, bn_scale, bn_shift, bn_act};   // dx = dgrad (+ residual) (+ BN-backward sums)
-            if (t == 0) return -2;   // would need a zero fill; does not occur for k>=stride
+            if (t == 0) {            // no tap reaches this class (k < stride): zero gradient unless the caller accumulates
+                const long long total = (long long)N * QH * QW * Cin;
+                if (!accumulate && total > 0) {
+                    if (dtype == ET_F32) hipLaunchKernelGGL((zero_lattice_kernel<float>), dim3(et_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (float*)dx, N, IH, IW, ldx, Cin, QH, QW, stride, py, px);
+                    else hipLaunchKernelGGL((zero_lattice_kernel<uint16_t>), dim3(et_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (uint16_t*)dx, N, IH, IW, ldx, Cin, QH, QW, stride, py, px);
+                }
+                continue;
+            }
             if (dtype == ET_F32) rc = launch_gemm<float>(dy, wT, dx, zero16, g, ep, (hipStream_t)stream);
             else if (dtype == ET_BF16) rc = launch_gemm<uint16_t>(dy, wT, dx, zero16, g, ep, (hipStream_t)stream);
             else return -2;
