@@ -1,0 +1,104 @@
+"""Seeded random sizes through the non-GEMM kernels on the GPU, against the oracle: both NMS entry points (bit-exact), the fused
+assignment + loss (value and gradient), train-mode BatchNorm + SiLU forward / backward.  Sizes nobody chose by hand: batch 1-5,
+anchor counts that are not multiples of anything, 1-40 classes, 0-200 targets, odd pyramid shapes."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import losses as o_loss
+from oracle import nms as o_nms
+from tests.conftest import golden
+from tests.test_nms import _clustered, _run, _run_general
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def dev():
+    from efficientteacher_amd import _lib
+    _lib._use_library_for_tests(None, False)
+    m = types.SimpleNamespace(device=torch.device("cuda:0"), emulated=False)
+    m.t = lambda a, dtype=None: (torch.as_tensor(np.ascontiguousarray(a)) if not isinstance(a, torch.Tensor) else a).to(m.device)
+    return m
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_nms_random_sizes(dev, seed):
+    rng = np.random.default_rng(1000 + seed)
+    B, A, nc = int(rng.integers(1, 6)), int(rng.integers(1, 2500)), int(rng.integers(1, 41))
+    pred = _clustered(seed, B, A, nc, ties=bool(seed % 2))
+    ct, it = float(rng.choice([0.05, 0.1, 0.3])), float(rng.choice([0.45, 0.65]))
+    ref, rkeep = o_nms.non_max_suppression_ssod(pred, ct, it)
+    dets, counts, keep, _ = _run(dev, pred, ct, it)
+    for i in range(B):
+        assert counts[i] == ref[i].shape[0], (B, A, nc, i)
+        assert np.array_equal(dets[i, :counts[i]], ref[i]) and np.array_equal(keep[i, :counts[i]], rkeep[i])
+    multi = bool(seed % 2)
+    refg = o_nms.non_max_suppression(pred, 0.05, 0.6, multi_label=multi)
+    dg, cg, _, _ = _run_general(dev, pred, 0.05, 0.6, multi_label=multi)
+    for i in range(B):
+        assert cg[i] == refg[i].shape[0] and np.array_equal(dg[i, :cg[i]], refg[i])
+
+
+@pytest.mark.parametrize("seed", range(5))
+def test_loss_random_sizes(dev, seed):
+    from efficientteacher_amd.models.loss import ComputeLoss
+    from tests.test_loss import _cfg, _fake_model
+    rng = np.random.default_rng(2000 + seed)
+    g = golden("compute_loss")
+    B = int(rng.integers(1, 5))
+    nc = int(rng.choice([1, 3, 20, 80]))
+    base = int(rng.integers(1, 6))
+    shapes = [(base * 4 + int(rng.integers(0, 3)), base * 4 + int(rng.integers(0, 3))), (base * 2 + 1, base * 2), (base, base + 1)]
+    nt = int(rng.choice([0, 1, 7, 60, 200]))
+    t = np.zeros((nt, 6), np.float32)
+    t[:, 0] = rng.integers(0, B, nt); t[:, 1] = rng.integers(0, nc, nt)
+    t[:, 2:4] = rng.uniform(0.0, 1.0, (nt, 2)); t[:, 4:6] = np.exp(rng.uniform(np.log(0.01), np.log(0.9), (nt, 2)))
+    cfg = _cfg()
+    cfg.merge_from_list(["Dataset.nc", nc])
+    fm = _fake_model(g["anchors"], dev.device)
+    fm.head.nc = nc
+    closs = ComputeLoss(fm, cfg)
+    p_np = [rng.normal(0, 1.5, (B, 3, ny, nx, 5 + nc)).astype(np.float32) for ny, nx in shapes]
+    p = [dev.t(x).requires_grad_(True) for x in p_np]
+    loss, _ = closs(p, dev.t(t))
+    pr = [torch.from_numpy(x).requires_grad_(True) for x in p_np]
+    lref, _ = o_loss.compute_loss(pr, torch.from_numpy(t), torch.from_numpy(g["anchors"]), nc=nc, box_w=closs.box_w, obj_w=closs.obj_w,
+                                  cls_w=closs.cls_w, anchor_t=closs.anchor_t)
+    assert abs(loss.item() - lref.item()) <= 1e-4 * abs(lref.item()), (B, nc, shapes, nt)
+    loss.backward(); lref.backward()
+    for a, b in zip(p, pr):
+        assert (a.grad.cpu() - b.grad).abs().max().item() <= 2e-4 * b.grad.abs().max().item() + 1e-7, (B, nc, shapes, nt)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_bn_silu_random_sizes(dev, seed):
+    """conv statistics -> finalize -> BN+SiLU forward / backward on a random (pixels, channels) problem vs torch autograd"""
+    from efficientteacher_amd import ops
+    rng = np.random.default_rng(3000 + seed)
+    N, H, W = int(rng.integers(1, 4)), int(rng.integers(1, 30)), int(rng.integers(1, 30))
+    C = int(rng.choice([8, 24, 64, 136, 256]))
+    if N * H * W < 2:
+        H = 2
+    g = torch.Generator().manual_seed(seed)
+    y = torch.randn((N, H, W, C), generator=g)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    dz = torch.randn((N, H, W, C), generator=g)
+    yr = y.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    zr = torch.nn.functional.silu(torch.nn.functional.batch_norm(yr.permute(0, 3, 1, 2), None, None, gr, br, True, 0.03, 1e-3)).permute(0, 2, 3, 1)
+    zr.backward(dz)
+    yd = dev.t(y)
+    P = N * H * W
+    flat = yd.reshape(P, C)
+    stats = torch.stack((flat.sum(0), (flat * flat).sum(0)))[None].contiguous()          # one partial row
+    rm, rv = torch.zeros(C, device=dev.device), torch.ones(C, device=dev.device)
+    scale, shift, mean, invstd = ops.bn_finalize(stats, P, dev.t(gamma), dev.t(beta), 1e-3, 0.03, rm, rv)
+    z = ops.bn_act_fwd(yd, scale, shift, ops.ACT_SILU)
+    assert (z.cpu() - zr.detach()).abs().max().item() <= 1e-4 * max(1.0, zr.abs().max().item())
+    gg, gb = torch.zeros(C, device=dev.device), torch.zeros(C, device=dev.device)
+    dy = ops.bn_act_bwd(dev.t(dz), yd, dev.t(gamma), scale, shift, mean, invstd, ops.ACT_SILU, gg, gb)
+    assert (dy.cpu() - yr.grad).abs().max().item() <= 2e-4 * max(1.0, yr.grad.abs().max().item()), (N, H, W, C)
+    assert torch.allclose(gg.cpu(), gr.grad, rtol=2e-4, atol=1e-4) and torch.allclose(gb.cpu(), br.grad, rtol=2e-4, atol=1e-4)
