@@ -102,3 +102,35 @@ def test_bn_silu_random_sizes(dev, seed):
     dy = ops.bn_act_bwd(dev.t(dz), yd, dev.t(gamma), scale, shift, mean, invstd, ops.ACT_SILU, gg, gb)
     assert (dy.cpu() - yr.grad).abs().max().item() <= 2e-4 * max(1.0, yr.grad.abs().max().item()), (N, H, W, C)
     assert torch.allclose(gg.cpu(), gr.grad, rtol=2e-4, atol=1e-4) and torch.allclose(gb.cpu(), br.grad, rtol=2e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_tal_assign_random_sizes(dev, seed):
+    """TaskAlignedAssigner on random anchors / boxes (padded gt rows, crowded and empty images) vs the oracle restatement that
+    is pinned on the reference (oracle/v8.py::tal_assign)"""
+    from efficientteacher_amd import ops
+    from oracle import v8 as o_v8
+    rng = np.random.default_rng(4000 + seed)
+    bs, nc, G = int(rng.integers(1, 4)), int(rng.choice([1, 5, 80])), int(rng.choice([1, 3, 17, 40]))
+    side = int(rng.integers(3, 25))
+    xs, ys = np.meshgrid(np.arange(side) + 0.5, np.arange(side) + 0.5)
+    pts = np.stack((xs.ravel(), ys.ravel()), 1).astype(np.float32) * 8.0
+    A = pts.shape[0]
+    c = pts[None] + rng.normal(0, 2, (bs, A, 2)).astype(np.float32)
+    wh = np.abs(rng.normal(24, 10, (bs, A, 2))).astype(np.float32) + 2
+    pb = np.concatenate((c - wh / 2, c + wh / 2), -1)
+    ps = (rng.uniform(0, 1, (bs, A, nc)) ** 2).astype(np.float32)
+    gxy = rng.uniform(0, side * 8, (bs, G, 2)).astype(np.float32)
+    gwh = np.abs(rng.normal(30, 15, (bs, G, 2))).astype(np.float32) + 4
+    gb = np.concatenate((gxy - gwh / 2, gxy + gwh / 2), -1)
+    gl = rng.integers(0, nc, (bs, G, 1)).astype(np.float32)
+    n_valid = rng.integers(0, G + 1, bs)
+    mg = (np.arange(G)[None] < n_valid[:, None]).astype(np.float32)[..., None]
+    gb = gb * mg
+    t = torch.from_numpy
+    rtl, rtb, rts, rfg = o_v8.tal_assign(t(ps), t(pb), t(pts), t(gl), t(gb), t(mg))
+    tl, tb, ts, fg = ops.tal_assign(dev.t(ps), dev.t(pb), dev.t(pts), dev.t(gl), dev.t(gb), dev.t(mg))
+    assert torch.equal(fg.cpu().bool(), rfg.bool()), (bs, A, nc, G)
+    eff = rts.sum(-1) > 0
+    assert torch.equal(tl.cpu()[eff], rtl[eff]) and torch.equal(tb.cpu()[eff], rtb[eff])
+    assert (ts.cpu() - rts).abs().max().item() <= 5e-6 and torch.equal(ts.cpu() > 0, rts > 0)
