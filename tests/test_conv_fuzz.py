@@ -94,3 +94,51 @@ def test_dgrad_of_a_1x1_stride2_conv(hip):
     ref = xr.grad.permute(0, 2, 3, 1)
     assert (dx.float().cpu() - ref).abs().max().item() <= 2e-2 * max(1.0, ref.abs().max().item())
     assert (dx.float().cpu()[:, 1::2] == 0).all() and (dx.float().cpu()[:, :, 1::2] == 0).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [10, 11, 12, 13])
+def test_random_epilogues_gpu(seed):
+    """random problems with random epilogue options: folded scale / bias, SiLU / ReLU, residual, output written into a channel
+    slice of a wider buffer; dgrad with accumulate or the shortcut residual; the packed-image stem at odd sizes"""
+    from efficientteacher_amd import _lib, ops
+    _lib._use_library_for_tests(None, False)
+    dev = torch.device("cuda:0")
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(seed)
+    rng = np.random.default_rng(seed)
+    probs = _problems(seed, 8) + [(int(rng.integers(1, 4)), int(rng.integers(6, 70)), int(rng.integers(6, 200)), 8, int(rng.choice([16, 32, 48, 64])), 6, 2, 2)]
+    for (N, H, W, Cin, Cout, k, s, p) in probs:
+        OH, OW = ops.conv_out_hw(H, W, k, s, p)
+        if OH < 1 or OW < 1:
+            continue
+        x = torch.randn((N, H, W, Cin), generator=g).to(dt).to(dev)
+        w = (torch.randn((Cout, k, k, Cin), generator=g) / (k * k * Cin) ** 0.5).to(dt).to(dev)
+        ref = F.conv2d(x.float().cpu().permute(0, 3, 1, 2), w.float().cpu().permute(0, 3, 1, 2), stride=s, padding=p).permute(0, 2, 3, 1)
+        act = int(rng.choice([ops.ACT_NONE, ops.ACT_SILU, ops.ACT_RELU]))
+        use_sc, use_res, use_slice = bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        sc = (torch.rand(Cout, generator=g) + 0.5).to(dev) if use_sc else None
+        bi = torch.randn(Cout, generator=g).to(dev) if use_sc else None
+        res = torch.randn((N, OH, OW, Cout), generator=g).to(dt).to(dev) if use_res else None
+        exp = ref * sc.cpu() + bi.cpu() if use_sc else ref.clone()
+        exp = F.silu(exp) if act == ops.ACT_SILU else F.relu(exp) if act == ops.ACT_RELU else exp
+        if use_res:
+            exp = exp + res.float().cpu()
+        if use_slice:
+            wide = torch.zeros((N, OH, OW, Cout + 24), dtype=dt, device=dev)
+            ops.conv2d_fwd(x, w, s, p, scale=sc, bias=bi, act=act, residual=res, out=wide[..., 16:16 + Cout])
+            y = wide[..., 16:16 + Cout]
+            assert (wide[..., :16] == 0).all() and (wide[..., 16 + Cout:] == 0).all()
+        else:
+            y = ops.conv2d_fwd(x, w, s, p, scale=sc, bias=bi, act=act, residual=res)
+        tag = (N, H, W, Cin, Cout, k, s, act, use_sc, use_res, use_slice)
+        assert (y.float().cpu() - exp).abs().max().item() <= 3e-2 * max(1.0, exp.abs().max().item()), tag
+        if k == 6 or s != 1:
+            continue
+        dy = torch.randn((N, OH, OW, Cout), generator=g).to(dt).to(dev)
+        xr = torch.zeros((N, Cin, H, W), requires_grad=True)
+        F.conv2d(xr, w.float().cpu().permute(0, 3, 1, 2), stride=s, padding=p).backward(dy.float().cpu().permute(0, 3, 1, 2))
+        dref = xr.grad.permute(0, 2, 3, 1)
+        r2 = torch.randn((N, H, W, Cin), generator=g).to(dt).to(dev)
+        dx = ops.conv2d_dgrad(dy, ops.weight_transpose(w), (H, W), s, p, residual=r2)
+        assert (dx.float().cpu() - (dref + r2.float().cpu())).abs().max().item() <= 3e-2 * max(1.0, dref.abs().max().item()) + 3e-2 * r2.float().abs().max().item(), ("dgrad+res",) + tag
