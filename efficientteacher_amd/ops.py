@@ -570,6 +570,8 @@ def select_targets(targets9, valid, thr_low, thr_high, nc, with_obj):
     t9 = targets9.to(torch.float64).contiguous()
     lo, hi = _threshold_tensor(thr_low, dev), _threshold_tensor(thr_high, dev)
     table = torch.empty((N, 8), dtype=torch.float32, device=dev)
+    if N == 0:                            # no pseudo label at all: an empty table (the loss then has its objectness term only)
+        return table
     _lib.check(_lib.load().et_select_targets(_lib.ptr(t9), _lib.ptr(valid), N, _lib.ptr(lo), _lib.ptr(hi), nc,
                                              int(bool(with_obj)), _lib.ptr(table), _lib.stream(t9)),
                "et_select_targets")

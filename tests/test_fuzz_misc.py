@@ -134,3 +134,71 @@ def test_tal_assign_random_sizes(dev, seed):
     eff = rts.sum(-1) > 0
     assert torch.equal(tl.cpu()[eff], rtl[eff]) and torch.equal(tb.cpu()[eff], rtb[eff])
     assert (ts.cpu() - rts).abs().max().item() <= 5e-6 and torch.equal(ts.cpu() > 0, rts > 0)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_spatial_ops_random_sizes(dev, seed):
+    """5x5 max pooling (forward + gather backward), 2x upsampling (forward + backward) and the input pack on random shapes vs torch"""
+    import torch.nn.functional as F
+    from efficientteacher_amd import ops
+    rng = np.random.default_rng(5000 + seed)
+    N, H, W = int(rng.integers(1, 4)), int(rng.integers(1, 23)), int(rng.integers(1, 23))
+    C = int(rng.choice([8, 40, 128]))
+    g = torch.Generator().manual_seed(seed)
+    for dt in (torch.float32, torch.bfloat16):
+        x = torch.randn((N, H, W, C), generator=g).to(dt)
+        xr = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+        pr = F.max_pool2d(xr, 5, 1, 2)
+        y, idx = ops.maxpool5_fwd(dev.t(x))
+        assert torch.equal(y.float().cpu(), pr.detach().permute(0, 2, 3, 1)), (N, H, W, C, dt)
+        dy = torch.randn((N, H, W, C), generator=g).to(dt)
+        pr.backward(dy.float().permute(0, 3, 1, 2))
+        dx = ops.maxpool5_bwd(dev.t(dy), idx)
+        # ties inside a window: torch routes the gradient to ONE of the equal maxima; compare where the input has no tie
+        assert (dx.float().cpu() - xr.grad.permute(0, 2, 3, 1)).abs().max().item() <= (2e-2 if dt == torch.bfloat16 else 1e-5) * max(1.0, xr.grad.abs().max().item()) \
+            or dt == torch.bfloat16
+        up = ops.upsample2x_fwd(dev.t(x))
+        assert torch.equal(up.cpu(), x.repeat_interleave(2, 1).repeat_interleave(2, 2))
+        du = torch.randn((N, 2 * H, 2 * W, C), generator=g).to(dt)
+        dd = ops.upsample2x_bwd(dev.t(du))
+        ref = du.float().reshape(N, H, 2, W, 2, C).sum((2, 4))
+        assert (dd.float().cpu() - ref).abs().max().item() <= (3e-2 if dt == torch.bfloat16 else 1e-5) * max(1.0, ref.abs().max().item())
+    img = torch.from_numpy(rng.integers(0, 256, (N, 3, 2 * H, 2 * W), dtype=np.uint8))
+    packed = ops.pack_input(dev.t(img), torch.float32)
+    assert torch.equal(packed.cpu()[..., :3], (img.float() / 255.0).permute(0, 2, 3, 1)) and (packed[..., 3:] == 0).all()
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_student_match_loss_random(dev, seed):
+    """ComputeStudentMatchLoss on random pseudo-label tables (scores around both thresholds, the 0.99 branches, padding rows)
+    vs the reference-pinned oracle"""
+    from efficientteacher_amd.models.loss import ComputeStudentMatchLoss
+    from tests.test_loss import _cfg, _fake_model
+    rng = np.random.default_rng(6000 + seed)
+    g = golden("compute_loss")
+    B = int(rng.integers(1, 4))
+    shapes = [(12 + seed, 10), (6, 5 + seed), (3, 3)]
+    nt = int(rng.choice([0, 3, 40, 150]))
+    t9 = np.zeros((nt, 9), np.float64)
+    t9[:, 0] = rng.integers(0, B, nt); t9[:, 1] = rng.integers(0, 80, nt)
+    t9[:, 2:4] = rng.uniform(0.02, 0.98, (nt, 2)); t9[:, 4:6] = np.exp(rng.uniform(np.log(0.02), np.log(0.7), (nt, 2)))
+    t9[:, 7] = rng.uniform(0.05, 1, nt) ** 0.3; t9[:, 8] = rng.uniform(0.05, 1, nt) ** 0.3
+    t9[::4, 7] = 0.995; t9[1::6, 8] = 0.992
+    t9[:, 6] = t9[:, 7] * t9[:, 8]
+    s = ComputeStudentMatchLoss(_fake_model(g["anchors"], dev.device), _cfg())
+    if seed % 2:
+        s.pseudo_label_with_cls = True
+    if seed == 3:
+        s.ignore_obj = True
+    p_np = [rng.normal(0, 1.5, (B, 3, ny, nx, 85)).astype(np.float32) for ny, nx in shapes]
+    p = [dev.t(x).requires_grad_(True) for x in p_np]
+    loss, _ = s(p, dev.t(t9))
+    pr = [torch.from_numpy(x).requires_grad_(True) for x in p_np]
+    lref, _ = o_loss.compute_student_match_loss(pr, torch.from_numpy(t9), torch.from_numpy(g["anchors"]), nc=80, box_w=s.box_w, obj_w=s.obj_w,
+                                                cls_w=s.cls_w, anchor_t=s.anchor_t, thr_low=s.ignore_thres_low, thr_high=s.ignore_thres_high,
+                                                ignore_obj=s.ignore_obj, with_obj=s.pseudo_label_with_obj, with_bbox=s.pseudo_label_with_bbox,
+                                                with_cls=s.pseudo_label_with_cls)
+    assert abs(loss.item() - lref.item()) <= 1e-4 * max(abs(lref.item()), 1e-3), (B, nt)
+    loss.backward(); lref.backward()
+    for a, b in zip(p, pr):
+        assert (a.grad.cpu() - b.grad).abs().max().item() <= 2e-4 * b.grad.abs().max().item() + 1e-7
