@@ -202,3 +202,51 @@ def test_student_match_loss_random(dev, seed):
     loss.backward(); lref.backward()
     for a, b in zip(p, pr):
         assert (a.grad.cpu() - b.grad).abs().max().item() <= 2e-4 * b.grad.abs().max().item() + 1e-7
+
+
+@pytest.mark.parametrize("width,depth,nc,B,H,W", [(0.25, 0.33, 3, 2, 128, 160), (0.5, 0.67, 80, 1, 96, 96), (0.375, 1.0, 20, 3, 64, 224)])
+def test_whole_model_random_configs(dev, width, depth, nc, B, H, W):
+    """other YOLOv5 scalings than the golden tiny model (channel counts 24 / 48 / 96 ..., deeper C3 stacks, other class counts),
+    rectangular inputs: fp32-mode eval output, training loss and three gradients against the oracle model with the same weights"""
+    import os
+    from efficientteacher_amd.configs import get_cfg
+    from efficientteacher_amd.models.detector.yolo_ssod import Model
+    from efficientteacher_amd.models.loss import ComputeLoss
+    from oracle import model as o_model
+    from tests.conftest import ROOT
+    from tests.test_model import YAML
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(ROOT, YAML))
+    cfg.merge_from_list(["Model.width_multiple", width, "Model.depth_multiple", depth, "Dataset.nc", nc,
+                         "Dataset.names", [str(i) for i in range(nc)]])
+    cfg.freeze()
+    torch.manual_seed(int(width * 1000) + nc)
+    model = Model(cfg)
+    ref = o_model.Model.from_cfg(cfg)
+    ref.load_state_dict(model.state_dict(), strict=True)
+    model = model.to(dev.device)
+    model.set_compute_dtype(torch.float32)
+    rng = np.random.default_rng(nc)
+    x = rng.uniform(0, 1, (B, 3, H, W)).astype(np.float32)
+    model.eval(); ref.eval()
+    with torch.no_grad():
+        (z, _), _ = model(dev.t(x))
+        zr = ref(torch.from_numpy(x))[0][0]
+    assert (z.cpu() - zr).abs().max().item() <= 2e-4 * max(1.0, zr.abs().max().item())
+    model.train(); ref.train()
+    nt = 5 * B
+    t = np.zeros((nt, 6), np.float32)
+    t[:, 0] = np.sort(rng.integers(0, B, nt)); t[:, 1] = rng.integers(0, nc, nt)
+    t[:, 2:4] = rng.uniform(0.1, 0.9, (nt, 2)); t[:, 4:6] = rng.uniform(0.05, 0.5, (nt, 2))
+    closs = ComputeLoss(model, cfg)
+    out, _ = model(dev.t(x))
+    loss, _ = closs(out, dev.t(t))
+    outr = ref(torch.from_numpy(x))[0]
+    lossr, _ = o_loss.compute_loss(outr, torch.from_numpy(t), ref.head.anchors, nc=nc, box_w=closs.box_w, obj_w=closs.obj_w, cls_w=closs.cls_w,
+                                   anchor_t=closs.anchor_t)
+    assert abs(loss.item() - lossr.item()) <= 2e-4 * abs(lossr.item()), (loss.item(), lossr.item())
+    model.zero_grad(); loss.backward(); lossr.backward()
+    gp, gr = dict(model.named_parameters()), dict(ref.named_parameters())
+    for k in ("backbone.stage1.conv.weight", "backbone.stage3_2.m.0.cv2.conv.weight", "head.m.1.weight"):
+        a, b = gp[k].grad.cpu(), gr[k].grad
+        assert (a - b).abs().max().item() <= 5e-3 * max(b.abs().max().item(), 1e-7), k
