@@ -250,3 +250,115 @@ def test_whole_model_random_configs(dev, width, depth, nc, B, H, W):
     for k in ("backbone.stage1.conv.weight", "backbone.stage3_2.m.0.cv2.conv.weight", "head.m.1.weight"):
         a, b = gp[k].grad.cpu(), gr[k].grad
         assert (a - b).abs().max().item() <= 5e-3 * max(b.abs().max().item(), 1e-7), k
+
+
+@pytest.mark.parametrize("seed,nc,shapes", [(0, 1, ((24, 40), (12, 20), (6, 10))), (1, 80, ((36, 28), (18, 14), (9, 7))),
+                                            (2, 3, ((8, 8), (4, 4), (2, 2))), (3, 17, ((52, 12), (26, 6), (13, 3)))])
+def test_ota_random_pyramids(dev, seed, nc, shapes):
+    """SimOTA matching + loss on rectangular / very small pyramids and other class counts (1, 3, 17, 80), against the oracle"""
+    from tests.test_ota import _closs
+    from tests.conftest import golden
+    g = golden("ota")
+    rng = np.random.default_rng(900 + seed)
+    B = int(rng.integers(1, 4))
+    rows = []
+    for b in range(B):
+        n = int(rng.integers(0, 15))
+        xy = rng.uniform(0.0, 1.0, (n, 2))
+        wh = np.exp(rng.uniform(np.log(0.01), np.log(0.9), (n, 2)))
+        rows.append(np.concatenate((np.full((n, 1), b), rng.integers(0, nc, (n, 1)), xy, wh), 1))
+    t = np.concatenate(rows, 0).astype(np.float32)
+    if t.shape[0] == 0:
+        t = np.array([[0, 0, 0.5, 0.5, 0.2, 0.2]], np.float32)
+    p_np = [rng.normal(0, 1.0, (B, 3, ny, nx, 5 + nc)).astype(np.float32) for ny, nx in shapes]
+    for pi in p_np:
+        pi[..., :4] *= 0.3
+    closs = _closs(g["anchors"], nc, dev.device)
+    p = [dev.t(x).requires_grad_(True) for x in p_np]
+    loss, items = closs(p, dev.t(t))
+    loss.backward()
+    po = [torch.from_numpy(x).requires_grad_(True) for x in p_np]
+    lo, io = o_loss.ota_loss(po, torch.from_numpy(t), torch.from_numpy(g["anchors"]), closs._strides, nc=nc, box_w=closs.box_w,
+                             obj_w=closs.obj_w, cls_w=closs.cls_w, anchor_t=closs.anchor_t)
+    lo.backward()
+    assert abs(loss.item() - lo.item()) <= 1e-4 * abs(lo.item()), (loss.item(), lo.item())
+    for k in ("box", "obj", "cls"):
+        assert abs(items[k].item() - io[k].item()) <= 1e-4 * abs(io[k].item()) + 1e-6, k
+    for a, b in zip(p, po):
+        ref = b.grad.numpy()
+        assert np.abs(a.grad.cpu().numpy() - ref).max() <= 1e-4 * np.abs(ref).max() + 1e-7
+
+
+@pytest.mark.parametrize("seed", range(5))
+def test_pseudo_label_transform_random(dev, seed):
+    """random detection tables (counts 0..max_det per image), rotations / scales / shears / shifts that push boxes out of the
+    frame, both flips, both clip variants: bit-for-bit (1e-12) against the oracle's fp64 pipeline"""
+    from efficientteacher_amd import ops
+    from oracle import pseudo_label as o_pl
+    rng = np.random.default_rng(1300 + seed)
+    B = int(rng.integers(1, 6))
+    max_det = int(rng.choice([1, 7, 64, 300]))
+    W, H = int(rng.integers(32, 700)), int(rng.integers(32, 700))
+    dets = np.zeros((B, max_det, 8), np.float32)
+    counts = rng.integers(0, max_det + 1, B).astype(np.int32)
+    counts[rng.integers(0, B)] = 0
+    lists = []
+    for b in range(B):
+        n = counts[b]
+        c = rng.uniform([-20, -20], [W + 20, H + 20], (n, 2))
+        wh = np.exp(rng.uniform(np.log(0.5), np.log(0.8 * max(W, H)), (n, 2)))
+        d = np.concatenate((c - wh / 2, c + wh / 2, rng.uniform(0, 1, (n, 1)), rng.integers(0, 80, (n, 1)), rng.uniform(0, 1, (n, 2))), 1)
+        dets[b, :n] = d.astype(np.float32)
+        dets[b, n:] = rng.normal(0, 100, (max_det - n, 8))           # rows past the count are never read
+        lists.append(dets[b, :n].copy())
+    M_s = np.zeros((B, 13))
+    for b in range(B):
+        a = np.deg2rad(rng.uniform(-30, 30)); s = rng.uniform(0.4, 1.6); sh = np.tan(np.deg2rad(rng.uniform(-10, 10, 2)))
+        R = np.array([[s * np.cos(a), s * np.sin(a), 0], [-s * np.sin(a), s * np.cos(a), 0], [0, 0, 1.0]])
+        S = np.array([[1, sh[0], 0], [sh[1], 1, 0], [0, 0, 1.0]])
+        T = np.array([[1, 0, rng.uniform(-0.3, 0.3) * W], [0, 1, rng.uniform(-0.3, 0.3) * H], [0, 0, 1.0]])
+        M_s[b] = np.concatenate(([b], (T @ S @ R).reshape(-1), [s, rng.integers(0, 2), rng.integers(0, 2)]))
+    for clip01 in (False, True):
+        t9, valid = ops.pseudo_label_transform(dev.t(dets), torch.from_numpy(counts).to(dev.device), dev.t(M_s, torch.float64), W, H, clip01=clip01)
+        got = t9[valid.bool()].cpu().numpy()
+        ref, _ = o_pl.create_pseudo_label(lists, M_s, W, H, clip01=clip01)
+        ref = np.asarray(ref, np.float64).reshape(-1, 9) if np.size(ref) else np.zeros((0, 9))
+        assert got.shape == ref.shape, (got.shape, ref.shape)
+        assert np.allclose(got, ref, rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("n", [1, 3, 5, 1023, 1025, 40961])
+def test_flat_arena_updates_at_ragged_lengths(dev, n):
+    """SGD-nesterov / AdamW / EMA / bf16 cast over arenas whose length is not a multiple of the 4-float vector (tail path),
+    against the same arithmetic in torch on the CPU; a misaligned arena pointer is refused (-2), not read"""
+    from efficientteacher_amd import ops, _lib
+    rng = np.random.default_rng(n)
+    p0 = rng.normal(0, 1, n).astype(np.float32); g0 = rng.normal(0, 0.1, n).astype(np.float32)
+    # --- SGD (two steps: first_step initialises the momentum buffer with the gradient, torch/optim/sgd.py) -------------------
+    p = dev.t(p0.copy()); buf = torch.zeros_like(p); sh = torch.empty(n, dtype=torch.bfloat16, device=dev.device)
+    pr = torch.from_numpy(p0.copy()).requires_grad_(True)
+    opt = torch.optim.SGD([pr], lr=0.01, momentum=0.937, nesterov=True, weight_decay=5e-4)
+    for step in range(2):
+        g = g0 * (step + 1)
+        ops.sgd_nesterov(p, dev.t(g * 8.0), buf, sh, 0.01, 0.937, 5e-4, step == 0, inv_scale=1 / 8.0)
+        pr.grad = torch.from_numpy(g.copy()); opt.step()
+    assert np.abs(p.cpu().numpy() - pr.detach().numpy()).max() <= 2e-7 * max(1.0, np.abs(p0).max())
+    assert torch.equal(sh.cpu(), p.cpu().to(torch.bfloat16))
+    # --- AdamW ------------------------------------------------------------------------------------------------------------
+    p = dev.t(p0.copy()); m = torch.zeros_like(p); v = torch.zeros_like(p)
+    pr = torch.from_numpy(p0.copy()).requires_grad_(True)
+    opt = torch.optim.AdamW([pr], lr=0.01, betas=(0.937, 0.999), weight_decay=0.01)
+    for step in range(1, 3):
+        ops.adamw(p, dev.t(g0 * step), m, v, sh, 0.01, 0.937, 0.999, 1e-8, 0.01, step)
+        pr.grad = torch.from_numpy(g0 * step); opt.step()
+    assert np.abs(p.cpu().numpy() - pr.detach().numpy()).max() <= 2e-6 * max(1.0, np.abs(p0).max())
+    # --- EMA (three separately rounded fp32 ops) -----------------------------------------------------------------------------
+    e = dev.t(g0.copy()); ops.ema_update(e, dev.t(p0), 0.9)
+    er = torch.from_numpy(g0.copy()); er *= 0.9; er += (1. - 0.9) * torch.from_numpy(p0)
+    assert torch.equal(e.cpu(), er)
+    e2 = dev.t(g0.copy()); ops.ema_update_dev(e2, dev.t(p0), dev.t(np.array([0.9, 1. - 0.9], np.float32)))
+    assert torch.equal(e2.cpu(), er)
+    if n >= 5:
+        big = dev.t(p0)
+        rc = _lib.load().et_ema_update(_lib.ptr(big[1:]), _lib.ptr(big[1:]), n - 1, 0.5, 0.5, _lib.stream(big))
+        assert rc == -2
