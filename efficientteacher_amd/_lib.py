@@ -44,8 +44,6 @@ SIGNATURES = {
     "et_weight_transpose": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "et_conv2d_kernel_name": (c_int, [c_int] * 13 + [c_char_p, c_int]),
     "et_env_knobs": (c_int, [c_char_p, c_int]),
-    "et_conv2d_workspace_bytes": (c_int64, []),
-    "et_conv2d_set_workspace": (c_int, [P, c_int64, P]),
     "et_colsum": (c_int, [P, c_int, c_int, c_int, c_int, P, P]),
     "et_bn_reduce_rows": (c_int, [c_int, c_int, c_int]),
     "et_bn_finalize": (c_int, [P, c_int, c_int, c_double, P, P, c_float, c_float, P, P, P, P, P, P, P, P]),

@@ -20,7 +20,6 @@
 // lane group hit 16 distinct (bank-half, slot) pairs; double buffered, one barrier per K-chunk,
 // next chunk's global loads are issued before the MFMAs of the current one.
 #include "et_device.h"
-#include <mutex>
 #include "../../include/et_hip.h"
 #include <stdlib.h>
 #include <stdio.h>
@@ -799,76 +798,66 @@ template <int N> __device__ __forceinline__ void et_wait_vmem_le_pp() {
     __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 0xF) | ((N >> 4) << 14));
 }
 
-// Stream-K bookkeeping (SK = true): the launch is ONE persistent workgroup per CU.  The tile sequence is cut into 8 contiguous
-// ranges (one per XCD: workgroups w, w+8, ... share an L2), and inside a range its workers split the K-CHUNKS of the tiles
-// evenly -- a worker's share is [k*C/n, (k+1)*C/n) of the range's chunk sequence, so it ends in the middle of a tile.  The
-// piece of a tile that does not contain the tile's LAST chunk is a contribution: its fp32 accumulators go to the worker's
-// workspace slot and a flag is raised; the worker that owns the last chunk adds the contributions and runs the epilogue.
-// A worker processes its contribution FIRST and its owned partial tile LAST, and contributors always have a lower
-// blockIdx than the owner (dispatched earlier; the emulator runs blocks in that order), so the owner practically never
-// waits.  What it buys: no residency-round quantisation (400 tiles on 256 CUs = 0.78 of two rounds) and the workgroups
-// drift apart, so the epilogues' store bursts no longer coincide.
-struct PpStreamK {
-    unsigned* ws;         // [gridDim.x][8 waves][128][64 lanes] fp32 bits : one 256x256 partial tile per worker
-    unsigned* flags;      // [gridDim.x], zero between launches (the owner clears what it consumed)
-};
-#define PP_SK_SLOT_FLOATS (256 * 256)
-
-template <bool SK>
-__device__ __forceinline__ void conv_gemm_pp_body(u32x4* lds_raw, const uint16_t* __restrict__ X, const uint16_t* __restrict__ W,
-                                                  uint16_t* __restrict__ Y, const uint16_t* __restrict__ ZERO,
-                                                  const GatherGeom& g, const Epilogue& ep, const PpStreamK& sk) {
+__global__ __launch_bounds__(512, 2) void conv_gemm_pp_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W,
+                                                              uint16_t* __restrict__ Y, const uint16_t* __restrict__ ZERO,
+                                                              GatherGeom g, Epilogue ep) {
     constexpr int BM = 256, BN = 256, WM = 2, WN = 4, BKV = 8, VEC = 8;
     constexpr int HALF_VEC = 128 * BKV;            // one half-tile in 16-byte vectors (16 KB)
+    constexpr int EPI_VEC = EpiLds<BM, BN, WM, WN>::VEC16;
+    constexpr int LDS_VEC = 8 * HALF_VEC > EPI_VEC ? 8 * HALF_VEC : EPI_VEC;
+    __shared__ __attribute__((aligned(16))) u32x4 lds_raw[LDS_VEC];
     // half-tile kinds: 0 = A0, 1 = A1, 2 = B0, 3 = B1; buffer b of kind k at lds_raw + (2*k + b) * HALF_VEC
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     ET_TS(0);
     const int wm = wave >> 2, wn = wave & 3;       // wm = the wave group (waves w and w+4 share a SIMD)
+    int bx, by;
+    tile_of_block(g, bx, by);
+    const int m0 = bx * BM, n0 = by * BN;
     const int lvec = tid & 7, lrow = tid >> 3;     // staging: 64 rows x 8 K-vectors per instruction of the workgroup
     const int lv = lvec ^ lds_swz<BKV>(lrow);      // logical K-vector this lane stages (swizzle on the SOURCE)
-    const int nchunks_tile = g.KV / BKV;           // host: Cin % 64 == 0
 
-    int bx = 0, by = 0, m0 = 0, n0 = 0;
     int a_off[2][2], a_iy[2][2], a_ix[2][2];
     unsigned a_okm = 0u, b_okm = 0u;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int p = m0 + jj * 128 + i * 64 + lrow;           // half i, LDS row jj*64 + lrow
+            const bool ok = p < g.M;
+            const uint32_t pp = ok ? p : 0;
+            const uint32_t t1 = fdiv(pp, g.dQW), qx = pp - t1 * g.QW;
+            const uint32_t n = fdiv(t1, g.dQH), qy = t1 - n * g.QH;
+            a_iy[i][jj] = qy * g.isy;
+            a_ix[i][jj] = qx * g.isx;
+            a_off[i][jj] = ((n * g.IH + a_iy[i][jj]) * g.IW + a_ix[i][jj]) * g.ldx;
+            a_okm |= ok ? (1u << (i * 2 + jj)) : 0u;
+        }
     int b_off[2][2];
-    // per-tile addressing of the staging lanes
-    auto setup_tile = [&]() {
-        m0 = bx * BM; n0 = by * BN;
-        a_okm = 0u; b_okm = 0u;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                const int p = m0 + jj * 128 + i * 64 + lrow;           // half i, LDS row jj*64 + lrow
-                const bool ok = p < g.M;
-                const uint32_t pp = ok ? p : 0;
-                const uint32_t t1 = fdiv(pp, g.dQW), qx = pp - t1 * g.QW;
-                const uint32_t n = fdiv(t1, g.dQH), qy = t1 - n * g.QH;
-                a_iy[i][jj] = qy * g.isy;
-                a_ix[i][jj] = qx * g.isx;
-                a_off[i][jj] = ((n * g.IH + a_iy[i][jj]) * g.IW + a_ix[i][jj]) * g.ldx;
-                a_okm |= ok ? (1u << (i * 2 + jj)) : 0u;
-            }
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                const int r = jj * 64 + lrow;
-                const int co = n0 + (r >> 5) * 64 + j * 32 + (r & 31);
-                const bool ok = co < g.Cout;
-                b_off[j][jj] = (ok ? co : 0) * g.TT * g.Cin;
-                b_okm |= ok ? (1u << (j * 2 + jj)) : 0u;
-            }
-    };
+        for (int jj = 0; jj < 2; ++jj) {
+            const int r = jj * 64 + lrow;
+            const int co = n0 + (r >> 5) * 64 + j * 32 + (r & 31);
+            const bool ok = co < g.Cout;
+            b_off[j][jj] = (ok ? co : 0) * g.TT * g.Cin;
+            b_okm |= ok ? (1u << (j * 2 + jj)) : 0u;
+        }
 
     f32x16 acc[4][2];
-    int nchunks = nchunks_tile;                    // chunks of the piece being computed
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+    const int nchunks = g.KV / BKV;                // host: Cin % 64 == 0
     // cursor of the chunk being STAGED (wave-uniform scalars; plain selects, no references: they must stay in SGPRs)
     int tap_u = 0, cv_u = 0;
-    int ti_cur = 0;                                // tap table entry of the cursor's chunk, loaded one chunk AHEAD of its use
+    int ti_cur = g.tapinfo[0];                     // tap table entry of the cursor's chunk, loaded one chunk AHEAD of its use
     int udy = 0, udx = 0, uwt = 0;
 #define ET_PP_DECODE()                                                   \
     do {                                                                 \
@@ -957,9 +946,17 @@ __device__ __forceinline__ void conv_gemm_pp_body(u32x4* lds_raw, const uint16_t
         __builtin_amdgcn_s_setprio(0);
     };
 
+    // prologue: the four half-tiles of chunk 0 into buffer 0
+    ET_PP_DECODE();
+    stage_a(0, 0); stage_b(0, 0); stage_b(1, 0); stage_a(1, 0);
+    ET_PP_ADVANCE();
+    et_wait_vmem();
+    __builtin_amdgcn_s_barrier();
+    ET_TS(1);
 #define ET_PP_BAR() do { if (!ET_PPA(28)) __builtin_amdgcn_s_barrier(); } while (0)
 #define ET_PP_WAIT(n) do { if (!ET_PPA(25)) et_wait_vmem_le_pp<n>(); } while (0)
 #define ET_PP_STAGE(call) do { if (!ET_PPA(21)) { call; } } while (0)
+    if (wm == 1 && !ET_PPA(26) && !ET_PPA(28)) __builtin_amdgcn_s_barrier();     // group 1 runs one barrier (half a phase) behind group 0
 
     // one chunk = four phases; `last`: nothing is staged during the final chunk and the waits drain the queue
     auto chunk = [&](int buf, auto last_tag) {
@@ -1022,153 +1019,25 @@ __device__ __forceinline__ void conv_gemm_pp_body(u32x4* lds_raw, const uint16_t
         if constexpr (!LAST) ET_PP_ADVANCE();
         ET_PP_BAR();
     };
-    // the chunks [c0, c0 + nchunks) of tile (bx, by) into acc
-    auto run_piece = [&](int c0) {
-        setup_tile();
-#pragma unroll
-        for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-            for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
-        if (SK && c0) {
-            const int ncc = g.CV / BKV;            // channel chunks per tap
-            if (g.tap_inner) { const int q = c0 / g.T; tap_u = c0 - q * g.T; cv_u = q * BKV; }
-            else { const int q = c0 / ncc; cv_u = (c0 - q * ncc) * BKV; tap_u = q; }
-        } else { tap_u = 0; cv_u = 0; }
-        ti_cur = g.tapinfo[__builtin_amdgcn_readfirstlane(tap_u)];
-        // prologue: the four half-tiles of the first chunk into buffer 0
-        ET_PP_DECODE();
-        stage_a(0, 0); stage_b(0, 0); stage_b(1, 0); stage_a(1, 0);
-        ET_PP_ADVANCE();
-        et_wait_vmem();
-        __builtin_amdgcn_s_barrier();
-        ET_TS(1);
-        if (wm == 1 && !ET_PPA(26) && !ET_PPA(28)) __builtin_amdgcn_s_barrier();     // group 1 runs one barrier (half a phase) behind group 0
-        int buf = 0;
-        for (int c = 0; c + 1 < nchunks; ++c) {
-            if (c == 1) ET_TS(2);
-            chunk(buf, std::false_type{});
-            buf ^= 1;
-        }
-        chunk(buf, std::true_type{});
-        if (wm == 0 && !ET_PPA(26) && !ET_PPA(28)) __builtin_amdgcn_s_barrier();     // balances group 1's extra barrier
-        __syncthreads();                           // the epilogue reuses the half-tile buffers as its staging area
-        ET_TS(3);
-    };
-    if constexpr (!SK) {
-        tile_of_block(g, bx, by);
-        run_piece(0);
-        conv_epilogue<uint16_t, BM, BN, WM, WN>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn);
-        __syncthreads();
-        ET_TS(4);
-    } else {
-        // ---- this worker's share of its XCD range ---------------------------------------------------------------------
-        const int G = gridDim.x, wid = blockIdx.x;
-        const int nx = G >= 8 ? 8 : 1, xcd = G >= 8 ? (wid & 7) : 0, k = G >= 8 ? (wid >> 3) : wid;
-        const int nw = G >= 8 ? ((G - xcd + 7) >> 3) : G;                       // workers of this range
-        const int ntiles = g.ntm * g.ntn;
-        const int t0 = (int)((unsigned)(ntiles * xcd) / (unsigned)nx), t1 = (int)((unsigned)(ntiles * (xcd + 1)) / (unsigned)nx);
-        const unsigned C = (unsigned)((t1 - t0) * nchunks_tile);                 // host: C * workers < 2^31
-        auto share_begin = [&](int kk) { return (int)(C * (unsigned)kk / (unsigned)nw); };
-        int lo = share_begin(k), hi = share_begin(k + 1);
-        auto tile_coords = [&](int t) {            // t: index in the tile sequence (channel tiles of a pixel tile adjacent)
-            if (g.nfast) { bx = t / g.ntn; by = t - bx * g.ntn; }
-            else { by = t / g.ntm; bx = t - by * g.ntm; }
-        };
-        unsigned* const my_ws = sk.ws + (size_t)wid * PP_SK_SLOT_FLOATS + wave * 128 * 64 + lane;
-        // piece order: 1. the trailing piece that does not reach its tile's end (a contribution), 2. whole tiles, 3. the leading
-        // piece that starts inside a tile and owns its end.  (Three inlined copies of the pipeline: ONE loop over a piece list
-        // made the compiler hoist the epilogue's address terms across the MFMA loop -- 400-1100 spilled VGPRs.)
-        if (hi > lo) {
-            const int tl = (hi - 1) / nchunks_tile;
-            if (hi != (tl + 1) * nchunks_tile) {
-                const int c0 = (lo > tl * nchunks_tile ? lo : tl * nchunks_tile) - tl * nchunks_tile;
-                nchunks = hi - tl * nchunks_tile - c0;
-                tile_coords(t0 + tl);
-                run_piece(c0);
-                // The partial tile travels through RELAXED ATOMIC stores / loads (cache-coherent accesses, no fence): an
-                // acquire / release pair at agent scope costs every wave an L2 write-back and an L2 invalidate (the XCD L2s are
-                // not coherent with each other), and with 256 workers that drained the weights and activations out of the
-                // L2s -- the first version of this kernel lost 50-130 us per launch to it.  Order: every wave waits for its own
-                // stores (vmcnt), the workgroup barrier collects the waves, then one thread raises the flag.
-#pragma unroll
-                for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-                    for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            if (!ET_PPA(50) && !ET_PPA(52)) __atomic_store_n(my_ws + ((tm * 2 + tn) * 16 + r) * 64, __float_as_uint(acc[tm][tn][r]), __ATOMIC_RELAXED);
-                et_wait_vmem();
-                __syncthreads();
-                if (tid == 0) __atomic_store_n(sk.flags + wid, 1u, __ATOMIC_RELAXED);
-                hi = tl * nchunks_tile + c0;
-            }
-        }
-        int own_t = -1, own_c0 = 0;
-        if (hi > lo) {
-            const int tf = lo / nchunks_tile;
-            if (lo != tf * nchunks_tile) { own_t = tf; own_c0 = lo - tf * nchunks_tile; lo = (tf + 1) * nchunks_tile; }
-        }
-        for (int t = lo / nchunks_tile; t * nchunks_tile < hi; ++t) {
-            nchunks = nchunks_tile;
-            tile_coords(t0 + t);
-            run_piece(0);
-            conv_epilogue<uint16_t, BM, BN, WM, WN>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn);
-            __syncthreads();
-        }
-        if (own_t >= 0) {
-            nchunks = nchunks_tile - own_c0;
-            tile_coords(t0 + own_t);
-            run_piece(own_c0);
-            // contributors: the workers below this one whose share ends inside this tile
-            for (int kk = k - 1; kk >= 0 && share_begin(kk + 1) > own_t * nchunks_tile; --kk) {
-                if (share_begin(kk + 1) == share_begin(kk)) continue;           // an empty share contributed nothing
-                const int cw = G >= 8 ? (kk * 8 + xcd) : kk;
-                if (ET_PPA(51) || ET_PPA(52)) { if (tid == 0) __atomic_store_n(sk.flags + cw, 0u, __ATOMIC_RELAXED); continue; }
-                if (tid == 0) {
-                    while (__atomic_load_n(sk.flags + cw, __ATOMIC_RELAXED) == 0u) __builtin_amdgcn_s_sleep(4);
-                    __atomic_store_n(sk.flags + cw, 0u, __ATOMIC_RELAXED);
-                }
-                __syncthreads();
-                const unsigned* src = sk.ws + (size_t)cw * PP_SK_SLOT_FLOATS + wave * 128 * 64 + lane;
-#pragma unroll
-                for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-                    for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            acc[tm][tn][r] += __uint_as_float(__atomic_load_n(src + ((tm * 2 + tn) * 16 + r) * 64, __ATOMIC_RELAXED));
-            }
-            conv_epilogue<uint16_t, BM, BN, WM, WN>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn);
-            __syncthreads();
-        }
+    int buf = 0;
+    for (int c = 0; c + 1 < nchunks; ++c) {
+        if (c == 1) ET_TS(2);
+        chunk(buf, std::false_type{});
+        buf ^= 1;
     }
+    chunk(buf, std::true_type{});
+    if (wm == 0 && !ET_PPA(26) && !ET_PPA(28)) __builtin_amdgcn_s_barrier();     // balances group 1's extra barrier
+    __syncthreads();                               // the epilogue reuses the half-tile buffers as its staging area
+    ET_TS(3);
+    conv_epilogue<uint16_t, BM, BN, WM, WN>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn);
+    __syncthreads();
+    ET_TS(4);
 #undef ET_PP_DECODE
 #undef ET_PP_ADVANCE
 #undef ET_PP_BAR
 #undef ET_PP_WAIT
 #undef ET_PP_STAGE
 #undef ET_PPA
-}
-
-__global__ __launch_bounds__(512, 2) void conv_gemm_pp_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W,
-                                                              uint16_t* __restrict__ Y, const uint16_t* __restrict__ ZERO,
-                                                              GatherGeom g, Epilogue ep) {
-    constexpr int EPI_VEC = EpiLds<256, 256, 2, 4>::VEC16;
-    constexpr int LDS_VEC = 8 * 128 * 8 > EPI_VEC ? 8 * 128 * 8 : EPI_VEC;
-    __shared__ __attribute__((aligned(16))) u32x4 lds_raw[LDS_VEC];
-    conv_gemm_pp_body<false>(lds_raw, X, W, Y, ZERO, g, ep, PpStreamK{nullptr, nullptr});
-}
-
-// the same tile loop as one persistent workgroup per CU with the K-chunks of all tiles dealt evenly (stream-K)
-__global__ __launch_bounds__(512, 2) void conv_gemm_ppsk_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W,
-                                                                uint16_t* __restrict__ Y, const uint16_t* __restrict__ ZERO,
-                                                                GatherGeom g, Epilogue ep, PpStreamK sk) {
-    constexpr int EPI_VEC = EpiLds<256, 256, 2, 4>::VEC16;
-    constexpr int LDS_VEC = 8 * 128 * 8 > EPI_VEC ? 8 * 128 * 8 : EPI_VEC;
-    __shared__ __attribute__((aligned(16))) u32x4 lds_raw[LDS_VEC];
-    conv_gemm_pp_body<true>(lds_raw, X, W, Y, ZERO, g, ep, sk);
 }
 
 // ---- the stem: 6x6 stride-2 pad-2 convolution of the packed image (8 channels, 3 used) ----------------------------
@@ -1844,7 +1713,7 @@ static int fill_common(GatherGeom& g, int N, int IH, int IW, int Cin, int ldx, i
 // ---- kernel selection ---------------------------------------------------------------------------------
 // ONE place decides which instantiation runs; et_conv2d_kernel_name() reports the same decision to the tests and
 // to bench.py's roofline tags (there is no second copy of this logic on the Python side).
-enum { GEMM_REG = 0, GEMM_GLDS = 1, GEMM_PP = 2, GEMM_PPSK = 3 };
+enum { GEMM_REG = 0, GEMM_GLDS = 1, GEMM_PP = 2 };
 struct GemmPlan { int kind, BM, BN, WM, WN, BKV, NS; bool utap; };
 
 static GemmPlan plan_gemm(const GatherGeom& g, int elem_bytes, bool have_zero_page) {
@@ -1881,24 +1750,8 @@ static GemmPlan plan_gemm(const GatherGeom& g, int elem_bytes, bool have_zero_pa
         const bool enough = blocks * 100 >= (long long)minfill * n_cu;
         if (enough && (g.TT > 1 || (g.T * g.Cin >= 512 && fills))) ring = use_pp ? 25680 : 25682;
     }
-    if (ring == 25680) {
-        // stream-K form of the ping-pong kernel (ET_CONV_SK: 0 never = default, 1 where it measured faster, 2 wherever the worker
-        // count allows; ET_CONV_SK_WORKERS: persistent workgroups, default one per CU; both read per launch -- the tests shrink
-        // the worker count to exercise the piece logic).  Rule for 1: whole-tile rounds would idle >= 20 % of the CU-time, tiles
-        // are >= 32 chunks deep (each worker's partial tile costs 256 KB of write + read: 16 us per launch at 255 cuts), and
-        // the weight matrix is <= 2 MB: workers sit at DIFFERENT K offsets, so the whole matrix -- not one chunk of it -- is
-        // the L2 working set (512->512 3x3, 4.7 MB: 164 us without any fix-up traffic against 126 us for whole tiles)
-        const int use_sk = env_int("ET_CONV_SK", 0);
-        const int n_cu = env_int("ET_CONV_SK_WORKERS", device_cus());
-        const long long blocks = (long long)((g.M + 255) / 256) * ((g.Cout + 255) / 256);
-        const long long chunks = blocks * (g.KV / 8);
-        const double waste = (double)((blocks + n_cu - 1) / n_cu) * n_cu / (double)blocks;
-        const bool pays = waste >= 1.2 && g.KV / 8 >= 32 && (long long)g.Cout * g.T * g.Cin * 2 <= (2ll << 20);
-        if (use_sk && n_cu > 0 && chunks >= 8ll * n_cu && chunks * n_cu < (1ll << 31) && (use_sk == 2 || pays)) ring = 25681;
-    }
     switch (ring) {
         case 25680: p = GemmPlan{GEMM_PP, 256, 256, 2, 4, 8, 2, true}; break;
-        case 25681: p = GemmPlan{GEMM_PPSK, 256, 256, 2, 4, 8, 2, true}; break;
         case 25682: p = GemmPlan{GEMM_GLDS, 256, 256, 2, 4, 8, 2, true}; break;
         case 25612: p = GemmPlan{GEMM_GLDS, 256, 128, 4, 2, 8, 2, true}; break;       // experiment
         case 12883: p.NS = 3; break;
@@ -1914,33 +1767,8 @@ static GemmPlan plan_gemm(const GatherGeom& g, int elem_bytes, bool have_zero_pa
 static void plan_name(const GemmPlan& p, int elem_bytes, char* buf, int n) {
     const char* t = elem_bytes == 2 ? "unsigned short" : "float";
     if (p.kind == GEMM_PP) snprintf(buf, n, "conv_gemm_pp_kernel");
-    else if (p.kind == GEMM_PPSK) snprintf(buf, n, "conv_gemm_ppsk_kernel");
     else if (p.kind == GEMM_GLDS) snprintf(buf, n, "conv_gemm_glds_kernel<%s, %d, %d, %d, %d, %d, %d, %s>", t, p.BM, p.BN, p.WM, p.WN, p.BKV, p.NS, p.utap ? "true" : "false");
     else snprintf(buf, n, "conv_gemm_kernel<%s, %d, %d, %d, %d, %d, %s>", t, p.BM, p.BN, p.WM, p.WN, p.BKV, p.utap ? "true" : "false");
-}
-
-// ---- stream-K workspace: one per stream (two streams run these kernels side by side), registered by the host -------------
-#define SK_FLAG_BYTES 4096
-struct SkWorkspace { hipStream_t stream; void* p; size_t bytes; };
-static SkWorkspace sk_ws_table[32];
-static int sk_ws_n = 0;
-static std::mutex sk_ws_mutex;
-extern "C" int et_conv2d_set_workspace(void* ws, int64_t bytes, et_stream_t stream) {
-    if (ws && (bytes < SK_FLAG_BYTES || ((uintptr_t)ws & 15))) return -2;
-    if (ws && hipMemsetAsync(ws, 0, SK_FLAG_BYTES, (hipStream_t)stream) != hipSuccess) return -3;
-    std::lock_guard<std::mutex> lock(sk_ws_mutex);
-    for (int i = 0; i < sk_ws_n; ++i)
-        if (sk_ws_table[i].stream == (hipStream_t)stream) { sk_ws_table[i].p = ws; sk_ws_table[i].bytes = ws ? (size_t)bytes : 0; return 0; }
-    if (sk_ws_n == 32) return -2;
-    sk_ws_table[sk_ws_n++] = SkWorkspace{(hipStream_t)stream, ws, ws ? (size_t)bytes : 0};
-    return 0;
-}
-extern "C" int64_t et_conv2d_workspace_bytes(void) { return (int64_t)SK_FLAG_BYTES + (int64_t)device_cus() * PP_SK_SLOT_FLOATS * 4; }
-static SkWorkspace sk_ws_lookup(hipStream_t s) {
-    std::lock_guard<std::mutex> lock(sk_ws_mutex);
-    for (int i = 0; i < sk_ws_n; ++i)
-        if (sk_ws_table[i].stream == s) return sk_ws_table[i];
-    return SkWorkspace{s, nullptr, 0};
 }
 
 template <typename T>
@@ -1959,20 +1787,7 @@ static int launch_gemm(const void* X, const void* W, void* Y, const void* zero16
 #define ET_REG(BN_, BKV_, UT_) \
     hipLaunchKernelGGL((conv_gemm_kernel<T, 128, BN_, 2, 2, BKV_, UT_>), grid, block, 0, s, x, w, y, g, ep)
     const int key = p.BM * 100000 + p.BN * 100 + p.BKV * 10 + p.NS;
-    if (p.kind == GEMM_PPSK) {
-        if constexpr (sizeof(T) == 2) {
-            // without a registered workspace for this stream the plain ping-pong launch below computes the same thing
-            const SkWorkspace ws = sk_ws_lookup(s);
-            const int G = env_int("ET_CONV_SK_WORKERS", device_cus());
-            if (ws.p && G <= SK_FLAG_BYTES / 4 && ws.bytes >= (size_t)SK_FLAG_BYTES + (size_t)G * PP_SK_SLOT_FLOATS * 4) {
-                const PpStreamK sk{(unsigned*)((char*)ws.p + SK_FLAG_BYTES), (unsigned*)ws.p};
-                hipLaunchKernelGGL(conv_gemm_ppsk_kernel, dim3(G), block, 0, s, (const uint16_t*)x, (const uint16_t*)w, (uint16_t*)y,
-                                   (const uint16_t*)z, g, ep, sk);
-                return 0;
-            }
-        }
-    }
-    if (p.kind == GEMM_PP || p.kind == GEMM_PPSK) {
+    if (p.kind == GEMM_PP) {
         if constexpr (sizeof(T) == 2) {
             hipLaunchKernelGGL(conv_gemm_pp_kernel, grid, block, 0, s, (const uint16_t*)x, (const uint16_t*)w, (uint16_t*)y, (const uint16_t*)z, g, ep);
             return 0;
@@ -2367,7 +2182,7 @@ extern "C" int et_conv2d_kernel_name(int op, int dtype, int N, int IH, int IW, i
 extern "C" int et_env_knobs(char* buf, int buflen) {
     // every ET_* tuning knob that is SET in this process's environment, as "NAME=value;..." (bench.py records it)
     static const char* names[] = {"ET_CONV_TAP_INNER", "ET_CONV_XCD", "ET_CONV_NARROW_K", "ET_CONV_NFAST", "ET_CONV_GLDS",
-                                  "ET_CONV_RING", "ET_CONV_BIG", "ET_CONV_BIG_MINFILL", "ET_CONV_PP", "ET_CONV_SK", "ET_CONV_SK_WORKERS", "ET_CONV_STEM", "ET_WGRAD_TR", "ET_WGRAD_BIG", "ET_WGRAD_BLOCKS",
+                                  "ET_CONV_RING", "ET_CONV_BIG", "ET_CONV_BIG_MINFILL", "ET_CONV_PP", "ET_CONV_STEM", "ET_WGRAD_TR", "ET_WGRAD_BIG", "ET_WGRAD_BLOCKS",
                                   "ET_WGRAD_XCD", "ET_EW_VPT", "ET_WGRAD_GROUP", "ET_WGRAD_STALE", "ET_HIP_LIB"};
     if (!buf || buflen < 1) return -1;
     int off = 0;

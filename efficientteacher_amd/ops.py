@@ -70,21 +70,6 @@ def zero_page(device):
     return z
 
 
-_SK_WORKSPACES = {}
-
-
-def conv_workspace(t):
-    """the stream-K workspace of the 256x256 gather-GEMM for t's device and the current stream, registered with the library on
-    first use (et_conv2d_set_workspace); kept alive here"""
-    key = (t.device, _lib.stream(t))
-    ws = _SK_WORKSPACES.get(key)
-    if ws is None:
-        lib = _lib.load()
-        ws = _SK_WORKSPACES[key] = torch.empty(int(lib.et_conv2d_workspace_bytes()), dtype=torch.uint8, device=t.device)
-        _lib.check(lib.et_conv2d_set_workspace(_lib.ptr(ws), ws.numel(), key[1]), "et_conv2d_set_workspace")
-    return ws
-
-
 _BN_TOTALS = {}
 
 
@@ -140,8 +125,6 @@ def conv2d_fwd(x, w, stride, pad, *, scale=None, bias=None, act=ACT_NONE, residu
                     shape=("fwd", N, IH, IW, Cin, Cout, KH, stride)) if TIMER else None
     if ev:
         ev[0].record()
-    if x.dtype == torch.bfloat16 and Cout >= 256:
-        conv_workspace(x)
     _lib.check(lib.et_conv2d_fwd(_lib.ptr(x), _lib.ptr(w), _lib.ptr(out), et_dtype(x), N, IH, IW, Cin, _nhwc(x),
                                  Cout, KH, KW, stride, pad, _nhwc(out), _lib.ptr(scale), _lib.ptr(bias), act,
                                  _lib.ptr(residual), ldr, _lib.ptr(stats), _lib.ptr(zero_page(x.device)),
@@ -338,8 +321,6 @@ def conv2d_dgrad(dy, wT, in_hw, stride, pad, *, out=None, accumulate=False, resi
                         shape=("dgrad", N, IH, IW, Cin, Cout, KH, stride)) if TIMER else None
         if ev:
             ev[0].record()
-        if dy.dtype == torch.bfloat16 and Cin >= 256:
-            conv_workspace(dy)
         _lib.check(lib.et_conv2d_dgrad_bn(_lib.ptr(dy), _lib.ptr(wT), _lib.ptr(out), et_dtype(dy), N, IH, IW, Cin, _nhwc(out), Cout,
                                           KH, KW, pad, _nhwc(dy), _lib.ptr(residual), _nhwc(residual) if residual is not None else 0,
                                           _lib.ptr(bn.y), _nhwc(bn.y), _lib.ptr(bn.scale), _lib.ptr(bn.shift), bn.act,
@@ -355,8 +336,6 @@ def conv2d_dgrad(dy, wT, in_hw, stride, pad, *, out=None, accumulate=False, resi
                     shape=("dgrad", N, IH, IW, Cin, Cout, KH, stride)) if TIMER else None
     if ev:
         ev[0].record()
-    if dy.dtype == torch.bfloat16 and Cin >= 256:
-        conv_workspace(dy)
     _lib.check(_lib.load().et_conv2d_dgrad(_lib.ptr(dy), _lib.ptr(wT), _lib.ptr(out), et_dtype(dy), N, IH, IW, Cin,
                                            _nhwc(out), Cout, KH, KW, stride, pad, _nhwc(dy), int(accumulate),
                                            _lib.ptr(residual), _nhwc(residual) if residual is not None else 0,

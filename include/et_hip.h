@@ -148,13 +148,6 @@ int et_weight_transpose(const void* w, void* wT, int dtype, int Cout, int taps, 
 int et_conv2d_kernel_name(int op, int dtype, int N, int IH, int IW, int Cin, int Cout, int KH, int KW, int stride,
                           int pad, int have_zero_page, int parity_class, char* buf /*host out*/, int buflen);
 int et_env_knobs(char* buf /*host out*/, int buflen);
-/* Stream-K workspace of the 256x256 ping-pong gather-GEMM (conv_gemm_ppsk_kernel: one persistent workgroup per CU, the
- * K-chunks of all tiles dealt evenly; partial tiles meet in this buffer).  Register ONE buffer of
- * et_conv2d_workspace_bytes() bytes (16-byte aligned) per stream that runs et_conv2d_fwd / et_conv2d_dgrad; the first
- * 4096 bytes are flags, zeroed here (on `stream`) and left zero by every launch.  Streams without a workspace run the
- * whole-tile ping-pong kernel instead (same results up to fp32 summation order).  ws = NULL unregisters. */
-int64_t et_conv2d_workspace_bytes(void);
-int et_conv2d_set_workspace(void* ws, int64_t bytes, et_stream_t stream);
 /* every layer of a flat weight arena at once: table = n_layers x {element offset, Cout, taps, Cin} (int32, device,
  * sorted by offset); wT_arena has the arena's layout with each layer stored (Cin, taps, Cout). */
 int et_weight_transpose_all(const void* w_arena, void* wT_arena, int dtype, const int* table, int n_layers,

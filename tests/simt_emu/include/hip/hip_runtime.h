@@ -175,7 +175,6 @@ static inline void __builtin_amdgcn_s_barrier_emu() { emu::block_sync(); }
 #endif
 #define __builtin_amdgcn_wave_barrier() emu::wave_sync()
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
-#define __builtin_amdgcn_s_sleep(x) ((void)0)
 #define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
 
 template <typename T> static inline T __shfl(T v, int src, int width = 64) {

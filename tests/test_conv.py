@@ -188,37 +188,11 @@ def test_lds_dma_pipelines_under_adversarial_schedules(emu, dma_late, seed):
     for case, kf, kd, kw in (SELECT[0], SELECT[4], SELECT[8]):
         _check_instantiation(emu, case, kf, kd, kw)
     import os
-    os.environ["ET_CONV_SK"], os.environ["ET_CONV_SK_WORKERS"] = "2", "3"     # the stream-K form of the ping-pong kernel
-    try:
-        _check_instantiation(emu, SELECT[0][0], "conv_gemm_ppsk_kernel", ["conv_gemm_ppsk_kernel"], SELECT[0][3])
-    finally:
-        del os.environ["ET_CONV_SK"], os.environ["ET_CONV_SK_WORKERS"]
     os.environ["ET_CONV_STEM_WGS"] = "2"          # 6 tiles on 2 persistent workgroups: the single patch buffer is re-staged
     try:
         _stem_case(emu, 1, 20, 300, 48)
     finally:
         del os.environ["ET_CONV_STEM_WGS"]
-
-
-@pytest.mark.parametrize("workers", [3, 5, 11])
-def test_stream_k_ping_pong(hip, workers, monkeypatch):
-    """conv_gemm_ppsk_kernel: the K-chunks of all 256x256 tiles dealt evenly to a fixed number of persistent workgroups.
-    With 3 / 5 / 11 workers the 4-tile and 1-tile problems below produce every piece kind: whole tiles, a trailing
-    contribution, a leading owned piece, a share that lies inside ONE tile (several contributors per tile), XCD ranges
-    without tiles (11 workers = 8 ranges over 4 tiles) -- element-wise against F.conv2d like every other instantiation."""
-    monkeypatch.setenv("ET_CONV_SK", "2")
-    monkeypatch.setenv("ET_CONV_SK_WORKERS", str(workers))
-    sk = "conv_gemm_ppsk_kernel"
-    _check_instantiation(hip, (2, 20, 20, 256, 256, 3, 1, 1), sk, [sk], "conv_wgrad_tr_kernel<256, 256, 2, 4>")
-    if workers == 5:
-        # one tile, 72 chunks, five shares of 14.4 chunks: four contributors and the owner; Cout / M tails masked
-        _check_instantiation(hip, (1, 12, 12, 512, 264, 3, 1, 1), sk, None, None)
-        # stride-2 dgrad parity classes run the same kernel on their own lattices (the 4-tap class has enough chunks here)
-        from efficientteacher_amd import ops
-        case = (4, 24, 24, 256, 256, 3, 2, 1)
-        names = [ops.kernel_name("dgrad", torch.bfloat16, *case, parity_class=c) for c in range(4)]
-        assert sk in names, names
-        _check_instantiation(hip, case, ops.kernel_name("fwd", torch.bfloat16, *case), names, ops.kernel_name("wgrad", torch.bfloat16, *case))
 
 
 def _check_instantiation(hip, case, kf, kd, kw):
