@@ -247,6 +247,7 @@ class _SsodHotPath(_HotPath):
                                             ni, pbar, callbacks)
         if self.RANK in [-1, 0] and getattr(self, "meter", None) is not None:      # ssod_trainer.py:653-678 (the numbers it prints)
             self.meter.update(items)
+            self.meter.update(self._pseudo_label_hit_rate(unlabeled_gt))
             if pbar is not None and hasattr(pbar, "set_description"):
                 n = len(self.meter.meters.items())
                 mem = f'{torch.cuda.memory_reserved() / 1E9 if torch.cuda.is_available() else 0:.3g}G'
@@ -255,6 +256,36 @@ class _SsodHotPath(_HotPath):
             if callbacks is not None:
                 callbacks.run('on_train_batch_end', ni, self.model, imgs, targets, paths, self.plots, self.sync_bn, self.cfg.Dataset.np)
         return items
+
+    def _pseudo_label_hit_rate(self, unlabeled_gt):
+        """the progress-bar statistics of ssod_trainer.py:657-673 (tp / fp_cls / fp_loc / pse_num / gt_num).  Without ground truth
+        (ssod_hyp.with_gt False, the recipes' setting) they are counts of reliable / uncertain pseudo labels
+        (utils/self_supervised_utils.py:587-609): computed on the device from the padded pseudo-label table; the reference's
+        meter reads them back with .item(), as it does for the loss items.  With ground truth the reference's own matching
+        routine runs on the compacted rows (logging code, host side in the reference too)."""
+        t9, valid = self._last_pseudo
+        lo = torch.as_tensor(self.compute_un_sup_loss.ignore_thres_low, dtype=torch.float64, device=t9.device)
+        hi = torch.as_tensor(self.compute_un_sup_loss.ignore_thres_high, dtype=torch.float64, device=t9.device)
+        v = valid.bool()
+        bs = self.batch_size // self.WORLD_SIZE
+        if getattr(self, "target_with_gt", False):
+            if not bool(v.any()):
+                return dict(tp=0, fp_cls=0, fp_loc=0, pse_num=0, gt_num=0)
+            from utils.self_supervised_utils import check_pseudo_label_with_gt          # the user's tree
+            tp, fp_cls, fp_loc, pse, gt = check_pseudo_label_with_gt(
+                t9[v].float().cpu(), unlabeled_gt.cpu(), ignore_thres_low=lo.tolist(), ignore_thres_high=hi.tolist(), batch_size=bs)
+            return dict(tp=tp, fp_cls=fp_cls, fp_loc=fp_loc, pse_num=pse, gt_num=gt)
+        cls = t9[:, 1].long().clamp_(0, lo.numel() - 1)
+        conf = t9[:, 6]
+        reliable = (v & (conf >= hi[cls])).sum().double() / bs
+        uncertain = (v & (conf < hi[cls]) & (conf >= lo[cls])).sum().double() / bs
+        n = v.sum().double()
+        both = reliable + uncertain
+        zero = torch.zeros((), dtype=torch.float64, device=t9.device)
+        tp = torch.where(both > 0, reliable / both.clamp_min(1e-300), zero)
+        recall = torch.where(n > 0, both * bs / n.clamp_min(1.0), zero)
+        # no pseudo label at all: the reference logs zeros (:657-659); the formulas above give zeros there too
+        return dict(tp=tp, fp_cls=0, fp_loc=recall, pse_num=both, gt_num=reliable)
 
     def _side_stream(self):
         if self._side is None:

@@ -189,6 +189,7 @@ class SSODTrainer(Trainer):
         loss = sup_loss + un_sup_loss * self.cfg.SSOD.teacher_loss_weight
         # 5 backward / optimizer / EMAs (:651)
         self.update_optimizer(loss, ni)
+        self._last_pseudo = (t9, valid)               # for the adapters' progress-bar statistics (ssod_trainer.py:657-673)
         return dict(sup_loss_items, **un_sup_loss_items)
 
     def train_with_unlabeled(self, labeled_batches, unlabeled_batches, start_ni=0):

@@ -135,6 +135,7 @@ def test_reference_epoch_loop_drives_the_hot_path_ssod(emu, ref_callbacks):
         e0 = t.ema.ema.flat_state().params.clone()
         t.last_opt_step = -1
         t.plots = False                                            # the reference's plotting thread needs an older PIL
+        t.target_with_gt = False                                   # the recipes' setting; the LabelMatch test below keeps with_gt
         t.before_epoch()
         t.train_in_epoch(ref_callbacks)                            # -> the reference's train_with_unlabeled -> OUR train_instance
         assert torch.isfinite(t.model.flat_state().params).all()
@@ -143,6 +144,16 @@ def test_reference_epoch_loop_drives_the_hot_path_ssod(emu, ref_callbacks):
         names = set(t.meter.meters.keys())
         assert {"box", "obj", "cls", "ss_box", "ss_obj", "ss_cls"} <= names, names
         assert float(t.meter.meters["ss_obj"].avg) > 0             # pseudo labels reached the unsupervised loss
+        # the progress-bar statistics of ssod_trainer.py:657-673, against the reference's own routine on the last step's labels
+        assert {"tp", "fp_cls", "fp_loc", "pse_num", "gt_num"} <= names, names
+        from utils.self_supervised_utils import check_pseudo_label
+        t9, valid = t._last_pseudo
+        rows = t9[valid.bool()].float().cpu()
+        want = check_pseudo_label(rows, ignore_thres_low=t.compute_un_sup_loss.ignore_thres_low,
+                                  ignore_thres_high=t.compute_un_sup_loss.ignore_thres_high, batch_size=t.batch_size)
+        got = [t.meter.meters[k].val for k in ("tp", "fp_loc", "pse_num", "gt_num")]
+        got, want = [float(np.asarray(x).reshape(-1)[0]) for x in got], [float(x) for x in want]
+        assert rows.shape[0] > 0 and np.allclose(got, want, rtol=1e-12, atol=0), (got, want)
 
 
 def test_reference_epoch_loop_with_labelmatch(emu, ref_callbacks):
