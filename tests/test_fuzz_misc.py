@@ -362,3 +362,85 @@ def test_flat_arena_updates_at_ragged_lengths(dev, n):
         big = dev.t(p0)
         rc = _lib.load().et_ema_update(_lib.ptr(big[1:]), _lib.ptr(big[1:]), n - 1, 0.5, 0.5, _lib.stream(big))
         assert rc == -2
+
+
+@pytest.mark.parametrize("seed,S,nc,B", [(0, 96, 3, 3), (1, 160, 80, 1), (2, 224, 1, 2), (3, 64, 17, 4)])
+def test_tal_loss_random(dev, seed, S, nc, B):
+    """ComputeTalLoss (assigner + class / IoU / DFL terms + gradients) on other image sizes, class counts and target tables
+    (images without targets, tiny and huge boxes) against oracle/v8.py::tal_loss through torch autograd"""
+    from efficientteacher_amd.models.loss import ComputeTalLoss
+    from oracle import v8
+    from tests.test_v8 import _cfg
+    rng = np.random.default_rng(1700 + seed)
+    shapes = [(S // 8, S // 8), (S // 16, S // 16), (S // 32, S // 32)]
+    A = sum(h * w for h, w in shapes)
+    g = torch.Generator().manual_seed(seed)
+    ps = torch.randn(B, A, nc, generator=g) - 2.0
+    pd = torch.randn(B, A, 68, generator=g) * 0.5 + 1.0
+    feats = [torch.zeros(B, 8, h, w) for h, w in shapes]
+    rows = []
+    for b in range(B):
+        n = 0 if (b == 1 and B > 2) else int(rng.integers(1, 9))
+        xy = rng.uniform(0.05, 0.95, (n, 2)); wh = np.exp(rng.uniform(np.log(0.02), np.log(0.9), (n, 2)))
+        rows.append(np.concatenate((np.full((n, 1), b), rng.integers(0, nc, (n, 1)), xy, wh), 1))
+    targets = torch.from_numpy(np.concatenate(rows, 0).astype(np.float32))
+    c2 = _cfg().clone(); c2.defrost(); c2.merge_from_list(["Dataset.img_size", S, "Dataset.nc", nc]); c2.freeze()
+
+    class M:
+        head = None
+    closs = ComputeTalLoss(M(), c2)
+    p1, d1 = dev.t(ps.numpy()).requires_grad_(True), dev.t(pd.numpy()).requires_grad_(True)
+    loss, items = closs(([dev.t(f.numpy()) for f in feats], p1, d1), targets)
+    loss.backward()
+    p2, d2 = ps.clone().requires_grad_(True), pd.clone().requires_grad_(True)
+    rl, ritems = v8.tal_loss((feats, p2, d2), targets, nc=nc, reg_max=16, img_size=S, iou_type=c2.Loss.iou_type,
+                             w_class=c2.Loss.qfl_loss_weight, w_iou=c2.Loss.box_loss_weight, w_dfl=c2.Loss.dfl_loss_weight)
+    rl.backward()
+    assert abs(float(items["num_fg"]) - float(ritems["num_fg"])) < 1e-6
+    assert abs(float(loss.detach()) - float(rl.detach())) <= 5e-5 * abs(float(rl.detach()))
+    assert (p1.grad.cpu() - p2.grad).abs().max().item() <= 2e-5 * max(1.0, p2.grad.abs().max().item()) + 1e-7
+    assert (d1.grad.cpu() - d2.grad).abs().max().item() <= 5e-4 * max(1e-3, d2.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_head_decodes_random(dev, seed):
+    """Detect's inference decode (yolov5_head.py:72-88) and YoloV8Detect's (yolov8_head.py:172-214) on random level shapes, class
+    counts, padded channel strides, fp32 and bf16 logits, written at a random anchor offset of a wider output"""
+    from efficientteacher_amd import ops
+    rng = np.random.default_rng(2100 + seed)
+    B, na = int(rng.integers(1, 4)), 3
+    ny, nx, nc = int(rng.integers(1, 23)), int(rng.integers(1, 23)), int(rng.choice([1, 3, 80]))
+    no = 5 + nc
+    stride = float(rng.choice([8, 16, 32]))
+    dt = torch.bfloat16 if seed % 2 else torch.float32
+    # --- Detect: raw (B, ny, nx, na*no padded to a multiple of 8) viewed as (B, na, ny, nx, no) ------------------------------
+    cp = (na * no + 7) // 8 * 8
+    raw = dev.t(rng.normal(0, 2, (B, ny, nx, cp)).astype(np.float32), dt)
+    raw5 = raw[..., :na * no].view(B, ny, nx, na, no).permute(0, 3, 1, 2, 4)
+    anchors_px = rng.uniform(4, 300, (na, 2)).astype(np.float32)
+    A_lvl, off = na * ny * nx, int(rng.integers(0, 50))
+    z = torch.full((B, off + A_lvl + 7, no), -7.0, dtype=torch.float32, device=dev.device)
+    ops.detect_decode(raw5, dev.t(anchors_px), stride, z, off)
+    y = raw5.float().cpu().sigmoid()
+    gy, gx = torch.meshgrid(torch.arange(ny), torch.arange(nx), indexing="ij")
+    grid = torch.stack((gx, gy), -1).view(1, 1, ny, nx, 2).float()
+    xy = (y[..., 0:2] * 2 - 0.5 + grid) * stride
+    wh = (y[..., 2:4] * 2) ** 2 * torch.from_numpy(anchors_px).view(1, na, 1, 1, 2)
+    ref = torch.cat((xy, wh, y[..., 4:]), -1).reshape(B, A_lvl, no)
+    got = z.cpu()
+    assert (got[:, off:off + A_lvl] - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item())
+    assert (got[:, :off] == -7).all() and (got[:, off + A_lvl:] == -7).all()
+    # --- YoloV8Detect: reg (B,H,W,68 + pad), cls (B,H,W,nc + pad) ------------------------------------------------------------
+    reg_max = 16
+    reg = dev.t(rng.normal(0, 1.5, (B, ny, nx, 72)).astype(np.float32), dt)
+    cls = dev.t(rng.normal(-1, 2, (B, ny, nx, (nc + 7) // 8 * 8)).astype(np.float32), dt)
+    z8 = torch.full((B, off + ny * nx + 5, 5 + nc), -7.0, dtype=torch.float32, device=dev.device)
+    ops.v8_decode(reg, cls, reg_max, nc, stride, 0.5, z8, off)
+    d = reg.float().cpu()[..., :68].reshape(B, ny * nx, 4, 17).softmax(-1) @ torch.arange(17.0)
+    pts = torch.stack((gx.reshape(-1) + 0.5, gy.reshape(-1) + 0.5), -1).float()
+    x1y1, x2y2 = pts - d[..., :2], pts + d[..., 2:]
+    ref8 = torch.cat(((x1y1 + x2y2) / 2 * stride, (x2y2 - x1y1) * stride, torch.ones(B, ny * nx, 1),
+                      cls.float().cpu()[..., :nc].reshape(B, ny * nx, nc).sigmoid()), -1)
+    got8 = z8.cpu()
+    assert (got8[:, off:off + ny * nx] - ref8).abs().max().item() <= 1e-4 * max(1.0, ref8.abs().max().item())
+    assert (got8[:, :off] == -7).all() and (got8[:, off + ny * nx:] == -7).all()
