@@ -51,6 +51,8 @@ def bench_conv(B=64, dtype=torch.bfloat16, with_ref=True):
         kname = ops.kernel_name("fwd", dtype, B, h, h, cin, cout, k, s, p)
         if only and only not in kname and only not in ops.kernel_name("dgrad", dtype, B, h, h, cin, cout, k, s, p):
             continue
+        if os.environ.get("MB_K") and int(os.environ["MB_K"]) != k:       # only layers with this kernel size
+            continue
         x = torch.randn(B, h, h, cin, device=dev).to(dtype)
         w = (torch.randn(cout, k, k, cin, device=dev) * 0.05).to(dtype)
         oh, ow = ops.conv_out_hw(h, h, k, s, p)
@@ -60,8 +62,24 @@ def bench_conv(B=64, dtype=torch.bfloat16, with_ref=True):
         y = torch.empty(B, oh, ow, cout, device=dev, dtype=dtype)
         dx = torch.empty_like(x)
         flop = 2.0 * B * oh * ow * cout * cin * k * k
-        t_f = timeit(lambda: ops.conv2d_fwd(x, w, s, p, out=y))
-        t_d = timeit(lambda: ops.conv2d_dgrad(dy, wT, (h, h), s, p, out=dx)) if k != 6 else 0.0
+        rot = int(os.environ.get("MB_ROTATE", "0"))   # > 0: cycle through that many input / output buffers (defeats the 256 MB MALL)
+        if rot > 1:
+            xs = [x] + [torch.randn_like(x) for _ in range(rot - 1)]; ys = [y] + [torch.empty_like(y) for _ in range(rot - 1)]
+            dys = [dy] + [torch.randn_like(dy) for _ in range(rot - 1)]; dxs = [dx] + [torch.empty_like(dx) for _ in range(rot - 1)]
+            ctr = [0]
+
+            def f_rot():
+                i = ctr[0] = (ctr[0] + 1) % rot
+                ops.conv2d_fwd(xs[i], w, s, p, out=ys[i])
+
+            def d_rot():
+                i = ctr[0] = (ctr[0] + 1) % rot
+                ops.conv2d_dgrad(dys[i], wT, (h, h), s, p, out=dxs[i])
+            t_f = timeit(f_rot, iters=2 * rot)
+            t_d = timeit(d_rot, iters=2 * rot) if k != 6 else 0.0
+        else:
+            t_f = timeit(lambda: ops.conv2d_fwd(x, w, s, p, out=y))
+            t_d = timeit(lambda: ops.conv2d_dgrad(dy, wT, (h, h), s, p, out=dx)) if k != 6 else 0.0
         t_w = timeit(lambda: ops.conv2d_wgrad(x, dy, dw, k, s, p))
         r = dict(cin=cin, cout=cout, k=k, s=s, h=h, count=cnt, gflop=flop / 1e9, fwd_kernel=kname,
                  fwd_ms=t_f * 1e3, dgrad_ms=t_d * 1e3, wgrad_ms=t_w * 1e3,
