@@ -142,19 +142,8 @@ extern "C" int et_debug_read(unsigned long long* host, int n) {
 // ---- one K-chunk of MFMAs from LDS --------------------------------------------------------------
 struct NoBetween { __device__ __forceinline__ void operator()(int) const {} };
 template <typename T, int BM, int BN, int WM, int WN, int BKV, typename BETWEEN = NoBetween>
-__device__ __forceinline__ void mma_chunk_ab(const u32x4* __restrict__ sm, const u32x4* __restrict__ smb,
-                                             f32x16 (&acc)[BM / WM / 32][BN / WN / 32], int wm, int wn, int lane,
-                                             BETWEEN between = BETWEEN());
-// A chunk at sm, B chunk right behind it
-template <typename T, int BM, int BN, int WM, int WN, int BKV, typename BETWEEN = NoBetween>
 __device__ __forceinline__ void mma_chunk(const u32x4* __restrict__ sm, f32x16 (&acc)[BM / WM / 32][BN / WN / 32],
                                           int wm, int wn, int lane, BETWEEN between = BETWEEN()) {
-    mma_chunk_ab<T, BM, BN, WM, WN, BKV, BETWEEN>(sm, sm + BM * BKV, acc, wm, wn, lane, between);
-}
-template <typename T, int BM, int BN, int WM, int WN, int BKV, typename BETWEEN>
-__device__ __forceinline__ void mma_chunk_ab(const u32x4* __restrict__ sm, const u32x4* __restrict__ smb,
-                                             f32x16 (&acc)[BM / WM / 32][BN / WN / 32], int wm, int wn, int lane,
-                                             BETWEEN between) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     const int l31 = lane & 31, g = lane >> 5;
     // Software-pipelined over the k-steps: the fragments of step kk+1 are requested BEFORE the MFMAs of step
@@ -176,7 +165,7 @@ __device__ __forceinline__ void mma_chunk_ab(const u32x4* __restrict__ sm, const
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
             const int r = wn * (BN / WN) + tn * 32 + l31;
-            bf[set][tn] = smb[r * BKV + ((kk * 2 + g) ^ lds_swz<BKV>(r))];
+            bf[set][tn] = sm[(BM + r) * BKV + ((kk * 2 + g) ^ lds_swz<BKV>(r))];
         }
     };
     fetch(0, 0);
@@ -779,86 +768,6 @@ __global__ __launch_bounds__(64 * WM * WN, (NS == 3 && BKV == 4 && BM == 128) ? 
     conv_epilogue<T, BM, BN, WM, WN>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn);
     __syncthreads();
     ET_TS(4);
-}
-
-__device__ __forceinline__ int bx_count(int ntm, int slot, int nslots) { return slot < ntm ? (ntm - slot + nslots - 1) / nslots : 0; }
-
-// ---- 1x1 stride-1 convolutions with K <= 256: a persistent streaming GEMM ------------------------------------------
-// (Bottleneck.cv1, the merged C3 stems, their dgrads: models/backbone/common.py:96-133.)  These layers are 4-8 chunks
-// deep: as ordinary tiles a workgroup lives ~13 us, most of it prologue, first-chunk latency and epilogue, and a grid of
-// 1600 such tiles is 2.08 residency rounds (3 in practice).  Here ONE workgroup per CU (8 waves, two per SIMD) keeps
-// its 128 output channels' weights -- the whole K x 128 matrix -- in LDS for its lifetime and streams 128-row
-// activation tiles through an NS-deep ring of 64-wide chunks: the ring keeps NS-1 chunks in flight ACROSS tile
-// boundaries, so the next tile's activations arrive behind the epilogue of the current one, and the weights are staged
-// once per workgroup instead of once per tile (half of all LDS-DMA instructions of the tile loop).  Workgroups w and
-// w + 8 (same XCD) take the two channel halves of the same row tiles, so the second read of a tile is an L2 hit.
-// The first chunk of a tile waits vmcnt(0): the epilogue's loads / stores are younger than the chunks in flight, and
-// counted waits are only valid among the LDS-DMA pieces themselves.
-template <int KCH>
-__global__ __launch_bounds__(512, 2) void conv1x1_stream_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W,
-                                                                uint16_t* __restrict__ Y, const uint16_t* __restrict__ ZERO,
-                                                                GatherGeom g, Epilogue ep) {
-    constexpr int BM = 128, BN = 128, WM = 2, WN = 4, BKV = 8, VEC = 8;
-    constexpr int NS = KCH >= 4 ? 3 : 4, LOOK = NS - 1;    // ring slots, chunks in flight
-    constexpr int CH_VEC = 128 * BKV;                      // one 128-row x 64-wide chunk, 16 KB
-    constexpr int EPI_VEC = EpiLds<BM, BN, WM, WN>::VEC16;
-    __shared__ __attribute__((aligned(16))) u32x4 lds_raw[(KCH + NS) * CH_VEC + EPI_VEC];
-    u32x4* const smB = lds_raw;                            // [KCH][128 rows][8]
-    u32x4* const ring = lds_raw + KCH * CH_VEC;            // [NS][128 rows][8]
-    u32x4* const slab = ring + NS * CH_VEC;                // epilogue staging
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-    const int lvec = tid & 7, lrow = tid >> 3;             // staging: 64 rows x 8 K-vectors per instruction of the workgroup
-    const int G = gridDim.x, wid = blockIdx.x;
-    // (channel tile, row-tile slot) of this workgroup; host: G is a multiple of 8 * ntn
-    const int by = (wid >> 3) % g.ntn;
-    const int slot = (wid & 7) + 8 * ((wid >> 3) / g.ntn), nslots = G / g.ntn;
-    const int n0 = by * BN;
-    const int ntiles = bx_count(g.ntm, slot, nslots);
-    // weights: all KCH chunks of this channel tile, once
-#pragma unroll
-    for (int c = 0; c < KCH; ++c)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int r = j * 64 + lrow, co = n0 + r;
-            const int lv = lvec ^ lds_swz<BKV>(r);
-            et_glds16(co < g.Cout ? W + ((size_t)co * g.Cin + (c * BKV + lv) * VEC) : ZERO, smB + c * CH_VEC + j * 512 + wave * 64);
-        }
-    // chunk q of this workgroup's stream = chunk q % KCH of its (q / KCH)-th row tile
-    auto stage = [&](int q) {
-        const int it = q / KCH, c = q - it * KCH;
-        const int m0 = (slot + it * nslots) * BM;
-        u32x4* const dst = ring + (q % NS) * CH_VEC + wave * 64;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int r = j * 64 + lrow, p = m0 + r;
-            const int lv = lvec ^ lds_swz<BKV>(r);
-            et_glds16(p < g.M ? X + ((size_t)p * g.ldx + (c * BKV + lv) * VEC) : ZERO, dst + j * 512);
-        }
-    };
-    const int nq = ntiles * KCH;
-#pragma unroll
-    for (int q = 0; q < LOOK; ++q)
-        if (q < nq) stage(q);
-    f32x16 acc[2][1];
-    int q = 0;
-    for (int it = 0; it < ntiles; ++it) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { acc[0][0][r] = 0.f; acc[1][0][r] = 0.f; }
-#pragma unroll
-        for (int c = 0; c < KCH; ++c, ++q) {
-            // chunk q has landed once only the younger LDS-DMA chunks of this wave are in flight
-            if (c == 0 || q + LOOK > nq) et_wait_vmem();
-            else et_wait_vmem_le<(LOOK - 1) * 2>();
-            __builtin_amdgcn_s_barrier();                  // ... for every wave; and slot (q-1) % NS has been read by all
-            if (q + LOOK < nq) stage(q + LOOK);
-            mma_chunk_ab<uint16_t, BM, BN, WM, WN, BKV>(ring + (q % NS) * CH_VEC, smB + c * CH_VEC, acc, wm, wn, lane);
-        }
-        const int bx = slot + it * nslots;
-        conv_epilogue<uint16_t, BM, BN, WM, WN>(acc, slab, Y, g, ep, bx, bx * BM, n0, tid, lane, wm, wn);
-    }
 }
 
 // ---- forward / dgrad gather-GEMM, 256x256 tile, two wave groups in anti-phase ("ping-pong") ----------------
@@ -1804,16 +1713,8 @@ static int fill_common(GatherGeom& g, int N, int IH, int IW, int Cin, int ldx, i
 // ---- kernel selection ---------------------------------------------------------------------------------
 // ONE place decides which instantiation runs; et_conv2d_kernel_name() reports the same decision to the tests and
 // to bench.py's roofline tags (there is no second copy of this logic on the Python side).
-enum { GEMM_REG = 0, GEMM_GLDS = 1, GEMM_PP = 2, GEMM_S1X1 = 3 };
+enum { GEMM_REG = 0, GEMM_GLDS = 1, GEMM_PP = 2 };
 struct GemmPlan { int kind, BM, BN, WM, WN, BKV, NS; bool utap; };
-
-// workgroups of the streaming 1x1 kernel: one per CU, a multiple of 8 * (channel tiles); 0 = not worth it (< 2 tiles each)
-static int s1x1_grid(const GatherGeom& g) {
-    const int ntm = (g.M + 127) / 128, ntn = (g.Cout + 127) / 128;
-    const int want = env_int("ET_CONV_S1X1_WGS", device_cus());
-    const int G = want / (8 * ntn) * (8 * ntn);
-    return (G > 0 && (long long)ntm * ntn >= 2ll * G && (long long)g.M * g.ldx < (1ll << 31)) ? G : 0;
-}
 
 static GemmPlan plan_gemm(const GatherGeom& g, int elem_bytes, bool have_zero_page) {
     // tuning knobs, read once.  ET_CONV_NARROW_K=<K>: GEMMs with K <= K elements use the 128x64 tile (smaller
@@ -1832,16 +1733,6 @@ static GemmPlan plan_gemm(const GatherGeom& g, int elem_bytes, bool have_zero_pa
     const bool glds = use_glds && have_zero_page;
     GemmPlan p{glds ? GEMM_GLDS : GEMM_REG, 128, wide ? 128 : 64, 2, 2, g.CV % 8 == 0 ? 8 : 4, 2, g.CV % 4 == 0};
     if (!(bf16 && glds && g.CV % 8 == 0)) return p;
-    // persistent streaming GEMM for 1x1 stride-1 layers with K = 64 / 128 / 256 and >= 128 output channels, when the grid is at
-    // least two tiles per workgroup (ET_CONV_S1X1=0: off; ET_CONV_S1X1_WGS: workgroup count, read per launch -- the tests
-    // shrink it to exercise the tile loop)
-    {
-        static const int use_s1 = env_int("ET_CONV_S1X1", 1);
-        const bool plain = g.T == 1 && g.TT == 1 && g.dy[0] == 0 && g.dx[0] == 0 && g.wt[0] == 0 && g.isy == 1 && g.isx == 1 &&
-                           g.IH == g.QH && g.IW == g.QW;      // row p of the GEMM is pixel p of the gathered tensor
-        if (use_s1 && plain && (g.Cin == 64 || g.Cin == 128 || g.Cin == 256) && g.Cout >= 128 && s1x1_grid(g) > 0)
-            return GemmPlan{GEMM_S1X1, 128, 128, 2, 4, 8, g.Cin / 64, true};
-    }
     // short-K GEMMs (K <= 256, i.e. <= 4 chunks of 64) run 32-wide chunks in a 3-deep ring -- 48 KB of LDS, three
     // workgroups per CU, two chunks in flight each (measured 3-10 % on the 1x1 layers); everything else the 64-wide
     // double buffer (deeper rings or taller 4-wave tiles cost occupancy and lose: profiles/)
@@ -1876,7 +1767,6 @@ static GemmPlan plan_gemm(const GatherGeom& g, int elem_bytes, bool have_zero_pa
 static void plan_name(const GemmPlan& p, int elem_bytes, char* buf, int n) {
     const char* t = elem_bytes == 2 ? "unsigned short" : "float";
     if (p.kind == GEMM_PP) snprintf(buf, n, "conv_gemm_pp_kernel");
-    else if (p.kind == GEMM_S1X1) snprintf(buf, n, "conv1x1_stream_kernel<%d>", p.NS);
     else if (p.kind == GEMM_GLDS) snprintf(buf, n, "conv_gemm_glds_kernel<%s, %d, %d, %d, %d, %d, %d, %s>", t, p.BM, p.BN, p.WM, p.WN, p.BKV, p.NS, p.utap ? "true" : "false");
     else snprintf(buf, n, "conv_gemm_kernel<%s, %d, %d, %d, %d, %d, %s>", t, p.BM, p.BN, p.WM, p.WN, p.BKV, p.utap ? "true" : "false");
 }
@@ -1897,16 +1787,6 @@ static int launch_gemm(const void* X, const void* W, void* Y, const void* zero16
 #define ET_REG(BN_, BKV_, UT_) \
     hipLaunchKernelGGL((conv_gemm_kernel<T, 128, BN_, 2, 2, BKV_, UT_>), grid, block, 0, s, x, w, y, g, ep)
     const int key = p.BM * 100000 + p.BN * 100 + p.BKV * 10 + p.NS;
-    if (p.kind == GEMM_S1X1) {
-        if constexpr (sizeof(T) == 2) {
-            const dim3 sgrid(s1x1_grid(g)), sblock(512);
-#define ET_S1(KCH_) hipLaunchKernelGGL(conv1x1_stream_kernel<KCH_>, sgrid, sblock, 0, s, (const uint16_t*)x, (const uint16_t*)w, (uint16_t*)y, (const uint16_t*)z, g, ep)
-            if (p.NS == 1) { ET_S1(1); } else if (p.NS == 2) { ET_S1(2); } else { ET_S1(4); }
-#undef ET_S1
-            return 0;
-        }
-        return -2;
-    }
     if (p.kind == GEMM_PP) {
         if constexpr (sizeof(T) == 2) {
             hipLaunchKernelGGL(conv_gemm_pp_kernel, grid, block, 0, s, (const uint16_t*)x, (const uint16_t*)w, (uint16_t*)y, (const uint16_t*)z, g, ep);
@@ -2272,7 +2152,7 @@ extern "C" int et_conv2d_kernel_name(int op, int dtype, int N, int IH, int IW, i
         wgrad_plan_name(plan_wgrad(g, eb, have_zero_page != 0), eb, buf, buflen);
         return 0;
     }
-    GatherGeom g{};
+    GatherGeom g;
     if (op == 0) {
         if (try_launch_stem(nullptr, nullptr, nullptr, dtype, N, IH, IW, Cin, Cin, Cout, KH, KW, stride, pad, Cout, nullptr, nullptr, 0,
                             nullptr, nullptr, have_zero_page ? (const void*)buf : nullptr, nullptr, false)) {
@@ -2282,8 +2162,6 @@ extern "C" int et_conv2d_kernel_name(int op, int dtype, int N, int IH, int IW, i
         g.T = g.TT = KH * KW;
         if (Cin % vec) return -2;
         g.Cin = Cin; g.Cout = Cout; g.CV = Cin / vec; g.KV = g.T * g.CV; g.M = N * OH * OW;
-        g.IH = IH; g.IW = IW; g.QH = OH; g.QW = OW; g.ldx = Cin; g.isy = g.isx = stride;
-        g.dy[0] = g.dx[0] = (signed char)(-pad);
     } else if (op == 1) {
         if (stride > 2 || Cout % vec) return -2;
         const int py = parity_class / stride, px = parity_class % stride;
@@ -2291,16 +2169,11 @@ extern "C" int et_conv2d_kernel_name(int op, int dtype, int N, int IH, int IW, i
         int t = 0;
         for (int ky = 0; ky < KH; ++ky) {
             if ((py + pad - ky) % stride) continue;
-            for (int kx = 0; kx < KW; ++kx)
-                if (!((px + pad - kx) % stride)) {
-                    if (t == 0) { g.dy[0] = (signed char)((py + pad - ky) / stride); g.dx[0] = (signed char)((px + pad - kx) / stride); g.wt[0] = (unsigned char)(ky * KW + kx); }
-                    ++t;
-                }
+            for (int kx = 0; kx < KW; ++kx) if (!((px + pad - kx) % stride)) ++t;
         }
         g.T = t; g.TT = KH * KW;
         const int QH = (IH - py + stride - 1) / stride, QW = (IW - px + stride - 1) / stride;
         g.Cin = Cout; g.Cout = Cin; g.CV = Cout / vec; g.KV = g.T * g.CV; g.M = N * QH * QW;
-        g.IH = OH; g.IW = OW; g.QH = QH; g.QW = QW; g.ldx = Cout; g.isy = g.isx = 1;
     } else return -2;
     plan_name(plan_gemm(g, eb, have_zero_page != 0), eb, buf, buflen);
     return 0;
@@ -2309,7 +2182,7 @@ extern "C" int et_conv2d_kernel_name(int op, int dtype, int N, int IH, int IW, i
 extern "C" int et_env_knobs(char* buf, int buflen) {
     // every ET_* tuning knob that is SET in this process's environment, as "NAME=value;..." (bench.py records it)
     static const char* names[] = {"ET_CONV_TAP_INNER", "ET_CONV_XCD", "ET_CONV_NARROW_K", "ET_CONV_NFAST", "ET_CONV_GLDS",
-                                  "ET_CONV_RING", "ET_CONV_BIG", "ET_CONV_BIG_MINFILL", "ET_CONV_PP", "ET_CONV_S1X1", "ET_CONV_STEM", "ET_WGRAD_TR", "ET_WGRAD_BIG", "ET_WGRAD_BLOCKS",
+                                  "ET_CONV_RING", "ET_CONV_BIG", "ET_CONV_BIG_MINFILL", "ET_CONV_PP", "ET_CONV_STEM", "ET_WGRAD_TR", "ET_WGRAD_BIG", "ET_WGRAD_BLOCKS",
                                   "ET_WGRAD_XCD", "ET_EW_VPT", "ET_WGRAD_GROUP", "ET_WGRAD_STALE", "ET_HIP_LIB"};
     if (!buf || buflen < 1) return -1;
     int off = 0;

@@ -188,32 +188,11 @@ def test_lds_dma_pipelines_under_adversarial_schedules(emu, dma_late, seed):
     for case, kf, kd, kw in (SELECT[0], SELECT[4], SELECT[8]):
         _check_instantiation(emu, case, kf, kd, kw)
     import os
-    os.environ["ET_CONV_S1X1_WGS"] = "16"         # the streaming 1x1 kernel: ring slots re-staged across tile boundaries
-    try:
-        _check_instantiation(emu, (2, 32, 32, 256, 256, 1, 1, 0), "conv1x1_stream_kernel<4>", ["conv1x1_stream_kernel<4>"],
-                             "conv_wgrad_tr_kernel<128, 128, 2, 2>")
-    finally:
-        del os.environ["ET_CONV_S1X1_WGS"]
     os.environ["ET_CONV_STEM_WGS"] = "2"          # 6 tiles on 2 persistent workgroups: the single patch buffer is re-staged
     try:
         _stem_case(emu, 1, 20, 300, 48)
     finally:
         del os.environ["ET_CONV_STEM_WGS"]
-
-
-@pytest.mark.parametrize("case,kch", [((2, 32, 32, 128, 128, 1, 1, 0), 2), ((2, 32, 32, 256, 256, 1, 1, 0), 4),
-                                      ((2, 32, 32, 64, 128, 1, 1, 0), 1), ((1, 45, 47, 128, 136, 1, 1, 0), 2)])
-def test_streaming_1x1(hip, case, kch, monkeypatch):
-    """conv1x1_stream_kernel: persistent workgroups, weights resident in LDS, activation chunks ringed across tile boundaries.
-    8 / 16 workgroups here, so every workgroup runs 2-3 row tiles (ring wrap, the drain before a tile's first chunk, the tail
-    chunks); the last case has ragged rows (M = 2115) and a partial channel tile (Cout = 136).  Forward (+ statistics, folded
-    scale / bias / SiLU / residual into a channel slice) and dgrad (+ residual) element-wise against F.conv2d."""
-    from efficientteacher_amd import ops
-    monkeypatch.setenv("ET_CONV_S1X1_WGS", "16" if case[4] > 128 else "8")
-    names = [ops.kernel_name("dgrad", torch.bfloat16, *case)]
-    _check_instantiation(hip, case, f"conv1x1_stream_kernel<{kch}>", names, ops.kernel_name("wgrad", torch.bfloat16, *case))
-    if case[3] == case[4]:
-        assert names[0] == f"conv1x1_stream_kernel<{kch}>"
 
 
 def _check_instantiation(hip, case, kf, kd, kw):
