@@ -128,7 +128,7 @@ template <int BKV> __device__ __forceinline__ int lds_swz(int r) {
     else return (r >> 2) & 3;
 }
 
-#if defined(ET_ABLATE) && (ET_ABLATE == 9)
+#if (defined(ET_ABLATE) && (ET_ABLATE == 9)) || defined(ET_STAMPS)
 // experiment build only: per-workgroup phase timestamps (s_memtime) of the LDS-DMA gather-GEMM
 __device__ unsigned long long et_dbg_ts[8 * 16384];
 extern "C" int et_debug_read(unsigned long long* host, int n) {
@@ -300,7 +300,11 @@ __device__ __forceinline__ void conv_epilogue_act(f32x16 (&acc)[BM / WM / 32][BN
                         }
                         const u32x4 packed = mk4(et_pack_bf2(v[0], v[1]), et_pack_bf2(v[2], v[3]), et_pack_bf2(v[4], v[5]),
                                                  et_pack_bf2(v[6], v[7]));
+#if defined(ET_ABLATE) && (ET_ABLATE == 60)
+                        asm volatile("" :: "v"(packed), "v"(yp));     // experiment: no global stores
+#else
                         *(u32x4*)yp = packed;
+#endif
                         if (bnb) {
                             // statistics of exactly what the apply pass will read back: the bf16-ROUNDED dz
                             const u32x4 yy = *(const u32x4*)((const T*)ep.bn_y + pix * ep.ld_bn + co);

@@ -15,6 +15,18 @@ static inline int et_cdiv(long long a, long long b) { return (int)((a + b - 1) /
 
 // ---- bf16 <-> f32 (round-to-nearest-even), storage type is uint16_t -------------------------
 __device__ __forceinline__ float et_bf2f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+#if defined(__HIP_DEVICE_COMPILE__)
+// gfx950 converts in hardware: v_cvt_pk_bf16_f32, round-to-nearest-even, two values per instruction (the bit-twiddling form
+// below is 7-8 VALU instructions per VALUE -- it was a third of the conv epilogue's and of the BN passes' instruction count)
+typedef __bf16 et_bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float et_f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t et_pack_bf2(float lo, float hi) {
+    const et_f32x2_t f = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, et_bf16x2_t));
+}
+__device__ __forceinline__ uint16_t et_f2bf(float f) { return (uint16_t)(et_pack_bf2(f, 0.f) & 0xffffu); }
+#else
+// host-side (CPU emulator) form of the same rounding
 __device__ __forceinline__ uint16_t et_f2bf(float f) {
     uint32_t u = __float_as_uint(f);
     if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // quiet NaN
@@ -24,6 +36,7 @@ __device__ __forceinline__ uint16_t et_f2bf(float f) {
 __device__ __forceinline__ uint32_t et_pack_bf2(float lo, float hi) {
     return (uint32_t)et_f2bf(lo) | ((uint32_t)et_f2bf(hi) << 16);
 }
+#endif
 
 // element-type traits: T = float (parity mode) or uint16_t holding bf16 (performance mode)
 template <typename T> struct et_elem;
