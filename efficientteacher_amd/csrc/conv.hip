@@ -244,6 +244,26 @@ __device__ __forceinline__ void conv_epilogue_act(f32x16 (&acc)[BM / WM / 32][BN
 #pragma unroll
         for (int e = 0; e < 8; ++e) { bsc[e] = ep.bn_scale[co + e]; bsh[e] = ep.bn_shift[co + e]; }
     }
+    // sums of du = dz * act'(y*s + b) and du*y over 8 channels of one pixel; the activation kind is resolved by ONE uniform
+    // branch per call (it used to be a scalar compare-and-branch chain per element: ~25 instructions each)
+    auto bn_bwd_sums = [&](const float (&dz8)[8], const float (&y8)[8]) {
+        auto body = [&](auto act_tag) {
+            constexpr int BACT = decltype(act_tag)::value;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float u = y8[e] * bsc[e] + bsh[e];
+                float gact = 1.f;
+                if constexpr (BACT == ACT_SILU) { const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-u)); gact = sg * (1.0f + u * (1.0f - sg)); }
+                else if constexpr (BACT == ACT_RELU) gact = u > 0.f ? 1.f : 0.f;
+                const float du = dz8[e] * gact;
+                bs1[e] += du;
+                bs2[e] += du * y8[e];
+            }
+        };
+        if (ep.bn_act == ACT_SILU) body(std::integral_constant<int, ACT_SILU>{});
+        else if (ep.bn_act == ACT_RELU) body(std::integral_constant<int, ACT_RELU>{});
+        else body(std::integral_constant<int, ACT_NONE>{});
+    };
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
@@ -309,18 +329,13 @@ __device__ __forceinline__ void conv_epilogue_act(f32x16 (&acc)[BM / WM / 32][BN
                             // statistics of exactly what the apply pass will read back: the bf16-ROUNDED dz
                             const u32x4 yy = *(const u32x4*)((const T*)ep.bn_y + pix * ep.ld_bn + co);
                             const unsigned pw[4] = {packed.x, packed.y, packed.z, packed.w}, yw[4] = {yy.x, yy.y, yy.z, yy.w};
+                            float dz8[8], y8[8];
 #pragma unroll
                             for (int e = 0; e < 8; ++e) {
-                                const float dz = __uint_as_float((e & 1) ? (pw[e >> 1] & 0xffff0000u) : (pw[e >> 1] << 16));
-                                const float yv = __uint_as_float((e & 1) ? (yw[e >> 1] & 0xffff0000u) : (yw[e >> 1] << 16));
-                                const float u = yv * bsc[e] + bsh[e];
-                                float gact = 1.f;
-                                if (ep.bn_act == ACT_SILU) { const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-u)); gact = sg * (1.0f + u * (1.0f - sg)); }
-                                else if (ep.bn_act == ACT_RELU) gact = u > 0.f ? 1.f : 0.f;
-                                const float du = dz * gact;
-                                bs1[e] += du;
-                                bs2[e] += du * yv;
+                                dz8[e] = __uint_as_float((e & 1) ? (pw[e >> 1] & 0xffff0000u) : (pw[e >> 1] << 16));
+                                y8[e] = __uint_as_float((e & 1) ? (yw[e >> 1] & 0xffff0000u) : (yw[e >> 1] << 16));
                             }
+                            bn_bwd_sums(dz8, y8);
                         }
                     } else {
                         if (ep.res) {
@@ -338,16 +353,7 @@ __device__ __forceinline__ void conv_epilogue_act(f32x16 (&acc)[BM / WM / 32][BN
                             const float* bp = (const float*)ep.bn_y + pix * ep.ld_bn + co;
                             const float4 y0 = *(const float4*)bp, y1 = *(const float4*)(bp + 4);
                             const float yv8[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) {
-                                const float u = yv8[e] * bsc[e] + bsh[e];
-                                float gact = 1.f;
-                                if (ep.bn_act == ACT_SILU) { const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-u)); gact = sg * (1.0f + u * (1.0f - sg)); }
-                                else if (ep.bn_act == ACT_RELU) gact = u > 0.f ? 1.f : 0.f;
-                                const float du = v[e] * gact;
-                                bs1[e] += du;
-                                bs2[e] += du * yv8[e];
-                            }
+                            bn_bwd_sums(v, yv8);
                         }
                     }
                 } else {
