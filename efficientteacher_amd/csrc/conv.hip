@@ -237,6 +237,7 @@ __device__ __forceinline__ void conv_epilogue_act(f32x16 (&acc)[BM / WM / 32][BN
     const int co = n0 + wn * WCOLS + scv * 8;
     // BN-backward statistics mode: this lane owns 8 channels in the store phase; per-channel affine in registers
     const bool bnb = ep.bn_y != nullptr;
+    const bool lean = ident && !bnb && ep.res == nullptr && !ep.accumulate && m0 + BM <= g.M && n0 + BN <= g.Cout;   // uniform
     float bsc[8], bsh[8], bs1[8], bs2[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { bsc[e] = 1.f; bsh[e] = 0.f; bs1[e] = 0.f; bs2[e] = 0.f; }
@@ -284,6 +285,23 @@ __device__ __forceinline__ void conv_epilogue_act(f32x16 (&acc)[BM / WM / 32][BN
         // only keep the compiler (and the CPU emulator's per-lane fibers) from reordering across it
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_wave_barrier();
+        if constexpr (sizeof(T) == 2) {
+            if (lean) {
+                // interior tile of a plain bf16 layer (no residual / accumulate / BN-backward sums, identity pixel map): the store
+                // pass without a single guard or branch, so that the compiler can overlap the slab reads of the four iterations
+#pragma unroll
+                for (int it = 0; it < 32 / RPI; ++it) {
+                    const int row = it * RPI + srow;
+                    const long long p = m0 + wm * (BM / WM) + tm * 32 + row;
+                    const float4 a = *(const float4*)(stg + row * SLD + scv * 8);
+                    const float4 b = *(const float4*)(stg + row * SLD + scv * 8 + 4);
+                    *(u32x4*)(Y + p * g.ldy + co) = mk4(et_pack_bf2(a.x, a.y), et_pack_bf2(a.z, a.w), et_pack_bf2(b.x, b.y), et_pack_bf2(b.z, b.w));
+                }
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                __builtin_amdgcn_wave_barrier();
+                continue;
+            }
+        }
 #pragma unroll
         for (int it = 0; it < 32 / RPI; ++it) {
             const int row = it * RPI + srow;
