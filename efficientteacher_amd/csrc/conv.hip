@@ -1652,17 +1652,31 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_tr_kernel(WgradGroup 
     if (nchunks <= 0) return;
     ET_TS(3);
     const int l31 = lane & 31, hi = lane >> 5;
+    if (m0 + BM <= g.Cout && n0 + BN <= g.NC) {
+        // interior tile: no per-lane guards (they compiled to an exec-mask save + branch around EVERY atomic: 12 instructions
+        // per atomic), one row pointer per accumulator row, the column tiles as immediate offsets
+        float* const base = DW + ((size_t)(m0 + wm * (BM / WM) + 4 * hi) * g.NC + n0 + wn * (BN / WN) + l31);
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
+        for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = m0 + wm * (BM / WM) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            for (int r = 0; r < 16; ++r) {
+                float* const rowp = base + (size_t)(tm * 32 + (r & 3) + 8 * (r >> 2)) * g.NC;
 #pragma unroll
-            for (int tn = 0; tn < TN; ++tn) {
-                const int col = n0 + wn * (BN / WN) + tn * 32 + l31;
-                if (co < g.Cout && col < g.NC) atomicAdd(DW + ((size_t)co * g.NC + col), acc[tm][tn][r]);
+                for (int tn = 0; tn < TN; ++tn) atomicAdd(rowp + tn * 32, acc[tm][tn][r]);
             }
-        }
+    } else {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = m0 + wm * (BM / WM) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    const int col = n0 + wn * (BN / WN) + tn * 32 + l31;
+                    if (co < g.Cout && col < g.NC) atomicAdd(DW + ((size_t)co * g.NC + col), acc[tm][tn][r]);
+                }
+            }
+    }
 #if defined(ET_ABLATE) && (ET_ABLATE == 9)
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
