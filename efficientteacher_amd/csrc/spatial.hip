@@ -11,9 +11,9 @@
 
 template <typename T>
 __global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict__ x, T* __restrict__ y, int C, int HW, long long total) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;      // pixel index over B*H*W
-    if (i >= total) return;
-    const long long b = i / HW, hw = i - b * HW;
+    const unsigned iu = blockIdx.x * 256u + threadIdx.x;                // pixel index over B*H*W (host: < 2^31; 32-bit divisions)
+    if (iu >= total) return;
+    const long long i = iu, b = iu / (unsigned)HW, hw = iu - (unsigned)b * (unsigned)HW;
     T v[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) v[c] = et_elem<T>::st(c < C ? x[(b * C + c) * HW + hw] : 0.f);
@@ -30,9 +30,9 @@ __global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict
 template <typename T>
 __global__ __launch_bounds__(256) void pack_input_u8_kernel(const uint8_t* __restrict__ x, T* __restrict__ y, int C, int HW,
                                                             long long total, float scale) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;      // pixel index over B*H*W
-    if (i >= total) return;
-    const long long b = i / HW, hw = i - b * HW;
+    const unsigned iu = blockIdx.x * 256u + threadIdx.x;                // pixel index over B*H*W (host: < 2^31; 32-bit divisions)
+    if (iu >= total) return;
+    const long long i = iu, b = iu / (unsigned)HW, hw = iu - (unsigned)b * (unsigned)HW;
     T v[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) v[c] = et_elem<T>::st(c < C ? (float)x[(b * C + c) * HW + hw] / scale : 0.f);
@@ -66,13 +66,14 @@ template <typename T>
 __global__ __launch_bounds__(256) void maxpool5_fwd_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy,
                                                            unsigned char* __restrict__ idx, int H, int W, int CV, long long total) {
     constexpr int N = PV<T>::N;
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;   // over B*H*W*CV
-    if (i >= total) return;
-    const int cv = (int)(i % CV);
-    const long long p = i / CV;
-    const int ox = (int)(p % W);
-    const int oy = (int)((p / W) % H);
-    const long long b = p / ((long long)W * H);
+    const unsigned iu = blockIdx.x * 256u + threadIdx.x;   // over B*H*W*CV
+    if (iu >= total) return;                                  // host: total < 2^31 (32-bit divisions: the 64-bit ones were ~600 instructions per thread)
+    const unsigned pu = iu / (unsigned)CV, tu = pu / (unsigned)W;
+    const int cv = (int)(iu - pu * (unsigned)CV);
+    const long long p = pu;
+    const int ox = (int)(pu - tu * (unsigned)W);
+    const long long b = tu / (unsigned)H;
+    const int oy = (int)(tu - (unsigned)b * (unsigned)H);
     float best[N];
     unsigned char bi[N];
 #pragma unroll
@@ -102,13 +103,14 @@ __global__ __launch_bounds__(256) void maxpool5_bwd_kernel(const T* __restrict__
                                                            const T* __restrict__ base, int ldb, T* __restrict__ dx, int lddx,
                                                            int H, int W, int CV, long long total) {
     constexpr int N = PV<T>::N;
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    const int cv = (int)(i % CV);
-    const long long p = i / CV;
-    const int ix = (int)(p % W);
-    const int iy = (int)((p / W) % H);
-    const long long b = p / ((long long)W * H);
+    const unsigned iu = blockIdx.x * 256u + threadIdx.x;
+    if (iu >= total) return;                                  // host: total < 2^31 (32-bit divisions: the 64-bit ones were ~600 instructions per thread)
+    const unsigned pu = iu / (unsigned)CV, tu = pu / (unsigned)W;
+    const int cv = (int)(iu - pu * (unsigned)CV);
+    const long long p = pu;
+    const int ix = (int)(pu - tu * (unsigned)W);
+    const long long b = tu / (unsigned)H;
+    const int iy = (int)(tu - (unsigned)b * (unsigned)H);
     float acc[N];
     if (base) PV<T>::load(base + p * ldb + cv * N, acc);
     else {
@@ -138,13 +140,14 @@ __global__ __launch_bounds__(256) void maxpool5_bwd_kernel(const T* __restrict__
 template <typename T>
 __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, int H, int W,
                                                              int CV, long long total) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;   // over B*2H*2W*CV
-    if (i >= total) return;
-    const int cv = (int)(i % CV);
-    const long long p = i / CV;
-    const int ox = (int)(p % (2 * W));
-    const int oy = (int)((p / (2 * W)) % (2 * H));
-    const long long b = p / ((long long)4 * W * H);
+    const unsigned iu = blockIdx.x * 256u + threadIdx.x;             // over B*2H*2W*CV (host: < 2^31)
+    if (iu >= total) return;
+    const unsigned pu = iu / (unsigned)CV, tu = pu / (unsigned)(2 * W);
+    const int cv = (int)(iu - pu * (unsigned)CV);
+    const long long p = pu;
+    const int ox = (int)(pu - tu * (unsigned)(2 * W));
+    const long long b = tu / (unsigned)(2 * H);
+    const int oy = (int)(tu - (unsigned)b * (unsigned)(2 * H));
     const uint4 v = *(const uint4*)((const char*)(x + ((b * H + (oy >> 1)) * W + (ox >> 1)) * ldx) + (size_t)cv * 16);
     *(uint4*)((char*)(y + p * ldy) + (size_t)cv * 16) = v;
 }
@@ -154,13 +157,14 @@ template <typename T>
 __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const T* __restrict__ dy, int lddy, T* __restrict__ dx, int lddx, int H, int W,
                                                              int CV, long long total) {
     constexpr int N = PV<T>::N;
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;   // over B*H*W*CV
-    if (i >= total) return;
-    const int cv = (int)(i % CV);
-    const long long p = i / CV;
-    const int w = (int)(p % W);
-    const int h = (int)((p / W) % H);
-    const long long b = p / ((long long)W * H);
+    const unsigned iu = blockIdx.x * 256u + threadIdx.x;   // over B*H*W*CV
+    if (iu >= total) return;                                  // host: total < 2^31 (32-bit divisions: the 64-bit ones were ~600 instructions per thread)
+    const unsigned pu = iu / (unsigned)CV, tu = pu / (unsigned)W;
+    const int cv = (int)(iu - pu * (unsigned)CV);
+    const long long p = pu;
+    const int w = (int)(pu - tu * (unsigned)W);
+    const long long b = tu / (unsigned)H;
+    const int h = (int)(tu - (unsigned)b * (unsigned)H);
     float acc[N];
 #pragma unroll
     for (int k = 0; k < N; ++k) acc[k] = 0.f;
@@ -179,6 +183,7 @@ extern "C" int et_pack_input(const float* x_nchw, void* y_nhwc8, int dtype, int 
     if (!x_nchw || !y_nhwc8) return -1;
     if (B <= 0 || C <= 0 || C > 8 || H <= 0 || W <= 0) return -2;
     const long long total = (long long)B * H * W;
+    if (total >= (1ll << 31)) return -2;               // the kernels index with 32-bit arithmetic
     const dim3 grid(et_cdiv(total, 256));
     if (dtype == ET_F32) hipLaunchKernelGGL((pack_input_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, x_nchw, (float*)y_nhwc8, C, H * W, total);
     else if (dtype == ET_BF16) hipLaunchKernelGGL((pack_input_kernel<uint16_t>), grid, dim3(256), 0, (hipStream_t)stream, x_nchw, (uint16_t*)y_nhwc8, C, H * W, total);
@@ -192,6 +197,7 @@ extern "C" int et_pack_input_u8(const uint8_t* x_nchw, void* y_nhwc8, int dtype,
     if (!x_nchw || !y_nhwc8) return -1;
     if (B <= 0 || C <= 0 || C > 8 || H <= 0 || W <= 0 || !(norm_scale > 0.f)) return -2;
     const long long total = (long long)B * H * W;
+    if (total >= (1ll << 31)) return -2;               // the kernels index with 32-bit arithmetic
     const dim3 grid(et_cdiv(total, 256));
     if (dtype == ET_F32) hipLaunchKernelGGL((pack_input_u8_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, x_nchw, (float*)y_nhwc8, C, H * W, total, norm_scale);
     else if (dtype == ET_BF16) hipLaunchKernelGGL((pack_input_u8_kernel<uint16_t>), grid, dim3(256), 0, (hipStream_t)stream, x_nchw, (uint16_t*)y_nhwc8, C, H * W, total, norm_scale);
@@ -207,6 +213,7 @@ extern "C" int et_maxpool5_fwd(const void* x, int ldx, void* y, int ldy, uint8_t
     if (B <= 0 || C % vec || ldx % vec || ldy % vec) return -2;
     const int CV = C / vec;
     const long long total = (long long)B * H * W * CV;
+    if (total >= (1ll << 31)) return -2;               // the kernels index with 32-bit arithmetic
     if (dtype == ET_F32) { const dim3 g(et_cdiv(total, 256)); hipLaunchKernelGGL((maxpool5_fwd_kernel<float>), g, dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, (float*)y, ldy, argmax, H, W, CV, total); }
     else if (dtype == ET_BF16) { const dim3 g(et_cdiv(total, 256)); hipLaunchKernelGGL((maxpool5_fwd_kernel<uint16_t>), g, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, ldx, (uint16_t*)y, ldy, argmax, H, W, CV, total); }
     else return -2;
@@ -221,6 +228,7 @@ extern "C" int et_maxpool5_bwd(const void* dy, int lddy, const uint8_t* argmax, 
     if (B <= 0 || C % vec || lddy % vec || lddx % vec || (base && ldb % vec)) return -2;
     const int CV = C / vec;
     const long long total = (long long)B * H * W * CV;
+    if (total >= (1ll << 31)) return -2;               // the kernels index with 32-bit arithmetic
     if (dtype == ET_F32) { const dim3 g(et_cdiv(total, 256)); hipLaunchKernelGGL((maxpool5_bwd_kernel<float>), g, dim3(256), 0, (hipStream_t)stream, (const float*)dy, lddy, argmax, (const float*)base, ldb, (float*)dx, lddx, H, W, CV, total); }
     else if (dtype == ET_BF16) { const dim3 g(et_cdiv(total, 256)); hipLaunchKernelGGL((maxpool5_bwd_kernel<uint16_t>), g, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)dy, lddy, argmax, (const uint16_t*)base, ldb, (uint16_t*)dx, lddx, H, W, CV, total); }
     else return -2;
@@ -234,6 +242,7 @@ extern "C" int et_upsample2x_fwd(const void* x, int ldx, void* y, int ldy, int d
     if (B <= 0 || C % vec || ldx % vec || ldy % vec) return -2;
     const int CV = C / vec;
     const long long total = (long long)B * 4 * H * W * CV;
+    if (total >= (1ll << 31)) return -2;               // the kernels index with 32-bit arithmetic
     if (dtype == ET_F32) { const dim3 g(et_cdiv(total, 256)); hipLaunchKernelGGL((upsample2x_fwd_kernel<float>), g, dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, (float*)y, ldy, H, W, CV, total); }
     else if (dtype == ET_BF16) { const dim3 g(et_cdiv(total, 256)); hipLaunchKernelGGL((upsample2x_fwd_kernel<uint16_t>), g, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, ldx, (uint16_t*)y, ldy, H, W, CV, total); }
     else return -2;
@@ -247,6 +256,7 @@ extern "C" int et_upsample2x_bwd(const void* dy, int lddy, void* dx, int lddx, i
     if (B <= 0 || C % vec || lddy % vec || lddx % vec) return -2;
     const int CV = C / vec;
     const long long total = (long long)B * H * W * CV;
+    if (total >= (1ll << 31)) return -2;               // the kernels index with 32-bit arithmetic
     if (dtype == ET_F32) { const dim3 g(et_cdiv(total, 256)); hipLaunchKernelGGL((upsample2x_bwd_kernel<float>), g, dim3(256), 0, (hipStream_t)stream, (const float*)dy, lddy, (float*)dx, lddx, H, W, CV, total); }
     else if (dtype == ET_BF16) { const dim3 g(et_cdiv(total, 256)); hipLaunchKernelGGL((upsample2x_bwd_kernel<uint16_t>), g, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)dy, lddy, (uint16_t*)dx, lddx, H, W, CV, total); }
     else return -2;
