@@ -1,5 +1,6 @@
 #!/bin/bash
 # same-box A/B of the in-tree library against tools/probe/libet_prev.so: conv tests, conv microbench, the step
+# usage: cp efficientteacher_amd/libet_hip.so tools/probe/libet_prev.so BEFORE rebuilding with the change under test, then gpurun this script
 OUT=gpurun_out/lib_ab; mkdir -p $OUT
 timeout 900 python -m pytest tests/test_conv.py tests/test_conv_fuzz.py tests/test_norm_spatial.py -x -q -m gpu > $OUT/pytest.log 2>&1; tail -2 $OUT/pytest.log
 for L in prev new; do
