@@ -444,3 +444,24 @@ def test_head_decodes_random(dev, seed):
     got8 = z8.cpu()
     assert (got8[:, off:off + ny * nx] - ref8).abs().max().item() <= 1e-4 * max(1.0, ref8.abs().max().item())
     assert (got8[:, :off] == -7).all() and (got8[:, off + ny * nx:] == -7).all()
+
+
+def test_bf16_rounding_is_round_to_nearest_even(dev):
+    """the hardware conversion every kernel stores bf16 with (v_cvt_pk_bf16_f32, csrc/et_device.h) against torch's
+    round-to-nearest-even on the CPU: random values, exact ties (odd / even mantissas), values that round up into the next
+    binade or to infinity, denormals, infinities -- bit for bit; NaN stays NaN"""
+    from efficientteacher_amd import ops
+    rng = np.random.default_rng(31)
+    bits = rng.integers(0, 2 ** 32, 1 << 16, dtype=np.uint64).astype(np.uint32)
+    hi = rng.integers(0, 2 ** 16, 4096, dtype=np.uint64).astype(np.uint32) << 16
+    ties = np.concatenate((hi | 0x8000, hi | 0x7fff, hi | 0x8001, hi | 0xffff))       # exactly half, just below, just above, max
+    special = np.array([0x7f7fffff, 0xff7fffff, 0x7f800000, 0xff800000, 0x00000001, 0x80000001, 0x00008000, 0x007fffff,
+                        0x7f7f8000, 0x3f808000, 0x3f818000], np.uint32)
+    u = np.concatenate((bits, ties, special))
+    u = np.concatenate((u, np.zeros((-len(u)) % 8, np.uint32)))                       # 16-byte vectors
+    x = torch.from_numpy(u.view(np.float32).copy())
+    got = ops.scale_cast(x.to(dev.device), torch.bfloat16)
+    ref = x.to(torch.bfloat16)
+    nan = torch.isnan(x)
+    assert torch.isnan(got.cpu()[nan].float()).all()
+    assert torch.equal(got.cpu()[~nan].view(torch.int16), ref[~nan].view(torch.int16))
