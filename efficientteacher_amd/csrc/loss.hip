@@ -275,34 +275,38 @@ __global__ __launch_bounds__(256) void loss_pos_kernel(LossArgs A, LossLevel L, 
 
 // mode 0: count non-ignored cells only; mode 1: loss sum + gradient (denominator read from acc)
 __global__ __launch_bounds__(256) void loss_obj_kernel(LossArgs A, LossLevel L, int level, int mode, float fixed_n) {
-    const long long ncell = (long long)A.B * A.na * L.ny * L.nx;
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    // grid-stride over the cells, ONE atomic per workgroup: with a thread per cell and an atomic per wave the 80x80 level
+    // sent 9600 adds to the same address (tools/probe/probe_stat_atomics: same-address atomics serialise at ~20-100 ns each)
+    const unsigned ncell = (unsigned)A.B * A.na * L.ny * L.nx;          // host: < 2^31
+    const unsigned plane = (unsigned)L.nx * L.ny;
     float lsum = 0.f, cnt = 0.f;
-    if (i < ncell) {
+    const float n = (mode == 1) ? (fixed_n > 0.f ? fixed_n : A.acc[level * 16 + ACC_OBJN]) : 1.f;
+    const float bal = (mode == 1) ? (A.balance_dev ? A.balance_dev[level] : L.balance) : 0.f;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < ncell; i += gridDim.x * 256u) {
         const unsigned long long w = L.tobj[i];
         const float t = w ? __uint_as_float((unsigned)(w & 0xffffffffull)) : 0.0f;
         if (t >= 0.0f) {
-            cnt = 1.f;
+            cnt += 1.f;
             if (mode == 1) {
-                const int gi = (int)(i % L.nx);
-                const int gj = (int)((i / L.nx) % L.ny);
-                const int a = (int)((i / ((long long)L.nx * L.ny)) % A.na);
-                const long long b = i / ((long long)L.nx * L.ny * A.na);
-                const long long off = b * L.sb + a * L.sa + gj * L.sy + gi * L.sx + A.obj_ch;
+                const unsigned q = i / plane, rem = i - q * plane;       // q = b * na + a
+                const unsigned gj = rem / (unsigned)L.nx, gi = rem - gj * (unsigned)L.nx;
+                const unsigned b = q / (unsigned)A.na, a = q - b * (unsigned)A.na;
+                const long long off = (long long)b * L.sb + (long long)a * L.sa + (long long)gj * L.sy + (long long)gi * L.sx + A.obj_ch;
                 const float x = ld_logit(L.p, A.dtype, off);
                 float g;
-                lsum = focal_bce_logits(x, t, A.obj_pw, A.fl_gamma, g);
-                const float n = fixed_n > 0.f ? fixed_n : A.acc[level * 16 + ACC_OBJN];
-                const float bal = A.balance_dev ? A.balance_dev[level] : L.balance;
+                lsum += focal_bce_logits(x, t, A.obj_pw, A.fl_gamma, g);
                 L.dp[off] += g * (A.obj_w * bal / n);   // += : in the SimOTA half this channel is also a class logit
             }
         }
     }
+    __shared__ float red[2][4];
     lsum = et_wave_sum(lsum);
     cnt = et_wave_sum(cnt);
-    if ((threadIdx.x & 63) == 0) {
-        if (mode == 1) atomicAdd(A.acc + level * 16 + ACC_OBJ, lsum);
-        else atomicAdd(A.acc + level * 16 + ACC_OBJN, cnt);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = lsum; red[1][threadIdx.x >> 6] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (mode == 1) atomicAdd(A.acc + level * 16 + ACC_OBJ, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+        else atomicAdd(A.acc + level * 16 + ACC_OBJN, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
     }
 }
 
@@ -741,7 +745,9 @@ extern "C" int et_yolo_loss(const et_loss_desc* d, et_stream_t stream) {
             hipLaunchKernelGGL(loss_count_kernel, grid, dim3(256), 0, s, A, L, l);
             hipLaunchKernelGGL(loss_pos_kernel, grid, dim3(256), 0, s, A, L, l);
         }
-        const dim3 og(et_cdiv(ncell[l], 256));
+        if (ncell[l] >= (1ll << 31)) return -2;
+        const long long ob = et_cdiv(ncell[l], 256);
+        const dim3 og((unsigned)(ob < 512 ? ob : 512));              // two workgroups per CU, grid-stride
         if (d->ignore_obj) hipLaunchKernelGGL(loss_obj_kernel, og, dim3(256), 0, s, A, L, l, 0, 0.f);
         hipLaunchKernelGGL(loss_obj_kernel, og, dim3(256), 0, s, A, L, l, 1, d->ignore_obj ? 0.f : (float)ncell[l]);
     }
