@@ -1,21 +1,30 @@
-"""bench.py -- SSOD images/sec of one Efficient-Teacher training step on MI355X.
+"""bench.py -- images/sec of one Efficient-Teacher training step on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload v5l-ssod | v5s-sup | v8-sup]
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-Metric (BASELINE.json): SSOD images/sec (teacher + student step), YOLOv5l, 640 px.
+Default workload ``v5l-ssod`` (BASELINE.json metric): SSOD images/sec (teacher + student step), YOLOv5l, 640 px.
 One step = SSODTrainer.train_instance on one batch of synthetic input already resident in HBM:
 EMA-teacher inference on the unlabeled weak view -> NMS + pseudo-label transform -> student forward on
 cat(labeled, unlabeled) -> ComputeLoss + ComputeStudentMatchLoss -> backward (+ RCCL gradient
 all-reduce for N > 1) -> SGD step + ModelEMA + semi-EMA update (optimizer every step:
-SSOD.fixed_accumulate).  Per-GPU work is fixed: 32 labeled + 32 unlabeled images per rank (config 3 of
-BASELINE.json at N = 1; weak scaling).  value = N * 64 * K / max-over-ranks time.
+SSOD.fixed_accumulate).  Per-GPU batch: N = 1, 2, 4: 32 labeled + 32 unlabeled images per rank (BASELINE configs[2] at
+N = 1, weak scaling); N = 8: 16 + 16 per rank = global 128 + 128, which IS BASELINE configs[3] -- the 32 + 32-per-rank
+weak-scaling point of the same 8 ranks is measured right after it and reported as ``weak_scaling_point``.
+value = N * images per rank per step * K / max-over-ranks time.
+
+Other workloads (the other single-GPU configs of BASELINE.json, same contract, same fields):
+  v5s-sup : configs[1], YOLOv5s supervised, bf16, batch 64 per GPU: Trainer.train_step (trainer/trainer.py:406-443)
+  v8-sup  : the kernels of configs[4]: YOLOv8 (C2f / decoupled DFL head, width = depth = 1.0) supervised step with
+            TaskAlignedAssigner + DFL loss, batch 32 per GPU (the reference has no runnable v8 SSOD step: SURVEY.md 8 a-14)
 
 Extra objects on the JSON line:
-  roofline     : the dominant kernel (bf16 MFMA implicit-GEMM conv), algorithmic FLOPs per launch
-                 divided by its HIP-event-measured average launch duration inside the timed region.
-  cpu_baseline : the plain-torch CPU port of the same step (oracle/model.py + oracle losses/NMS) timed
-                 on the host cores, rank 0 at N = 1 only, on a bounded sample.
+  roofline            : the dominant kernel (bf16 MFMA implicit-GEMM conv), algorithmic FLOPs per launch divided by its
+                        HIP-event-measured average launch duration inside the timed region.
+  kernel_ms_by_family : HIP-event time budget of ONE step by kernel family and stream (one extra instrumented step right
+                        after the timed region, same overlap mode), so that the line itself shows where the step goes.
+  cpu_baseline        : the plain-torch CPU port of the same step (oracle/) timed on the host cores, rank 0 at N = 1 only,
+                        on a bounded sample;  parity_check: fp32-mode and bf16-mode HIP steps against that oracle step.
 """
 import argparse
 import json
@@ -31,10 +40,22 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-YAML = os.path.join(ROOT, "efficientteacher_amd", "configs", "ssod", "coco-standard",
-                    "yolov5l_coco_ssod_10_percent.yaml")
+CFG_DIR = os.path.join(ROOT, "efficientteacher_amd", "configs")
+YAML = os.path.join(CFG_DIR, "ssod", "coco-standard", "yolov5l_coco_ssod_10_percent.yaml")
 F_IMG = 111.52e9          # conv FLOPs / image forward, YOLOv5l SSOD model
 PEAK_BF16 = 2.5e15        # dense bf16 MFMA peak, MI355X_MICROARCH.md
+
+WORKLOADS = {
+    "v5l-ssod": dict(kind="ssod", yaml=YAML, merge=[], per_rank=32,
+                     metric="SSOD images/sec (teacher+student step) YOLOv5l 640px",
+                     name="YOLOv5l Efficient-Teacher SSOD"),
+    "v5s-sup": dict(kind="sup", yaml=os.path.join(CFG_DIR, "sup", "public", "yolov5s_coco.yaml"), merge=[], per_rank=64,
+                    metric="supervised images/sec (train step) YOLOv5s 640px bf16", name="YOLOv5s supervised (BASELINE configs[1])"),
+    "v8-sup": dict(kind="sup", yaml=os.path.join(CFG_DIR, "sup", "public", "yolov8m_coco.yaml"),
+                   merge=["Model.width_multiple", 1.0, "Model.depth_multiple", 1.0], per_rank=32,
+                   metric="supervised images/sec (train step) YOLOv8 (width = depth = 1.0) 640px bf16, TaskAlignedAssigner + DFL loss",
+                   name="YOLOv8 anchor-free head, supervised TAL step (the kernels of BASELINE configs[4])"),
+}
 
 
 def synth_targets(rng, B):
@@ -60,42 +81,88 @@ def make_batch(rng, Bl, Bu, S, device):
     return f(imgs), synth_targets(rng, Bl).to(device), f(u_ori), f(u_ori), M_s.to(device)
 
 
-def build_trainer(device, rank, world, local_rank, per_rank):
+def load_cfg(wl, batch_size, extra=()):
     from efficientteacher_amd.configs import get_cfg
-    from efficientteacher_amd.trainer import SSODTrainer
     cfg = get_cfg()
-    cfg.merge_from_file(YAML)
-    cfg.merge_from_list(["Dataset.batch_size", per_rank * world, "SSOD.fixed_accumulate", True])
+    cfg.merge_from_file(wl["yaml"])
+    cfg.merge_from_list(list(wl["merge"]) + ["Dataset.batch_size", batch_size] + list(extra))
     cfg.freeze()
+    return cfg
+
+
+def build_trainer(device, rank, world, local_rank, per_rank, wl=None):
+    wl = wl or WORKLOADS["v5l-ssod"]
     torch.manual_seed(0)
-    return cfg, SSODTrainer(cfg, device, None, local_rank if world > 1 else -1, rank if world > 1 else -1, world, nb=1000)
+    lr, rk = (local_rank if world > 1 else -1), (rank if world > 1 else -1)
+    if os.environ.get("ET_DP_SINGLE_RANK", "0") == "1" and world == 1 and dist.is_initialized():
+        lr, rk = local_rank, rank                        # single-GPU box: run the data-parallel code path over a 1-rank RCCL group
+    if wl["kind"] == "ssod":
+        from efficientteacher_amd.trainer import SSODTrainer
+        cfg = load_cfg(wl, per_rank * world, ["SSOD.fixed_accumulate", True])
+        return cfg, SSODTrainer(cfg, device, None, lr, rk, world, nb=1000)
+    from efficientteacher_amd.trainer import Trainer
+    cfg = load_cfg(wl, max(64, per_rank * world))        # accumulate = max(round(64 / batch), 1) = 1: optimizer every step
+    return cfg, Trainer(cfg, device, None, lr, rk, world, nb=1000)
 
 
-def cpu_baseline(cfg, device, seconds=25.0):
-    """The oracle (oracle/step.py: plain-torch CPU restatement of trainer/ssod_trainer.py:587-680, `kind: "port"`) timed on
-    the host cores for a bounded number of 1 + 1 image steps -- and, on the way, the PARITY CHECK of the benchmarked
-    configuration: the very first oracle step and one bf16 step of the HIP trainer start from the same weights and see
-    the same two images / targets / M_s / injected teacher scores, and their loss terms, pseudo-label sets and NMS
-    decisions are compared (what tests/test_step_fullsize.py asserts, reported here next to the throughput)."""
-    import copy
+# ---- CPU baseline + parity ---------------------------------------------------------------------------------------------
+def _hip_ssod_losses(cfg, device, dtype, batch, synth):
+    """one HIP SSODTrainer.train_instance in compute dtype `dtype` from seed-0 weights on `batch`; -> (items, teacher_pred, state_dict)"""
     from efficientteacher_amd.trainer import SSODTrainer
+    from efficientteacher_amd.utils.torch_utils import ModelEMA
+    imgs, targets, u_str, u_ori, M_s = batch
+    torch.manual_seed(0)
+    tr = SSODTrainer(cfg, device, None, -1, -1, 1, nb=1000)
+    if dtype != torch.bfloat16:
+        tr.model.set_compute_dtype(dtype)
+        tr.build_optimizer(cfg)
+        tr.ema = ModelEMA(tr.model)
+        tr.semi_ema = None
+    sd = {k: v.detach().cpu().clone() for k, v in tr.model.state_dict().items()}
+    cap = {}
+
+    def hook(tp):
+        tp[..., 4:] = synth.to(device)
+        cap["tp"] = tp.detach().clone()
+        return tp
+    tr.teacher_pred_hook = hook
+    items = tr.train_instance(imgs.to(device), targets.to(device), None, u_str.to(device), u_ori.to(device), None,
+                              M_s.to(device), 2000)
+    items = {k: float(v) for k, v in items.items()}
+    tp = cap["tp"]
+    del tr
+    torch.cuda.empty_cache()
+    return items, tp, sd
+
+
+def cpu_baseline_ssod(cfg, device, seconds=25.0, Bl=2, Bu=2):
+    """The oracle (oracle/step.py: plain-torch CPU restatement of trainer/ssod_trainer.py:587-680, `kind: "port"`) timed on
+    the host cores for a bounded number of Bl + Bu image steps -- and, on the way, the PARITY CHECK of the benchmarked
+    configuration: the very first oracle step and one HIP trainer step in EACH compute mode (fp32 parity mode, bf16
+    performance mode) start from the same weights and see the same images / targets / M_s / injected teacher scores; their
+    loss terms, pseudo-label sets and NMS decisions are compared (what tests/test_step_fullsize.py asserts at 1 + 1 images,
+    reported here at Bl + Bu next to the throughput)."""
+    import copy
     from efficientteacher_amd.utils.general import nms_ssod_padded
     from oracle import model as o_model, nms as o_nms, step as o_step
-    # 32 threads: beyond that the many small layers of a 2-image batch only add oversubscription
+    # 32 threads: beyond that the many small layers of a small batch only add oversubscription
     # (measured on the 256-core MI355X host: 256 threads are ~100x slower than 8)
     cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     rng = np.random.default_rng(0)
-    S, Bl, Bu = cfg.Dataset.img_size, 1, 1
+    S = cfg.Dataset.img_size
     c2 = cfg.clone(); c2.defrost(); c2.merge_from_list(["Dataset.batch_size", Bl + Bu]); c2.freeze()
-    torch.manual_seed(0)
-    tr = SSODTrainer(c2, device, None, -1, -1, 1, nb=1000)
+    batch = make_batch(rng, Bl, Bu, S, "cpu")
+    imgs, targets, u_str, u_ori, M_s = batch
+    A = 3 * ((S // 8) ** 2 + (S // 16) ** 2 + (S // 32) ** 2)
+    synth = torch.rand(Bu, A, 81) ** torch.cat((torch.full((1,), 16.0), torch.full((80,), 4.0)))
+    hip = {}
+    for name, dt in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+        hip[name] = _hip_ssod_losses(c2, device, dt, batch, synth)
     student = o_model.Model.from_cfg(cfg)
-    student.load_state_dict({k: v.detach().cpu() for k, v in tr.model.state_dict().items()}, strict=True)
+    student.load_state_dict(hip["fp32"][2], strict=True)
     student.train()
     teacher = copy.deepcopy(student).eval()
-    imgs, targets, u_str, u_ori, M_s = make_batch(rng, Bl, Bu, S, "cpu")
-    synth = torch.rand(Bu, 25200, 81) ** torch.cat((torch.full((1,), 16.0), torch.full((80,), 4.0)))
     opt = torch.optim.SGD(student.parameters(), lr=0.01, momentum=0.937, nesterov=True)
 
     def step():
@@ -111,28 +178,22 @@ def cpu_baseline(cfg, device, seconds=25.0):
     t0 = time.time()
     ref = step()                             # warm-up (allocator, oneDNN primitive caches) == the parity reference
     warm = time.time() - t0
-    # ---- parity of the benchmarked configuration (bf16, YOLOv5l, 640 px) ------------------------------------
-    cap = {}
-
-    def hook(tp):
-        tp[..., 4:] = synth.to(device)
-        cap["tp"] = tp.detach().clone()
-        return tp
-    tr.teacher_pred_hook = hook
-    items = tr.train_instance(imgs.to(device), targets.to(device), None, u_str.to(device), u_ori.to(device), None,
-                              M_s.to(device), 2000)
     want = {**{k: ref["sup_items"][k] for k in ("box", "obj", "cls")}, **ref["un_items"]}
-    loss_rel = {k: abs(float(items[k]) - v) / max(abs(v), 1e-12) for k, v in want.items()}
-    dets, counts, keep, _ = nms_ssod_padded(cap["tp"], cfg.SSOD.nms_conf_thres, cfg.SSOD.nms_iou_thres)
-    rd, rk = o_nms.non_max_suppression_ssod(cap["tp"].cpu().numpy(), cfg.SSOD.nms_conf_thres, cfg.SSOD.nms_iou_thres)
-    keep_ok = all(int(counts[i]) == rk[i].shape[0] and np.array_equal(keep[i, :int(counts[i])].cpu().numpy(), rk[i])
-                  for i in range(Bu))
-    parity = dict(against="oracle/step.py (fp32 CPU restatement of the reference step), same weights and inputs, 1+1 images",
-                  dtype="bf16", loss_rel_dev={k: round(v, 6) for k, v in loss_rel.items()}, max_loss_rel_dev=max(loss_rel.values()),
-                  nms_keep_indices_bit_exact=bool(keep_ok), n_pseudo_labels=[int(counts.sum()), int(sum(k.shape[0] for k in rk))],
-                  tolerance="loss terms 5e-2 (bf16 storage); NMS indices bit-exact on identical decoded inputs; fp32 mode "
-                            "1e-4: tests/test_step_fullsize.py")
-    del tr
+    parity = dict(against=f"oracle/step.py (fp32 CPU restatement of the reference step), same weights and inputs, {Bl}+{Bu} images",
+                  tolerance="fp32 mode: loss terms 1e-4; bf16 mode: loss terms 5e-2 (bf16 storage, fp32 accumulation); NMS kept "
+                            "indices bit-exact on identical decoded inputs in both (tests/test_step_fullsize.py)")
+    for name in ("fp32", "bf16"):
+        items, tp, _ = hip[name]
+        rel = {k: abs(items[k] - v) / max(abs(v), 1e-12) for k, v in want.items()}
+        dets, counts, keep, _ = nms_ssod_padded(tp, cfg.SSOD.nms_conf_thres, cfg.SSOD.nms_iou_thres)
+        rd, rk = o_nms.non_max_suppression_ssod(tp.cpu().numpy(), cfg.SSOD.nms_conf_thres, cfg.SSOD.nms_iou_thres)
+        keep_ok = all(int(counts[i]) == rk[i].shape[0] and np.array_equal(keep[i, :int(counts[i])].cpu().numpy(), rk[i])
+                      for i in range(Bu))
+        parity[name] = dict(loss_rel_dev={k: round(v, 7) for k, v in rel.items()}, max_loss_rel_dev=max(rel.values()),
+                            nms_keep_indices_bit_exact=bool(keep_ok),
+                            n_pseudo_labels=[int(counts.sum()), int(sum(k.shape[0] for k in rk))],
+                            within_tolerance=bool(max(rel.values()) <= (1e-4 if name == "fp32" else 5e-2) and keep_ok))
+    hip.clear()
     torch.cuda.empty_cache()
     t0, n = time.time(), 0
     if warm < seconds:                       # bounded: ~`seconds` of timed CPU work, at least one step
@@ -142,8 +203,82 @@ def cpu_baseline(cfg, device, seconds=25.0):
     else:
         n, dt = 1, warm
     base = dict(value=(Bl + Bu) / dt, unit="images/s", cores=cores, kind="port",
-                sample=f"YOLOv5l SSOD step, {Bl} labeled + {Bu} unlabeled 640x640, {n} steps, plain-torch fp32 CPU port "
+                sample=f"YOLOv5l SSOD step, {Bl} labeled + {Bu} unlabeled {S}x{S}, {n} steps, plain-torch fp32 CPU port "
                        f"(oracle/step.py; all {ref['t9'].shape[0]} pseudo labels)")
+    return base, parity
+
+
+def cpu_baseline_sup(wl_name, cfg, device, seconds=25.0, B=2):
+    """supervised workloads: oracle model + oracle loss + backward + SGD on the host (kind "port"), and the parity of one
+    HIP forward + loss in fp32 mode and in bf16 mode against it on the same weights and images"""
+    from oracle import losses as o_loss
+    cores = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(cores)
+    rng = np.random.default_rng(0)
+    S = cfg.Dataset.img_size
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(B, 3, S, S, generator=g)
+    targets = synth_targets(rng, B)
+    v8 = wl_name == "v8-sup"
+    if v8:
+        from efficientteacher_amd.models.loss import ComputeTalLoss
+        from oracle import v8 as o_v8
+        ref = o_v8.Model.from_cfg(cfg)
+    else:
+        from efficientteacher_amd.models.loss import ComputeLoss
+        from oracle import model as o_model
+        ref = o_model.Model.from_cfg(cfg)
+    import importlib
+    mod = "efficientteacher_amd.models.detector.yolo"
+    hip_items = {}
+    for name, dt in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+        torch.manual_seed(0)
+        model = importlib.import_module(mod).Model(cfg).to(device).train()
+        model.set_compute_dtype(dt)
+        if name == "fp32":
+            miss = ref.load_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()}, strict=False)
+            assert not miss.unexpected_keys and all(k.startswith("det_") for k in miss.missing_keys), miss   # the oracle carries the (unused) netD
+        closs = (ComputeTalLoss if v8 else ComputeLoss)(model, cfg)
+        if not v8:
+            hp_w = (float(closs.box_w), float(closs.obj_w), float(closs.cls_w))
+        loss, items = closs(model(x.to(device)), targets.to(device))
+        hip_items[name] = {k: float(v) for k, v in items.items() if torch.is_tensor(v) and v.numel() == 1}
+        del model, closs, loss, items
+        torch.cuda.empty_cache()
+    ref.train()
+    opt = torch.optim.SGD(ref.parameters(), lr=0.01, momentum=0.937, nesterov=True)
+    def step():
+        opt.zero_grad()
+        out = ref(x)
+        if v8:
+            rl, ri = o_v8.tal_loss(out, targets, nc=cfg.Dataset.nc, reg_max=cfg.Loss.reg_max, img_size=S, iou_type=cfg.Loss.iou_type,
+                                   w_class=cfg.Loss.qfl_loss_weight, w_iou=cfg.Loss.box_loss_weight, w_dfl=cfg.Loss.dfl_loss_weight)
+            ri = {k: float(ri[k].detach()) for k in ("loss_iou", "loss_dfl", "loss_cls")}
+        else:
+            rl, ri = o_loss.compute_loss(out[0] if isinstance(out, tuple) else out, targets, ref.head.anchors, nc=cfg.Dataset.nc,
+                                         box_w=hp_w[0], obj_w=hp_w[1], cls_w=hp_w[2])
+            ri = {k: float(torch.as_tensor(ri[k]).detach()) for k in ("box", "obj", "cls")}
+        rl.backward()
+        opt.step()
+        return ri
+    t0 = time.time()
+    want = step()
+    warm = time.time() - t0
+    parity = dict(against=f"oracle ({'oracle/v8.py written spec: loss parity UNPINNED, see SURVEY.md 8 a-14' if v8 else 'oracle/model.py + oracle/losses.py'}), "
+                          f"same weights and inputs, {B} images, forward + loss",
+                  tolerance="fp32 mode 1e-4 (v8: 1e-3), bf16 mode 5e-2 on the loss terms")
+    for name in ("fp32", "bf16"):
+        rel = {k: abs(hip_items[name].get(k, float('nan')) - v) / max(abs(v), 1e-12) for k, v in want.items()}
+        parity[name] = dict(loss_rel_dev={k: round(v, 7) for k, v in rel.items()}, max_loss_rel_dev=max(rel.values()))
+    t0, n = time.time(), 0
+    if warm < seconds:
+        while n < 1 or (time.time() - t0 + warm < seconds and n < 8):
+            step(); n += 1
+        dt = (time.time() - t0) / n
+    else:
+        n, dt = 1, warm
+    base = dict(value=B / dt, unit="images/s", cores=cores, kind="port",
+                sample=f"{WORKLOADS[wl_name]['name']}: forward + loss + backward + SGD, batch {B} {S}x{S}, {n} steps, plain-torch fp32 CPU port (oracle/)")
     return base, parity
 
 
@@ -161,64 +296,41 @@ def _respawn(a):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--per-rank", type=int, default=32, help="labeled (= unlabeled) images per rank")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-overlap", action="store_true", help="run the teacher on the main stream (A/B)")
-    ap.add_argument("--graph", action="store_true", help="replay the step as one captured HIP graph (trainer/graph_step.py) instead of "
-                    "issuing every launch from Python (A/B: the 32+32 step is GPU-bound, both take ~64 ms)")
-    ap.add_argument("--host-inputs", action="store_true", help="PCIe-inclusive variant: every step receives its three "
-                    "uint8 image batches from pinned host memory (never the reported `value`; noted in DESIGN.md)")
-    ap.add_argument("--dump-launches", default=None, help="write (kernel, flops, bytes, ms) of every timed conv launch of the "
-                    "instrumented step to this JSON file (tools/launch_table.py prints it)")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); 'gloo' lets two "
-                    "ranks share ONE GPU to exercise the N>1 code path where only a single GPU is available")
-    a = ap.parse_args()
-
-    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        _respawn(a)
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    rank = int(os.environ.get("RANK", 0))
-    local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
-    ndev = torch.cuda.device_count()
-    if a.backend == "nccl" and ndev < world:
-        raise SystemExit(f"bench.py --gpus {a.gpus}: only {ndev} GPU(s) visible (use --backend gloo to share one GPU for a functional check)")
-    dev_index = local_rank % max(ndev, 1)
-    torch.cuda.set_device(dev_index)
-    device = torch.device("cuda", dev_index)
-    if world > 1:
-        if a.backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
-        else:
-            dist.init_process_group(a.backend)
-
-    from efficientteacher_amd import ops
-    cfg, tr = build_trainer(device, rank, world, dev_index, a.per_rank)
+# ---- one measured configuration ----------------------------------------------------------------------------------------
+def measure(a, wl_name, per_rank, device, rank, world, dev_index, full=True):
+    """warm-up + timed region + (full=True) the instrumented extras for ONE per-rank batch size; returns a dict of results.
+    Collective: every rank calls this with the same arguments."""
+    from efficientteacher_amd import _lib, ops
+    wl = WORKLOADS[wl_name]
+    ssod = wl["kind"] == "ssod"
+    cfg, tr = build_trainer(device, rank, world, dev_index, per_rank, wl)
     rng = np.random.default_rng(1234 + rank)
     S = cfg.Dataset.img_size
-    Bl = Bu = a.per_rank
-    imgs, targets, u_str, u_ori, M_s = make_batch(rng, Bl, Bu, S, device)
-    g = torch.Generator(device="cpu").manual_seed(99 + rank)
-    pw = torch.cat((torch.full((1,), 16.0), torch.full((80,), 4.0)))
-    synth = (torch.rand(Bu, 25200, 81, generator=g) ** pw).to(device)
+    Bl = Bu = per_rank
+    if ssod:
+        imgs, targets, u_str, u_ori, M_s = make_batch(rng, Bl, Bu, S, device)
+        g = torch.Generator(device="cpu").manual_seed(99 + rank)
+        pw = torch.cat((torch.full((1,), 16.0), torch.full((80,), 4.0)))
+        A = 3 * ((S // 8) ** 2 + (S // 16) ** 2 + (S // 32) ** 2)
+        synth = (torch.rand(Bu, A, 81, generator=g) ** pw).to(device)
 
-    def hook(tp):           # a random-init teacher scores nothing above 0.1: SURVEY.md 8(d) synthetic scores
-        tp[..., 4:] = synth
-        return tp
-    tr.teacher_pred_hook = hook
-    tr.overlap_teacher = not a.no_overlap
-    if a.graph:
-        tr.use_graph = True
-
+        def hook(tp):           # a random-init teacher scores nothing above 0.1: SURVEY.md 8(d) synthetic scores
+            tp[..., 4:] = synth
+            return tp
+        tr.teacher_pred_hook = hook
+        tr.overlap_teacher = not a.no_overlap
+        if a.graph:
+            tr.use_graph = True
+        imgs_per_step = Bl + Bu
+    else:
+        g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+        imgs = torch.randint(0, 256, (per_rank, 3, S, S), generator=g, dtype=torch.uint8).to(device)   # what the loader delivers
+        targets = synth_targets(rng, per_rank).to(device)
+        imgs_per_step = per_rank
     ni = 2000               # past the warm-up ramp's first iterations, inside warm-up like early training
 
     feed = None
-    if a.host_inputs:           # what a data loader hands over: uint8 NCHW batches in host memory, every step
+    if a.host_inputs and ssod:  # what a data loader hands over: uint8 NCHW batches in host memory, every step
         from efficientteacher_amd.utils.prefetch import DevicePrefetcher
         host = [(t * 255).round().to(torch.uint8).cpu() for t in (imgs, u_str, u_ori)]
 
@@ -228,6 +340,8 @@ def main():
         feed = DevicePrefetcher(batches(), device)      # copy stream, one step ahead; /255 happens in the pack kernel
 
     def step(i):
+        if not ssod:
+            return tr.train_step(imgs, targets, ni + i)
         if feed is not None:
             im, us, uo = next(feed)
             return tr.train_instance(im, targets, None, us, uo, None, M_s, ni + i)
@@ -247,29 +361,41 @@ def main():
     timed = {a.steps // 2} if a.steps > 2 else set(range(a.steps))
     sync()
     t0 = time.perf_counter()
-    ar_rows = []
     ddp = tr.model if hasattr(tr.model, "collect_timing") else None
-    graph_default = tr.use_graph
+    graph_default = getattr(tr, "use_graph", False)
+    items = None
     for i in range(a.steps):
-        ops.TIMER = timer if i in timed else None
-        tr.use_graph = graph_default and i not in timed      # HIP events cannot be recorded inside a replayed graph:
-        if ddp is not None:                                     # the instrumented step(s) of the timed region run eagerly
+        ops.TIMER = timer if (i in timed and full) else None
+        if ssod:
+            tr.use_graph = graph_default and not (i in timed and full)   # HIP events cannot be recorded inside a replayed graph:
+        if ddp is not None:                                              # the instrumented step(s) of the timed region run eagerly
             ddp.timing = i in timed
         items = step(a.warmup + i)
+        if graph_default and getattr(tr, "graph_error", None):
+            graph_default = False                                        # capture was rejected: the trainer fell back to eager steps
     ops.TIMER = None
-    tr.use_graph = graph_default
+    if ssod:
+        tr.use_graph = graph_default
     t_enq = time.perf_counter() - t0          # host time to enqueue the K steps (no device sync inside a step)
     sync()
     dt = time.perf_counter() - t0
-    if ddp is not None:
-        t_ar = ddp.collect_timing()
-        if t_ar is not None:
-            ar_rows.append(t_ar)
+    t_ar = ddp.collect_timing() if ddp is not None else None
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    loss_ok = all(math.isfinite(float(v)) for v in items.values())
+    vals = items.values() if isinstance(items, dict) else [items]
+    res = dict(per_rank=per_rank, dt=dt, t_enq=t_enq, imgs_per_step=imgs_per_step, cfg=cfg,
+               loss_ok=all(math.isfinite(float(v)) for v in vals if torch.is_tensor(v) and v.numel() == 1),
+               t_ar=t_ar, grad_bytes=int(tr.model.flat_state().grads.numel() * 4), graph_default=bool(graph_default),
+               graph_replays=(getattr(tr._graph, "replays", 0) if getattr(tr, "_graph", None) else 0),
+               graph_recaptures=(getattr(tr._graph, "recaptures", 0) if getattr(tr, "_graph", None) else 0),
+               graph_error=getattr(tr, "graph_error", None), graph_requested=bool(a.graph and ssod),
+               n_timed=len(timed), timer=timer, S=S)
+    if not full:
+        del tr
+        torch.cuda.empty_cache()
+        return res
     # outside the timed region: what issuing ONE step costs the host when the HIP queue is empty at its start (inside the
     # timed loop the host runs ahead until the queue is full and then advances at the GPU's pace, so t_enq ~ dt there)
     enq_empty = []
@@ -279,97 +405,244 @@ def main():
         step(a.warmup + a.steps + j)
         enq_empty.append((time.perf_counter() - t1) * 1e3)
     torch.cuda.synchronize()
-    # also outside the timed region: ONE instrumented step with the teacher on the main stream (no kernel shares the GPU with
-    # the timed one): the same launches' durations without the inflation the overlapped teacher stream causes
-    solo = None
+    res["enq_empty"] = sorted(enq_empty)[1]
+    # also outside the timed region: ONE step with every launching library call bracketed by HIP events (time budget by kernel
+    # family and stream), in the overlap mode of the timed region
+    fam = None
     try:
-        t_solo = ops.KernelTimer()
-        keep_overlap = tr.overlap_teacher
-        tr.overlap_teacher, ops.TIMER, tr.use_graph = False, t_solo, False
+        ft = ops.FamilyTimer()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        if ssod:
+            tr.use_graph = False
+        _lib.CALL_TIMER = ft
+        e0.record()
         step(a.warmup + a.steps + 3)
-        ops.TIMER, tr.overlap_teacher, tr.use_graph = None, keep_overlap, graph_default
+        e1.record()
+        _lib.CALL_TIMER = None
         torch.cuda.synchronize()
-        solo = t_solo.summary()
-    except Exception:
-        ops.TIMER = None
+        main_id = torch.cuda.current_stream().cuda_stream
+        by_stream = ft.summary()
+        span = e0.elapsed_time(e1)
+        main = by_stream.pop(main_id, {})
+        side = {}
+        for d in by_stream.values():
+            for k, v in d.items():
+                side[k] = side.get(k, 0.0) + v
+        fam = dict(main_stream={k: round(v, 3) for k, v in sorted(main.items())},
+                   teacher_stream={k: round(v, 3) for k, v in sorted(side.items())},
+                   main_stream_span_ms=round(span, 3), main_stream_busy_ms=round(sum(main.values()), 3),
+                   teacher_stream_ms=round(sum(side.values()), 3),
+                   aten_and_gaps_ms=round(span - sum(main.values()), 3),
+                   note="one instrumented step after the timed region; an event pair spans from the retirement of the stream's previous "
+                        "command to the end of the call, so the families of a stream sum to its busy time; aten_and_gaps = span of the "
+                        "main stream minus that sum (torch's own kernels: gradient-branch adds, fills, copies; launch gaps; the HIP-event "
+                        "overhead of this instrumentation, ~2 x 1000 events)")
+    except Exception as e:          # never lose the throughput line to an instrumentation leg
+        _lib.CALL_TIMER = None
+        fam = dict(error=f"{type(e).__name__}: {e}")
+    finally:
+        if ssod:
+            tr.use_graph = graph_default
+    res["families"] = fam
+    # ONE instrumented step with the teacher on the main stream (no kernel shares the GPU with the timed one): the same
+    # launches' durations without the inflation the overlapped teacher stream causes
+    solo = None
+    if ssod:
+        try:
+            t_solo = ops.KernelTimer()
+            keep_overlap = tr.overlap_teacher
+            tr.overlap_teacher, ops.TIMER, tr.use_graph = False, t_solo, False
+            step(a.warmup + a.steps + 4)
+            ops.TIMER, tr.overlap_teacher, tr.use_graph = None, keep_overlap, graph_default
+            torch.cuda.synchronize()
+            solo = t_solo.summary()
+        except Exception:
+            ops.TIMER = None
+    res["solo"] = solo
+    del tr
+    torch.cuda.empty_cache()
+    return res
+
+
+def roofline_of(res, dump=None):
+    timer, n_timed = res["timer"], res["n_timed"]
+    agg = timer.summary()
+    if dump:
+        with open(dump, "w") as f:
+            json.dump([dict(kernel=t, flops=fl, launches=n, bytes=nb, ms=ea.elapsed_time(eb), shape=sh)
+                       for (t, fl, n, nb, ea, eb), sh in zip(timer.rows, timer.shapes)], f)
+    dom = max((k for k in agg if k.startswith("conv_gemm") and "parity classes" not in k), key=lambda k: agg[k]["ms"])
+    d = agg[dom]
+    per_launch_flops = d["flops"] / d["launches"]
+    per_launch_s = d["ms"] * 1e-3 / d["launches"]
+    conv_ms = sum(v["ms"] for v in agg.values()) / n_timed
+    conv_fl = sum(v["flops"] for v in agg.values()) / n_timed
+    # HBM/fabric traffic of the same kernel from the committed PMC passes over this very command
+    # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs; tools/pmc_summarize.py, tools/pmc_to_traffic.py)
+    traffic, traffic_src = None, None
+    try:
+        pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        if dom in pt["kernels"]:
+            traffic, traffic_src = pt["kernels"][dom]["bytes_per_launch"], pt["source"]
+    except (OSError, ValueError, KeyError):
+        pass
+    roof = dict(bound="mfma", kernel=dom, achieved=per_launch_flops / per_launch_s / 1e12, peak=PEAK_BF16 / 1e12,
+                unit="TFLOP/s", frac=per_launch_flops / per_launch_s / PEAK_BF16, traffic=traffic,
+                traffic_unit="bytes per launch (2*FETCH_SIZE + WRITE_SIZE)", traffic_source=traffic_src,
+                algorithmic_bytes_per_launch=d["bytes"] / d["launches"],
+                launches_per_step=d["launches"] / n_timed, instrumented_steps=n_timed,
+                avg_launch_us=per_launch_s * 1e6, algorithmic_gflop_per_launch=per_launch_flops / 1e9,
+                all_conv_kernels=dict(ms_per_step=conv_ms, tflops=conv_fl / (conv_ms * 1e-3) / 1e12,
+                                      algorithmic_tflop_per_step=conv_fl / 1e12))
+    solo = res.get("solo")
+    if solo and dom in solo:
+        sd = solo[dom]
+        roof["same_kernel_teacher_not_overlapped"] = dict(
+            avg_launch_us=sd["ms"] * 1e3 / sd["launches"], frac=sd["flops"] / (sd["ms"] * 1e-3) / PEAK_BF16,
+            all_conv_ms=sum(v["ms"] for v in solo.values()),
+            note="one extra step outside the timed region with the teacher forward on the main stream: in the timed "
+                 "region the teacher's launches share the GPU with the student's and lengthen them")
+    return roof, conv_fl
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="v5l-ssod", choices=sorted(WORKLOADS))
+    ap.add_argument("--per-rank", type=int, default=0, help="images per rank (SSOD: labeled = unlabeled = this); default: the "
+                    "BASELINE config of the workload (v5l-ssod: 32, and 16 at --gpus 8 = configs[3], global 128+128)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-weak-point", action="store_true", help="--gpus 8: skip the second (32+32 per rank) measurement")
+    ap.add_argument("--no-overlap", action="store_true", help="run the teacher on the main stream (A/B)")
+    ap.add_argument("--graph", action="store_true", help="replay the step as one captured HIP graph (trainer/graph_step.py) instead of "
+                    "issuing every launch from Python (A/B: the 32+32 step is GPU-bound; default ON for per-rank batches < 32)")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--host-inputs", action="store_true", help="PCIe-inclusive variant: every step receives its three "
+                    "uint8 image batches from pinned host memory (never the reported `value`; noted in DESIGN.md)")
+    ap.add_argument("--dump-launches", default=None, help="write (kernel, flops, bytes, ms) of every timed conv launch of the "
+                    "instrumented step to this JSON file (tools/launch_table.py prints it)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); 'gloo' lets two "
+                    "ranks share ONE GPU to exercise the N>1 code path where only a single GPU is available")
+    ap.add_argument("--force-dp", action="store_true", help="--gpus 1 only: run the data-parallel code path (broadcasts, chunked "
+                    "asynchronous AVG all-reduce from the gradient-ready hook, graph capture of the collectives) over a ONE-rank "
+                    "RCCL group -- the way to execute that path on a single-GPU box")
+    a = ap.parse_args()
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        _respawn(a)
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    ndev = torch.cuda.device_count()
+    if a.backend == "nccl" and ndev < world:
+        raise SystemExit(f"bench.py --gpus {a.gpus}: only {ndev} GPU(s) visible (use --backend gloo to share one GPU for a functional check)")
+    dev_index = local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    from efficientteacher_amd.parallel import apply_rccl_knobs
+    rccl_env = apply_rccl_knobs()              # ET_RCCL_CHANNELS & co: before the communicator exists
+    if world > 1 or a.force_dp:
+        if a.force_dp and world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(29500 + (os.getpid() % 2000)))
+            os.environ["ET_DP_SINGLE_RANK"] = "1"
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+        elif a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(a.backend)
+
+    from efficientteacher_amd import ops
+    wl = WORKLOADS[a.workload]
+    ssod = wl["kind"] == "ssod"
+    per_rank = a.per_rank or (16 if (ssod and world == 8) else wl["per_rank"])
+    if ssod and not a.no_graph and per_rank < 32 and a.backend == "nccl":
+        a.graph = True          # small per-GPU batches: the ~16 ms of host enqueue are no longer small against the GPU step
+    res = measure(a, a.workload, per_rank, device, rank, world, dev_index, full=True)
+    weak = None
+    if ssod and world == 8 and per_rank != 32 and not a.no_weak_point and not a.per_rank:
+        keep_graph = a.graph
+        a.graph = False
+        weak = measure(a, a.workload, 32, device, rank, world, dev_index, full=False)
+        a.graph = keep_graph
 
     if rank == 0:
+        cfg, dt, S = res["cfg"], res["dt"], res["S"]
+        ips = res["imgs_per_step"]
         try:                 # the roofline leg must never cost the throughput line
-            agg = timer.summary()
-            if a.dump_launches:
-                with open(a.dump_launches, "w") as f:
-                    json.dump([dict(kernel=t, flops=fl, launches=n, bytes=nb, ms=ea.elapsed_time(eb), shape=sh)
-                               for (t, fl, n, nb, ea, eb), sh in zip(timer.rows, timer.shapes)], f)
-            dom = max((k for k in agg if k.startswith("conv_gemm") and "parity classes" not in k), key=lambda k: agg[k]["ms"])
-            d = agg[dom]
-            per_launch_flops = d["flops"] / d["launches"]
-            per_launch_s = d["ms"] * 1e-3 / d["launches"]
-            conv_ms = sum(v["ms"] for v in agg.values()) / len(timed)
-            conv_fl = sum(v["flops"] for v in agg.values()) / len(timed)
-            # HBM/fabric traffic of the same kernel from the committed PMC passes over this very command
-            # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs; tools/pmc_summarize.py, tools/pmc_to_traffic.py)
-            traffic, traffic_src = None, None
-            try:
-                pt = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")))
-                if dom in pt["kernels"]:
-                    traffic, traffic_src = pt["kernels"][dom]["bytes_per_launch"], pt["source"]
-            except (OSError, ValueError, KeyError):
-                pass
-            roof = dict(bound="mfma", kernel=dom, achieved=per_launch_flops / per_launch_s / 1e12, peak=PEAK_BF16 / 1e12,
-                        unit="TFLOP/s", frac=per_launch_flops / per_launch_s / PEAK_BF16, traffic=traffic,
-                        traffic_unit="bytes per launch (2*FETCH_SIZE + WRITE_SIZE)", traffic_source=traffic_src,
-                        algorithmic_bytes_per_launch=d["bytes"] / d["launches"],
-                        launches_per_step=d["launches"] / len(timed), instrumented_steps=len(timed),
-                        avg_launch_us=per_launch_s * 1e6, algorithmic_gflop_per_launch=per_launch_flops / 1e9,
-                        all_conv_kernels=dict(ms_per_step=conv_ms, tflops=conv_fl / (conv_ms * 1e-3) / 1e12,
-                                              algorithmic_tflop_per_step=conv_fl / 1e12))
-            if solo and dom in solo:
-                sd = solo[dom]
-                roof["same_kernel_teacher_not_overlapped"] = dict(
-                    avg_launch_us=sd["ms"] * 1e3 / sd["launches"], frac=sd["flops"] / (sd["ms"] * 1e-3) / PEAK_BF16,
-                    all_conv_ms=sum(v["ms"] for v in solo.values()),
-                    note="one extra step outside the timed region with the teacher forward on the main stream: in the timed "
-                         "region the teacher's launches share the GPU with the student's and lengthen them")
+            roof, conv_fl = roofline_of(res, a.dump_launches)
         except Exception as e:
-            roof = dict(bound="mfma", kernel=None, achieved=None, peak=PEAK_BF16 / 1e12, unit="TFLOP/s", frac=None,
-                        traffic=None, error=f"{type(e).__name__}: {e}")
-        step_flop = F_IMG * Bu + 3 * F_IMG * (Bl + Bu)
+            roof, conv_fl = dict(bound="mfma", kernel=None, achieved=None, peak=PEAK_BF16 / 1e12, unit="TFLOP/s", frac=None,
+                                 traffic=None, error=f"{type(e).__name__}: {e}"), None
+        if ssod:
+            step_flop = F_IMG * per_rank + 3 * F_IMG * (2 * per_rank)
+        else:
+            step_flop = conv_fl if conv_fl else float("nan")      # measured: sum of 2*M*N*K over every conv launch of the step
+        if ssod:
+            base_cfg = "BASELINE configs[2]" if (world == 1 and per_rank == 32) else \
+                       ("BASELINE configs[3]: global 128 labeled + 128 unlabeled over 8 ranks" if (world == 8 and per_rank == 16) else
+                        ("configs[2]'s per-GPU batch on every rank (weak scaling)" if per_rank == 32 else "reduced per-rank batch"))
+            workload = f"{wl['name']}, {per_rank} labeled + {per_rank} unlabeled 640px per GPU ({base_cfg})"
+        else:
+            workload = f"{wl['name']}, batch {per_rank} per GPU, 640px, synthetic COCO-80 targets"
+        t_ar = res["t_ar"]
         out = {
-            "metric": "SSOD images/sec (teacher+student step) YOLOv5l 640px",
-            "value": world * (Bl + Bu) * a.steps / dt, "unit": "images/s", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic (random-init YOLOv5l; teacher obj/cls scores "
-            "replaced by U^16 / U^4 so that NMS and the pseudo-label loss do representative work)",
-            "config": {"workload": f"YOLOv5l Efficient-Teacher SSOD, {Bl} labeled + {Bu} unlabeled 640px per GPU "
-                                   "(BASELINE configs[2]" + ("" if Bl == 32 else ", reduced per-rank batch") + ")", "global_batch": world * (Bl + Bu), "img_size": S,
+            "metric": wl["metric"],
+            "value": world * ips * a.steps / dt, "unit": "images/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong" if (ssod and world == 8 and per_rank == 16) else "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic (random-init weights" + ("; teacher obj/cls scores "
+            "replaced by U^16 / U^4 so that NMS and the pseudo-label loss do representative work)" if ssod else "; uniform uint8 images, synthetic COCO-80 targets)"),
+            "config": {"workload": workload, "global_batch": world * ips, "img_size": S,
                        "parallelism": f"dp{world}", "optimizer_every_step": True,
                        "algorithmic_tflop_per_step_per_gpu": step_flop / 1e12,
                        "step_tflops_per_gpu": step_flop / (dt / a.steps) / 1e12,
-                       "frac_of_bf16_mfma_peak": step_flop / (dt / a.steps) / PEAK_BF16, "loss_finite": loss_ok,
-                       "rccl_ranks": dist.get_world_size() if world > 1 else 1, "env_knobs": ops.env_knobs(),
-                       "grad_allreduce": (dict(bytes=int(tr.model.flat_state().grads.numel() * 4), span_ms=ar_rows[-1][0],
-                                               exposed_ms=ar_rows[-1][1], note="span: first chunk launch (during backward) -> "
-                                               "last collective complete; exposed: compute stream waiting after backward")
-                                          if ar_rows else None),
-                       "host_enqueue_ms_per_step": t_enq / a.steps * 1e3,
-                       "host_enqueue_ms_empty_queue": sorted(enq_empty)[1],
+                       "frac_of_bf16_mfma_peak": step_flop / (dt / a.steps) / PEAK_BF16, "loss_finite": res["loss_ok"],
+                       "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1, "env_knobs": ops.env_knobs(),
+                       "rccl_env": rccl_env or None,
+                       "grad_allreduce": (dict(bytes=res["grad_bytes"], span_ms=t_ar[0], exposed_ms=t_ar[1],
+                                               per_collective=[dict(bytes=b, exposed_ms=round(ms, 4)) for b, ms in t_ar[2]],
+                                               note="span: first chunk launch (during backward) -> last collective complete; exposed: "
+                                                    "compute stream waiting after backward, in total and per collective in wait order "
+                                                    "(conv-weight chunks from the tail of the arena first, then biases, then BN weights)")
+                                          if t_ar else None),
+                       "host_enqueue_ms_per_step": res["t_enq"] / a.steps * 1e3,
+                       "host_enqueue_ms_empty_queue": res.get("enq_empty"),
                        "host_enqueue_note": "per_step is measured inside the timed loop, where the host blocks on the full HIP "
                                             "queue (back-pressure: it tracks the GPU step time); empty_queue is the median host time "
-                                            "to issue one step after a device synchronise, i.e. the real launch cost",
-                       "step_graph": dict(enabled=bool(graph_default and world == 1), replays=getattr(tr._graph, "replays", 0) if getattr(tr, "_graph", None) else 0,
-                                          eager_instrumented_steps=len(timed)), "inputs": "host uint8 (PCIe inclusive)" if a.host_inputs else "resident in HBM"},
+                                            "to issue one step after a device synchronise, i.e. the real launch cost (a graph replay "
+                                            "when step_graph.enabled)",
+                       "step_graph": dict(enabled=res["graph_default"], requested=res["graph_requested"], error=res["graph_error"],
+                                          replays=res["graph_replays"], recaptures=res["graph_recaptures"],
+                                          eager_instrumented_steps=res["n_timed"]),
+                       "inputs": "host uint8 (PCIe inclusive)" if a.host_inputs else "resident in HBM"},
             "roofline": roof,
+            "kernel_ms_by_family": res.get("families"),
         }
+        if ssod and world == 8 and per_rank == 16:
+            out["scaling_note"] = ("BASELINE configs[3]: the global batch equals that of 4 ranks at configs[2]'s per-GPU batch (strong "
+                                   "scaling 4 -> 8); the per-GPU-work-fixed point of the same 8 ranks is `weak_scaling_point`")
+        if weak is not None:
+            out["weak_scaling_point"] = dict(per_rank=f"{weak['per_rank']} labeled + {weak['per_rank']} unlabeled",
+                                             value=world * weak["imgs_per_step"] * a.steps / weak["dt"], unit="images/s",
+                                             ms_per_step=weak["dt"] / a.steps * 1e3, steps=a.steps, warmup=a.warmup, scaling="weak",
+                                             global_batch=world * weak["imgs_per_step"])
         if world == 1 and not a.no_cpu_baseline:
             try:
-                del tr, imgs, u_str, u_ori, synth
+                res.clear()
                 torch.cuda.empty_cache()
-                out["cpu_baseline"], out["parity_check"] = cpu_baseline(cfg, device)
+                if ssod:
+                    out["cpu_baseline"], out["parity_check"] = cpu_baseline_ssod(cfg, device)
+                else:
+                    out["cpu_baseline"], out["parity_check"] = cpu_baseline_sup(a.workload, cfg, device)
             except Exception as e:   # never lose the GPU number to the baseline leg
                 out["cpu_baseline"] = dict(value=None, unit="images/s", cores=os.cpu_count(), kind="port",
                                            sample=f"failed: {type(e).__name__}: {e}")
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

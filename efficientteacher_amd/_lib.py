@@ -99,6 +99,36 @@ class LossDesc(ctypes.Structure):
 
 _dll = None
 _emulated = False
+# bench.py's per-family time budget (ops.FamilyTimer): when set, every launching entry point is bracketed by two HIP events on
+# the launching stream.  None (always, outside that one instrumented step) = the library object itself, no wrapper.
+CALL_TIMER = None
+_NO_LAUNCH = frozenset(n for n in (
+    "et_build_arch", "et_abi_version", "et_nms_ssod_workspace_bytes", "et_nms_workspace_bytes", "et_conv2d_stats_rows",
+    "et_conv2d_kernel_name", "et_env_knobs", "et_bn_reduce_rows", "et_ota_workspace_bytes", "et_tal_assign_workspace_bytes"))
+
+
+class _TimedDll:
+    """the loaded library with every launching entry point wrapped: timer.begin(name) / timer.end(token) around the call"""
+
+    def __init__(self, dll, timer):
+        self._dll, self._timer, self._cache = dll, timer, {}
+
+    def __getattr__(self, name):
+        fn = self._cache.get(name)
+        if fn is None:
+            raw = getattr(self._dll, name)
+            if name in _NO_LAUNCH or not name.startswith("et_"):
+                fn = raw
+            else:
+                timer = self._timer
+
+                def fn(*a, _raw=raw, _name=name):
+                    tok = timer.begin(_name)
+                    rc = _raw(*a)
+                    timer.end(tok)
+                    return rc
+            self._cache[name] = fn
+        return fn
 
 
 class EtHipError(RuntimeError):
@@ -123,6 +153,11 @@ def load(path=None):
                 f"{path} not found: build the gfx950 kernels first "
                 f"(python -m efficientteacher_amd.csrc.build).  There is no CPU fallback.")
         _dll = _declare(ctypes.CDLL(path))
+    if CALL_TIMER is not None:
+        w = getattr(CALL_TIMER, "_wrapped", None)
+        if w is None or w._dll is not _dll:
+            w = CALL_TIMER._wrapped = _TimedDll(_dll, CALL_TIMER)
+        return w
     return _dll
 
 

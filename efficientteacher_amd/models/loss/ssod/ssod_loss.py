@@ -43,11 +43,17 @@ class ComputeStudentMatchLoss:
         for k in 'na', 'nc', 'nl', 'anchors', 'stride':
             setattr(self, k, getattr(det, k))
         self._anchors_host = [[[float(v) for v in a] for a in lvl] for lvl in det.anchors.detach().cpu().tolist()]
+        self._thr_dev = ops.DeviceThresholds()
+
+    def refresh_thresholds(self, dev):
+        """upload ignore_thres_low / _high into their persistent device tensor if the lists changed (LabelMatch's after_epoch
+        rewrites them); trainer/graph_step.py calls this before every replay of a captured step"""
+        return self._thr_dev.refresh(self.ignore_thres_low, self.ignore_thres_high, dev)
 
     def select_targets(self, targets, valid=None):
         """(N,9) [batch, cls, x, y, w, h, conf, obj_conf, cls_conf] -> device target table (N,8)."""
         return ops.select_targets(targets, valid, self.ignore_thres_low, self.ignore_thres_high, self.nc,
-                                  self.pseudo_label_with_obj)
+                                  self.pseudo_label_with_obj, thresholds=self._thr_dev)
 
     def _hp(self, pass_mask):
         return dict(nc=self.nc, anchor_t=float(self.anchor_t), gr=float(self.gr), cp=float(self.cp), cn=float(self.cn),

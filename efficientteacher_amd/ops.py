@@ -38,6 +38,50 @@ class KernelTimer:
 TIMER = None
 
 
+class FamilyTimer:
+    """HIP-event time budget of ONE step by kernel family (bench.py ``kernel_ms_by_family``): every launching entry point of
+    the library is bracketed by two events on the stream it launches on (``_lib.CALL_TIMER``).  An event pair measures what
+    the STREAM spends on the call: from the retirement of the stream's previous command to the end of the call's last
+    kernel, so the pairs of one stream tile its busy time; what lies between them (torch's own kernels, launch gaps) is the
+    remainder ``span - sum`` that bench.py reports as ``aten_and_gaps``."""
+
+    FAMILY = {
+        "et_conv2d_fwd": "gather_gemm", "et_conv2d_dgrad": "gather_gemm", "et_conv2d_dgrad_bn": "gather_gemm",
+        "et_conv2d_wgrad": "wgrad", "et_conv2d_wgrad_grouped": "wgrad",
+        "et_bn_finalize": "bn", "et_bn_act_fwd": "bn", "et_bn_act_bwd": "bn", "et_bn_act_bwd_from_partials": "bn", "et_act_bwd": "bn",
+        "et_nms": "nms_loss_pl", "et_nms_ssod": "nms_loss_pl", "et_detect_decode": "nms_loss_pl", "et_pseudo_label_transform": "nms_loss_pl",
+        "et_select_targets": "nms_loss_pl", "et_yolo_loss": "nms_loss_pl", "et_ota_assign": "nms_loss_pl", "et_score_log_append": "nms_loss_pl",
+        "et_scale_cast": "nms_loss_pl", "et_domain_focal": "nms_loss_pl", "et_scale_inplace": "nms_loss_pl", "et_v8_decode": "nms_loss_pl",
+        "et_tal_loss": "nms_loss_pl", "et_tal_assign": "nms_loss_pl", "et_colsum": "nms_loss_pl",
+        "et_sgd_nesterov": "optimizer_ema", "et_sgd_nesterov_dev": "optimizer_ema", "et_adamw": "optimizer_ema", "et_ema_update": "optimizer_ema",
+        "et_ema_update_dev": "optimizer_ema", "et_cast_f32_to_bf16": "optimizer_ema", "et_weight_transpose": "optimizer_ema",
+        "et_weight_transpose_all": "optimizer_ema", "et_bn_eval_affine": "optimizer_ema",
+    }
+
+    def __init__(self):
+        self.rows = []          # (family, stream id, start event, end event)
+
+    def begin(self, name):
+        fam = self.FAMILY.get(name, "pool_upsample_pack")
+        if fam == "gather_gemm":
+            fam = "gather_gemm_student" if torch.is_grad_enabled() else "gather_gemm_teacher"
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        return (fam, torch.cuda.current_stream().cuda_stream, a, b)
+
+    def end(self, tok):
+        tok[3].record()
+        self.rows.append(tok)
+
+    def summary(self):
+        """{stream id: {family: ms}} -- call after a device synchronise"""
+        out = {}
+        for fam, sid, a, b in self.rows:
+            d = out.setdefault(sid, {})
+            d[fam] = d.get(fam, 0.0) + a.elapsed_time(b)
+        return out
+
+
 def kernel_name(op, dtype, N, IH, IW, Cin, Cout, k, stride, pad, parity_class=0, zero_page=True):
     """Name of the kernel instantiation the library launches for this conv problem (op: 'fwd' | 'dgrad' | 'wgrad';
     arguments of the FORWARD conv), as rocprofv3 prints it.  The selection lives in csrc/conv.hip only
@@ -548,27 +592,38 @@ def score_log_append(dets, counts, conf_log, cls_log, log_count):
                                                _lib.stream(dets)), "et_score_log_append")
 
 
-_THR_CACHE = {}
+class DeviceThresholds:
+    """The per-class (low, high) pseudo-label thresholds of ComputeStudentMatchLoss as ONE persistent fp64 device tensor
+    (2, nc) per loss object.  The trainer rewrites the host lists when LabelMatch adapts them (ssod_trainer.py:322-323);
+    ``refresh`` then copies the new values INTO the same device memory (stream-ordered, in place), so a captured step graph
+    -- which bakes in the tensor's address -- reads the new thresholds at its next replay and the buffer it points at is
+    never freed or replaced (the value-keyed cache this replaces handed a captured graph a tensor that a later cache
+    eviction could free)."""
+
+    def __init__(self):
+        self._dev = {}          # device -> [tensor (2, nc) fp64, snapshot of the host lists last uploaded]
+
+    def refresh(self, low, high, dev):
+        key = (tuple(float(v) for v in low), tuple(float(v) for v in high))
+        st = self._dev.get(dev)
+        if st is None:
+            st = self._dev[dev] = [torch.empty((2, len(key[0])), dtype=torch.float64, device=dev), None]
+        if st[1] != key:
+            if st[0].shape[1] != len(key[0]):
+                raise ValueError("the number of classes of the threshold lists changed")
+            st[0].copy_(torch.tensor([key[0], key[1]], dtype=torch.float64))
+            st[1] = key
+        return st[0]
 
 
-def _threshold_tensor(values, dev):
-    """per-class thresholds as a device fp64 tensor, cached by value: the trainer rewrites the lists only when LabelMatch
-    adapts them (ssod_trainer.py:322-323), and a host->device copy of a temporary cannot live inside a captured graph"""
-    key = (tuple(float(v) for v in values), dev)
-    t = _THR_CACHE.get(key)
-    if t is None:
-        if len(_THR_CACHE) > 64:
-            _THR_CACHE.clear()
-        t = _THR_CACHE[key] = torch.as_tensor(key[0], dtype=torch.float64).to(dev)
-    return t
-
-
-def select_targets(targets9, valid, thr_low, thr_high, nc, with_obj):
-    """(N,9) fp64 pseudo labels (+ optional valid mask) -> (N,8) fp32 target table for et_yolo_loss."""
+def select_targets(targets9, valid, thr_low, thr_high, nc, with_obj, thresholds=None):
+    """(N,9) fp64 pseudo labels (+ optional valid mask) -> (N,8) fp32 target table for et_yolo_loss.
+    thresholds: the caller's DeviceThresholds (persistent device copy of the two lists); without one a temporary is made."""
     N = targets9.shape[0]
     dev = targets9.device
     t9 = targets9.to(torch.float64).contiguous()
-    lo, hi = _threshold_tensor(thr_low, dev), _threshold_tensor(thr_high, dev)
+    thr = (thresholds if thresholds is not None else DeviceThresholds()).refresh(thr_low, thr_high, dev)
+    lo, hi = thr[0], thr[1]
     table = torch.empty((N, 8), dtype=torch.float32, device=dev)
     if N == 0:                            # no pseudo label at all: an empty table (the loss then has its objectness term only)
         return table

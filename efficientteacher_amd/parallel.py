@@ -11,25 +11,61 @@ Because all gradients already live in one contiguous fp32 arena there is nothing
 traverse: the arena is cut into a few large chunks sized for xGMI's per-link bandwidth and each chunk
 is all-reduced asynchronously as soon as backward has passed the layers it covers.
 """
+import os
+
+import torch
 import torch.distributed as dist
 import torch.nn as nn
 
 
+def apply_rccl_knobs(env=None):
+    """Tuning knobs of the collective library, to be called BEFORE ``init_process_group`` (RCCL reads its environment when
+    the communicator is created).  ``ET_RCCL_CHANNELS=n`` pins the number of RCCL channels (= workgroups = CUs the
+    all-reduce kernel occupies): the gradient all-reduce runs beside backward's 256x256-tile kernels, which want every CU,
+    so the CU share of the collective is a trade between its own bandwidth (7 xGMI links x ~153 GB/s per GPU, a ring is
+    per-link bound) and the compute it displaces.  ``ET_RCCL_PROTO`` / ``ET_RCCL_ALGO`` pass through to NCCL_PROTO / NCCL_ALGO.
+    Values already present in the environment win.  Returns what was set (bench.py records it)."""
+    env = os.environ if env is None else env
+    out = {}
+    n = env.get("ET_RCCL_CHANNELS")
+    if n:
+        for k in ("NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS"):
+            if k not in env:
+                env[k] = str(int(n))
+            out[k] = env[k]
+    for src, dst in (("ET_RCCL_PROTO", "NCCL_PROTO"), ("ET_RCCL_ALGO", "NCCL_ALGO")):
+        if env.get(src):
+            env.setdefault(dst, env[src])
+            out[dst] = env[dst]
+    return out
+
+
 class FlatDataParallel(nn.Module):
-    def __init__(self, module, process_group=None, chunk_mb=48, broadcast_buffers=True, overlap=True):
+    def __init__(self, module, process_group=None, chunk_mb=None, broadcast_buffers=True, overlap=True, single_rank_collectives=None):
+        """chunk_mb: size of the all-reduce pieces of the conv-weight gradient segment (default 48, ``ET_ALLREDUCE_CHUNK_MB``).
+        single_rank_collectives (``ET_DP_SINGLE_RANK=1``): issue every collective even in a group of ONE rank -- the way to
+        execute the RCCL code path (AVG all-reduce from the gradient-ready hook, broadcast, capture into a step graph) on a
+        single-GPU box; with more ranks it changes nothing."""
         super().__init__()
         self.module = module
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        if chunk_mb is None:
+            chunk_mb = float(os.environ.get("ET_ALLREDUCE_CHUNK_MB", "48"))
         self.chunk = int(chunk_mb * (1 << 20) // 4)
         self.broadcast_buffers = broadcast_buffers
         self.overlap = overlap
+        if single_rank_collectives is None:
+            single_rank_collectives = os.environ.get("ET_DP_SINGLE_RANK", "0") == "1"
+        # `active`: collectives are issued (more than one rank, or the single-rank test mode with an initialised group)
+        self.active = self.world > 1 or (bool(single_rank_collectives) and dist.is_initialized())
         self._works = []
         self._launched = set()
         self.timing = False              # bench.py: HIP events around the collective phase of a step
         self.last_timing = None          # (first launch -> all complete, exposed wait after backward) in ms
         self._ev0 = None
-        if self.world > 1:
+        self._pending_timing = None
+        if self.active:
             f = module.flat_state()
             dist.broadcast(f.params, 0, group=self.pg)
             dist.broadcast(f.buffers, 0, group=self.pg)
@@ -73,12 +109,11 @@ class FlatDataParallel(nn.Module):
 
     def _all_reduce(self, view):
         if self.timing and self._ev0 is None and view.is_cuda:
-            import torch
             self._ev0 = torch.cuda.Event(enable_timing=True)
             self._ev0.record()
         avg = dist.get_backend(self.pg) == "nccl"        # RCCL averages inside the collective
         w = dist.all_reduce(view, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=self.pg, async_op=True)
-        self._works.append((w, None if avg else view))
+        self._works.append((w, None if avg else view, int(view.numel()) * 4))
 
     def _on_conv_grad_ready(self, slot):
         """Called from the conv backward right after its wgrad launch: when every layer of a chunk has
@@ -93,14 +128,21 @@ class FlatDataParallel(nn.Module):
             self._all_reduce(self.module.flat_state().grads[o:o + n])
 
     def forward(self, *a, **k):
-        if self.world > 1 and self.broadcast_buffers and self.module.training:
+        if self._works or self._launched:
+            # a backward whose collectives nobody finished (an exception between backward and reduce_gradients, or a caller
+            # that skipped it): never let an all-reduce in flight overlap the next backward's writes into the same arena
+            self.reduce_gradients()
+        if self.active and self.broadcast_buffers and self.module.training:
             # DDP broadcast_buffers=True: rank 0's BN running stats / anchors at every forward
             dist.broadcast(self.module.flat_state().buffers, 0, group=self.pg)
         return self.module(*a, **k)
 
     def reduce_gradients(self):
-        """Finish the gradient all-reduce (mean over ranks); call after backward()."""
-        if self.world <= 1:
+        """Finish the gradient all-reduce (mean over ranks); call after EVERY backward() -- also on the micro-steps of a
+        gradient accumulation: the arena then holds (sum of the earlier, already averaged micro-gradients) + (this rank's
+        local micro-gradient), and the mean over ranks of that is the sum of the averaged micro-gradients, exactly what
+        DistributedDataParallel accumulates in .grad."""
+        if not self.active:
             return
         g = self.module.flat_state().grads
         wo, wn = self.module.flat_state().w_range
@@ -109,18 +151,24 @@ class FlatDataParallel(nn.Module):
                 self._all_reduce(g[o:o + n])
         self._all_reduce(g[:wo])                           # biases (BN + conv)
         self._all_reduce(g[wo + wn:])                      # BN weights
-        ev1 = ev2 = None
-        if self.timing and self._ev0 is not None:
-            import torch
-            ev1, ev2 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            ev1.record()                                   # backward is over on this stream: what follows is exposed
-        for w, view in self._works:
+        timed = self.timing and self._ev0 is not None
+        evs = []
+        if timed:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()                                     # backward is over on this stream: what follows is exposed
+            evs.append(e)
+        sizes = []
+        for w, view, nbytes in self._works:
             w.wait()
             if view is not None:                           # gloo (CPU tests) has no AVG
                 view.mul_(1.0 / self.world)
-        if ev2 is not None:
-            ev2.record()
-            self._pending_timing = (self._ev0, ev1, ev2)
+            if timed:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()                                 # the compute stream has passed this collective's completion
+                evs.append(e)
+                sizes.append(nbytes)
+        if timed:
+            self._pending_timing = (self._ev0, evs, sizes)
             self._ev0 = None
         self._works = []
         self._launched = set()
@@ -128,14 +176,16 @@ class FlatDataParallel(nn.Module):
 
     def collect_timing(self):
         """(ms from the first all-reduce launch to the completion of the last, ms the compute stream waited for the
-        collectives after backward) of the last timed step; synchronises the events."""
-        t = getattr(self, "_pending_timing", None)
+        collectives after backward, [(bytes, exposed ms) per collective in wait order]) of the last timed step;
+        synchronises the events."""
+        t = self._pending_timing
         if t is None:
             return None
-        e0, e1, e2 = t
-        e2.synchronize()
+        e0, evs, sizes = t
+        evs[-1].synchronize()
         self._pending_timing = None
-        return e0.elapsed_time(e2), e1.elapsed_time(e2)
+        per = [(sizes[i], evs[i].elapsed_time(evs[i + 1])) for i in range(len(sizes))]
+        return e0.elapsed_time(evs[-1]), evs[0].elapsed_time(evs[-1]), per
 
     def flat_state(self):
         return self.module.flat_state()

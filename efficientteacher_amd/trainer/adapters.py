@@ -9,8 +9,9 @@ SUBCLASS the trainers of the tree they are used in and override only
     build_model       this package's Model (same state_dict keys), cfg.weights loaded through utils/checkpoint.py with the
                       reference's intersect / exclude-anchors / strict=False rules (trainer.py:127-144)
     build_optimizer   FlatSGD over the parameter arena, the reference's scheduler and warm-up fields; ``self.scaler`` is a
-                      unit scaler (bf16 needs no loss scaling) whose ``step`` also finishes the RCCL gradient all-reduce,
-                      so the reference's ``update_optimizer`` (trainer.py:381, ssod_trainer.py:458) runs UNCHANGED
+                      unit scaler (bf16 needs no loss scaling) whose ``scale(loss).backward()`` also finishes the RCCL
+                      gradient all-reduce after every backward (DDP semantics, also under gradient accumulation), so the
+                      reference's ``update_optimizer`` (trainer.py:381, ssod_trainer.py:458) runs UNCHANGED
     build_ddp_model   FlatDataParallel instead of DistributedDataParallel (trainer.py:313); this package's losses
     train_instance    (SSOD) the device-resident step: teacher on a side stream, padded pseudo labels, no host sync
                       except for the progress-bar numbers the reference prints
@@ -31,20 +32,37 @@ from ..utils.torch_utils import CosineEMA, ModelEMA, SemiSupModelEMA, is_paralle
 LOGGER = logging.getLogger(__name__)
 
 
+class _ReducedLoss:
+    """what ``UnitScaler.scale(loss)`` returns: ``backward()`` runs the backward pass and then COMPLETES the data-parallel
+    gradient all-reduce -- after EVERY backward, as DistributedDataParallel does (trainer.py:313) and as this package's
+    own ``update_optimizer`` does.  With gradient accumulation (accumulate > 1: total batch <= 42, or the warm-up
+    interpolation of trainer.py:390) the reference's ``update_optimizer`` reaches ``scaler.step`` only on optimizer-step
+    iterations; finishing the collectives there would leave the chunks that the overlap hook launched during an earlier
+    micro-step un-waited and marked as launched, so the later micro-steps' conv gradients would never be averaged and a
+    collective in flight would race with the next wgrad's writes into the same arena."""
+
+    def __init__(self, loss, trainer):
+        self._loss, self._t = loss, trainer
+
+    def backward(self, *a, **k):
+        self._loss.backward(*a, **k)
+        m = self._t.model
+        if isinstance(m, FlatDataParallel):
+            m.reduce_gradients()
+
+
 class UnitScaler:
     """stands in for torch.cuda.amp.GradScaler (trainer.py:248): bf16 activations with fp32 accumulation and fp32 master
-    weights need no loss scaling; ``step`` is where the data-parallel gradient all-reduce is completed."""
+    weights need no loss scaling; ``scale(loss).backward()`` is where the data-parallel gradient all-reduce is completed
+    (every micro-step, see _ReducedLoss)."""
 
     def __init__(self, trainer):
         self._t = trainer
 
     def scale(self, loss):
-        return loss
+        return _ReducedLoss(loss, self._t)
 
     def step(self, optimizer):
-        m = self._t.model
-        if isinstance(m, FlatDataParallel):
-            m.reduce_gradients()
         optimizer.step()
 
     def update(self):
@@ -151,6 +169,8 @@ class _HotPath:
         from ..models.loss import ComputeLoss
         if self.cuda and self.RANK != -1:
             self.model = FlatDataParallel(self.model)
+            from .trainer import Trainer as _Core
+            _Core._sync_ema_from_rank0(self)          # the EMA copy was taken before the broadcast (see there)
         inner = self.model.module if is_parallel(self.model) else self.model
         inner.nc = self.nc
         inner.names = self.names

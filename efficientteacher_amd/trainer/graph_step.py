@@ -15,7 +15,13 @@ What has to be true for a capture to be replayable, and how it is arranged:
   * inputs are STATIC buffers: the image batches, M_s and a fixed-capacity padded target table (flags = 0 rows are
     ignored by et_yolo_loss) are copied into place before the replay (skipped when the caller hands over the static
     buffers themselves, e.g. a prefetcher that writes into them);
-  * every side stream forks from and joins the capturing stream (the teacher stream and the wgrad stream already did).
+  * every side stream forks from and joins the capturing stream (the teacher stream and the wgrad stream already did);
+  * under data parallelism (one process per GPU, RCCL) the per-forward buffer broadcast and the chunked asynchronous gradient
+    all-reduce are part of the capture: torch's NCCL process group records a collective into the capturing stream as a
+    fork to its own stream and a join at `work.wait()`.  Every rank captures and replays the same sequence of collectives, so
+    the ranks stay matched; the instrumented steps of bench.py (HIP events around the collectives) run eagerly;
+  * host-side decisions frozen by the capture (loss variant, domain-loss flag, hooks, shapes, optimizer type) are hashed and a
+    change drops the graph and re-captures it (`_signature`).
 The host-side bookkeeping the eager step interleaves with its launches (warm-up interpolation, EMA counters,
 `last_opt_step`) runs before the replay, in the same order.
 """
@@ -56,16 +62,45 @@ class StepGraph:
         self.graph = None
         self.items = None
         self.replays = 0
+        self.recaptures = 0
+        self.sig = None
 
     # ---- eligibility ------------------------------------------------------------------------------------------
+    def _signature(self, imgs):
+        """every HOST-side decision a capture freezes (trainer/ssod_trainer.py::_train_instance_eager takes them while it issues
+        the launches): a replay is only valid while none of them has changed -- otherwise the graph is dropped and re-captured"""
+        t = self.t
+        cfg = t.cfg
+        cl = t.compute_loss
+        return (tuple(imgs.shape), imgs.dtype, type(t.optimizer).__name__, bool(getattr(cl, 'ota', False)), type(cl).__name__,
+                bool(cfg.SSOD.with_da_loss), str(cfg.SSOD.pseudo_label_type), id(t.teacher_pred_hook), bool(t.overlap_teacher),
+                t.semi_ema is not None, id(t.compute_un_sup_loss), int(t.WORLD_SIZE), int(t.RANK),
+                float(cfg.SSOD.teacher_loss_weight), float(t.da_loss_weights))
+
     def usable(self, imgs, targets):
         t = self.t
-        if not t.cuda or t.RANK != -1:                    # the RCCL path stays eager (collectives inside a captured graph
-            return False                                  # could not be validated on a multi-GPU node in this build)
+        if not t.cuda:
+            return False
+        if t.RANK != -1:
+            # data parallel: the per-forward buffer broadcast and the chunked asynchronous gradient all-reduce are captured with
+            # the step (RCCL collectives are stream operations; torch's NCCL process group records them into a capturing stream).
+            # gloo collectives run on the host and cannot be captured.
+            import torch.distributed as dist
+            from ..parallel import FlatDataParallel
+            if not (isinstance(t.model, FlatDataParallel) and dist.is_initialized() and dist.get_backend(t.model.pg) == "nccl"):
+                return False
+        from ..optim import FlatSGD
+        opt = t.optimizer
+        # FlatSGD only (FlatAdamW passes its bias-correction step BY VALUE: a replay would repeat step 1 for ever), and not before
+        # its first eager step (the `first` flag of the momentum buffer is a by-value kernel argument too)
+        if not isinstance(opt, FlatSGD) or opt.first:
+            return False
         if targets.shape[0] > self.TARGET_CAPACITY:
             return False
-        if self.graph is not None and (tuple(imgs.shape) != tuple(self.s_imgs.shape) or imgs.dtype != self.s_imgs.dtype):
-            return False
+        if self.graph is not None and self._signature(imgs) != self.sig:
+            torch.cuda.synchronize(t.device)              # replays in flight still read the old graph's buffers
+            self.graph, self.items = None, None
+            self.recaptures += 1
         return True
 
     # ---- capture ------------------------------------------------------------------------------------------------
@@ -92,7 +127,8 @@ class StepGraph:
         t._capturing = True
         opt.capturing = True
         try:
-            with torch.cuda.graph(g):
+            # data parallel: torch's NCCL watchdog thread may touch the device while this thread captures
+            with torch.cuda.graph(g, capture_error_mode="thread_local" if t.RANK != -1 else "global"):
                 self.items = t._train_instance_eager(self.s_imgs, None, None, self.s_ustr, self.s_uori, None, self.s_M, 0,
                                                      sup_table=self.s_table)
         finally:
@@ -101,6 +137,7 @@ class StepGraph:
             for e in emas:
                 e.capturing = False
         self.graph = g
+        self.sig = self._signature(imgs)
 
     def _scalars(self, advance=True):
         vals = self.t.optimizer.hp_values()
@@ -118,6 +155,12 @@ class StepGraph:
         t.accumulate = 1
         t._warmup(ni, 1 if t.fixed_accumulate else 64 / t.batch_size)
         self.hp.push(self._scalars())
+        # host-side bookkeeping the eager step does between its launches (ssod_trainer.py:616-617) and the loss thresholds:
+        # LabelMatch's after_epoch rewrites the per-class lists; the captured select_targets reads them from ONE persistent
+        # device tensor that is refreshed in place here (stream-ordered before the replay)
+        if t.cfg.SSOD.pseudo_label_type == 'LabelMatch':
+            t.pseudo_label_creator.update(targets, imgs.shape[0], u_str.shape[0])
+        t.compute_un_sup_loss.refresh_thresholds(t.device)
         # inputs
         for dst, src in ((self.s_imgs, imgs), (self.s_ustr, u_str), (self.s_uori, u_ori)):
             if src.data_ptr() != dst.data_ptr():

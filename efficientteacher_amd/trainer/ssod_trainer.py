@@ -70,6 +70,7 @@ class SSODTrainer(Trainer):
         self._eager_steps = 0
         self._capturing = False
         self._graph = None
+        self.graph_error = None
         self._strong_view = None           # utils/augment.StrongViewGenerator, created on first use (weak-view-only batches)
 
     def _side_stream(self):
@@ -95,6 +96,8 @@ class SSODTrainer(Trainer):
     def update_optimizer(self, loss, ni):
         loss.backward()
         if self._capturing:                # graph capture: launches only; the host-side schedule runs before each replay
+            if isinstance(self.model, FlatDataParallel):
+                self.model.reduce_gradients()      # the remaining chunks + the waits of the async all-reduces, captured too
             self.optimizer.step()
             self.optimizer.zero_grad()
             self.ema.update(self.model)
@@ -135,7 +138,16 @@ class SSODTrainer(Trainer):
                 from .graph_step import StepGraph
                 self._graph = StepGraph(self)
             if accumulate == 1 and self._graph.usable(imgs, targets):
-                return self._graph.run(imgs, targets, unlabeled_imgs, unlabeled_imgs_ori, unlabeled_M, ni)
+                try:
+                    return self._graph.run(imgs, targets, unlabeled_imgs, unlabeled_imgs_ori, unlabeled_M, ni)
+                except Exception as e:                 # a capture the runtime rejects (e.g. a collective library that cannot be
+                    if self._graph.graph is not None:  # captured): this step and all later ones are issued eagerly, loudly
+                        raise                          # (a failure of an already captured graph is a real error)
+                    import logging
+                    logging.getLogger(__name__).warning("step-graph capture failed (%s: %s): falling back to eager steps", type(e).__name__, e)
+                    self.graph_error = f"{type(e).__name__}: {e}"
+                    self.use_graph = False
+                    torch.cuda.synchronize(self.device)
         self._eager_steps += 1
         return self._train_instance_eager(imgs, targets, paths, unlabeled_imgs, unlabeled_imgs_ori, unlabeled_gt, unlabeled_M, ni,
                                           pbar, callbacks)

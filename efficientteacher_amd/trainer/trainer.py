@@ -118,13 +118,32 @@ class Trainer:
             self.nw = -1
 
     def build_ddp_model(self, cfg, device):
-        if self.cuda and self.RANK != -1:
+        from .. import _lib
+        if (self.cuda or _lib.is_emulated()) and self.RANK != -1:      # emulated: the world-size-2 gloo tests on CPU
             self.model = FlatDataParallel(self.model)
+            self._sync_ema_from_rank0()
         if cfg.Loss.type == 'ComputeTalLoss':          # YOLOv8 head (trainer.py:320-327 dispatches on cfg.Loss.type)
             from ..models.loss import ComputeTalLoss
             self.compute_loss = ComputeTalLoss(self.model, cfg)
         else:
             self.compute_loss = ComputeLoss(self.model, cfg)
+
+    def _sync_ema_from_rank0(self):
+        """The EMA model is a copy of the student taken in build_model, i.e. BEFORE the data-parallel wrapper broadcast rank 0's
+        parameters (trainer.py:125 vs :313; the reference seeds every rank differently, trainer.py:294).  The student is made
+        identical on all ranks by the broadcast; the EMA teacher -- which the SSOD step runs on every rank -- is made
+        identical here the same way (a no-op when the ranks started from one checkpoint, as the reference's recipes do)."""
+        import torch.distributed as dist
+        m = self.model
+        if not (isinstance(m, FlatDataParallel) and m.active):
+            return
+        for e in (getattr(self, "ema", None), getattr(self, "semi_ema", None)):
+            if e is None:
+                continue
+            f = e.ema.flat_state()
+            dist.broadcast(f.params, 0, group=m.pg)
+            dist.broadcast(f.buffers, 0, group=m.pg)
+            f.mark_weights_changed()
 
     # ---- the step ------------------------------------------------------------------------------------------
     def _warmup(self, ni, accumulate_target):
@@ -152,7 +171,14 @@ class Trainer:
 
     def train_step(self, imgs, targets, ni):
         """Body of train_in_epoch (trainer.py:411-430) for one batch: imgs uint8/float NCHW, targets (n,6)."""
-        imgs = imgs.to(self.device, non_blocking=True).float() / self.norm_scale
+        imgs = imgs.to(self.device, non_blocking=True)
+        if imgs.dtype == torch.uint8 and self.cuda:
+            # the loaders' uint8 batch goes to the model as it is: the division by norm_scale (trainer.py:414) happens inside
+            # the input pack kernel (et_pack_input_u8), bit-equal to the float division
+            inner = self.model.module if isinstance(self.model, FlatDataParallel) else self.model
+            inner.input_norm_scale = float(self.norm_scale)
+        else:
+            imgs = imgs.float() / self.norm_scale
         pred = self.model(imgs)
         loss, loss_items = self.compute_loss(pred, targets.to(self.device))
         if self.RANK != -1:

@@ -10,7 +10,13 @@ import torch
 
 
 class DevicePrefetcher:
-    """Wraps an iterable of batches (tuples / lists whose tensor items are moved; other items pass through)."""
+    """Wraps an iterable of batches (tuples / lists whose tensor items are moved; other items pass through).
+
+    Pinned staging: one ring of ``depth + 1`` SLOTS; batch number s (a monotonically increasing stage counter) uses slot
+    ``s % (depth + 1)``.  A slot's pinned buffers are rewritten only after the event recorded behind the slot's previous
+    host->device copies has completed (the copies are asynchronous: without that wait the host would overwrite pixels the
+    DMA engine is still reading).  A buffer is a flat byte arena per (item index, slot) that grows to the largest item seen,
+    so variable-length label tensors (n, 6) reuse one allocation instead of pinning a new one per distinct n."""
 
     def __init__(self, iterable, device, depth=2):
         self.it = iter(iterable)
@@ -19,25 +25,40 @@ class DevicePrefetcher:
         self.depth = max(1, depth)
         self.stream = torch.cuda.Stream(device=self.device) if self.cuda else None
         self.queue = []
-        self._pinned = {}
+        self._slots = self.depth + 1
+        self._stage_no = 0                 # batches staged so far
+        self._pinned = {}                  # (item index, slot) -> flat uint8 pinned arena
+        self._slot_ev = [None] * self._slots
+
+    def _pinned_view(self, k, slot, t):
+        nbytes = t.numel() * t.element_size()
+        buf = self._pinned.get((k, slot))
+        if buf is None or buf.numel() < nbytes:
+            buf = self._pinned[(k, slot)] = torch.empty(max(nbytes, 16), dtype=torch.uint8).pin_memory()
+        return buf[:nbytes].view(t.dtype).view(t.shape)
 
     def _stage(self, batch):
         if not self.cuda:
             return batch, None
+        slot = self._stage_no % self._slots
+        self._stage_no += 1
+        if self._slot_ev[slot] is not None:        # the copies that last read this slot's pinned buffers are done
+            self._slot_ev[slot].synchronize()
         out = []
         with torch.cuda.stream(self.stream):
             for k, t in enumerate(batch):
                 if torch.is_tensor(t) and not t.is_cuda:
-                    key = (k, tuple(t.shape), t.dtype, len(self.queue) % (self.depth + 1))
-                    buf = self._pinned.get(key)
-                    if buf is None:
-                        buf = self._pinned[key] = torch.empty(t.shape, dtype=t.dtype).pin_memory()
+                    if t.numel() == 0:
+                        out.append(torch.empty(t.shape, dtype=t.dtype, device=self.device))
+                        continue
+                    buf = self._pinned_view(k, slot, t)
                     buf.copy_(t)
                     out.append(buf.to(self.device, non_blocking=True))
                 else:
                     out.append(t)
             ev = torch.cuda.Event()
             ev.record(self.stream)
+        self._slot_ev[slot] = ev
         return out, ev
 
     def _fill(self):

@@ -48,3 +48,33 @@ def test_train_with_unlabeled_generates_the_strong_view(hip):
     out = t.train_with_unlabeled([(imgs, targets, ["a", "b"], None)], [(None, None, ["c", "d"], None, u_ori, None)], start_ni=500)
     assert t._strong_view is not None
     assert all(np.isfinite(float(v)) for v in out.values()) and {"ss_box", "ss_obj", "ss_cls"} <= set(out)
+
+
+@pytest.mark.gpu
+def test_prefetcher_keeps_consecutive_batches_apart():
+    """equal-shaped consecutive batches shared one pinned slot and were overwritten while their asynchronous
+    host->device copy was still reading it.  Eight distinct uint8 batches (+ labels of varying length) through the
+    prefetcher: every delivered batch equals its source, and the pinned arenas stay bounded (one per item and slot)."""
+    from efficientteacher_amd.utils.prefetch import DevicePrefetcher
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu selected but no GPU is visible")
+    rng = np.random.default_rng(0)
+    src = [(torch.from_numpy(rng.integers(0, 256, (8, 3, 320, 320), dtype=np.uint8)),
+            torch.from_numpy(rng.random((3 + i, 6), dtype=np.float32)), ["p"] * 8) for i in range(8)]
+    pf = DevicePrefetcher(iter(src), "cuda:0")
+    got = []
+    for b in pf:
+        torch.cuda._sleep(20_000_000)                    # keep the compute stream busy: the copy stream runs ahead
+        got.append((b[0].clone(), b[1].clone()))
+    torch.cuda.synchronize()
+    assert len(got) == len(src)
+    for (gi, gl), (si, sl, _) in zip(got, src):
+        assert torch.equal(gi.cpu(), si) and torch.equal(gl.cpu(), sl)
+    assert len(pf._pinned) <= 2 * (pf.depth + 1)
+
+
+def test_prefetcher_cpu_passthrough():
+    from efficientteacher_amd.utils.prefetch import DevicePrefetcher
+    src = [(torch.full((2, 3), i), None, "x") for i in range(4)]
+    out = list(DevicePrefetcher(iter(src), "cpu"))
+    assert len(out) == 4 and all(torch.equal(o[0], s[0]) and o[2] == "x" for o, s in zip(out, src))

@@ -117,3 +117,19 @@ def test_trainer_step_and_epoch_end(hip):
     items = t.train_instance(hip.t(g["imgs"]), hip.t(g["targets"]), None, hip.t(g["u_str"]), hip.t(g["u_ori"]), None,
                              hip.t(g["M_s"]), 502)
     assert all(np.isfinite(float(v)) for v in items.values())
+
+
+def test_thresholds_live_in_one_persistent_device_tensor(hip):
+    """the per-class thresholds of select_targets were cached BY VALUE; a captured step graph kept reading the
+    tensor of the old values after LabelMatch rewrote the lists (and a cache eviction could free it).  They now live in ONE
+    tensor per loss object that is refreshed in place: same address before and after a change, new values in effect."""
+    from efficientteacher_amd import ops
+    th = ops.DeviceThresholds()
+    t9 = np.zeros((2, 9)); t9[:, 1] = [0, 1]; t9[:, 2:6] = 0.5; t9[:, 6] = [0.5, 0.5]; t9[:, 7] = 0.9; t9[:, 8] = 0.9
+    valid = hip.t(np.ones(2, np.uint8))
+    a = ops.select_targets(hip.t(t9), valid, [0.1, 0.1], [0.4, 0.6], 2, True, thresholds=th).cpu().numpy()
+    p0 = th.refresh([0.1, 0.1], [0.4, 0.6], hip.device).data_ptr()
+    b = ops.select_targets(hip.t(t9), valid, [0.1, 0.1], [0.6, 0.4], 2, True, thresholds=th).cpu().numpy()
+    assert th.refresh([0.1, 0.1], [0.6, 0.4], hip.device).data_ptr() == p0
+    # flags (column 7): class 0 was reliable (0.5 >= 0.4) and becomes uncertain (0.5 < 0.6); class 1 the other way round
+    assert a[0, 7] != b[0, 7] and a[1, 7] != b[1, 7] and a[0, 7] == b[1, 7]

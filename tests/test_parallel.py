@@ -167,3 +167,242 @@ def test_two_rank_gradient_mean_rccl():
     ref = (acc / world).cpu().numpy()
     scale = np.abs(ref).max()
     assert np.abs(r0["grads"] - ref).max() <= 1e-4 * scale, np.abs(r0["grads"] - ref).max() / scale
+
+
+# ---- gradient accumulation under data parallelism (the adapters' UnitScaler) ----------------------------------
+def _micro_data(rank, micro):
+    g = torch.Generator().manual_seed(1000 + 10 * micro + rank)
+    x = torch.rand(2, 3, 64, 64, generator=g)
+    t = torch.tensor([[0, 3 + micro, .5, .5, .3, .4], [1, 17, .3 + .1 * rank, .6, .2, .2], [1, rank, .7, .3 + .1 * micro, .4, .5]])
+    return x, t
+
+
+def _worker_accumulate(rank, world, port, emu_path, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from types import SimpleNamespace
+    from efficientteacher_amd import _lib
+    _lib._use_library_for_tests(emu_path, emulated=True)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from efficientteacher_amd.models.detector.yolo_ssod import Model
+    from efficientteacher_amd.models.loss import ComputeLoss
+    from efficientteacher_amd.parallel import FlatDataParallel
+    from efficientteacher_amd.trainer.adapters import UnitScaler
+    cfg = _cfg()
+    torch.manual_seed(rank)
+    model = Model(cfg).to("cpu").train()
+    ddp = FlatDataParallel(model, chunk_mb=0.05)         # several chunks: the overlap hook launches all-reduces DURING backward
+    assert len(ddp._chunks) > 1
+    scaler = UnitScaler(SimpleNamespace(model=ddp))      # what the reference's update_optimizer calls (trainer.py:383, :399)
+    closs = ComputeLoss(ddp, cfg)
+    model.zero_grad()
+    for micro in range(2):                               # accumulate = 2: two backward passes, ONE optimizer step
+        x, t = _micro_data(rank, micro)
+        pred, _ = ddp(x)
+        loss, _ = closs(pred, t)
+        scaler.scale(loss * world).backward()
+        assert not ddp._works and not ddp._launched      # every collective of this micro-step was finished by backward()
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), grads=model.flat_state().grads.numpy())
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_accumulation_gloo(emu_lib_path):
+    """accumulate = 2 on two ranks through UnitScaler.scale(loss).backward(): after the second micro-step the arena holds the
+    sum over the micro-steps of the mean over ranks -- what DistributedDataParallel leaves in .grad (trainer.py:313, :383-404).
+    With the all-reduce finished only at scaler.step (r02) the second micro-step's conv gradients were never averaged."""
+    world = 2
+    port = 29500 + ((os.getpid() + 7) % 2000)
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker_accumulate, args=(world, port, emu_lib_path, d), nprocs=world, join=True)
+        r0, r1 = np.load(os.path.join(d, "rank0.npz")), np.load(os.path.join(d, "rank1.npz"))
+    assert np.array_equal(r0["grads"], r1["grads"])
+    from efficientteacher_amd import _lib
+    from efficientteacher_amd.models.detector.yolo_ssod import Model
+    from efficientteacher_amd.models.loss import ComputeLoss
+    _lib._use_library_for_tests(emu_lib_path, emulated=True)
+    try:
+        cfg = _cfg()
+        torch.manual_seed(0)
+        model = Model(cfg).to("cpu").train()
+        closs = ComputeLoss(model, cfg)
+        acc = torch.zeros_like(model.flat_state().grads)
+        for micro in range(2):
+            for rank in range(world):
+                x, t = _micro_data(rank, micro)
+                model.zero_grad()
+                pred, _ = model(x)
+                loss, _ = closs(pred, t)
+                (loss * world).backward()
+                acc += model.flat_state().grads / world
+        ref = acc.numpy()
+    finally:
+        _lib._use_library_for_tests(None, False)
+    scale = np.abs(ref).max()
+    assert np.abs(r0["grads"] - ref).max() <= 2e-5 * scale, np.abs(r0["grads"] - ref).max() / scale
+
+
+# ---- a full SSOD train_instance on two ranks -------------------------------------------------------------------------------
+def _ssod_batch(rank, step):
+    g = torch.Generator().manual_seed(500 + 10 * step + rank)
+    imgs = torch.rand(2, 3, 64, 64, generator=g)
+    u_ori = torch.rand(2, 3, 64, 64, generator=g)
+    targets = torch.tensor([[0, 3, .5, .5, .3, .4], [1, 17, .3 + .1 * rank, .6, .2, .2], [1, rank + step, .7, .3, .4, .5]])
+    M_s = torch.zeros(2, 13, dtype=torch.float64)
+    for i in range(2):
+        M_s[i] = torch.tensor([i, 1, 0, 0, 0, 1, 0, 0, 0, 1, 1.0, 0, 0], dtype=torch.float64)     # identity warp
+    A = 3 * (8 * 8 + 4 * 4 + 2 * 2)
+    synth = torch.rand(2, A, 81, generator=g) ** torch.cat((torch.full((1,), 2.0), torch.full((80,), 3.0)))
+    return imgs, targets, u_ori.clone(), u_ori, M_s, synth
+
+
+def _ssod_trainer(rank, world):
+    from efficientteacher_amd.configs import get_cfg
+    from efficientteacher_amd.trainer import SSODTrainer
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(ROOT, YAML))
+    cfg.merge_from_list(["Model.width_multiple", 0.125, "Model.depth_multiple", 0.33, "Dataset.batch_size", 2 * world,
+                         "SSOD.fixed_accumulate", True, "Dataset.img_size", 64])
+    cfg.freeze()
+    return cfg, SSODTrainer(cfg, torch.device("cpu"), None, rank, rank, world, nb=1000)
+
+
+def _run_ssod_steps(tr, rank_of_step, steps=2, backward_only_until_last_rank=None):
+    for s in range(steps):
+        for r in rank_of_step:
+            imgs, targets, u_str, u_ori, M_s, synth = _ssod_batch(r, s)
+
+            def hook(tp, synth=synth):
+                tp[..., 4:] = synth
+                return tp
+            tr.teacher_pred_hook = hook
+            if backward_only_until_last_rank is not None and r != rank_of_step[-1]:
+                keep = tr.update_optimizer
+                tr.update_optimizer = lambda loss, ni: loss.backward()       # the other rank's share of the summed gradient
+                tr.train_instance(imgs, targets, None, u_str, u_ori, None, M_s, 2000 + s)
+                tr.update_optimizer = keep
+            else:
+                tr.train_instance(imgs, targets, None, u_str, u_ori, None, M_s, 2000 + s)
+
+
+def _worker_ssod(rank, world, port, emu_path, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from efficientteacher_amd import _lib
+    _lib._use_library_for_tests(emu_path, emulated=True)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from efficientteacher_amd.parallel import FlatDataParallel
+    torch.manual_seed(rank)                       # the reference seeds every rank differently (trainer.py:294)
+    cfg, tr = _ssod_trainer(rank, world)
+    assert isinstance(tr.model, FlatDataParallel) and tr.model.active
+    tr.overlap_teacher = False
+    e0 = tr.ema.ema.flat_state().params.clone()
+    _run_ssod_steps(tr, [rank])
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), params=tr.model.flat_state().params.numpy(), ema0=e0.numpy(),
+             ema=tr.ema.ema.flat_state().params.numpy(), semi=tr.semi_ema.ema.flat_state().params.numpy())
+    dist.destroy_process_group()
+
+
+def test_two_rank_ssod_train_instance_gloo(emu_lib_path):
+    """Two full SSODTrainer.train_instance steps (EMA-teacher forward, NMS + pseudo labels, student forward on the concatenated
+    batch, ComputeLoss + ComputeStudentMatchLoss, backward, all-reduce, SGD, both EMAs) on two gloo ranks with different local
+    batches: student and teacher parameters stay identical across the ranks, and equal a single process that accumulates the
+    two ranks' gradients of every step before its optimizer step (loss x WORLD_SIZE and the mean over ranks = the sum,
+    ssod_trainer.py:638-649 + trainer.py:313)."""
+    world = 2
+    port = 29500 + ((os.getpid() + 13) % 2000)
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker_ssod, args=(world, port, emu_lib_path, d), nprocs=world, join=True)
+        r0, r1 = np.load(os.path.join(d, "rank0.npz")), np.load(os.path.join(d, "rank1.npz"))
+    assert np.array_equal(r0["ema0"], r1["ema0"])            # the teacher copy was re-synchronised from rank 0 at construction
+    for k in ("params", "ema", "semi"):
+        assert np.array_equal(r0[k], r1[k]), k
+    from efficientteacher_amd import _lib
+    _lib._use_library_for_tests(emu_lib_path, emulated=True)
+    try:
+        torch.manual_seed(0)
+        cfg, tr = _ssod_trainer(-1, 1)
+        tr.overlap_teacher = False
+        assert np.array_equal(tr.ema.ema.flat_state().params.numpy(), r0["ema0"])
+        _run_ssod_steps(tr, [0, 1], backward_only_until_last_rank=True)
+        ref = {"params": tr.model.flat_state().params.numpy(), "ema": tr.ema.ema.flat_state().params.numpy()}
+    finally:
+        _lib._use_library_for_tests(None, False)
+    for k, v in ref.items():
+        den = max(np.abs(v).max(), 1e-12)
+        assert np.abs(r0[k] - v).max() <= 2e-5 * den, (k, np.abs(r0[k] - v).max() / den)
+
+
+# ---- the RCCL code path on ONE GPU -----------------------------------------------------------------------------------------
+def _worker_rccl_single(rank, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", ET_DP_SINGLE_RANK="1")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    from efficientteacher_amd.configs import get_cfg
+    from efficientteacher_amd.parallel import FlatDataParallel
+    from efficientteacher_amd.trainer import SSODTrainer
+
+    def make(rk):
+        cfg = get_cfg()
+        cfg.merge_from_file(os.path.join(ROOT, YAML))
+        cfg.merge_from_list(["Model.width_multiple", 0.125, "Model.depth_multiple", 0.33, "Dataset.batch_size", 2,
+                             "SSOD.fixed_accumulate", True, "Dataset.img_size", 64])
+        cfg.freeze()
+        torch.manual_seed(0)
+        t = SSODTrainer(cfg, dev, None, rk, rk, 1, nb=1000)
+        t.model.module.set_compute_dtype(torch.float32) if rk != -1 else t.model.set_compute_dtype(torch.float32)
+        return t
+
+    def run(t, graph):
+        losses = []
+        for s in range(6):
+            imgs, targets, u_str, u_ori, M_s, synth = (x.to(dev) for x in _ssod_batch(0, 0))
+
+            def hook(tp, synth=synth):
+                tp[..., 4:] = synth
+                return tp
+            t.teacher_pred_hook = hook
+            t.use_graph = graph and s >= 3
+            items = t.train_instance(imgs, targets, None, u_str, u_ori, None, M_s, 2000 + s)
+            losses.append([float(items[k]) for k in ("box", "obj", "cls", "ss_box", "ss_obj", "ss_cls")])
+        torch.cuda.synchronize()
+        return np.array(losses)
+
+    # set_compute_dtype rebuilds the arenas: wrap AFTER it (as the trainers do when they build the model in its final dtype)
+    plain = make(-1)
+    plain.build_optimizer(plain.cfg)
+    from efficientteacher_amd.utils.torch_utils import ModelEMA, SemiSupModelEMA
+    plain.ema = ModelEMA(plain.model); plain.semi_ema = SemiSupModelEMA(plain.ema.ema, plain.cfg.SSOD.ema_rate)
+    a = run(plain, graph=False)
+    del plain
+    dp = make(0)
+    inner = dp.model.module
+    dp.model = inner
+    dp.build_optimizer(dp.cfg)
+    dp.ema = ModelEMA(inner); dp.semi_ema = SemiSupModelEMA(dp.ema.ema, dp.cfg.SSOD.ema_rate)
+    dp.build_ddp_model(dp.cfg, dev)
+    assert isinstance(dp.model, FlatDataParallel) and dp.model.active and dp.model.world == 1
+    b = run(dp, graph=True)
+    np.savez(os.path.join(out_dir, "single.npz"), eager=a, dp_graph=b, replays=dp._graph.replays if dp._graph else -1,
+             err=str(dp.graph_error), nchunks=len(dp.model._chunks))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_single_rank_rccl_collectives_eager_and_captured():
+    """The data-parallel step over a ONE-rank RCCL group (ET_DP_SINGLE_RANK): construction broadcasts, the per-forward buffer
+    broadcast, ReduceOp.AVG all-reduces launched asynchronously from the gradient-ready hook, their waits -- issued eagerly for
+    three steps and then captured into the step graph and replayed for three more.  AVG over one rank is the identity, so the
+    six steps must reproduce the plain single-process trainer.  This is what a single-GPU box can execute of the N > 1 path."""
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu selected but no GPU is visible")
+    port = 29500 + ((os.getpid() + 29) % 2000)
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker_rccl_single, args=(port, d), nprocs=1, join=True)
+        r = np.load(os.path.join(d, "single.npz"))
+    assert str(r["err"]) == "None", str(r["err"])
+    assert int(r["replays"]) == 3
+    a, b = r["eager"], r["dp_graph"]
+    assert np.abs(a[:3] - b[:3]).max() <= 1e-5 * np.abs(a).max()        # eager steps with collectives
+    assert np.abs(a[3:] - b[3:]).max() <= 1e-4 * np.abs(a).max()        # captured + replayed steps with collectives
