@@ -398,9 +398,11 @@ class UpsampleCatFn(Function):
     def forward(ctx, a, b):
         N, H, W, Ca = a.shape
         Cb = b.shape[3]
-        cat = torch.empty((N, 2 * H, 2 * W, Ca + Cb), dtype=a.dtype, device=a.device)
+        cat = in_place_concat_buffer(b, Ca)
+        if cat is None or cat.shape != (N, 2 * H, 2 * W, Ca + Cb):
+            cat = torch.empty((N, 2 * H, 2 * W, Ca + Cb), dtype=a.dtype, device=a.device)
+            cat[..., Ca:].copy_(b)
         ops.upsample2x_fwd(a, out=cat[..., :Ca])
-        cat[..., Ca:].copy_(b)
         ctx.Ca = Ca
         return cat
 
@@ -408,6 +410,19 @@ class UpsampleCatFn(Function):
     def backward(ctx, dcat):
         dcat = _dense_or_slice(dcat)
         return ops.upsample2x_bwd(dcat[..., :ctx.Ca]), dcat[..., ctx.Ca:]
+
+
+def in_place_concat_buffer(b, Ca):
+    """`b` was produced IN PLACE as channels [Ca, Ca + Cb) of a wider NHWC buffer (YoloV5Neck.concat_slots: the backbone's C3 / C4
+    blocks wrote P3 / P4 there): return that buffer, else None.  The producer tags the slice (`_et_cat_buf`)."""
+    buf = getattr(b, "_et_cat_buf", None)
+    if buf is None:
+        return None
+    es = buf.element_size()
+    if (b.data_ptr() == buf.data_ptr() + Ca * es and b.stride() == buf[..., Ca:].stride() and b.shape[:3] == buf.shape[:3]
+            and Ca + b.shape[3] == buf.shape[3]):
+        return buf
+    return None
 
 
 class GradReverseFn(Function):  # reference models/detector/yolo_ssod.py:158-171

@@ -399,3 +399,123 @@ extern "C" int et_tal_loss(const float* pred_scores, const float* pred_distri, c
     ET_CHECK_LAUNCH();
     return 0;
 }
+
+
+// ---- pseudo labels on the anchor-free head (EXTENSION: the reference has no TAL variant of ComputeStudentMatchLoss) ----------------
+// Specification: oracle/v8.py::tal_student_match_loss (parity unpinned by construction; DESIGN.md "a-14").  It mirrors
+// ComputeStudentMatchLoss (models/loss/ssod/ssod_loss.py:130-296) on the YOLOv8 head:
+//   split   (:130-192)  reliable  = conf >= high[cls]                      -> ordinary TaskAlignedAssigner targets
+//                       uncertain = low[cls] <= conf < high[cls]           -> soft class target: aligned score * s,
+//                                   s = obj_conf (pseudo_label_with_obj) or conf; box / DFL terms only for uncertain labels with
+//                                   obj_conf >= 0.99 (pseudo_label_with_bbox), full-strength class target for cls_conf >= 0.99
+//                                   (pseudo_label_with_cls)
+//   merge   (:231,:248) where a reliable and an uncertain label both own an anchor the UNCERTAIN one wins (the reference writes
+//                       tobj for the reliable cells first and for the uncertain cells afterwards)
+// The padded pseudo-label table (B * G rows of 9 fp64 + valid mask, utils/self_supervised_utils.py) never leaves the device.
+__global__ __launch_bounds__(256) void tal_pseudo_split_kernel(const double* __restrict__ t9, const unsigned char* __restrict__ valid,
+                                                               const double* __restrict__ lo, const double* __restrict__ hi, int n, int nc,
+                                                               int with_obj, int with_bbox, int with_cls, float img_w, float img_h,
+                                                               float* __restrict__ glabel_r, float* __restrict__ gbox_r,
+                                                               float* __restrict__ glabel_u, float* __restrict__ gbox_u,
+                                                               float* __restrict__ mask_r, float* __restrict__ mask_u,
+                                                               float* __restrict__ u_score, unsigned char* __restrict__ u_flags) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double* r = t9 + (size_t)i * 9;
+    const bool ok = valid == nullptr || valid[i] != 0;
+    int c = ok ? (int)r[1] : 0;
+    c = c < 0 ? 0 : (c >= nc ? nc - 1 : c);
+    const double conf = r[6], oc = r[7], cc = r[8];
+    const bool rel = ok && conf >= hi[c];
+    const bool unc = ok && !rel && conf >= lo[c];
+    // normalised xywh -> xyxy pixels, the arithmetic of ComputeTalLoss.preprocess (tal_loss.py:139-142) in fp32.  Each set gets its
+    // OWN table: a row that is not in the set is a padded row (label -1, zero box) exactly as in the supervised loss -- the assigner's
+    // multi-owner resolution takes the arg-max IoU over ALL rows of the table it is given (tal_assigner.py:100-104)
+    const float x = (float)r[2] * img_w, y = (float)r[3] * img_h, w = (float)r[4] * img_w, h = (float)r[5] * img_h;
+    const float x1 = x - w * 0.5f, y1 = y - h * 0.5f;
+    const float bx[4] = {x1, y1, x1 + w, y1 + h};
+    glabel_r[i] = rel ? (float)c : -1.0f;
+    glabel_u[i] = unc ? (float)c : -1.0f;
+    for (int k = 0; k < 4; ++k) { gbox_r[i * 4 + k] = rel ? bx[k] : 0.f; gbox_u[i * 4 + k] = unc ? bx[k] : 0.f; }
+    mask_r[i] = rel ? 1.f : 0.f;
+    mask_u[i] = unc ? 1.f : 0.f;
+    u_score[i] = unc ? (float)(with_obj ? oc : conf) : 0.f;
+    unsigned char f = 0;
+    if (unc && with_obj) {                                    // the reference forms the two subsets only under pseudo_label_with_obj
+        if (with_bbox && oc >= 0.99) f |= 1;
+        if (with_cls && cc >= 0.99) f |= 2;
+    }
+    u_flags[i] = f;
+}
+
+__global__ __launch_bounds__(256) void tal_merge_pseudo_kernel(const float* __restrict__ ts_r, const float* __restrict__ tb_r,
+                                                               const unsigned char* __restrict__ fg_r, const float* __restrict__ ts_u,
+                                                               const float* __restrict__ tb_u, const unsigned char* __restrict__ fg_u,
+                                                               const int* __restrict__ idx_u, const float* __restrict__ u_score,
+                                                               const unsigned char* __restrict__ u_flags, int B, int A, int G, int nc,
+                                                               float* __restrict__ ts, float* __restrict__ tb,
+                                                               unsigned char* __restrict__ fg_box) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)B * A) return;
+    const int b = (int)(i / A);
+    const bool u = fg_u[i] != 0, r = fg_r[i] != 0;
+    float scale = 0.f;
+    bool box = false;
+    const float* src_s = ts_r + i * nc;
+    const float* src_b = tb_r + i * 4;
+    if (u) {
+        const int g = idx_u[i];
+        const unsigned char f = u_flags[(size_t)b * G + g];
+        scale = (f & 2) ? 1.0f : u_score[(size_t)b * G + g];
+        box = (f & 1) != 0;
+        src_s = ts_u + i * nc; src_b = tb_u + i * 4;
+    } else if (r) {
+        scale = 1.0f; box = true;
+    }
+    for (int k = 0; k < nc; ++k) ts[i * nc + k] = (u || r) ? src_s[k] * scale : 0.f;
+    for (int k = 0; k < 4; ++k) tb[i * 4 + k] = src_b[k];
+    fg_box[i] = box ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void copy_i32_kernel(const int* __restrict__ src, int* __restrict__ dst, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
+extern "C" int et_tal_pseudo_split(const double* targets9, const uint8_t* valid, const double* thr_low, const double* thr_high, int B,
+                                   int G, int nc, int with_obj, int with_bbox, int with_cls, float img_w, float img_h, float* gt_labels_r,
+                                   float* gt_bboxes_r, float* gt_labels_u, float* gt_bboxes_u, float* mask_reliable,
+                                   float* mask_uncertain, float* u_score, uint8_t* u_flags, et_stream_t stream) {
+    if (!targets9 || !thr_low || !thr_high || !gt_labels_r || !gt_bboxes_r || !gt_labels_u || !gt_bboxes_u || !mask_reliable ||
+        !mask_uncertain || !u_score || !u_flags) return -1;
+    if (B <= 0 || G <= 0 || nc <= 0) return -2;
+    const int n = B * G;
+    hipLaunchKernelGGL(tal_pseudo_split_kernel, dim3(et_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, targets9, valid, thr_low, thr_high,
+                       n, nc, with_obj, with_bbox, with_cls, img_w, img_h, gt_labels_r, gt_bboxes_r, gt_labels_u, gt_bboxes_u, mask_reliable,
+                       mask_uncertain, u_score, u_flags);
+    ET_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int et_tal_assigned_gt(const void* workspace, int B, int A, int G, int32_t* gt_idx, et_stream_t stream) {
+    // the (B, A) gt index et_tal_assign left in its workspace (valid where its fg_mask is set)
+    if (!workspace || !gt_idx) return -1;
+    if (B <= 0 || A <= 0 || G <= 0) return -2;
+    const char* w = (const char*)workspace + (((size_t)B * G * A + 15) / 16) * 16;
+    hipLaunchKernelGGL(copy_i32_kernel, dim3(et_cdiv((long long)B * A, 256)), dim3(256), 0, (hipStream_t)stream, (const int*)w, gt_idx,
+                       (long long)B * A);
+    ET_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int et_tal_merge_pseudo(const float* ts_r, const float* tb_r, const uint8_t* fg_r, const float* ts_u, const float* tb_u,
+                                   const uint8_t* fg_u, const int32_t* gt_idx_u, const float* u_score, const uint8_t* u_flags, int B, int A,
+                                   int G, int nc, float* target_scores, float* target_bboxes, uint8_t* fg_box, et_stream_t stream) {
+    if (!ts_r || !tb_r || !fg_r || !ts_u || !tb_u || !fg_u || !gt_idx_u || !u_score || !u_flags || !target_scores || !target_bboxes || !fg_box)
+        return -1;
+    if (B <= 0 || A <= 0 || G <= 0 || nc <= 0) return -2;
+    hipLaunchKernelGGL(tal_merge_pseudo_kernel, dim3(et_cdiv((long long)B * A, 256)), dim3(256), 0, (hipStream_t)stream, ts_r, tb_r, fg_r, ts_u,
+                       tb_u, fg_u, gt_idx_u, u_score, u_flags, B, A, G, nc, target_scores, target_bboxes, fg_box);
+    ET_CHECK_LAUNCH();
+    return 0;
+}

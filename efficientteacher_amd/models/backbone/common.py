@@ -130,8 +130,10 @@ class C3(nn.Module):
         self.cv3 = Conv(2 * c_, c2, 1, act=last_act)
         self.m = nn.Sequential(*[Bottleneck(c_, c_, shortcut, g, e=1.0, act=act) for _ in range(n)])
 
-    def forward(self, x):
+    def forward(self, x, dst=None):
         # cv3(cat(m(cv1(x)), cv2(x))): both halves are written in place into one buffer (no cat copy)
+        # dst = (buffer, channel offset): cv3 writes the block's output straight into a slice of a wider buffer (the backbone's
+        # P3 / P4 go into the neck's upsample-concat buffers this way: yolov5_neck.py:92-98 without the copy)
         N, H, W, _ = x.shape
         c_ = self.cv2.conv.out_channels
         c1s, c2s = getattr(self.cv1.conv, "_et_slot", None), getattr(self.cv2.conv, "_et_slot", None)
@@ -151,7 +153,7 @@ class C3(nn.Module):
                 nxt = [] if (fuse and i != last) else None
                 t = b(t, dst=(buf, c_) if i == last else None, bn_in=hand[0] if hand else None, bn_out=nxt)
                 hand = nxt
-            return self.cv3(JoinSlicesFn.apply((buf[..., c_:],), t, y2))
+            return self.cv3(JoinSlicesFn.apply((buf[..., c_:],), t, y2), dst=dst)
         buf = torch.empty((N, H, W, 2 * c_), dtype=x.dtype, device=x.device)
         y2 = self.cv2(x, dst=(buf, c_))
         train = self.cv1.bn.training and torch.is_grad_enabled() and _ag.FUSE_BN_BWD and len(self.m) > 0
@@ -165,7 +167,7 @@ class C3(nn.Module):
             cat = JoinSlicesFn.apply((buf,), t, y2)
         else:
             cat = buf
-        return self.cv3(cat)
+        return self.cv3(cat, dst=dst)
 
 
 class C2f(nn.Module):

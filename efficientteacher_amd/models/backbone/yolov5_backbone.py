@@ -33,14 +33,15 @@ class YoloV5BackBone(nn.Module):
         self.sppf = SPPF(c['csp1'], c['spp'], 5, CONV_ACT)
         self.out_shape = {'C3_size': c['stage3_2'], 'C4_size': c['stage4_2'], 'C5_size': c['conv1']}
 
-    def forward(self, x):
+    def forward(self, x, dst_c3=None, dst_c4=None):
+        """dst_c3 / dst_c4 = (buffer, channel offset): produce C3 / C4 in place inside the neck's concat buffers"""
         x1 = self.stage1(x)        # P1/2
         x21 = self.stage2_1(x1)    # P2/4
         x22 = self.stage2_2(x21)
         x31 = self.stage3_1(x22)   # P3/8
-        c3 = self.stage3_2(x31)
+        c3 = self.stage3_2(x31, dst=dst_c3)
         x41 = self.stage4_1(c3)    # P4/16
-        c4 = self.stage4_2(x41)
+        c4 = self.stage4_2(x41, dst=dst_c4)
         x51 = self.stage5_1(c4)    # P5/32
         x5 = self.stage5_2(x51)
         return c3, c4, self.sppf(x5)

@@ -73,32 +73,43 @@ class ComputeTalLoss:
         out[..., 1:5] = torch.stack([x1, y1, x1 + box[..., 2], y1 + box[..., 3]], -1)
         return out, sum(len(p) for p in per) + batch_size     # the reference counts its dummy row per image
 
-    def __call__(self, outputs, targets):
-        feats, pred_scores, pred_distri = outputs
+    def assigner_inputs(self, feats, pred_scores, pred_distri):
+        """what the TaskAlignedAssigner sees (detached, tal_loss.py:95-102): sigmoid class scores (B,A,nc), predicted xyxy boxes in
+        pixels (B,A,4), and the anchor tables -- decoded exactly as the inference head does (DFL expectation, dist2bbox)"""
         dev = pred_scores.device
         B, A, nc = pred_scores.shape
-        anchor_points, stride_tensor = self._anchor_points([tuple(f.shape[-2:]) for f in feats], dev)
-        tg, num_gts = self.preprocess(targets, B)
-        tg = tg.to(dev)
-        gt_labels, gt_bboxes = tg[..., :1], tg[..., 1:]
-        mask_gt = (gt_bboxes.sum(-1, keepdim=True) > 0).float()
-        anchor_points_s = anchor_points / stride_tensor
-        with torch.no_grad():                               # the assigner sees detached predictions (:95-102)
+        shapes = [tuple(f.shape[-2:]) for f in feats]
+        anchor_points, stride_tensor = self._anchor_points(shapes, dev)
+        with torch.no_grad():
             z = torch.empty((B, A, 5 + nc), dtype=torch.float32, device=dev)
-            # decoded boxes + sigmoid scores exactly as the inference head computes them (DFL expectation, dist2bbox), in pixels
             off = 0
             nb = 4 * (self.reg_max + 1)
-            for (h, w), s in zip([tuple(f.shape[-2:]) for f in feats], self.fpn_strides):
+            for (h, w), s in zip(shapes, self.fpn_strides):
                 n = h * w
                 ops.v8_decode(pred_distri[:, off:off + n].float().contiguous().view(B, h, w, nb), pred_scores[:, off:off + n].float().contiguous().view(B, h, w, nc),
                               self.reg_max, nc, float(s), self.grid_cell_offset, z, off)
                 off += n
             cxcywh = z[..., :4]
             pd_xyxy = torch.cat([cxcywh[..., :2] - cxcywh[..., 2:] / 2, cxcywh[..., :2] + cxcywh[..., 2:] / 2], -1)
-            tl, tb, ts, fg = ops.tal_assign(z[..., 5:], pd_xyxy, anchor_points, gt_labels, gt_bboxes, mask_gt, topk=13, alpha=1.0, beta=6.0)
+        return z[..., 5:], pd_xyxy, anchor_points, anchor_points / stride_tensor, stride_tensor
+
+    def loss_terms(self, pred_scores, pred_distri, anchor_points_s, stride_tensor, tb, ts, fg):
         aux = (anchor_points_s, stride_tensor, tb, ts, fg, self.reg_max, self.iou_type, self.loss_weight['class'],
                self.loss_weight['iou'], self.loss_weight['dfl'])
-        out = _TalLossFn.apply(pred_scores, pred_distri, aux)
+        return _TalLossFn.apply(pred_scores, pred_distri, aux)
+
+    def __call__(self, outputs, targets):
+        feats, pred_scores, pred_distri = outputs
+        dev = pred_scores.device
+        B, A, nc = pred_scores.shape
+        tg, num_gts = self.preprocess(targets, B)
+        tg = tg.to(dev)
+        gt_labels, gt_bboxes = tg[..., :1], tg[..., 1:]
+        mask_gt = (gt_bboxes.sum(-1, keepdim=True) > 0).float()
+        scores, pd_xyxy, anchor_points, anchor_points_s, stride_tensor = self.assigner_inputs(feats, pred_scores, pred_distri)
+        with torch.no_grad():
+            tl, tb, ts, fg = ops.tal_assign(scores, pd_xyxy, anchor_points, gt_labels, gt_bboxes, mask_gt, topk=13, alpha=1.0, beta=6.0)
+        out = self.loss_terms(pred_scores, pred_distri, anchor_points_s, stride_tensor, tb, ts, fg)
         loss = out[3:4]
         d = out.detach()
         return loss, dict(loss_iou=d[0], loss_dfl=d[1], loss_cls=d[2], loss=loss, num_fg=fg.sum() / max(num_gts, 1))

@@ -47,6 +47,17 @@ class YoloV5Neck(nn.Module):
         for k, v in self.channels.items():
             self.channels[k] = self.get_width(v)
 
+    def concat_slots(self, N, H3, W3, dtype, device):
+        """The two top-down concat buffers [upsample(conv1(P5)) | P4] and [upsample(conv2(.)) | P3] allocated BEFORE the backbone
+        runs, so that its C4 / C3 blocks write P4 / P3 straight into their halves: ((buf, offset) for C3, (buf, offset) for C4),
+        or None when a channel count is not a multiple of 8 (16-byte vectors)."""
+        c1o, c2o = self.conv1.conv.out_channels, self.conv2.conv.out_channels
+        if c1o % 8 or c2o % 8 or self.input_p3 % 8 or self.input_p4 % 8:
+            return None
+        cat2 = torch.empty((N, H3, W3, c2o + self.input_p3), dtype=dtype, device=device)
+        cat1 = torch.empty((N, H3 // 2, W3 // 2, c1o + self.input_p4), dtype=dtype, device=device)
+        return (cat2, c2o), (cat1, c1o)
+
     def forward(self, inputs):
         P3, P4, P5 = inputs
         # the two bottom-up concats [conv3(x2) | xp_2] and [conv4(x3) | xp_1] are produced IN PLACE: the lateral

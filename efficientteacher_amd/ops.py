@@ -36,6 +36,7 @@ class KernelTimer:
 
 
 TIMER = None
+SCOPE = None          # "teacher" while the trainer issues the EMA teacher's forward (bench.py's per-family time budget)
 
 
 class FamilyTimer:
@@ -52,7 +53,8 @@ class FamilyTimer:
         "et_nms": "nms_loss_pl", "et_nms_ssod": "nms_loss_pl", "et_detect_decode": "nms_loss_pl", "et_pseudo_label_transform": "nms_loss_pl",
         "et_select_targets": "nms_loss_pl", "et_yolo_loss": "nms_loss_pl", "et_ota_assign": "nms_loss_pl", "et_score_log_append": "nms_loss_pl",
         "et_scale_cast": "nms_loss_pl", "et_domain_focal": "nms_loss_pl", "et_scale_inplace": "nms_loss_pl", "et_v8_decode": "nms_loss_pl",
-        "et_tal_loss": "nms_loss_pl", "et_tal_assign": "nms_loss_pl", "et_colsum": "nms_loss_pl",
+        "et_tal_loss": "nms_loss_pl", "et_tal_assign": "nms_loss_pl", "et_colsum": "nms_loss_pl", "et_tal_pseudo_split": "nms_loss_pl",
+        "et_tal_assigned_gt": "nms_loss_pl", "et_tal_merge_pseudo": "nms_loss_pl",
         "et_sgd_nesterov": "optimizer_ema", "et_sgd_nesterov_dev": "optimizer_ema", "et_adamw": "optimizer_ema", "et_ema_update": "optimizer_ema",
         "et_ema_update_dev": "optimizer_ema", "et_cast_f32_to_bf16": "optimizer_ema", "et_weight_transpose": "optimizer_ema",
         "et_weight_transpose_all": "optimizer_ema", "et_bn_eval_affine": "optimizer_ema",
@@ -64,7 +66,7 @@ class FamilyTimer:
     def begin(self, name):
         fam = self.FAMILY.get(name, "pool_upsample_pack")
         if fam == "gather_gemm":
-            fam = "gather_gemm_student" if torch.is_grad_enabled() else "gather_gemm_teacher"
+            fam = "gather_gemm_teacher" if SCOPE == "teacher" else "gather_gemm_student"
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         return (fam, torch.cuda.current_stream().cuda_stream, a, b)
@@ -187,12 +189,13 @@ class WgradQueue:
     the backward pass (autograd engine callback); ``on_done`` callbacks (gradient-ready hooks of the data-parallel
     wrapper) run right after the launch that covers their layer.  ET_WGRAD_GROUP=1 launches every layer at once.
 
-    Nothing in backward consumes a weight gradient, so on a GPU the grouped launches CAN go to a second HIP stream
-    (ET_WGRAD_STREAM=1): the MFMA-bound wgrad workgroups then fill the CUs the critical path leaves idle -- the partially
-    filled last residency round of every dgrad (YOLOv5's pixel counts are 25 * 2^k: 400 tiles on 256 CUs run as two
-    rounds), the HBM-write burst of its epilogue, and the HBM-bound BatchNorm backward passes.  Measured on the YOLOv5l
-    SSOD step (gpurun g3): 62.3 vs 62.8 ms per step -- the step is throughput-bound, the teacher stream already fills those
-    gaps -- so the default keeps the launches on the launching stream; the stream is kept for small-batch runs.  Ordering: the side stream waits for the launching stream at every group launch (dy
+    Nothing in backward consumes a weight gradient, so on a GPU the grouped launches go to a second HIP stream (default;
+    ET_WGRAD_STREAM=0 keeps them on the launching stream): the MFMA-bound wgrad workgroups then run beside the critical path
+    (dgrad -> BatchNorm backward -> dgrad ...) instead of inside it.  Measured on the YOLOv5l SSOD step, alternating runs on one
+    box (profiles/r03_wgrad_stream_ab.txt): 58.13 / 58.10 ms against 58.77 / 58.75 ms -- about 1 %.  The GPU is close to
+    work-conserving here: with the 12.6 ms of wgrad kernels off the main stream its own kernels stretch by ~6 ms (BatchNorm
+    passes 14.1 -> 17.2 ms, gather-GEMMs 26.0 -> 29.2 ms), which is why the gain is 0.6 ms and not 12 (r02 measured +0.5 ms
+    once and nothing once, and left it off).  Ordering: the side stream waits for the launching stream at every group launch (dy
     and x are complete), the launching stream joins the side stream at the end of backward (before the optimizer /
     the final all-reduces); gradient-ready hooks run with the side stream current, so an RCCL all-reduce they start
     is ordered behind the wgrads it covers."""
@@ -205,7 +208,7 @@ class WgradQueue:
         self.last = {}
         self.tick = 0
         self._cb_armed = False
-        self.use_side = os.environ.get("ET_WGRAD_STREAM", "0") == "1"
+        self.use_side = os.environ.get("ET_WGRAD_STREAM", "1") == "1"
         self._side = {}              # device -> side stream
         self._dirty = set()          # devices whose side stream holds work the launching stream has not joined yet
 
@@ -818,9 +821,9 @@ def v8_decode(reg_nhwc, cls_nhwc, reg_max, nc, stride, cell_offset, out, a_offse
                                         int(a_offset), _lib.stream(out)), "et_v8_decode")
 
 
-def tal_assign(pd_scores, pd_bboxes, anc_points, gt_labels, gt_bboxes, mask_gt, topk=13, alpha=1.0, beta=6.0, eps=1e-9):
+def tal_assign(pd_scores, pd_bboxes, anc_points, gt_labels, gt_bboxes, mask_gt, topk=13, alpha=1.0, beta=6.0, eps=1e-9, return_idx=False):
     """TaskAlignedAssigner.forward on the device: -> (target_labels (B,A) int64, target_bboxes (B,A,4), target_scores (B,A,nc),
-    fg_mask (B,A) bool)."""
+    fg_mask (B,A) bool [, gt_idx (B,A) int32: the owning gt where fg_mask is set])."""
     import ctypes
     B, A, nc = pd_scores.shape
     G = gt_bboxes.shape[1]
@@ -831,7 +834,8 @@ def tal_assign(pd_scores, pd_bboxes, anc_points, gt_labels, gt_bboxes, mask_gt, 
     ts = torch.empty((B, A, nc), dtype=torch.float32, device=dev)
     fg = torch.empty((B, A), dtype=torch.uint8, device=dev)
     if G == 0:                                       # tal_assigner.py:52-57
-        return tl.fill_(nc), tb.zero_(), ts.zero_(), fg.zero_().bool()
+        r = (tl.fill_(nc), tb.zero_(), ts.zero_(), fg.zero_().bool())
+        return r + (torch.zeros((B, A), dtype=torch.int32, device=dev),) if return_idx else r
     lib = _lib.load()
     n = ctypes.c_size_t()
     _lib.check(lib.et_tal_assign_workspace_bytes(B, A, G, ctypes.byref(n)), "et_tal_assign_workspace_bytes")
@@ -841,7 +845,45 @@ def tal_assign(pd_scores, pd_bboxes, anc_points, gt_labels, gt_bboxes, mask_gt, 
     _lib.check(lib.et_tal_assign(_lib.ptr(ps), _lib.ptr(pb), _lib.ptr(ap), _lib.ptr(gl), _lib.ptr(gb), _lib.ptr(gm), B, A, G, nc,
                                  int(topk), float(alpha), float(beta), float(eps), _lib.ptr(tl), _lib.ptr(tb), _lib.ptr(ts),
                                  _lib.ptr(fg), _lib.ptr(ws), n.value, _lib.stream(ps)), "et_tal_assign")
+    if return_idx:
+        idx = torch.empty((B, A), dtype=torch.int32, device=dev)
+        _lib.check(lib.et_tal_assigned_gt(_lib.ptr(ws), B, A, G, _lib.ptr(idx), _lib.stream(ps)), "et_tal_assigned_gt")
+        return tl, tb, ts, fg.bool(), idx
     return tl, tb, ts, fg.bool()
+
+
+def tal_pseudo_split(targets9, valid, thr, B, nc, with_obj, with_bbox, with_cls, img_w, img_h):
+    """padded pseudo labels (B*G, 9) fp64 (+ valid) and thr = (2, nc) fp64 [low; high] -> per set (reliable, uncertain) a padded gt
+    table (labels (B,G,1), boxes (B,G,4) xyxy px, mask (B,G,1)), then u_score (B,G), u_flags (B,G) uint8  (EXTENSION: include/et_hip.h)"""
+    n = targets9.shape[0]
+    assert n % B == 0 and targets9.dtype == torch.float64 and targets9.is_contiguous()
+    G = n // B
+    dev = targets9.device
+    f32 = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)
+    glr, gbr, glu, gbu, mr, mu, us = f32(B, G, 1), f32(B, G, 4), f32(B, G, 1), f32(B, G, 4), f32(B, G, 1), f32(B, G, 1), f32(B, G)
+    uf = torch.empty((B, G), dtype=torch.uint8, device=dev)
+    _lib.check(_lib.load().et_tal_pseudo_split(_lib.ptr(targets9), _lib.ptr(valid), _lib.ptr(thr[0]), _lib.ptr(thr[1]), B, G, nc,
+                                               int(bool(with_obj)), int(bool(with_bbox)), int(bool(with_cls)), float(img_w), float(img_h),
+                                               _lib.ptr(glr), _lib.ptr(gbr), _lib.ptr(glu), _lib.ptr(gbu), _lib.ptr(mr), _lib.ptr(mu),
+                                               _lib.ptr(us), _lib.ptr(uf), _lib.stream(targets9)), "et_tal_pseudo_split")
+    return (glr, gbr, mr), (glu, gbu, mu), us, uf
+
+
+def tal_merge_pseudo(rel, unc, u_score, u_flags):
+    """rel = (tb, ts, fg) of the reliable labels, unc = (tb, ts, fg, gt_idx) of the uncertain ones -> merged (target_bboxes,
+    target_scores, fg_box uint8): the uncertain owner of an anchor wins (ssod_loss.py:231 then :248)"""
+    tb_r, ts_r, fg_r = rel
+    tb_u, ts_u, fg_u, idx_u = unc
+    B, A, nc = ts_r.shape
+    G = u_score.shape[1]
+    dev = ts_r.device
+    ts, tb = torch.empty_like(ts_r), torch.empty_like(tb_r)
+    fg = torch.empty((B, A), dtype=torch.uint8, device=dev)
+    fr8, fu8 = fg_r.to(torch.uint8).contiguous(), fg_u.to(torch.uint8).contiguous()     # named: they must outlive the launch
+    _lib.check(_lib.load().et_tal_merge_pseudo(_lib.ptr(ts_r), _lib.ptr(tb_r), _lib.ptr(fr8), _lib.ptr(ts_u), _lib.ptr(tb_u),
+                                               _lib.ptr(fu8), _lib.ptr(idx_u), _lib.ptr(u_score), _lib.ptr(u_flags), B, A, G, nc,
+                                               _lib.ptr(ts), _lib.ptr(tb), _lib.ptr(fg), _lib.stream(ts_r)), "et_tal_merge_pseudo")
+    return tb, ts, fg
 
 
 def tal_loss(pred_scores, pred_distri, anchor_points_s, stride_tensor, target_bboxes_px, target_scores, fg_mask, reg_max, iou_type,
@@ -858,8 +900,9 @@ def tal_loss(pred_scores, pred_distri, anchor_points_s, stride_tensor, target_bb
     acc = torch.zeros(4, dtype=torch.float32, device=dev)
     out = torch.empty(4, dtype=torch.float32, device=dev)
     fg8 = fg_mask.to(torch.uint8).contiguous()
-    _lib.check(_lib.load().et_tal_loss(_lib.ptr(ps), _lib.ptr(pd), _lib.ptr(f(anchor_points_s)), _lib.ptr(f(stride_tensor.reshape(-1))),
-                                       _lib.ptr(f(target_bboxes_px)), _lib.ptr(f(target_scores)), _lib.ptr(fg8), B, A, nc, int(reg_max),
+    aps, stv, tbp, tsc = f(anchor_points_s), f(stride_tensor.reshape(-1)), f(target_bboxes_px), f(target_scores)   # named: alive across the launch
+    _lib.check(_lib.load().et_tal_loss(_lib.ptr(ps), _lib.ptr(pd), _lib.ptr(aps), _lib.ptr(stv),
+                                       _lib.ptr(tbp), _lib.ptr(tsc), _lib.ptr(fg8), B, A, nc, int(reg_max),
                                        kind, float(w_class), float(w_iou), float(w_dfl), _lib.ptr(gs), _lib.ptr(gd), _lib.ptr(acc),
                                        _lib.ptr(out), _lib.stream(ps)), "et_tal_loss")
     return out, gs, gd

@@ -120,6 +120,11 @@ class SSODTrainer(Trainer):
     def split_predict_and_feature(total_pred, total_feature, n_img):
         sup_feature = [f[:n_img] for f in total_feature]
         un_sup_feature = [f[n_img:] for f in total_feature]
+        if isinstance(total_pred, tuple) and len(total_pred) == 3 and isinstance(total_pred[0], (list, tuple)):
+            # anchor-free head (YoloV8Detect train output): (feats, cls (B,A,nc), reg (B,A,4*(reg_max+1)))
+            feats, cls, reg = total_pred
+            return (([f[:n_img] for f in feats], cls[:n_img], reg[:n_img]), sup_feature,
+                    ([f[n_img:] for f in feats], cls[n_img:], reg[n_img:]), un_sup_feature)
         from ..autograd import split_batch     # views whose loss gradients are stitched without copies
         halves = [split_batch(p, n_img) for p in total_pred]
         sup_pred = [h[0] for h in halves]
@@ -167,7 +172,12 @@ class SSODTrainer(Trainer):
         if self.cfg.SSOD.pseudo_label_type == 'LabelMatch':         # ssod_trainer.py:616-617
             self.pseudo_label_creator.update(targets, n_img, unlabeled_imgs.shape[0])
         with torch.no_grad(), (torch.cuda.stream(side) if side is not None else _nullcontext()):
-            (teacher_pred, _), _ = self.ema.ema(unlabeled_imgs_ori, augment=False)
+            from .. import ops as _ops
+            _ops.SCOPE = "teacher"
+            try:
+                (teacher_pred, _), _ = self.ema.ema(unlabeled_imgs_ori, augment=False)
+            finally:
+                _ops.SCOPE = None
             if self.teacher_pred_hook is not None:
                 teacher_pred = self.teacher_pred_hook(teacher_pred)
             t9, valid = self.pseudo_label_creator.create_pseudo_label_padded(teacher_pred, unlabeled_M, width, height)

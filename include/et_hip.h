@@ -336,6 +336,29 @@ int et_tal_assign(const float* pd_scores, const float* pd_bboxes, const float* a
                   const float* gt_bboxes, const float* mask_gt, int B, int A, int G, int nc, int topk, float alpha, float beta,
                   float eps, int64_t* target_labels, float* target_bboxes, float* target_scores, uint8_t* fg_mask,
                   void* workspace, size_t ws_bytes, et_stream_t stream);
+/* ---- EXTENSION (no counterpart in the reference): pseudo labels on the anchor-free head.  The reference's
+ * ComputeStudentMatchLoss needs det.anchors (models/loss/ssod/ssod_loss.py:69) and its SSOD trainer raises for model types other
+ * than yolov5 (trainer/ssod_trainer.py:598-606), although update_train_logger anticipates a 'tal' variant (:271-272).  These three
+ * entry points carry the reliable / uncertain split of ssod_loss.py:130-192 over to TaskAlignedAssigner targets; the specification
+ * is oracle/v8.py::tal_student_match_loss (parity unpinned by construction).
+ * et_tal_pseudo_split: padded pseudo-label rows targets9 (B*G, 9) fp64 [img, cls, x, y, w, h (normalised), conf, obj_conf, cls_conf]
+ *   (+ valid mask or NULL) and the per-class thresholds (fp64, nc each) -> ONE padded gt table per set, as ComputeTalLoss.preprocess
+ *   builds it (rows outside the set: label -1, zero box): gt_labels_r/_u (B,G), gt_bboxes_r/_u (B,G,4) xyxy pixels,
+ *   mask_reliable / mask_uncertain (B,G) 0/1, u_score (B,G) = obj_conf (with_obj) or conf of the uncertain rows, u_flags (B,G):
+ *   bit 0 = contributes box / DFL terms (with_bbox and obj_conf >= 0.99), bit 1 = full-strength class target (with_cls and
+ *   cls_conf >= 0.99); both only under with_obj, as the reference forms those subsets.
+ * et_tal_assigned_gt: the (B,A) gt index of the last et_tal_assign that used `workspace` (valid where its fg_mask is set).
+ * et_tal_merge_pseudo: per anchor: uncertain owner (fg_u) wins over reliable owner (fg_r) -- ssod_loss.py:231 then :248 --;
+ *   target_scores = ts_u * (u_score or 1) | ts_r | 0, target_bboxes from the winner, fg_box = reliable, or uncertain with bit 0. */
+int et_tal_pseudo_split(const double* targets9, const uint8_t* valid, const double* thr_low, const double* thr_high, int B, int G, int nc,
+                        int with_obj, int with_bbox, int with_cls, float img_w, float img_h, float* gt_labels_r, float* gt_bboxes_r,
+                        float* gt_labels_u, float* gt_bboxes_u, float* mask_reliable, float* mask_uncertain, float* u_score,
+                        uint8_t* u_flags, et_stream_t stream);
+int et_tal_assigned_gt(const void* workspace, int B, int A, int G, int32_t* gt_idx, et_stream_t stream);
+int et_tal_merge_pseudo(const float* ts_r, const float* tb_r, const uint8_t* fg_r, const float* ts_u, const float* tb_u,
+                        const uint8_t* fg_u, const int32_t* gt_idx_u, const float* u_score, const uint8_t* u_flags, int B, int A, int G,
+                        int nc, float* target_scores, float* target_bboxes, uint8_t* fg_box, et_stream_t stream);
+
 
 #ifdef __cplusplus
 }

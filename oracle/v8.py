@@ -185,13 +185,14 @@ def iou_calculator(box1, box2, eps=1e-9):
     return overlap / (area1 + area2 - overlap + eps)
 
 
-def tal_assign(pd_scores, pd_bboxes, anc_points, gt_labels, gt_bboxes, mask_gt, topk=13, alpha=1.0, beta=6.0, eps=1e-9):
+def tal_assign(pd_scores, pd_bboxes, anc_points, gt_labels, gt_bboxes, mask_gt, topk=13, alpha=1.0, beta=6.0, eps=1e-9, return_idx=False):
     """tal_assigner.py:30-158.  Ties between EQUAL metrics go to the smaller anchor index (torch.topk leaves them
     unspecified; see csrc/tal.hip) -- implemented with a stable descending sort."""
     bs, A, nc = pd_scores.shape
     G = gt_bboxes.shape[1]
     if G == 0:
-        return (torch.full((bs, A), nc, dtype=torch.int64), torch.zeros(bs, A, 4), torch.zeros(bs, A, nc), torch.zeros(bs, A, dtype=torch.bool))
+        r = (torch.full((bs, A), nc, dtype=torch.int64), torch.zeros(bs, A, 4), torch.zeros(bs, A, nc), torch.zeros(bs, A, dtype=torch.bool))
+        return r + (torch.zeros(bs, A, dtype=torch.int64),) if return_idx else r
     lab = gt_labels.long().squeeze(-1)
     bbox_scores = pd_scores.permute(0, 2, 1)[torch.arange(bs).view(-1, 1).expand(bs, G), lab]          # (bs, G, A)
     overlaps = iou_calculator(gt_bboxes, pd_bboxes, eps)
@@ -219,6 +220,8 @@ def tal_assign(pd_scores, pd_bboxes, anc_points, gt_labels, gt_bboxes, mask_gt, 
     pos_am = am.max(-1, keepdim=True)[0]
     pos_ov = (overlaps * mask_pos).max(-1, keepdim=True)[0]
     norm = (am * pos_ov / (pos_am + eps)).max(-2)[0].unsqueeze(-1)
+    if return_idx:
+        return tl, tb, ts * norm, fg > 0, idx
     return tl, tb, ts * norm, fg > 0
 
 
@@ -244,6 +247,40 @@ def bbox_iou_xyxy(b1, b2, kind="giou", eps=1e-7):
     with torch.no_grad():
         a = v / (v - iou + (1 + eps))
     return iou - (rho2 / c2 + v * a)
+
+
+def _tal_terms(pred_scores, pred_distri, pred_bboxes, anchor_points_s, stride_tensor, tl, tb, ts, fg, nc, reg_max, use_dfl, use_gfl, iou_type):
+    """the three loss terms of ComputeTalLoss for given assigner outputs (tb in pixels); shared by tal_loss and
+    tal_student_match_loss"""
+    B, A = pred_scores.shape[:2]
+    tb = tb / stride_tensor
+    if use_gfl:      # VarifocalLoss(alpha 0.75, gamma 2.0)
+        label = F.one_hot(torch.where(fg, tl, torch.full_like(tl, nc)), nc + 1)[..., :-1].float()
+        weight = 0.75 * pred_scores.sigmoid().pow(2.0) * (1 - label) + ts * label
+        loss_cls = (F.binary_cross_entropy_with_logits(pred_scores, ts, reduction="none") * weight).sum()
+    else:
+        loss_cls = F.binary_cross_entropy_with_logits(pred_scores, ts, reduction="none").sum()
+    ts_sum = max(ts.sum(), 1)
+    loss_cls = loss_cls / ts_sum
+    # BboxLoss: IoU term weighted by the target score, DFL on the distance targets
+    if fg.sum() > 0:
+        w = ts.sum(-1)[fg].unsqueeze(-1)
+        iou = bbox_iou_xyxy(pred_bboxes[fg], tb[fg], iou_type)
+        loss_iou = ((1.0 - iou).unsqueeze(-1) * w).sum() / ts_sum
+        if use_dfl:
+            lt, rb = anchor_points_s.expand(B, A, 2)[fg] - tb[fg][:, :2], tb[fg][:, 2:] - anchor_points_s.expand(B, A, 2)[fg]
+            tdist = torch.cat([lt, rb], -1).clip(0, reg_max - 0.01)
+            pd = pred_distri.view(B, A, 4, reg_max + 1)[fg].view(-1, reg_max + 1)
+            tl_, tr_ = tdist.long(), tdist.long() + 1
+            wl, wr = tr_.float() - tdist, tdist - tl_.float()
+            ce = (F.cross_entropy(pd, tl_.view(-1), reduction="none").view(tl_.shape) * wl +
+                  F.cross_entropy(pd, tr_.view(-1), reduction="none").view(tl_.shape) * wr).mean(-1, keepdim=True)
+            loss_dfl = (ce * w).sum() / ts_sum
+        else:
+            loss_dfl = pred_distri.sum() * 0.0
+    else:
+        loss_iou, loss_dfl = pred_distri.sum() * 0.0, pred_distri.sum() * 0.0
+    return loss_cls, loss_iou, loss_dfl
 
 
 def tal_loss(outputs, targets, strides=(8, 16, 32), nc=80, reg_max=16, img_size=640, use_dfl=True, use_gfl=False, iou_type="giou",
@@ -276,33 +313,83 @@ def tal_loss(outputs, targets, strides=(8, 16, 32), nc=80, reg_max=16, img_size=
     pred_bboxes = dist2bbox(dist, anchor_points_s)
     tl, tb, ts, fg = tal_assign(pred_scores.detach().sigmoid(), pred_bboxes.detach() * stride_tensor, anchor_points, gt_labels,
                                 gt_bboxes, mask_gt)
-    tb = tb / stride_tensor
-    if use_gfl:      # VarifocalLoss(alpha 0.75, gamma 2.0)
-        label = F.one_hot(torch.where(fg, tl, torch.full_like(tl, nc)), nc + 1)[..., :-1].float()
-        weight = 0.75 * pred_scores.sigmoid().pow(2.0) * (1 - label) + ts * label
-        loss_cls = (F.binary_cross_entropy_with_logits(pred_scores, ts, reduction="none") * weight).sum()
-    else:
-        loss_cls = F.binary_cross_entropy_with_logits(pred_scores, ts, reduction="none").sum()
-    ts_sum = max(ts.sum(), 1)
-    loss_cls = loss_cls / ts_sum
-    # BboxLoss: IoU term weighted by the target score, DFL on the distance targets
-    if fg.sum() > 0:
-        w = ts.sum(-1)[fg].unsqueeze(-1)
-        iou = bbox_iou_xyxy(pred_bboxes[fg], tb[fg], iou_type)
-        loss_iou = ((1.0 - iou).unsqueeze(-1) * w).sum() / ts_sum
-        if use_dfl:
-            lt, rb = anchor_points_s.expand(B, A, 2)[fg] - tb[fg][:, :2], tb[fg][:, 2:] - anchor_points_s.expand(B, A, 2)[fg]
-            tdist = torch.cat([lt, rb], -1).clip(0, reg_max - 0.01)
-            pd = pred_distri.view(B, A, 4, reg_max + 1)[fg].view(-1, reg_max + 1)
-            tl_, tr_ = tdist.long(), tdist.long() + 1
-            wl, wr = tr_.float() - tdist, tdist - tl_.float()
-            ce = (F.cross_entropy(pd, tl_.view(-1), reduction="none").view(tl_.shape) * wl +
-                  F.cross_entropy(pd, tr_.view(-1), reduction="none").view(tl_.shape) * wr).mean(-1, keepdim=True)
-            loss_dfl = (ce * w).sum() / ts_sum
-        else:
-            loss_dfl = pred_distri.sum() * 0.0
-    else:
-        loss_iou, loss_dfl = pred_distri.sum() * 0.0, pred_distri.sum() * 0.0
+    loss_cls, loss_iou, loss_dfl = _tal_terms(pred_scores, pred_distri, pred_bboxes, anchor_points_s, stride_tensor, tl, tb, ts, fg, nc,
+                                              reg_max, use_dfl, use_gfl, iou_type)
     loss = torch.zeros(1) + w_class * loss_cls + w_iou * loss_iou + w_dfl * loss_dfl
     return loss, dict(loss_iou=w_iou * loss_iou, loss_dfl=w_dfl * loss_dfl, loss_cls=w_class * loss_cls, loss=loss,
                       num_fg=fg.sum() / max(num_gts, 1))
+
+
+# ---- EXTENSION: ComputeStudentMatchLoss on the anchor-free head ---------------------------------------------------------------
+def tal_student_match_loss(outputs, targets9, thr_low, thr_high, strides=(8, 16, 32), nc=80, reg_max=16, img_size=640,
+                           iou_type="giou", w_class=0.5, w_iou=7.5, w_dfl=1.5, cell_offset=0.5, with_obj=True, with_bbox=True,
+                           with_cls=False):
+    """SPECIFICATION of the TAL variant of ComputeStudentMatchLoss.  **Not in the reference** (its ComputeStudentMatchLoss needs
+    det.anchors, models/loss/ssod/ssod_loss.py:69, and trainer/ssod_trainer.py:598-606 raises for model types other than yolov5;
+    update_train_logger :271-272 merely anticipates a 'tal' variant): parity is UNPINNED BY CONSTRUCTION, this function IS the
+    definition that csrc/tal.hip (et_tal_pseudo_split / et_tal_merge_pseudo + et_tal_assign / et_tal_loss) is tested against.
+
+    It carries ssod_loss.py:130-296 over to TaskAlignedAssigner targets.  targets9 (N, 9) = [img, cls, x, y, w, h (normalised),
+    conf, obj_conf, cls_conf]:
+      split (:130-192)   reliable  R = {conf >= thr_high[cls]};  uncertain U = {thr_low[cls] <= conf < thr_high[cls]} with the soft
+                         score s = obj_conf (with_obj) else conf;  U_box = {u in U: obj_conf >= 0.99},  U_cls = {u in U: cls_conf >= 0.99}
+                         (both formed only under with_obj, as in the reference)
+      assign             R and U are assigned SEPARATELY by the TaskAlignedAssigner on the (detached) student predictions, like the
+                         reference runs its anchor assigner once per subset (:199-207)
+      merge (:231,:248)  an anchor owned by an uncertain label takes that label's targets even if a reliable label owns it too (the
+                         reference writes tobj for the reliable cells first and for the uncertain cells afterwards);
+                         class target of an uncertain anchor = aligned score * s  (the soft objectness target of :248 on a head whose
+                         class score IS its objectness), or the un-scaled aligned score for U_cls under with_cls (:268-277);
+                         box / DFL terms: reliable anchors, and uncertain anchors of U_box under with_bbox (:251-266)
+      loss               the three ComputeTalLoss terms on the merged targets, same normalisation (sum of target scores) and weights.
+    Returns (loss [1], dict(ss_box, ss_dfl, ss_cls))."""
+    feats, pred_scores, pred_distri = outputs
+    pred_scores, pred_distri = pred_scores.float(), pred_distri.float()
+    anchor_points, stride_tensor = anchor_points_train([f.shape[-2:] for f in feats], strides, cell_offset)
+    B, A = pred_scores.shape[:2]
+    rows = [[float(v) for v in r] for r in (targets9.tolist() if hasattr(targets9, "tolist") else targets9)]
+    rel = [[] for _ in range(B)]
+    unc = [[] for _ in range(B)]
+    for r in rows:
+        b, c = int(r[0]), min(max(int(r[1]), 0), nc - 1)
+        x1, y1 = np.float32(r[2]) * np.float32(img_size) - np.float32(r[4]) * np.float32(img_size) * np.float32(0.5), \
+            np.float32(r[3]) * np.float32(img_size) - np.float32(r[5]) * np.float32(img_size) * np.float32(0.5)
+        box = [x1, y1, x1 + np.float32(r[4]) * np.float32(img_size), y1 + np.float32(r[5]) * np.float32(img_size)]
+        if r[6] >= thr_high[c]:
+            rel[b].append([c] + box)
+        elif r[6] >= thr_low[c]:
+            s = r[7] if with_obj else r[6]
+            unc[b].append([c] + box + [s, 1.0 if (with_obj and with_bbox and r[7] >= 0.99) else 0.0,
+                                       1.0 if (with_obj and with_cls and r[8] >= 0.99) else 0.0])
+
+    def padded(per, width):
+        G = max(max(len(p) for p in per), 1)
+        t = torch.zeros(B, G, width)
+        t[..., 0] = -1
+        m = torch.zeros(B, G, 1)
+        for i, p in enumerate(per):
+            if p:
+                t[i, :len(p)] = torch.tensor(p, dtype=torch.float32)
+                m[i, :len(p)] = 1
+        return t, m
+    tr, mr = padded(rel, 5)
+    tu, mu = padded(unc, 8)
+    anchor_points_s = anchor_points / stride_tensor
+    proj = torch.linspace(0, reg_max, reg_max + 1)
+    dist = F.softmax(pred_distri.view(B, A, 4, reg_max + 1), -1).matmul(proj)
+    pred_bboxes = dist2bbox(dist, anchor_points_s)
+    sc, bx = pred_scores.detach().sigmoid(), pred_bboxes.detach() * stride_tensor
+    tl_r, tb_r, ts_r, fg_r = tal_assign(sc, bx, anchor_points, tr[..., :1], tr[..., 1:5], mr)
+    tl_u, tb_u, ts_u, fg_u, idx_u = tal_assign(sc, bx, anchor_points, tu[..., :1], tu[..., 1:5], mu, return_idx=True)
+    bi = torch.arange(B).view(-1, 1).expand(B, A)
+    s_u, box_u, cls_u = tu[bi, idx_u, 5], tu[bi, idx_u, 6] > 0, tu[bi, idx_u, 7] > 0
+    scale_u = torch.where(cls_u, torch.ones_like(s_u), s_u)
+    ts = torch.where(fg_u.unsqueeze(-1), ts_u * scale_u.unsqueeze(-1), torch.where(fg_r.unsqueeze(-1), ts_r, torch.zeros_like(ts_r)))
+    tb = torch.where(fg_u.unsqueeze(-1), tb_u, tb_r)
+    tl = torch.where(fg_u, tl_u, tl_r)
+    fg_box = (fg_u & box_u) | (fg_r & ~fg_u)
+    loss_cls, loss_iou, loss_dfl = _tal_terms(pred_scores, pred_distri, pred_bboxes, anchor_points_s, stride_tensor, tl, tb, ts, fg_box, nc,
+                                              reg_max, True, False, iou_type)
+    loss = torch.zeros(1) + w_class * loss_cls + w_iou * loss_iou + w_dfl * loss_dfl
+    return loss, dict(ss_box=w_iou * loss_iou, ss_dfl=w_dfl * loss_dfl, ss_cls=w_class * loss_cls, n_reliable=sum(len(p) for p in rel),
+                      n_uncertain=sum(len(p) for p in unc), n_fg_box=int(fg_box.sum()), n_fg_soft=int(fg_u.sum()))

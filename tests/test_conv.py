@@ -168,6 +168,12 @@ SELECT = [
     ((1, 5, 5, 64, 264, 3, 1, 1), "conv_gemm_pp_kernel", [GLDS + "128, 64, 2, 2, 4, 2, false>"],
      "conv_wgrad_tr_kernel<256, 256, 2, 4>"),                                                  # ragged M and Cout on the 256^2 tiles
     ((3, 14, 14, 192, 320, 3, 1, 1), "conv_gemm_pp_kernel", [GLDS + "128, 128, 2, 2, 8, 2, true>"], "conv_wgrad_tr_kernel<256, 256, 2, 4>"),
+    # YOLOv8 head: its 68 (-> 72) channel DFL branch is not a multiple of the 32-wide K chunk: per-lane tap decode (UTAP false)
+    ((1, 9, 11, 256, 72, 3, 1, 1), GLDS + "128, 128, 2, 2, 8, 2, true>", [GLDS + "128, 128, 2, 2, 4, 2, false>"],
+     "conv_wgrad_tr_kernel<128, 128, 2, 2>"),
+    # YOLOv5s (BASELINE configs[1]): 32 -> 64 stride-2 3x3, K = 288 in 32-wide chunks on the 64-wide tile
+    ((2, 24, 24, 32, 64, 3, 2, 1), GLDS + "128, 64, 2, 2, 4, 2, true>", [GLDS + "128, 64, 2, 2, 4, 3, true>"] * 4,
+     "conv_wgrad_tr_kernel<64, 128, 2, 2>"),
 ]
 
 
@@ -379,3 +385,54 @@ def test_stem_kernel_full_size():
     assert torch.allclose(a, b, rtol=1e-4, atol=1e-2)
     ref = y2.float().reshape(-1, Cout)
     assert torch.allclose(a[0], ref.double().sum(0), rtol=2e-3, atol=1.0)
+
+
+# ---- the benchmarked workloads only launch instantiations that SELECT compares element-wise -------------------------------
+def _workload_conv_shapes(wl_name):
+    """(H, W, Cin, Cout, k, s, p) of every conv of the workload's model at 640 px, read off the oracle's nn.Conv2d modules
+    (forward hooks at 64 px, scaled by 10: the graph is fully convolutional)"""
+    import bench
+    import torch.nn as nn
+    wl = bench.WORKLOADS[wl_name]
+    cfg = bench.load_cfg(wl, 64)
+    if "v8" in wl_name:
+        from oracle import v8 as o
+    else:
+        from oracle import model as o
+    om = o.Model.from_cfg(cfg).eval()
+    shapes = []
+
+    def hook(mod, inp, out):
+        x = inp[0]
+        shapes.append((x.shape[2] * 10, x.shape[3] * 10, mod.in_channels, mod.out_channels, mod.kernel_size[0], mod.stride[0], mod.padding[0]))
+    for mm in om.modules():
+        if isinstance(mm, nn.Conv2d):
+            mm.register_forward_hook(hook)
+    with torch.no_grad():
+        om(torch.zeros(1, 3, 64, 64))
+    return shapes
+
+
+@pytest.mark.parametrize("wl_name,batches", [("v5l-ssod", (16, 32, 64)), ("v5s-sup", (64,)), ("v8-sup", (32,))])
+def test_bench_workloads_launch_only_covered_instantiations(hip_lib_path, wl_name, batches):
+    """Every conv launch of every bench.py workload (forward, each dgrad parity class, wgrad; teacher batch and student batch)
+    resolves -- through the library's own selection logic, et_conv2d_kernel_name -- to an instantiation that SELECT above
+    compares element-wise with torch (pin the YOLOv8 kernels by name as well).  Host logic only."""
+    from efficientteacher_amd import _lib, ops
+    _lib._use_library_for_tests(None, False)
+    covered = set()
+    for _, kf, kd, kw in SELECT:
+        covered.add(kf)
+        covered.update(kd or [])
+        if kw:
+            covered.add(kw)
+    missing = {}
+    for B in batches:
+        for (h, w, ci, co, k, s, p) in _workload_conv_shapes(wl_name):
+            cip, cop = (8 if k == 6 else (ci + 7) // 8 * 8), (co + 7) // 8 * 8
+            for op in (("fwd",) if k == 6 else ("fwd", "dgrad", "wgrad")):
+                for pc in (range(s * s) if (op == "dgrad" and s == 2) else (0,)):
+                    n = ops.kernel_name(op, torch.bfloat16, B, h, w, cip, cop, k, s, p, parity_class=pc)
+                    if n not in covered:
+                        missing.setdefault(n, (op, B, h, w, ci, co, k, s))
+    assert not missing, missing

@@ -376,6 +376,11 @@ def _worker_rccl_single(rank, port, out_dir):
     plain.ema = ModelEMA(plain.model); plain.semi_ema = SemiSupModelEMA(plain.ema.ema, plain.cfg.SSOD.ema_rate)
     a = run(plain, graph=False)
     del plain
+    plain2 = make(-1)                      # the same once more: the run-to-run noise floor (fp32 atomics in the wgrad split-K)
+    plain2.build_optimizer(plain2.cfg)
+    plain2.ema = ModelEMA(plain2.model); plain2.semi_ema = SemiSupModelEMA(plain2.ema.ema, plain2.cfg.SSOD.ema_rate)
+    a2 = run(plain2, graph=False)
+    del plain2
     dp = make(0)
     inner = dp.model.module
     dp.model = inner
@@ -384,7 +389,7 @@ def _worker_rccl_single(rank, port, out_dir):
     dp.build_ddp_model(dp.cfg, dev)
     assert isinstance(dp.model, FlatDataParallel) and dp.model.active and dp.model.world == 1
     b = run(dp, graph=True)
-    np.savez(os.path.join(out_dir, "single.npz"), eager=a, dp_graph=b, replays=dp._graph.replays if dp._graph else -1,
+    np.savez(os.path.join(out_dir, "single.npz"), eager=a, eager2=a2, dp_graph=b, replays=dp._graph.replays if dp._graph else -1,
              err=str(dp.graph_error), nchunks=len(dp.model._chunks))
     dist.destroy_process_group()
 
@@ -403,6 +408,8 @@ def test_single_rank_rccl_collectives_eager_and_captured():
         r = np.load(os.path.join(d, "single.npz"))
     assert str(r["err"]) == "None", str(r["err"])
     assert int(r["replays"]) == 3
-    a, b = r["eager"], r["dp_graph"]
-    assert np.abs(a[:3] - b[:3]).max() <= 1e-5 * np.abs(a).max()        # eager steps with collectives
-    assert np.abs(a[3:] - b[3:]).max() <= 1e-4 * np.abs(a).max()        # captured + replayed steps with collectives
+    a, a2, b = r["eager"], r["eager2"], r["dp_graph"]
+    noise = max(np.abs(a - a2).max(), 1e-6 * np.abs(a).max())
+    print("dp+graph vs eager", np.abs(a - b).max(1), "eager vs eager", np.abs(a - a2).max(1))
+    assert np.abs(a[0] - b[0]).max() <= 1e-5 * np.abs(a).max()          # first step: same state, same inputs, collectives issued eagerly
+    assert np.abs(a - b).max() <= 20 * noise                             # eager + captured steps with collectives vs the plain trainer

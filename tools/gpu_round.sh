@@ -25,13 +25,21 @@ bench_fill) run bench_fill; for F in 45 80; do ET_CONV_BIG_MINFILL=$F timeout 90
 mb_all) run mb_all; MB_REF=0 timeout 900 python tools/microbench.py conv > $OUT/mb_all.log 2>&1; tail -1 $OUT/mb_all.log ;;
 mb_bn) run mb_bn; timeout 600 python tools/microbench.py bn > $OUT/mb_bn.log 2>&1; tail -1 $OUT/mb_bn.log ;;
 host) run host; timeout 600 python tools/host_bound.py > $OUT/host_bound.log 2>&1; tail -1 $OUT/host_bound.log ;;
-bench) run bench; timeout 900 python bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err; cut -c1-400 $OUT/bench.json ;;
+bench) run bench; timeout 900 python bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err; cut -c1-400 $OUT/bench.json; tail -3 $OUT/bench.err ;;
 bench_lock) run bench_lock; ET_CONV_PP=0 timeout 900 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_pp0.json 2> $OUT/bench_pp0.err; cut -c1-300 $OUT/bench_pp0.json ;;
 bench_nostream) run bench_nostream; ET_WGRAD_STREAM=0 timeout 900 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_nostream.json 2> $OUT/bench_nostream.err; cut -c1-300 $OUT/bench_nostream.json ;;
 bench_nofuse) run bench_nofuse; ET_FUSE_BN_BWD=0 timeout 900 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_nofuse.json 2> $OUT/bench_nofuse.err; cut -c1-300 $OUT/bench_nofuse.json ;;
 bench_graph) run bench_graph; timeout 900 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --graph > $OUT/bench_graph.json 2> $OUT/bench_graph.err; cut -c1-300 $OUT/bench_graph.json ;;
 bench_host) run bench_host; timeout 900 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --host-inputs > $OUT/bench_host_inputs.json 2> $OUT/bench_host.err; cut -c1-300 $OUT/bench_host_inputs.json ;;
 bench_quick) run bench_quick; timeout 900 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_quick.json 2> $OUT/bench_quick.err; cut -c1-300 $OUT/bench_quick.json ;;
+bench_v5s) run bench_v5s; timeout 900 python bench.py --workload v5s-sup --steps 20 --warmup 5 > $OUT/bench_v5s.json 2> $OUT/bench_v5s.err; cut -c1-500 $OUT/bench_v5s.json; tail -3 $OUT/bench_v5s.err ;;
+bench_v8) run bench_v8; timeout 900 python bench.py --workload v8-sup --steps 20 --warmup 5 > $OUT/bench_v8.json 2> $OUT/bench_v8.err; cut -c1-500 $OUT/bench_v8.json; tail -3 $OUT/bench_v8.err ;;
+bench_dp1) run bench_dp1; timeout 900 python bench.py --force-dp --no-graph --per-rank 16 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_dp1_eager.json 2> $OUT/bench_dp1_eager.err; cut -c1-300 $OUT/bench_dp1_eager.json; tail -3 $OUT/bench_dp1_eager.err ;;
+bench_dp1g) run bench_dp1g; timeout 900 python bench.py --force-dp --graph --per-rank 16 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_dp1_graph.json 2> $OUT/bench_dp1_graph.err; cut -c1-300 $OUT/bench_dp1_graph.json; tail -3 $OUT/bench_dp1_graph.err ;;
+bench16) run bench16; timeout 900 python bench.py --per-rank 16 --no-graph --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench16_eager.json 2> $OUT/bench16_eager.err; cut -c1-300 $OUT/bench16_eager.json; timeout 900 python bench.py --per-rank 16 --graph --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench16_graph.json 2> $OUT/bench16_graph.err; cut -c1-300 $OUT/bench16_graph.json ;;
+t_par) run t_par; timeout 900 python -m pytest tests/test_parallel.py tests/test_step_fullsize.py tests/test_input_path.py tests/test_labelmatch.py -x -q -m gpu -s > $OUT/pytest_sel.log 2>&1; grep -E 'PARITY|dp\+graph|passed|failed' $OUT/pytest_sel.log | cut -c1-600 ;;
+ab_bn) run ab_bn; for L in base new base new; do if [ $L = base ]; then export ET_HIP_LIB=$PWD/tools/probe/libet_base.so; else unset ET_HIP_LIB; fi; timeout 300 python tools/microbench.py bn 2>&1 | tail -1 | cut -c1-200; timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('$L', round(d['ms_per_step'],2), d['kernel_ms_by_family']['main_stream'])"; done; unset ET_HIP_LIB ;;
+knobs) run knobs; for K in "X=0" "ET_WGRAD_STREAM=1" "ET_WGRAD_STREAM=1 ET_WGRAD_GROUP=1" "ET_WGRAD_STREAM=1 ET_WGRAD_GROUP=4" "X=0"; do env $K timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('$K', round(d['ms_per_step'],2), d['kernel_ms_by_family']['main_stream'], d['kernel_ms_by_family']['teacher_stream_ms'])"; done ;;
 smoke) run smoke; timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -3 $OUT/smoke.log ;;
 prof) run prof; (cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/bench_under_rocprof.json 2> $GRAFT_REPO_ROOT/$OUT/prof.err); find $OUT/prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv; find $OUT/prof -name "*kernel_trace.csv" | head -1 | xargs -I{} python tools/trace_streams.py {} > $OUT/trace_streams.txt 2>&1; cat $OUT/trace_streams.txt; find $OUT/prof -name "*.db" -delete; find $OUT/prof -name "*kernel_trace.csv" -size +20M -delete; head -8 $OUT/kernel_stats.csv | cut -c1-160 ;;
 pmc) run pmc; for C in FETCH_SIZE WRITE_SIZE; do (cd /tmp && timeout 900 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmc_$C -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/bench_pmc_$C.json 2> $GRAFT_REPO_ROOT/$OUT/pmc_$C.err); done; python tools/pmc_summarize.py $OUT > $OUT/pmc_bench_summary.csv; find $OUT -name "*.db" -delete; find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*kernel_trace.csv" -delete; head -12 $OUT/pmc_bench_summary.csv ;;
