@@ -343,8 +343,7 @@ static int ew_blocks(long long P, int CV, int vpt_default = 8) {
     const long long need = (P * CV + 255) / 256;
     // ~8+ vectors per thread (amortises the per-thread channel constants and the partial-sum rows),
     // but never fewer than ~2 blocks per CU
-    static const int vpt_env = getenv("ET_EW_VPT") ? atoi(getenv("ET_EW_VPT")) : 0;   // tuning knob, read once
-    long long blocks = need / (vpt_env > 0 ? vpt_env : vpt_default);
+    long long blocks = need / vpt_default;          // (vectors per thread was a knob until r02: 1 / 2 / 4 / 8 / 16 / 32 swept, 8 / 16 kept)
     if (blocks < 512) blocks = need < 512 ? need : 512;
     if (blocks > 2048) blocks = 2048;
     blocks = ((blocks + unit - 1) / unit) * unit;

@@ -60,3 +60,40 @@ def ssod_step(student, teacher, imgs, targets, u_str, u_ori, M_s, cfg, *, synth_
     return dict(teacher_pred=tp, dets=dets, keep=keep, t9=np.asarray(t9), invalid=invalid, pred=pred, loss=loss,
                 sup_items={k: float(v.detach()) for k, v in sup_items.items()},
                 un_items={k: float(v.detach()) for k, v in un_items.items()})
+
+
+def ssod_step_v8(student, teacher, imgs, targets, u_str, u_ori, M_s, cfg, *, synth_scores=None, teacher_pred=None, backward=True):
+    """The same step on the anchor-free YOLOv8 head -- an EXTENSION: the reference cannot run it (trainer/ssod_trainer.py:598-606
+    raises for model types other than yolov5).  Composition of oracle/v8.py (model, tal_loss, and the written specification
+    tal_student_match_loss of the unsupervised term) with the reference-pinned NMS and pseudo-label restatements."""
+    from . import v8 as o_v8
+    n_img = imgs.shape[0]
+    height, width = u_str.shape[2], u_str.shape[3]
+    with torch.no_grad():
+        if teacher_pred is None:
+            tp, _ = teacher(u_ori)
+            if synth_scores is not None:
+                tp[..., 4:] = synth_scores
+        else:
+            tp = teacher_pred
+    dets, keep = o_nms.non_max_suppression_ssod(tp.numpy(), cfg.SSOD.nms_conf_thres, cfg.SSOD.nms_iou_thres)
+    t9, invalid = o_pl.create_pseudo_label(dets, M_s.numpy(), width, height)
+    feats, cls, reg = student(torch.cat([imgs, u_str], 0))
+    kw = dict(nc=cfg.Dataset.nc, reg_max=cfg.Loss.reg_max, img_size=cfg.Dataset.img_size, iou_type=cfg.Loss.iou_type,
+              w_class=cfg.Loss.qfl_loss_weight, w_iou=cfg.Loss.box_loss_weight, w_dfl=cfg.Loss.dfl_loss_weight)
+    sup_loss, sup_items = o_v8.tal_loss(([f[:n_img] for f in feats], cls[:n_img], reg[:n_img]), targets, **kw)
+    nc = cfg.Dataset.nc
+    if not invalid:
+        un_loss, un_items = o_v8.tal_student_match_loss(([f[n_img:] for f in feats], cls[n_img:], reg[n_img:]), np.asarray(t9),
+                                                        [cfg.SSOD.ignore_thres_low] * nc, [cfg.SSOD.ignore_thres_high] * nc,
+                                                        with_obj=cfg.SSOD.pseudo_label_with_obj, with_bbox=cfg.SSOD.pseudo_label_with_bbox,
+                                                        with_cls=cfg.SSOD.pseudo_label_with_cls, **kw)
+    else:
+        un_loss = torch.zeros(1)
+        un_items = dict(ss_box=torch.zeros(1), ss_dfl=torch.zeros(1), ss_cls=torch.zeros(1))
+    loss = sup_loss + un_loss * cfg.SSOD.teacher_loss_weight
+    if backward:
+        loss.backward()
+    return dict(teacher_pred=tp, dets=dets, keep=keep, t9=np.asarray(t9), invalid=invalid, loss=loss,
+                sup_items={k: float(torch.as_tensor(sup_items[k]).detach()) for k in ("loss_iou", "loss_dfl", "loss_cls")},
+                un_items={k: float(torch.as_tensor(un_items[k]).detach()) for k in ("ss_box", "ss_dfl", "ss_cls")})

@@ -1,10 +1,10 @@
 #!/bin/bash
-# experiment builds of libet_hip.so with -DET_ABLATE=<n> on conv.hip (see the ET_ABLATE hooks there)
+# experiment builds of libet_hip.so with -DET_ABLATE=<n> on tools/probe/conv_probe.hip (the r02 copy of csrc/conv.hip that still carries the ET_ABLATE / ET_STAMPS hooks; the product source has none)
 set -e
 cd "$(dirname "$0")/../.."
 python -m efficientteacher_amd.csrc.build >/dev/null
 for n in "$@"; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I include -DET_ABLATE=$n -c efficientteacher_amd/csrc/conv.hip -o /tmp/conv_abl$n.o &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I include -DET_ABLATE=$n -c tools/probe/conv_probe.hip -o /tmp/conv_abl$n.o &
 done
 wait
 for n in "$@"; do

@@ -1,3 +1,8 @@
+// EXPERIMENT BUILD of efficientteacher_amd/csrc/conv.hip (copy taken at the start of round 3, before the compile-time ablation
+// hooks were stripped from the product source): -DET_ABLATE=<n> variants of the gather-GEMM loops (no DMA / zero page / no
+// ds_read / no MFMA / placement experiments of the ping-pong kernel ...), -DET_STAMPS s_memtime phase stamps per workgroup.
+// Built by tools/probe/build_ablate.sh / tools/probe/epi_probe.sh into tools/probe/libet_*.so and selected with ET_HIP_LIB; never
+// part of libet_hip.so.  Results: NOTEBOOK.md (round 2), profiles/r02_ablation_pp_kernel.log, profiles/r02_epilogue_stamps.txt.
 // Implicit-GEMM convolution on the gfx950 matrix cores: forward, dgrad and wgrad of the
 // conv in `Conv` (reference models/backbone/common.py:471-481; shapes: SURVEY.md appendix A), the
 // Detect output convs (models/head/yolov5_head.py:30) and the netD 1x1 convs (yolo_ssod.py:224-238).
@@ -19,7 +24,7 @@
 // LDS rows hold BKV 16-byte K-vectors, XOR-swizzled so that the ds_read_b128 fragment reads of a
 // lane group hit 16 distinct (bank-half, slot) pairs; double buffered, one barrier per K-chunk,
 // next chunk's global loads are issued before the MFMAs of the current one.
-#include "et_device.h"
+#include "../../efficientteacher_amd/csrc/et_device.h"
 #include "../../include/et_hip.h"
 #include <stdlib.h>
 #include <stdio.h>
@@ -128,6 +133,16 @@ template <int BKV> __device__ __forceinline__ int lds_swz(int r) {
     else return (r >> 2) & 3;
 }
 
+#if (defined(ET_ABLATE) && (ET_ABLATE == 9)) || defined(ET_STAMPS)
+// experiment build only: per-workgroup phase timestamps (s_memtime) of the LDS-DMA gather-GEMM
+__device__ unsigned long long et_dbg_ts[8 * 16384];
+extern "C" int et_debug_read(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(et_dbg_ts), sizeof(unsigned long long) * n, 0, hipMemcpyDeviceToHost);
+}
+#define ET_TS(slot) do { if (threadIdx.x == 0) { const int b_ = blockIdx.x; if (b_ < 16384) et_dbg_ts[b_ * 8 + (slot)] = __builtin_readcyclecounter(); } } while (0)
+#else
+#define ET_TS(slot) do { } while (0)
+#endif
 
 // ---- one K-chunk of MFMAs from LDS --------------------------------------------------------------
 struct NoBetween { __device__ __forceinline__ void operator()(int) const {} };
@@ -142,6 +157,11 @@ __device__ __forceinline__ void mma_chunk(const u32x4* __restrict__ sm, f32x16 (
     // back below the MFMAs; the waitcnt pass then waits for the older set only (lgkmcnt(TM+TN)).
     u32x4 af[2][TM], bf[2][TN];
     auto fetch = [&](int kk, int set) {
+#if defined(ET_ABLATE) && (ET_ABLATE == 4 || ET_ABLATE == 5)
+        for (int tm = 0; tm < TM; ++tm) af[set][tm] = mk4(kk, lane, kk, lane);
+        for (int tn = 0; tn < TN; ++tn) bf[set][tn] = mk4(lane, kk, lane, kk);
+        return;
+#endif
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
             const int r = wm * (BM / WM) + tm * 32 + l31;
@@ -323,7 +343,11 @@ __device__ __forceinline__ void conv_epilogue_act(f32x16 (&acc)[BM / WM / 32][BN
                         }
                         const u32x4 packed = mk4(et_pack_bf2(v[0], v[1]), et_pack_bf2(v[2], v[3]), et_pack_bf2(v[4], v[5]),
                                                  et_pack_bf2(v[6], v[7]));
+#if defined(ET_ABLATE) && (ET_ABLATE == 60)
+                        asm volatile("" :: "v"(packed), "v"(yp));     // experiment: no global stores
+#else
                         *(u32x4*)yp = packed;
+#endif
                         if (bnb) {
                             // statistics of exactly what the apply pass will read back: the bf16-ROUNDED dz
                             const u32x4 yy = *(const u32x4*)((const T*)ep.bn_y + pix * ep.ld_bn + co);
@@ -384,6 +408,7 @@ __device__ __forceinline__ void conv_epilogue_act(f32x16 (&acc)[BM / WM / 32][BN
             }
         }
     }
+    ET_TS(6);
     if (ep.stats) {
         // rows beyond M were zero-filled, so they add nothing.  Reduce lane halves, then the WM waves
         // that share these channels (through LDS), then one plain store per channel per block.
@@ -617,6 +642,7 @@ __global__ __launch_bounds__(64 * WM * WN, (NS == 3 && BKV == 4 && BM == 128) ? 
     __shared__ __attribute__((aligned(16))) u32x4 lds_raw[LDS_VEC];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    ET_TS(0);
     const int wm = wave / WN, wn = wave % WN;
     int bx, by;
     tile_of_block(g, bx, by);
@@ -683,7 +709,11 @@ __global__ __launch_bounds__(64 * WM * WN, (NS == 3 && BKV == 4 && BM == 128) ? 
             }
             const bool ok = kok && a_ok[j] && (unsigned)(a_iy[j] + dy) < (unsigned)g.IH &&
                             (unsigned)(a_ix[j] + dx) < (unsigned)g.IW;
+#if defined(ET_ABLATE) && (ET_ABLATE == 3 || ET_ABLATE == 5)
+            const T* src = ZERO; (void)ok; (void)cv; (void)dy; (void)dx;
+#else
             const T* src = ok ? X + (a_off[j] + (dy * g.IW + dx) * g.ldx + cv * VEC) : ZERO;
+#endif
             et_glds16(src, wbase + j * NT);
         }
 #pragma unroll
@@ -702,7 +732,11 @@ __global__ __launch_bounds__(64 * WM * WN, (NS == 3 && BKV == 4 && BM == 128) ? 
                 wt = g.wt[tap];
             }
             const bool ok = kok && b_ok[j];
+#if defined(ET_ABLATE) && (ET_ABLATE == 3 || ET_ABLATE == 5)
+            const T* src = ZERO; (void)ok; (void)cv; (void)wt;
+#else
             const T* src = ok ? W + (b_off[j] + wt * g.Cin + cv * VEC) : ZERO;
+#endif
             et_glds16(src, wbase + BM * BKV + j * NT);
         }
     };
@@ -722,7 +756,9 @@ __global__ __launch_bounds__(64 * WM * WN, (NS == 3 && BKV == 4 && BM == 128) ? 
     for (int s = 0; s < NS - 1; ++s)
         if (s < nchunks) { stage(lds_raw + s * STAGE_VEC, s, tap_u, cv_u); ET_ADVANCE_CURSOR(); }
     int rd = 0, wr = NS - 1;                       // ring slots of chunk c and of chunk c+NS-1
+    ET_TS(1);
     for (int c = 0; c < nchunks; ++c) {
+        if (c == 1) ET_TS(2);
         // chunk c has landed once at most `ahead` younger chunks of this wave are still in flight
         const int ahead = min(NS - 2, nchunks - 1 - c);
         if constexpr (!UTAP) {
@@ -737,15 +773,34 @@ __global__ __launch_bounds__(64 * WM * WN, (NS == 3 && BKV == 4 && BM == 128) ? 
         // barrier must be the bare s_barrier: __syncthreads() carries a fence that waits vmcnt(0), i.e. drains
         // the very LDS-DMA the ring keeps in flight
         if constexpr (NS > 2) __builtin_amdgcn_s_barrier(); else __syncthreads();
+#if defined(ET_ABLATE) && (ET_ABLATE == 40)
+        // experiment: the next chunk's pieces issued BETWEEN the k-steps of this chunk's MFMAs instead of in one burst before them
+        {
+            const bool more = c + NS - 1 < nchunks;
+            u32x4* const dstp = lds_raw + wr * STAGE_VEC;
+            const int cn = c + NS - 1, tu = tap_u, cu = cv_u;
+            constexpr int KS = BKV / 2, PPK = (PER + KS - 1) / KS;
+            auto between = [&](int kk) { if (more) stage_range(dstp, cn, tu, cu, kk * PPK, min((kk + 1) * PPK, PER)); };
+            mma_chunk<T, BM, BN, WM, WN, BKV>(lds_raw + rd * STAGE_VEC, acc, wm, wn, lane, between);
+            if (more) { ET_ADVANCE_CURSOR(); }
+        }
+#else
+#if !defined(ET_ABLATE) || (ET_ABLATE != 2)
         if (c + NS - 1 < nchunks) { stage(lds_raw + wr * STAGE_VEC, c + NS - 1, tap_u, cv_u); ET_ADVANCE_CURSOR(); }
+#endif
+#if !defined(ET_ABLATE) || (ET_ABLATE != 1)
         mma_chunk<T, BM, BN, WM, WN, BKV>(lds_raw + rd * STAGE_VEC, acc, wm, wn, lane);
+#endif
+#endif
         rd = rd + 1 == NS ? 0 : rd + 1;
         wr = wr + 1 == NS ? 0 : wr + 1;
     }
     __syncthreads();                               // the epilogue reuses the ring as its staging area
+    ET_TS(3);
 #undef ET_ADVANCE_CURSOR
     conv_epilogue<T, BM, BN, WM, WN>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn);
     __syncthreads();
+    ET_TS(4);
 }
 
 // ---- forward / dgrad gather-GEMM, 256x256 tile, two wave groups in anti-phase ("ping-pong") ----------------
@@ -788,6 +843,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_pp_kernel(const uint16_t* __
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    ET_TS(0);
     const int wm = wave >> 2, wn = wave & 3;       // wm = the wave group (waves w and w+4 share a SIMD)
     int bx, by;
     tile_of_block(g, bx, by);
@@ -852,19 +908,25 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_pp_kernel(const uint16_t* __
         cv_u = g.tap_inner ? ca_ : cb_;                                  \
         ti_cur = g.tapinfo[__builtin_amdgcn_readfirstlane(tap_u < g.T ? tap_u : 0)]; \
     } while (0)
-    // one LDS-DMA piece (jj = 0 / 1: rows 0-63 / 64-127 of the half-tile) of half-tile kind k (0 A0, 1 A1, 2 B0, 3 B1) of the cursor's chunk
+    // issue the LDS-DMA of ONE half-tile of the cursor's chunk (two instructions per thread)
+#if defined(ET_ABLATE) && (ET_ABLATE >= 20)
+#define ET_PPA(n) (ET_ABLATE == (n))
+#else
+#define ET_PPA(n) 0
+#endif
+    // one LDS-DMA piece (jj = 0 / 1: rows 0-63 / 64-127 of the half-tile) of half-tile kind k (0 A0, 1 A1, 2 B0, 3 B1)
     auto stage_piece = [&](int k, int buf, int jj) {
         u32x4* const wbase = lds_raw + (2 * k + buf) * HALF_VEC + wave * 64;
         if (k < 2) {
             const int i = k;
             const int doff = (udy * g.IW + udx) * g.ldx + (cv_u + lv) * VEC;
             const bool ok = (bool)((a_okm >> (i * 2 + jj)) & 1u) & ((unsigned)(a_iy[i][jj] + udy) < (unsigned)g.IH) &
-                            ((unsigned)(a_ix[i][jj] + udx) < (unsigned)g.IW);
+                            ((unsigned)(a_ix[i][jj] + udx) < (unsigned)g.IW) & !ET_PPA(22);
             et_glds16(ok ? X + (a_off[i][jj] + doff) : ZERO, wbase + jj * 512);
         } else {
             const int j = k - 2;
             const int woff = uwt * g.Cin + (cv_u + lv) * VEC;
-            const bool ok = (b_okm >> (j * 2 + jj)) & 1u;
+            const bool ok = ((b_okm >> (j * 2 + jj)) & 1u) & !ET_PPA(22);
             et_glds16(ok ? W + (b_off[j][jj] + woff) : ZERO, wbase + jj * 512);
         }
     };
@@ -874,6 +936,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_pp_kernel(const uint16_t* __
     const int l31 = lane & 31, gk = lane >> 5;
     u32x4 af[2][4], bf[4];                         // A fragments of one half (2 row tiles x 4 k-steps), B of one half
     auto load_a = [&](int i, int buf) {
+        if (ET_PPA(23)) { for (int t = 0; t < 2; ++t) for (int kk = 0; kk < 4; ++kk) af[t][kk] = mk4(lane, kk, t, i); return; }
         const u32x4* sm = lds_raw + (2 * i + buf) * HALF_VEC;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -883,6 +946,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_pp_kernel(const uint16_t* __
         }
     };
     auto load_b = [&](int j, int buf) {
+        if (ET_PPA(23)) { for (int kk = 0; kk < 4; ++kk) bf[kk] = mk4(kk, lane, j, kk); return; }
         const u32x4* sm = lds_raw + (2 * (2 + j) + buf) * HALF_VEC;
         const int r = wn * 32 + l31;
 #pragma unroll
@@ -890,10 +954,10 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_pp_kernel(const uint16_t* __
     };
     // 8 MFMAs of one phase; `sk >= 0`: the two LDS-DMA pieces of half-tile kind sk (next chunk, buffer sb) are issued BETWEEN
     // them (after the 2nd and the 5th), where an LDS-DMA instruction costs ~60 cycles of issue instead of the 100-185 it costs in
-    // a load section that is also issuing a dozen ds_reads (MI355X_MICROARCH.md "LDS-DMA piece ... issue cost"; the other
-    // placements that were measured are in tools/probe/conv_probe.hip, -DET_ABLATE=31..34, profiles/r02_pp_stage_placement_ab.txt)
+    // a load section that is also issuing a dozen ds_reads (MI355X_MICROARCH.md "LDS-DMA piece ... issue cost")
     auto mfma8 = [&](int i, int j, int sk, int sb) {
-        __builtin_amdgcn_s_setprio(1);
+        if (ET_PPA(24)) { for (int t = 0; t < 2; ++t) for (int kk = 0; kk < 4; ++kk) { asm volatile("" :: "v"(af[t][kk]), "v"(bf[kk])); } return; }
+        if (!ET_PPA(27)) __builtin_amdgcn_s_setprio(1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
@@ -902,9 +966,12 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_pp_kernel(const uint16_t* __
                 acc[2 * i + t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[t][kk]),
                                                                            __builtin_bit_cast(bf16x8, bf[kk]), acc[2 * i + t][j], 0, 0, 0);
                 const int n = kk * 2 + t;
-                if (sk >= 0 && (n == 1 || n == 4)) {
+                // placement experiments (ET_ABLATE 31 / 32 / 33): pieces after MFMA (0,1) / second piece only, the first stays in the
+                // load section / (3,6); default (1,4)
+                const int p0 = ET_PPA(31) ? 0 : ET_PPA(33) ? 3 : ET_PPA(32) ? -1 : 1, p1 = ET_PPA(31) ? 1 : ET_PPA(33) ? 6 : ET_PPA(32) ? 3 : 4;
+                if (sk >= 0 && (n == p0 || n == p1) && !ET_PPA(21)) {
                     __builtin_amdgcn_sched_barrier(0);
-                    stage_piece(sk, sb, n == 1 ? 0 : 1);
+                    stage_piece(sk, sb, n == p0 ? 0 : 1);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -918,20 +985,46 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_pp_kernel(const uint16_t* __
     ET_PP_ADVANCE();
     et_wait_vmem();
     __builtin_amdgcn_s_barrier();
-#define ET_PP_BAR() __builtin_amdgcn_s_barrier()
-#define ET_PP_WAIT(n) et_wait_vmem_le_pp<n>()
-    if (wm == 1) __builtin_amdgcn_s_barrier();     // group 1 runs one barrier (half a phase) behind group 0
+    ET_TS(1);
+#define ET_PP_BAR() do { if (!ET_PPA(28)) __builtin_amdgcn_s_barrier(); } while (0)
+#define ET_PP_WAIT(n) do { if (!ET_PPA(25)) et_wait_vmem_le_pp<n>(); } while (0)
+#define ET_PP_STAGE(call) do { if (!ET_PPA(21)) { call; } } while (0)
+    if (wm == 1 && !ET_PPA(26) && !ET_PPA(28)) __builtin_amdgcn_s_barrier();     // group 1 runs one barrier (half a phase) behind group 0
 
-    // one chunk = four phases; `last`: nothing is staged during the final chunk and the waits drain the queue.
-    // The half-tile of a phase is issued inside its MFMA section, i.e. AFTER that phase's wait: a counted wait sees the two
-    // pieces of ONE younger half-tile in flight (vmcnt 2), the tail chunk drains (2, then 0).
+    // one chunk = four phases; `last`: nothing is staged during the final chunk and the waits drain the queue
     auto chunk = [&](int buf, auto last_tag) {
         constexpr bool LAST = decltype(last_tag)::value;
         const int nb = buf ^ 1;
         if constexpr (!LAST) ET_PP_DECODE();
+        if (ET_PPA(29) | ET_PPA(34)) {
+            // ---- r02 first version: the half-tile of a phase is issued in its LOAD section (34: BEFORE the fragment reads)
+            constexpr bool F = ET_PPA(34);
+            if constexpr (!LAST && F) ET_PP_STAGE(stage_a(0, nb));
+            load_a(0, buf); load_b(0, buf);
+            if constexpr (!LAST && !F) ET_PP_STAGE(stage_a(0, nb));
+            if constexpr (LAST) ET_PP_WAIT(2); else ET_PP_WAIT(4);     // B1 of this chunk has landed
+            ET_PP_BAR(); mfma8(0, 0, -1, 0); ET_PP_BAR();
+            if constexpr (!LAST && F) ET_PP_STAGE(stage_b(0, nb));
+            load_b(1, buf);
+            if constexpr (!LAST && !F) ET_PP_STAGE(stage_b(0, nb));
+            if constexpr (LAST) ET_PP_WAIT(0); else ET_PP_WAIT(4);     // A1 of this chunk has landed
+            ET_PP_BAR(); mfma8(0, 1, -1, 0); ET_PP_BAR();
+            if constexpr (!LAST && F) ET_PP_STAGE(stage_b(1, nb));
+            load_a(1, buf);
+            if constexpr (!LAST && !F) ET_PP_STAGE(stage_b(1, nb));
+            ET_PP_BAR(); mfma8(1, 1, -1, 0); ET_PP_BAR();
+            if constexpr (!LAST && F) ET_PP_STAGE(stage_a(1, nb));
+            load_b(0, buf);
+            if constexpr (!LAST) { if constexpr (!F) ET_PP_STAGE(stage_a(1, nb)); ET_PP_ADVANCE(); ET_PP_WAIT(4); }   // A0, B0 of the next chunk
+            ET_PP_BAR(); mfma8(1, 0, -1, 0); ET_PP_BAR();
+            return;
+        }
+        // The half-tile of a phase is issued inside its MFMA section, i.e. AFTER that phase's wait: every counted wait sees
+        // two pieces fewer in flight than in the first version (vmcnt 2 where it was 4; the tail chunk is unchanged).
         // ---- ph0: (A0, B0); issues A0 of the next chunk
         load_a(0, buf); load_b(0, buf);
-        ET_PP_WAIT(2);                                                 // B1 of this chunk has landed (A1 may be in flight)
+        if (ET_PPA(32)) { if constexpr (!LAST) stage_piece(0, nb, 0); if constexpr (LAST) ET_PP_WAIT(2); else ET_PP_WAIT(3); }
+        else ET_PP_WAIT(2);                                            // B1 of this chunk has landed (A1 may be in flight)
         ET_PP_BAR();
         mfma8(0, 0, LAST ? -1 : 0, nb);
         ET_PP_BAR();
@@ -939,18 +1032,21 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_pp_kernel(const uint16_t* __
         // barrier behind and retires its pieces of B1 only at its own ph0 wait -- tried, and the emulator's plain schedule
         // caught it; fetching B0 early for ph3 is legal but measured no gain, 5.58 vs 5.58 ms over the model's layers)
         load_b(1, buf);
-        if constexpr (LAST) ET_PP_WAIT(0); else ET_PP_WAIT(2);         // A1 of this chunk has landed (A0' may be in flight)
+        if (ET_PPA(32)) { if constexpr (!LAST) stage_piece(2, nb, 0); if constexpr (LAST) ET_PP_WAIT(0); else ET_PP_WAIT(3); }
+        else if constexpr (LAST) ET_PP_WAIT(0); else ET_PP_WAIT(2);    // A1 of this chunk has landed (A0' may be in flight)
         ET_PP_BAR();
         mfma8(0, 1, LAST ? -1 : 2, nb);
         ET_PP_BAR();
         // ---- ph2: (A1, B1); issues B1'
         load_a(1, buf);
+        if (ET_PPA(32)) { if constexpr (!LAST) stage_piece(3, nb, 0); }
         ET_PP_BAR();
         mfma8(1, 1, LAST ? -1 : 3, nb);
         ET_PP_BAR();
         // ---- ph3: (A1, B0); issues A1', then the cursor moves on
         load_b(0, buf);
-        if constexpr (!LAST) ET_PP_WAIT(2);                            // A0', B0' have landed (B1' may be in flight)
+        if (ET_PPA(32)) { if constexpr (!LAST) { stage_piece(1, nb, 0); ET_PP_WAIT(3); } }
+        else if constexpr (!LAST) ET_PP_WAIT(2);                       // A0', B0' have landed (B1' may be in flight)
         ET_PP_BAR();
         mfma8(1, 0, LAST ? -1 : 1, nb);
         if constexpr (!LAST) ET_PP_ADVANCE();
@@ -958,18 +1054,23 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_pp_kernel(const uint16_t* __
     };
     int buf = 0;
     for (int c = 0; c + 1 < nchunks; ++c) {
+        if (c == 1) ET_TS(2);
         chunk(buf, std::false_type{});
         buf ^= 1;
     }
     chunk(buf, std::true_type{});
-    if (wm == 0) __builtin_amdgcn_s_barrier();     // balances group 1's extra barrier
+    if (wm == 0 && !ET_PPA(26) && !ET_PPA(28)) __builtin_amdgcn_s_barrier();     // balances group 1's extra barrier
     __syncthreads();                               // the epilogue reuses the half-tile buffers as its staging area
+    ET_TS(3);
     conv_epilogue<uint16_t, BM, BN, WM, WN>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn);
     __syncthreads();
+    ET_TS(4);
 #undef ET_PP_DECODE
 #undef ET_PP_ADVANCE
 #undef ET_PP_BAR
 #undef ET_PP_WAIT
+#undef ET_PP_STAGE
+#undef ET_PPA
 }
 
 // ---- the stem: 6x6 stride-2 pad-2 convolution of the packed image (8 channels, 3 used) ----------------------------
@@ -1426,6 +1527,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_tr_kernel(WgradGroup 
     __shared__ __attribute__((aligned(16))) u32x4 lds_raw[2 * (A_VEC + B_VEC)];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    ET_TS(0);
     const int wm = wave / WN, wn = wave % WN;
     int bid = blockIdx.x;
     if (g.xcd) {
@@ -1540,9 +1642,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_tr_kernel(WgradGroup 
     u32x4* const A1 = lds_raw + A_VEC + B_VEC;
     u32x4* const B1 = A1 + A_VEC;
     const int nchunks = (pk_end - pk_begin + BKP - 1) / BKP;
+    ET_TS(1);
     if (nchunks > 0) stage(A0, B0, pk_begin);
     et_wait_vmem();
     __syncthreads();
+    ET_TS(2);
     for (int c = 0; c < nchunks; ++c) {
         const bool odd = c & 1;
         if (c + 1 < nchunks) stage(odd ? A0 : A1, odd ? B0 : B1, pk_begin + (c + 1) * BKP);
@@ -1551,6 +1655,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_tr_kernel(WgradGroup 
         __syncthreads();
     }
     if (nchunks <= 0) return;
+    ET_TS(3);
     const int l31 = lane & 31, hi = lane >> 5;
     if (m0 + BM <= g.Cout && n0 + BN <= g.NC) {
         // interior tile: no per-lane guards (they compiled to an exec-mask save + branch around EVERY atomic: 12 instructions
@@ -1577,6 +1682,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_tr_kernel(WgradGroup 
                 }
             }
     }
+#if defined(ET_ABLATE) && (ET_ABLATE == 9)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    ET_TS(4); ET_TS(5); ET_TS(6);
+#endif
 }
 
 // ---- small helpers ---------------------------------------------------------------------------------
@@ -1640,9 +1750,8 @@ static int fill_common(GatherGeom& g, int N, int IH, int IW, int Cin, int ldx, i
     g.OH = OH; g.OW = OW; g.Cout = Cout; g.ldy = ldy;
     g.CV = Cin / vec; g.KV = g.T * g.CV;
     g.dQW = make_fastdiv(QW); g.dQH = make_fastdiv(QH); g.dCV = make_fastdiv(g.CV);
-    // K-chunk order: channel chunk outer / tap inner; XCD-contiguous tile ranges (both were knobs in r01 / r02; two single-knob
-    // sweeps of the step showed no other setting within noise of these: profiles/r02_step_knob_sweep*_same_box.log)
-    const int tap_inner = 1, xcd_swz = 1;
+    static const int tap_inner = getenv("ET_CONV_TAP_INNER") ? atoi(getenv("ET_CONV_TAP_INNER")) : 1;
+    static const int xcd_swz = getenv("ET_CONV_XCD") ? atoi(getenv("ET_CONV_XCD")) : 1;
     g.tap_inner = tap_inner; g.xcd_swz = xcd_swz;
     if ((long long)N * IH * IW * ldx >= (1ll << 31) || (long long)Cout * g.TT * Cin >= (1ll << 31)) return -2;
     return 0;
@@ -1655,14 +1764,15 @@ enum { GEMM_REG = 0, GEMM_GLDS = 1, GEMM_PP = 2 };
 struct GemmPlan { int kind, BM, BN, WM, WN, BKV, NS; bool utap; };
 
 static GemmPlan plan_gemm(const GatherGeom& g, int elem_bytes, bool have_zero_page) {
-    // Build-time constants that were tuning knobs in r01 / r02 (swept on the step, profiles/r02_step_knob_sweep*_same_box.log, and
-    // per layer, profiles/r02_microbench_narrow_k.log): GEMMs with K <= 128 elements use the 128x64 tile (3 workgroups per CU for
-    // the HBM-bound short-K 1x1 layers; at K = 256 the 128-wide tile re-reads the activations half as often: 150 -> 124 us on
-    // 256->256 @80x80, B=64); the LDS ring shape follows K (below).  What stays switchable are whole code paths, for A/B runs and
-    // for the tests that exercise them: ET_CONV_GLDS=0 VGPR staging, ET_CONV_BIG=0 no 256x256 tiles, ET_CONV_PP=0 the lockstep
-    // 256x256 kernel instead of the ping-pong one, ET_CONV_BIG_MINFILL (below), ET_CONV_STEM=0 the generic kernel for the stem.
-    constexpr int narrow_k = 128;
+    // tuning knobs, read once.  ET_CONV_NARROW_K=<K>: GEMMs with K <= K elements use the 128x64 tile (smaller
+    // register/LDS footprint: 3 workgroups per CU for the HBM-bound short-K 1x1 layers); default 128 -- at K = 256 the
+    // 128-wide tile re-reads the activations half as often and measured 150 -> 124 us on 256->256 @80x80, B=64
+    // (profiles/r02_microbench_narrow_k.log).  ET_CONV_GLDS=0: VGPR staging.
+    // ET_CONV_RING=<rows><kvec><depth> forces one LDS-DMA instantiation.  ET_CONV_BIG=0: no 256x256 tiles.
+    // ET_CONV_PP=0: the lockstep 256x256 kernel instead of the ping-pong one.
+    static const int narrow_k = env_int("ET_CONV_NARROW_K", 128);
     static const int use_glds = env_int("ET_CONV_GLDS", 1);
+    static const int ring_env = env_int("ET_CONV_RING", 0);
     static const int big = env_int("ET_CONV_BIG", 1);
     static const int use_pp = env_int("ET_CONV_PP", 1);
     const bool bf16 = elem_bytes == 2;
@@ -1673,10 +1783,10 @@ static GemmPlan plan_gemm(const GatherGeom& g, int elem_bytes, bool have_zero_pa
     // short-K GEMMs (K <= 256, i.e. <= 4 chunks of 64) run 32-wide chunks in a 3-deep ring -- 48 KB of LDS, three
     // workgroups per CU, two chunks in flight each (measured 3-10 % on the 1x1 layers); everything else the 64-wide
     // double buffer (deeper rings or taller 4-wave tiles cost occupancy and lose: profiles/)
-    int ring = g.T * g.Cin <= 256 ? 12843 : 12882;
+    int ring = ring_env ? ring_env : (g.T * g.Cin <= 256 ? 12843 : 12882);
     // 8-wave 256x256 tile (one workgroup per CU, half the L2->LDS bytes per flop): 3x3 layers with >= 256 output
     // channels, and deep 1x1 layers when the grid fills whole residency rounds reasonably
-    if (big && g.Cout >= 256) {
+    if (!ring_env && big && g.Cout >= 256) {
         const int n_cu = device_cus();
         const long long blocks = (long long)((g.M + 255) / 256) * ((g.Cout + 255) / 256);
         const double rounds = (double)blocks / n_cu;
@@ -1690,7 +1800,11 @@ static GemmPlan plan_gemm(const GatherGeom& g, int elem_bytes, bool have_zero_pa
     switch (ring) {
         case 25680: p = GemmPlan{GEMM_PP, 256, 256, 2, 4, 8, 2, true}; break;
         case 25682: p = GemmPlan{GEMM_GLDS, 256, 256, 2, 4, 8, 2, true}; break;
+        case 25612: p = GemmPlan{GEMM_GLDS, 256, 128, 4, 2, 8, 2, true}; break;       // experiment
+        case 12883: p.NS = 3; break;
         case 12843: p.BKV = 4; p.NS = 3; break;
+        case 12844: p.BKV = 4; p.NS = 4; break;
+        case 25683: p.BM = 256; p.NS = 3; break;
         default: break;
     }
     return p;
@@ -1708,7 +1822,7 @@ template <typename T>
 static int launch_gemm(const void* X, const void* W, void* Y, const void* zero16, GatherGeom g, const Epilogue& ep,
                        hipStream_t s) {
     if (g.M <= 0) return 0;
-    const int nfast = 1;
+    static const int nfast = env_int("ET_CONV_NFAST", 1);
     g.nfast = nfast;
     const GemmPlan p = plan_gemm(g, (int)sizeof(T), zero16 != nullptr);
     g.ntm = (g.M + p.BM - 1) / p.BM;
@@ -1729,10 +1843,17 @@ static int launch_gemm(const void* X, const void* W, void* Y, const void* zero16
     }
     if (p.kind == GEMM_GLDS) {
         if constexpr (sizeof(T) == 2) {
-            if (p.WN == 4) { ET_GLDS(256, 256, 2, 4, 8, 2, true); return 0; }      // lockstep 256x256 (ET_CONV_PP=0)
+            if (p.WN == 4) { ET_GLDS(256, 256, 2, 4, 8, 2, true); return 0; }
+            if (p.WM == 4) { ET_GLDS(256, 128, 4, 2, 8, 2, true); return 0; }
             switch (key) {
-                case 12812843: ET_GLDS(128, 128, 2, 2, 4, 3, true); return 0;     // short-K: 32-wide chunks, 3-deep ring
+                case 12812883: ET_GLDS(128, 128, 2, 2, 8, 3, true); return 0;
+                case 12806483: ET_GLDS(128, 64, 2, 2, 8, 3, true); return 0;
+                case 12812843: ET_GLDS(128, 128, 2, 2, 4, 3, true); return 0;
                 case 12806443: ET_GLDS(128, 64, 2, 2, 4, 3, true); return 0;
+                case 12812844: ET_GLDS(128, 128, 2, 2, 4, 4, true); return 0;
+                case 12806444: ET_GLDS(128, 64, 2, 2, 4, 4, true); return 0;
+                case 25612883: ET_GLDS(256, 128, 2, 2, 8, 3, true); return 0;
+                case 25606483: ET_GLDS(256, 64, 2, 2, 8, 3, true); return 0;
                 default: break;
             }
         }
@@ -1921,25 +2042,32 @@ static void launch_wgrad(const WgradGroup& grp, const void* zero16, WgradGeom& g
     // Split K so that the grid is a whole number of residency rounds: `slots` workgroups of this tile fit on
     // a CU (LDS- or register-limited), so up to slots*CUs run at once and a grid a little OVER a multiple of
     // that costs a whole extra round (e.g. 36 tiles x 29 splits = 1044 workgroups on 1024 slots).  Fewer
-    // splits also mean fewer fp32 atomics on dW.
+    // splits also mean fewer fp32 atomics on dW.  ET_WGRAD_BLOCKS overrides the target (tuning knob).
     const int n_cu = device_cus();
     const int lds_kb = tr ? (bm + bn) / 4 : 64;                // 2 stages x 64 pixels x (bm+bn) channels x 2 B
     int slots = tr ? max(1, min(160 / lds_kb, bm * bn <= 64 * 64 ? 5 : (bm * bn <= 128 * 64 ? 3 : 2))) : 2;
     // measured: ONE full round of co-resident workgroups with >= ~25 chunks (1600 pixels) each beats two
     // shorter rounds (prologue, first-chunk latency and the atomic epilogue are per workgroup)
     const int cap = slots * n_cu;
+    static const int target_env = getenv("ET_WGRAD_BLOCKS") ? atoi(getenv("ET_WGRAD_BLOCKS")) : 0;
     const int max_sk = max(1, g.P / (BKP * 25));
-    auto eff = [&](int k) { const int b = tiles * k; return (double)b / ((double)((b + cap - 1) / cap) * cap); };
-    int sk = max(1, min(cap / tiles, max_sk));
-    // grids that cannot fill one round evenly: take the split (a few rounds at most) that wastes least
-    if (eff(sk) < 0.8)
-        for (int k = sk + 1; k <= min(max_sk, max(4, 2 * cap / tiles)); ++k)
-            if (eff(k) > eff(sk) + 0.1) sk = k;
+    int sk;
+    if (target_env > 0) {
+        sk = target_env / tiles;
+    } else {
+        auto eff = [&](int k) { const int b = tiles * k; return (double)b / ((double)((b + cap - 1) / cap) * cap); };
+        sk = max(1, min(cap / tiles, max_sk));
+        // grids that cannot fill one round evenly: take the split (a few rounds at most) that wastes least
+        if (eff(sk) < 0.8)
+            for (int k = sk + 1; k <= min(max_sk, max(4, 2 * cap / tiles)); ++k)
+                if (eff(k) > eff(sk) + 0.1) sk = k;
+    }
     sk = max(1, min(sk, max_sk));
     int per = (g.P + sk - 1) / sk;
     per = ((per + BKP - 1) / BKP) * BKP;
     sk = (g.P + per - 1) / per;
-    g.xcd = 1;                                     // the K-splits of one dW tile share an XCD (a knob until r02: always on)
+    static const int wxcd = getenv("ET_WGRAD_XCD") ? atoi(getenv("ET_WGRAD_XCD")) : 2;   // 0 never, 1 1x1 only, 2 always
+    g.xcd = wxcd == 2 || (wxcd == 1 && g.T == 1);
     g.Pper = per;
     g.ntn = (g.NC + bn - 1) / bn; g.ntm = (g.Cout + bm - 1) / bm; g.nsk = sk;
     const dim3 block(256);
@@ -2100,9 +2228,9 @@ extern "C" int et_conv2d_kernel_name(int op, int dtype, int N, int IH, int IW, i
 
 extern "C" int et_env_knobs(char* buf, int buflen) {
     // every ET_* tuning knob that is SET in this process's environment, as "NAME=value;..." (bench.py records it)
-    static const char* names[] = {"ET_CONV_GLDS", "ET_CONV_BIG", "ET_CONV_BIG_MINFILL", "ET_CONV_PP", "ET_CONV_STEM", "ET_CONV_STEM_WGS",
-                                  "ET_WGRAD_TR", "ET_WGRAD_BIG", "ET_WGRAD_GROUP", "ET_WGRAD_STALE", "ET_WGRAD_STREAM", "ET_FUSE_BN_BWD",
-                                  "ET_STEP_GRAPH", "ET_ALLREDUCE_CHUNK_MB", "ET_RCCL_CHANNELS", "ET_DP_SINGLE_RANK", "ET_HIP_LIB"};
+    static const char* names[] = {"ET_CONV_TAP_INNER", "ET_CONV_XCD", "ET_CONV_NARROW_K", "ET_CONV_NFAST", "ET_CONV_GLDS",
+                                  "ET_CONV_RING", "ET_CONV_BIG", "ET_CONV_BIG_MINFILL", "ET_CONV_PP", "ET_CONV_STEM", "ET_WGRAD_TR", "ET_WGRAD_BIG", "ET_WGRAD_BLOCKS",
+                                  "ET_WGRAD_XCD", "ET_EW_VPT", "ET_WGRAD_GROUP", "ET_WGRAD_STALE", "ET_HIP_LIB"};
     if (!buf || buflen < 1) return -1;
     int off = 0;
     buf[0] = 0;

@@ -1,7 +1,7 @@
 #!/bin/bash
 # what the shared conv epilogue costs: s_memtime stamps per workgroup (build -DET_STAMPS) with and without its global stores (-DET_ABLATE=60)
 # build first (in the container):
-#   for v in "S:-DET_STAMPS" "S60:-DET_STAMPS -DET_ABLATE=60"; do n=${v%%:*}; f=${v#*:}; hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I include $f -c efficientteacher_amd/csrc/conv.hip -o /tmp/conv_$n.o;
+#   for v in "S:-DET_STAMPS" "S60:-DET_STAMPS -DET_ABLATE=60"; do n=${v%%:*}; f=${v#*:}; hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I include $f -c tools/probe/conv_probe.hip -o /tmp/conv_$n.o;
 #     hipcc --offload-arch=gfx950 -shared -fPIC -o tools/probe/libet_$n.so /tmp/conv_$n.o $(ls efficientteacher_amd/csrc/_obj/*.o | grep -v conv.o); done
 for L in S S60; do
   echo "== lib $L"
