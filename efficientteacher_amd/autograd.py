@@ -14,10 +14,83 @@ ACT_CODE = {"silu": ops.ACT_SILU, "relu": ops.ACT_RELU, "none": ops.ACT_NONE}
 # (et_conv2d_dgrad_bn); ET_FUSE_BN_BWD=0 restores the separate reduce pass everywhere (A/B knob)
 import os as _os
 FUSE_BN_BWD = _os.environ.get("ET_FUSE_BN_BWD", "1") != "0"
+# two-consumer tensors: the later consumer's backward adds into the earlier one's gradient in its own kernel (GradFork below);
+# ET_GRAD_FORK=0 leaves the sum to autograd (a torch bf16 add per tensor: A/B knob)
+GRAD_FORK = _os.environ.get("ET_GRAD_FORK", "1") != "0"
 
 # set by parallel.FlatDataParallel: callable(ConvSlot) invoked right after a layer's wgrad has been
 # launched, so that the gradient all-reduce of finished arena chunks overlaps the rest of backward
 GRAD_READY_HOOK = None
+
+
+class GradFork:
+    """A tensor with TWO consumers whose gradients would otherwise be added by autograd in a separate (torch) pass.
+    ``a, b, fork = GradFork.split(x)``: branch `b`'s consumer runs its backward FIRST (it is the one created later in the forward
+    pass) and its gradient is parked here (TapFn); branch `a`'s consumer -- a conv block or the upsample-concat -- then ADDS
+    its own gradient into that buffer inside its kernel (dgrad epilogue `accumulate`, et_upsample2x_bwd `accumulate`) and
+    marks the fork merged; ForkFn.backward returns the merged buffer as the gradient of x.  Any other order, layout or dtype
+    falls back to the ordinary sum."""
+
+    def __init__(self):
+        self.gb = None
+        self.merged = False
+
+    @staticmethod
+    def split(x):
+        """-> (a, b, fork).  Pass `fork` to branch a's consumer (Conv(acc=fork) / UpsampleCatFn(.., fork)), then call
+        ``b = GradFork.tap(b, fork)`` AFTER that consumer's forward: the autograd engine runs ready nodes in reverse creation
+        order, so the tap -- created after branch a's node -- hands b's gradient over before branch a's backward looks for it."""
+        if not (GRAD_FORK and torch.is_grad_enabled() and x.requires_grad):
+            return x, x, None
+        h = GradFork()
+        a, b = _ForkFn.apply(x, h)
+        return a, b, h
+
+    @staticmethod
+    def tap(b, fork):
+        return b if fork is None else _TapFn.apply(b, fork)
+
+    def take(self, shape, dtype):
+        """the parked gradient of the other branch if this consumer can accumulate into it in place, else None"""
+        g = self.gb
+        if g is None or tuple(g.shape) != tuple(shape) or g.dtype != dtype or g.dim() != 4 or g.stride(3) != 1:
+            return None
+        ld = g.stride(2)
+        if not (ld >= g.shape[3] and g.stride(1) == ld * g.shape[2] and g.stride(0) == ld * g.shape[2] * g.shape[1]):
+            return None
+        return g
+
+
+class _ForkFn(Function):
+    @staticmethod
+    def forward(ctx, x, holder):
+        ctx.holder = holder
+        # exact aliases (view_as may re-derive the stride of a size-1 dimension, which the NHWC pixel-stride check relies on)
+        return (x.as_strided(x.size(), x.stride(), x.storage_offset()), x.as_strided(x.size(), x.stride(), x.storage_offset()))
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        h = ctx.holder
+        merged = h.merged
+        h.gb, h.merged = None, False
+        if ga is None or gb is None:
+            return (gb if ga is None else ga), None
+        if merged:
+            return ga, None                  # ga IS gb's buffer with both gradients in it
+        return ga + gb, None
+
+
+class _TapFn(Function):
+    @staticmethod
+    def forward(ctx, x, holder):
+        ctx.holder = holder
+        return x.as_strided(x.size(), x.stride(), x.storage_offset())
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.holder.gb = g
+        ctx.holder.merged = False
+        return g, None
 
 
 def _wgrad(x, dy, cs, *more_slots):
@@ -44,14 +117,16 @@ class ConvBnActFn(Function):
     train mode, plus the Bottleneck shortcut (common.py:544)."""
 
     @staticmethod
-    def forward(ctx, x, residual, wparam, cs, bs, act, nbt, dst=None, bn_in=None, bn_out=None):
+    def forward(ctx, x, residual, wparam, cs, bs, act, nbt, dst=None, bn_in=None, bn_out=None, acc=None):
         # wparam (the nn.Parameter) only ties the op into the autograd graph; its gradient is written
         # by the wgrad kernel directly into the flat arena, so backward returns None for it.
         # bn_in: BnBwdSums of the block that produced x, passed ONLY when this conv is x's sole consumer (the caller knows
         # the graph): this layer's dgrad then does that block's BatchNorm-backward reduce pass in its epilogue.
         # bn_out: a one-element list that receives this block's BnBwdSums for the (sole) consumer of z.
+        # acc: the GradFork of x when x has a second consumer (see GradFork): this layer's dgrad adds into the parked gradient.
         ctx.w_needs_grad = wparam.requires_grad
         ctx.bn_in = bn_in if (bn_in is not None and cs.stride == 1 and residual is None) else None
+        ctx.acc = acc
         y, stats = ops.conv2d_fwd(x, cs.w_lp, cs.stride, cs.pad, want_stats=True)
         N, OH, OW, _ = y.shape
         scale, shift, mean, invstd = ops.bn_finalize(stats, N * OH * OW, bs.gamma, bs.beta, bs.eps, bs.momentum,
@@ -84,8 +159,13 @@ class ConvBnActFn(Function):
         dx = None
         if ctx.x_needs_grad:
             wT = cs.transposed()
-            dx = ops.conv2d_dgrad(dy, wT, (x.shape[1], x.shape[2]), cs.stride, cs.pad, bn=ctx.bn_in)
-        return dx, (dz if ctx.has_res else None), None, None, None, None, None, None, None, None
+            into = ctx.acc.take(x.shape, dy.dtype) if (ctx.acc is not None and ctx.bn_in is None) else None
+            if into is not None:
+                dx = ops.conv2d_dgrad(dy, wT, (x.shape[1], x.shape[2]), cs.stride, cs.pad, out=into, accumulate=True)
+                ctx.acc.merged = True
+            else:
+                dx = ops.conv2d_dgrad(dy, wT, (x.shape[1], x.shape[2]), cs.stride, cs.pad, bn=ctx.bn_in)
+        return dx, (dz if ctx.has_res else None), None, None, None, None, None, None, None, None, None
 
 
 class BottleneckFn(Function):
@@ -395,7 +475,8 @@ class UpsampleCatFn(Function):
     the upsampled rows are written straight into the concat buffer."""
 
     @staticmethod
-    def forward(ctx, a, b):
+    def forward(ctx, a, b, acc=None):
+        """acc: the GradFork of `a` when `a` has a second consumer (the neck's lateral outputs also sit in a bottom-up concat)"""
         N, H, W, Ca = a.shape
         Cb = b.shape[3]
         cat = in_place_concat_buffer(b, Ca)
@@ -404,12 +485,21 @@ class UpsampleCatFn(Function):
             cat[..., Ca:].copy_(b)
         ops.upsample2x_fwd(a, out=cat[..., :Ca])
         ctx.Ca = Ca
+        ctx.acc = acc
+        ctx.a_shape = tuple(a.shape)
         return cat
 
     @staticmethod
     def backward(ctx, dcat):
         dcat = _dense_or_slice(dcat)
-        return ops.upsample2x_bwd(dcat[..., :ctx.Ca]), dcat[..., ctx.Ca:]
+        da_src = dcat[..., :ctx.Ca]
+        into = ctx.acc.take(ctx.a_shape, dcat.dtype) if ctx.acc is not None else None
+        if into is not None:
+            da = ops.upsample2x_bwd(da_src, out=into, accumulate=True)
+            ctx.acc.merged = True
+        else:
+            da = ops.upsample2x_bwd(da_src)
+        return da, dcat[..., ctx.Ca:], None
 
 
 def in_place_concat_buffer(b, Ca):

@@ -152,10 +152,11 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const T* __restrict
     *(uint4*)((char*)(y + p * ldy) + (size_t)cv * 16) = v;
 }
 
-// dx[b,h,w,:] = sum of dy over the 4 children
+// dx[b,h,w,:] (+)= sum of dy over the 4 children.  accumulate: dx already holds the gradient of another consumer of the upsampled
+// tensor (autograd would add the two branches in a separate bf16 pass)
 template <typename T>
 __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const T* __restrict__ dy, int lddy, T* __restrict__ dx, int lddx, int H, int W,
-                                                             int CV, long long total) {
+                                                             int CV, long long total, int accumulate) {
     constexpr int N = PV<T>::N;
     const unsigned iu = blockIdx.x * 256u + threadIdx.x;   // over B*H*W*CV
     if (iu >= total) return;                                  // host: total < 2^31 (32-bit divisions: the 64-bit ones were ~600 instructions per thread)
@@ -166,8 +167,11 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const T* __restrict
     const long long b = tu / (unsigned)H;
     const int h = (int)(tu - (unsigned)b * (unsigned)H);
     float acc[N];
+    if (accumulate) PV<T>::load(dx + p * lddx + cv * N, acc);
+    else {
 #pragma unroll
-    for (int k = 0; k < N; ++k) acc[k] = 0.f;
+        for (int k = 0; k < N; ++k) acc[k] = 0.f;
+    }
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
         const long long q = (b * 2 * H + (2 * h + (d >> 1))) * 2 * W + (2 * w + (d & 1));
@@ -250,15 +254,16 @@ extern "C" int et_upsample2x_fwd(const void* x, int ldx, void* y, int ldy, int d
     return 0;
 }
 
-extern "C" int et_upsample2x_bwd(const void* dy, int lddy, void* dx, int lddx, int dtype, int B, int H, int W, int C, et_stream_t stream) {
+extern "C" int et_upsample2x_bwd(const void* dy, int lddy, void* dx, int lddx, int dtype, int B, int H, int W, int C, int accumulate,
+                                 et_stream_t stream) {
     if (!dy || !dx) return -1;
     const int vec = dtype == ET_F32 ? 4 : 8;
     if (B <= 0 || C % vec || lddy % vec || lddx % vec) return -2;
     const int CV = C / vec;
     const long long total = (long long)B * H * W * CV;
     if (total >= (1ll << 31)) return -2;               // the kernels index with 32-bit arithmetic
-    if (dtype == ET_F32) { const dim3 g(et_cdiv(total, 256)); hipLaunchKernelGGL((upsample2x_bwd_kernel<float>), g, dim3(256), 0, (hipStream_t)stream, (const float*)dy, lddy, (float*)dx, lddx, H, W, CV, total); }
-    else if (dtype == ET_BF16) { const dim3 g(et_cdiv(total, 256)); hipLaunchKernelGGL((upsample2x_bwd_kernel<uint16_t>), g, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)dy, lddy, (uint16_t*)dx, lddx, H, W, CV, total); }
+    if (dtype == ET_F32) { const dim3 g(et_cdiv(total, 256)); hipLaunchKernelGGL((upsample2x_bwd_kernel<float>), g, dim3(256), 0, (hipStream_t)stream, (const float*)dy, lddy, (float*)dx, lddx, H, W, CV, total, accumulate); }
+    else if (dtype == ET_BF16) { const dim3 g(et_cdiv(total, 256)); hipLaunchKernelGGL((upsample2x_bwd_kernel<uint16_t>), g, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)dy, lddy, (uint16_t*)dx, lddx, H, W, CV, total, accumulate); }
     else return -2;
     ET_CHECK_LAUNCH();
     return 0;

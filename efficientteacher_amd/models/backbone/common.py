@@ -55,10 +55,11 @@ class Conv(nn.Module):
         self.bn = nn.BatchNorm2d(c2)
         self.act, self.act_name = get_activation(act=act)
 
-    def forward(self, x, residual=None, dst=None, bn_in=None, bn_out=None):
+    def forward(self, x, residual=None, dst=None, bn_in=None, bn_out=None, acc=None):
         """dst = (buffer, channel offset): produce the output in place inside a wider NHWC buffer.
         bn_in / bn_out: BatchNorm-backward hand-over between a block and the SOLE consumer of its output
-        (autograd.ConvBnActFn); only callers that know the graph pass them."""
+        (autograd.ConvBnActFn); only callers that know the graph pass them.
+        acc: the autograd.GradFork of x when x has a second consumer: this layer's dgrad adds into that gradient in place."""
         cs = getattr(self.conv, "_et_slot", None)
         if cs is None:
             raise RuntimeError("model state is not on the device arenas yet: move the Model to a GPU "
@@ -67,7 +68,7 @@ class Conv(nn.Module):
         act = _act_code(self.act)
         if self.bn.training:
             nbt = None if self._et_flat().bulk_nbt else self.bn.num_batches_tracked   # bulk: bumped once per forward
-            return ConvBnActFn.apply(x, residual, self.conv.weight, cs, bs, act, nbt, dst, bn_in, bn_out)
+            return ConvBnActFn.apply(x, residual, self.conv.weight, cs, bs, act, nbt, dst, bn_in, bn_out, acc)
         # eval (EMA teacher): BatchNorm is an affine of the running statistics, folded into the conv epilogue
         flat = self._et_flat()
         o = bs.aff_off

@@ -1,6 +1,8 @@
 """CSPDarknet backbone (host-side mirror of reference models/backbone/yolov5_backbone.py:26-98)."""
 import torch.nn as nn
 
+from ...autograd import GradFork
+
 from ...utils.general import make_divisible
 from .common import C3, SPPF, Conv
 
@@ -39,12 +41,13 @@ class YoloV5BackBone(nn.Module):
         x21 = self.stage2_1(x1)    # P2/4
         x22 = self.stage2_2(x21)
         x31 = self.stage3_1(x22)   # P3/8
-        c3 = self.stage3_2(x31, dst=dst_c3)
-        x41 = self.stage4_1(c3)    # P4/16
-        c4 = self.stage4_2(x41, dst=dst_c4)
-        x51 = self.stage5_1(c4)    # P5/32
+        # C3 / C4 feed the next stage AND the neck: the stride-2 conv adds its input gradient into the neck's (autograd.GradFork)
+        c3, c3n, f3 = GradFork.split(self.stage3_2(x31, dst=dst_c3))
+        x41 = self.stage4_1(c3, acc=f3)    # P4/16
+        c4, c4n, f4 = GradFork.split(self.stage4_2(x41, dst=dst_c4))
+        x51 = self.stage5_1(c4, acc=f4)    # P5/32
         x5 = self.stage5_2(x51)
-        return c3, c4, self.sppf(x5)
+        return GradFork.tap(c3n, f3), GradFork.tap(c4n, f4), self.sppf(x5)
 
     def get_depth(self, n):
         return max(round(n * self.gd), 1) if n > 1 else n

@@ -2,7 +2,7 @@
 import torch
 import torch.nn as nn
 
-from ...autograd import JoinSlicesFn, UpsampleCatFn
+from ...autograd import GradFork, JoinSlicesFn, UpsampleCatFn
 from ...utils.general import make_divisible
 from ..backbone.common import C3, Concat, Conv
 
@@ -75,15 +75,21 @@ class YoloV5Neck(nn.Module):
             return x2, x3, x4
         c4o = self.conv4.conv.out_channels
         buf4 = torch.empty((N, H5, W5, c4o + c1o), dtype=P5.dtype, device=P5.device)
-        xp_1 = self.conv1(P5, dst=(buf4, c4o))
-        x1 = self.C1(UpsampleCatFn.apply(xp_1, P4))     # upsample1 + concat, no intermediate tensor
+        # xp_1 / xp_2 (lateral outputs) and x2 / x3 (pyramid outputs) have two consumers each; the one that runs its backward LAST
+        # (upsample-concat, stride-2 conv) adds its gradient into the other's in place (autograd.GradFork) instead of a torch add
+        xp_1u, xp_1, f1 = GradFork.split(self.conv1(P5, dst=(buf4, c4o)))
+        x1 = self.C1(UpsampleCatFn.apply(xp_1u, P4, f1))     # upsample1 + concat, no intermediate tensor
+        xp_1 = GradFork.tap(xp_1, f1)
         c2o, c3o = self.conv2.conv.out_channels, self.conv3.conv.out_channels
         buf3 = torch.empty((N, x1.shape[1], x1.shape[2], c3o + c2o), dtype=x1.dtype, device=x1.device)
-        xp_2 = self.conv2(x1, dst=(buf3, c3o))
-        x2 = self.C2(UpsampleCatFn.apply(xp_2, P3))     # upsample2 + concat
-        t3 = self.conv3(x2, dst=(buf3, 0))
-        x3 = self.C3(self._join(buf3, t3, xp_2))
-        t4 = self.conv4(x3, dst=(buf4, 0))
+        xp_2u, xp_2, f2 = GradFork.split(self.conv2(x1, dst=(buf3, c3o)))
+        x2c, x2, g2 = GradFork.split(self.C2(UpsampleCatFn.apply(xp_2u, P3, f2)))     # upsample2 + concat
+        xp_2 = GradFork.tap(xp_2, f2)
+        t3 = self.conv3(x2c, dst=(buf3, 0), acc=g2)
+        x2 = GradFork.tap(x2, g2)
+        x3c, x3, g3 = GradFork.split(self.C3(self._join(buf3, t3, xp_2)))
+        t4 = self.conv4(x3c, dst=(buf4, 0), acc=g3)
+        x3 = GradFork.tap(x3, g3)
         x4 = self.C4(self._join(buf4, t4, xp_1))
         return x2, x3, x4
 

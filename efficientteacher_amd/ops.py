@@ -189,16 +189,17 @@ class WgradQueue:
     the backward pass (autograd engine callback); ``on_done`` callbacks (gradient-ready hooks of the data-parallel
     wrapper) run right after the launch that covers their layer.  ET_WGRAD_GROUP=1 launches every layer at once.
 
-    Nothing in backward consumes a weight gradient, so on a GPU the grouped launches go to a second HIP stream (default;
-    ET_WGRAD_STREAM=0 keeps them on the launching stream): the MFMA-bound wgrad workgroups then run beside the critical path
-    (dgrad -> BatchNorm backward -> dgrad ...) instead of inside it.  Measured on the YOLOv5l SSOD step, alternating runs on one
-    box (profiles/r03_wgrad_stream_ab.txt): 58.13 / 58.10 ms against 58.77 / 58.75 ms -- about 1 %.  The GPU is close to
-    work-conserving here: with the 12.6 ms of wgrad kernels off the main stream its own kernels stretch by ~6 ms (BatchNorm
-    passes 14.1 -> 17.2 ms, gather-GEMMs 26.0 -> 29.2 ms), which is why the gain is 0.6 ms and not 12 (r02 measured +0.5 ms
-    once and nothing once, and left it off).  Ordering: the side stream waits for the launching stream at every group launch (dy
-    and x are complete), the launching stream joins the side stream at the end of backward (before the optimizer /
-    the final all-reduces); gradient-ready hooks run with the side stream current, so an RCCL all-reduce they start
-    is ordered behind the wgrads it covers."""
+    Nothing in backward consumes a weight gradient, so on a GPU the grouped launches CAN go to a second HIP stream
+    (ET_WGRAD_STREAM=1): the MFMA-bound wgrad workgroups then run beside the critical path (dgrad -> BatchNorm backward -> dgrad ...)
+    instead of inside it.  Measured on the YOLOv5l SSOD step, alternating runs on one box (profiles/r03_wgrad_stream_ab.txt):
+    58.13 / 58.10 ms against 58.77 / 58.75 ms -- about 1 %.  The GPU is close to work-conserving here: with the 12.6 ms of wgrad
+    kernels off the main stream its own kernels stretch by ~6 ms (BatchNorm passes 14.1 -> 17.2 ms, gather-GEMMs 26.0 -> 29.2 ms),
+    which is why the gain is 0.6 ms and not 12 -- and why the PER-LAUNCH figures get worse while the step gets faster (the
+    dominant gather-GEMM's HIP-event duration 132 -> 149 us, bench.py `roofline.frac` 0.23 -> 0.21).  The default therefore keeps
+    the launches on the launching stream; the side stream is an opt-in for throughput.  Ordering: the side stream waits for the
+    launching stream at every group launch (dy and x are complete), the launching stream joins the side stream at the end of
+    backward (before the optimizer / the final all-reduces); gradient-ready hooks run with the side stream current, so an RCCL
+    all-reduce they start is ordered behind the wgrads it covers."""
 
     def __init__(self):
         import os
@@ -208,7 +209,7 @@ class WgradQueue:
         self.last = {}
         self.tick = 0
         self._cb_armed = False
-        self.use_side = os.environ.get("ET_WGRAD_STREAM", "1") == "1"
+        self.use_side = os.environ.get("ET_WGRAD_STREAM", "0") == "1"
         self._side = {}              # device -> side stream
         self._dirty = set()          # devices whose side stream holds work the launching stream has not joined yet
 
@@ -547,13 +548,16 @@ def upsample2x_fwd(x, out=None):
     return out
 
 
-def upsample2x_bwd(dy, out=None):
+def upsample2x_bwd(dy, out=None, accumulate=False):
+    """accumulate: out += (out already holds the gradient of another consumer of the upsampled tensor)"""
     N, H2, W2, C = dy.shape
     H, W = H2 // 2, W2 // 2
     if out is None:
+        assert not accumulate
         out = torch.empty((N, H, W, C), dtype=dy.dtype, device=dy.device)
+    assert out.shape == (N, H, W, C) and out.dtype == dy.dtype
     _lib.check(_lib.load().et_upsample2x_bwd(_lib.ptr(dy), _nhwc(dy), _lib.ptr(out), _nhwc(out), et_dtype(dy), N, H, W, C,
-                                             _lib.stream(dy)), "et_upsample2x_bwd")
+                                             int(bool(accumulate)), _lib.stream(dy)), "et_upsample2x_bwd")
     return out
 
 

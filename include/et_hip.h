@@ -212,7 +212,8 @@ int et_maxpool5_fwd(const void* x, int ldx, void* y, int ldy, uint8_t* argmax, i
 int et_maxpool5_bwd(const void* dy, int lddy, const uint8_t* argmax, const void* base, int ldb, void* dx, int lddx,
                     int dtype, int B, int H, int W, int C, et_stream_t stream);
 int et_upsample2x_fwd(const void* x, int ldx, void* y, int ldy, int dtype, int B, int H, int W, int C, et_stream_t stream);
-int et_upsample2x_bwd(const void* dy, int lddy, void* dx, int lddx, int dtype, int B, int H, int W, int C, et_stream_t stream);
+int et_upsample2x_bwd(const void* dy, int lddy, void* dx, int lddx, int dtype, int B, int H, int W, int C,
+                      int accumulate /* dx += (the other consumer's gradient is already there) */, et_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Strong view of an unlabeled batch from its weak view: the per-pixel work of the reference's data-loader

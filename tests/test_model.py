@@ -182,3 +182,38 @@ def test_rectangular_inputs_match_the_oracle(hip, B, H, W):
         a = dict(model.named_parameters())[k].grad.cpu()
         b = dict(ref.named_parameters())[k].grad
         assert (a - b).abs().max().item() <= 2e-3 * max(b.abs().max().item(), 1e-6), k
+
+
+def test_two_consumer_gradients_are_merged_in_kernels(hip):
+    """The six tensors of the YOLOv5 graph with two consumers (backbone C3 / C4, the neck's two lateral outputs and its P3 / P4
+    outputs): the consumer whose backward runs last adds its gradient into the other's inside its own kernel (autograd.GradFork:
+    dgrad epilogue `accumulate`, et_upsample2x_bwd `accumulate`) -- no torch `add` of gradient branches is left in the step
+    (VERDICT r02 item 8).  Counts the merges of one backward and checks that none fell back to the sum."""
+    from efficientteacher_amd import autograd as ag
+    from efficientteacher_amd.configs import get_cfg
+    from efficientteacher_amd.models.detector.yolo_ssod import Model
+    from efficientteacher_amd.models.loss import ComputeLoss
+    import os
+    from tests.conftest import ROOT
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(ROOT, YAML))
+    cfg.merge_from_list(["Model.width_multiple", 0.125, "Model.depth_multiple", 0.33])
+    cfg.freeze()
+    torch.manual_seed(0)
+    model = Model(cfg).to(hip.device).train()
+    counts = {"merged": 0, "summed": 0}
+    orig = ag._ForkFn.backward
+
+    def spy(ctx, ga, gb):
+        if ga is not None and gb is not None:
+            counts["merged" if ctx.holder.merged else "summed"] += 1
+        return orig(ctx, ga, gb)
+    ag._ForkFn.backward = staticmethod(spy)
+    try:
+        x = hip.t(np.random.default_rng(0).random((2, 3, 64, 64), dtype=np.float32))
+        pred, _ = model(x)
+        loss, _ = ComputeLoss(model, cfg)(pred, hip.t(np.array([[0, 3, .5, .5, .3, .4], [1, 7, .4, .6, .2, .2]], np.float32)))
+        loss.backward()
+    finally:
+        ag._ForkFn.backward = orig
+    assert counts == {"merged": 6, "summed": 0}, counts
