@@ -180,10 +180,10 @@ __device__ __forceinline__ void mma_chunk(const u32x4* __restrict__ sm, f32x16 (
 }
 
 // ---- shared epilogue of the gather-GEMM kernels -----------------------------------------------------
-// LDS floats the epilogue needs: one private [32][BN/WN + 4] fp32 slab per wave + the [WM][BN][2] statistics
+// LDS floats the epilogue needs: one private [32][BN/WN + 4] fp32 slab per wave
 template <int BM, int BN, int WM, int WN> struct EpiLds {
     static constexpr int WCOLS = BN / WN, SLD = WCOLS + 4, SLAB = 32 * SLD;
-    static constexpr int FLOATS = WM * WN * SLAB + WM * BN * 2;
+    static constexpr int FLOATS = WM * WN * SLAB;
     static constexpr int VEC16 = (FLOATS * 4 + 15) / 16;
 };
 
@@ -368,55 +368,52 @@ __device__ __forceinline__ void conv_epilogue_act(f32x16 (&acc)[BM / WM / 32][BN
         __builtin_amdgcn_s_waitcnt(0xC07F);        // slab reads done before the next 32 rows overwrite it
         __builtin_amdgcn_wave_barrier();
     }
-    if (bnb) {
-        // lanes of a wave that share a channel group (same scv, different srow) are CVN apart: xor-reduce over the srow bits,
-        // then hand the 8 channel sums of lane scv to the [WM][BN][2] reduction the forward statistics use
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-            for (int m = CVN; m < 64; m <<= 1) { bs1[e] += __shfl_xor(bs1[e], m); bs2[e] += __shfl_xor(bs2[e], m); }
-        float* red = (float*)lds_raw + WM * WN * L::SLAB;
-        if (lane < CVN) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int c = wn * WCOLS + scv * 8 + e;
-                red[(wm * BN + c) * 2 + 0] = bs1[e];
-                red[(wm * BN + c) * 2 + 1] = bs2[e];
-            }
-        }
-    }
     if (ep.stats) {
-        // rows beyond M were zero-filled, so they add nothing.  Reduce lane halves, then the WM waves
-        // that share these channels (through LDS), then one plain store per channel per block.
-        float* red = (float*)lds_raw + WM * WN * L::SLAB;     // [WM][BN][2], behind the slabs
+        // Partial statistics, one row of the (rows, 2, Cout) buffer per 64 output rows (et_conv2d_stats_rows).  Every wave writes
+        // the sums of ITS rows and channels straight to global memory -- no LDS hop, no workgroup barrier: the barrier made every
+        // wave of the tile wait for the slowest one's store passes (measured with s_memtime stamps, profiles/r03_epilogue_stamps.txt:
+        // 1.0 k of the 10.1 k cycles of a short-K 1x1 tile, 3.6 k of the 130 k of a 256x256 3x3 tile).  A wave whose tile part is
+        // taller than 64 rows writes its sums into its first row and zeros the others it covers; rows beyond M were zero-filled
+        // operands, so they add nothing.
+        constexpr int RPW = (BM / WM) / 64;                      // 64-row blocks per wave
+        static_assert((BM / WM) % 64 == 0, "wave tiles are whole 64-row blocks");
+        const int nrows = (g.M + 63) / 64;
+        const int rw = (m0 + wm * (BM / WM)) / 64;
+        if (bnb) {
+            // BN-backward sums: lanes of a wave that share a channel group (same scv, different srow) are CVN apart: xor-reduce over
+            // the srow bits, lane scv then holds the sums of its 8 channels
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-            const float s = ssum[tn] + __shfl_xor(ssum[tn], 32);
-            const float q = ssq[tn] + __shfl_xor(ssq[tn], 32);
-            if (hi == 0 && !bnb) {
-                const int c = wn * WCOLS + tn * 32 + l31;
-                red[(wm * BN + c) * 2 + 0] = s;
-                red[(wm * BN + c) * 2 + 1] = q;
-            }
-        }
-        __syncthreads();
-        if (tid < BN) {
-            float s = 0.f, q = 0.f;
+            for (int e = 0; e < 8; ++e)
+                for (int m = CVN; m < 64; m <<= 1) { bs1[e] += __shfl_xor(bs1[e], m); bs2[e] += __shfl_xor(bs2[e], m); }
+            if (lane < CVN && co + 8 <= g.Cout) {
 #pragma unroll
-            for (int w = 0; w < WM; ++w) { s += red[(w * BN + tid) * 2]; q += red[(w * BN + tid) * 2 + 1]; }
-            const int cc = n0 + tid;
-            if (cc < g.Cout) {
-                // the partial buffer has one row per 128 output rows (et_conv2d_stats_rows): a taller tile
-                // writes its sums into its first row and zeros the others it covers
-                constexpr int SR = BM / 128;
-                const int nrows = (g.M + 127) / 128;
-                ep.stats[((size_t)bx * SR * 2 + 0) * g.Cout + cc] = s;
-                ep.stats[((size_t)bx * SR * 2 + 1) * g.Cout + cc] = q;
-#pragma unroll
-                for (int e = 1; e < SR; ++e)
-                    if (bx * SR + e < nrows) {
-                        ep.stats[((size_t)(bx * SR + e) * 2 + 0) * g.Cout + cc] = 0.f;
-                        ep.stats[((size_t)(bx * SR + e) * 2 + 1) * g.Cout + cc] = 0.f;
+                for (int r = 0; r < RPW; ++r) {
+                    if (rw + r >= nrows) break;
+                    float* d0 = ep.stats + ((size_t)(rw + r) * 2 + 0) * g.Cout + co;
+                    float* d1 = ep.stats + ((size_t)(rw + r) * 2 + 1) * g.Cout + co;
+                    if (r == 0) {
+                        *(float4*)d0 = make_float4(bs1[0], bs1[1], bs1[2], bs1[3]); *(float4*)(d0 + 4) = make_float4(bs1[4], bs1[5], bs1[6], bs1[7]);
+                        *(float4*)d1 = make_float4(bs2[0], bs2[1], bs2[2], bs2[3]); *(float4*)(d1 + 4) = make_float4(bs2[4], bs2[5], bs2[6], bs2[7]);
+                    } else {
+                        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                        *(float4*)d0 = z; *(float4*)(d0 + 4) = z; *(float4*)d1 = z; *(float4*)(d1 + 4) = z;
                     }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const float sv = ssum[tn] + __shfl_xor(ssum[tn], 32);   // the two lane halves hold the two row halves of a channel
+                const float qv = ssq[tn] + __shfl_xor(ssq[tn], 32);
+                const int cc = n0 + wn * WCOLS + tn * 32 + l31;
+                if (hi == 0 && cc < g.Cout) {
+#pragma unroll
+                    for (int r = 0; r < RPW; ++r) {
+                        if (rw + r >= nrows) break;
+                        ep.stats[((size_t)(rw + r) * 2 + 0) * g.Cout + cc] = r == 0 ? sv : 0.f;
+                        ep.stats[((size_t)(rw + r) * 2 + 1) * g.Cout + cc] = r == 0 ? qv : 0.f;
+                    }
+                }
             }
         }
     }
@@ -745,7 +742,6 @@ __global__ __launch_bounds__(64 * WM * WN, (NS == 3 && BKV == 4 && BM == 128) ? 
     __syncthreads();                               // the epilogue reuses the ring as its staging area
 #undef ET_ADVANCE_CURSOR
     conv_epilogue<T, BM, BN, WM, WN>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn);
-    __syncthreads();
 }
 
 // ---- forward / dgrad gather-GEMM, 256x256 tile, two wave groups in anti-phase ("ping-pong") ----------------
@@ -965,7 +961,6 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_pp_kernel(const uint16_t* __
     if (wm == 0) __builtin_amdgcn_s_barrier();     // balances group 1's extra barrier
     __syncthreads();                               // the epilogue reuses the half-tile buffers as its staging area
     conv_epilogue<uint16_t, BM, BN, WM, WN>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn);
-    __syncthreads();
 #undef ET_PP_DECODE
 #undef ET_PP_ADVANCE
 #undef ET_PP_BAR
@@ -1182,7 +1177,7 @@ static int try_launch_stem(const void* x, const void* w, void* y, int dtype, int
     a.trn = (a.OH + STEM_TR - 1) / STEM_TR; a.tcn = (a.OW + STEM_TC - 1) / STEM_TC;
     a.ntiles = N * a.trn * a.tcn;
     a.scale = scale; a.bias = bias; a.act = act; a.stats = stats;
-    a.stat_rows = (N * a.OH * a.OW + 127) / 128;
+    a.stat_rows = (N * a.OH * a.OW + 63) / 64;        // == et_conv2d_stats_rows
     int grid = env_int("ET_CONV_STEM_WGS", 2 * device_cus());      // read per launch: tests shrink it to exercise the tile loop
     if (grid < 1) grid = 1;
     if (grid > a.ntiles) grid = a.ntiles;
@@ -1759,7 +1754,7 @@ static int launch_gemm(const void* X, const void* W, void* Y, const void* zero16
 #undef ET_REG
 }
 
-extern "C" int et_conv2d_stats_rows(int N, int OH, int OW) { return (N * OH * OW + 127) / 128; }
+extern "C" int et_conv2d_stats_rows(int N, int OH, int OW) { return (N * OH * OW + 63) / 64; }
 
 extern "C" int et_conv2d_fwd(const void* x, const void* w, void* y, int dtype, int N, int IH, int IW, int Cin,
                              int ldx, int Cout, int KH, int KW, int stride, int pad, int ldy, const float* scale,
