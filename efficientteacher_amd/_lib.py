@@ -74,6 +74,7 @@ SIGNATURES = {
     "et_tal_loss": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_float, P, P, P, P, P]),
     "et_tal_assign_workspace_bytes": (c_int, [c_int, c_int, c_int, ctypes.POINTER(c_size_t)]),
     "et_tal_assign": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_float, P, P, P, P, P, c_size_t, P]),
+    "et_tal_targets_pad": (c_int, [P, c_int, c_int, c_int, c_float, c_float, P, P, P]),
     "et_tal_pseudo_split": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float, P, P, P, P, P, P, P, P, P]),
     "et_tal_assigned_gt": (c_int, [P, c_int, c_int, c_int, P, P]),
     "et_tal_merge_pseudo": (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P, P, P, P]),

@@ -123,13 +123,16 @@ __global__ __launch_bounds__(256) void tal_topk_kernel(TalArgs t) {
     __shared__ int ri[256];
     const int b = blockIdx.x / t.G, g = blockIdx.x % t.G;
     unsigned char* pos = t.pos + ((size_t)b * t.G + g) * t.A;
+    if (t.gmask[(size_t)b * t.G + g] <= 0.f) {                  // padded gt: its k picks all collapse onto index 0 and are dropped
+        for (int a = threadIdx.x; a < t.A; a += 256) pos[a] = 0;   // (:139-142); block-uniform, so no metric scan at all
+        return;
+    }
     for (int a = threadIdx.x; a < t.A; a += 256) {
         pos[a] = 0;
         const bool in = tal_in_gt(t, b, g, a);
         met[a] = in ? tal_metric(t, b, g, a, nullptr) : 0.f;   // metric * mask_in_gts (tal_assigner.py:93)
     }
     __syncthreads();
-    if (t.gmask[(size_t)b * t.G + g] <= 0.f) return;           // padded gt: its k picks all collapse onto index 0 and are dropped (:139-142)
     for (int k = 0; k < t.topk && k < t.A; ++k) {
         float bv = -1.f;
         int bi = 0x7fffffff;
@@ -516,6 +519,50 @@ extern "C" int et_tal_merge_pseudo(const float* ts_r, const float* tb_r, const u
     if (B <= 0 || A <= 0 || G <= 0 || nc <= 0) return -2;
     hipLaunchKernelGGL(tal_merge_pseudo_kernel, dim3(et_cdiv((long long)B * A, 256)), dim3(256), 0, (hipStream_t)stream, ts_r, tb_r, fg_r, ts_u,
                        tb_u, fg_u, gt_idx_u, u_score, u_flags, B, A, G, nc, target_scores, target_bboxes, fg_box);
+    ET_CHECK_LAUNCH();
+    return 0;
+}
+
+
+// ---- ComputeTalLoss.preprocess on the device (models/loss/tal_loss.py:131-143) ------------------------------------------------
+// (n, 6) rows [img, cls, x, y, w, h] (normalised) -> per-image padded table (B, G, 5) [cls, x1, y1, x2, y2] in pixels + mask (B, G).
+// The reference builds it with a python loop over targets.cpu() (a host synchronisation per step when the targets live on the
+// device); here G = n (the capacity that can never overflow -- padded rows cost the assigner one early-exiting workgroup each) and
+// a row's slot inside its image is the number of earlier rows of the same image (O(n^2) over at most a few thousand rows).
+__global__ __launch_bounds__(256) void tal_targets_pad_kernel(const float* __restrict__ t, int n, int B, int G, float img_w, float img_h,
+                                                              float* __restrict__ out, float* __restrict__ mask) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < B * G) {                                              // initialise every slot: label -1, zero box, mask 0
+        out[(size_t)i * 5] = -1.f;
+        for (int k = 1; k < 5; ++k) out[(size_t)i * 5 + k] = 0.f;
+        mask[i] = 0.f;
+    }
+}
+__global__ __launch_bounds__(256) void tal_targets_scatter_kernel(const float* __restrict__ t, int n, int B, int G, float img_w, float img_h,
+                                                                  float* __restrict__ out, float* __restrict__ mask) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int img = (int)t[(size_t)i * 6];
+    if (img < 0 || img >= B) return;
+    int rank = 0;
+    for (int j = 0; j < i; ++j) rank += ((int)t[(size_t)j * 6] == img) ? 1 : 0;
+    if (rank >= G) return;
+    const float x = t[(size_t)i * 6 + 2] * img_w, y = t[(size_t)i * 6 + 3] * img_h, w = t[(size_t)i * 6 + 4] * img_w, h = t[(size_t)i * 6 + 5] * img_h;
+    const float x1 = x - w * 0.5f, y1 = y - h * 0.5f;
+    float* o = out + ((size_t)img * G + rank) * 5;
+    o[0] = t[(size_t)i * 6 + 1]; o[1] = x1; o[2] = y1; o[3] = x1 + w; o[4] = y1 + h;
+    // mask_gt = (gt_bboxes.sum(-1) > 0) (tal_loss.py:84)
+    mask[(size_t)img * G + rank] = (x1 + y1 + (x1 + w) + (y1 + h)) > 0.f ? 1.f : 0.f;
+}
+
+extern "C" int et_tal_targets_pad(const float* targets, int n, int B, int G, float img_w, float img_h, float* out /* (B,G,5) */,
+                                  float* mask /* (B,G) */, et_stream_t stream) {
+    if (!out || !mask || (n > 0 && !targets)) return -1;
+    if (n < 0 || B <= 0 || G <= 0) return -2;
+    hipLaunchKernelGGL(tal_targets_pad_kernel, dim3(et_cdiv(B * G, 256)), dim3(256), 0, (hipStream_t)stream, targets, n, B, G, img_w, img_h, out, mask);
+    if (n > 0)
+        hipLaunchKernelGGL(tal_targets_scatter_kernel, dim3(et_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, targets, n, B, G, img_w, img_h,
+                           out, mask);
     ET_CHECK_LAUNCH();
     return 0;
 }

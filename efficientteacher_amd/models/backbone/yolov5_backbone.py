@@ -7,6 +7,17 @@ from ...utils.general import make_divisible
 from .common import C3, SPPF, Conv
 
 
+STAGE_EVENTS = None      # dict filled with a HIP event per pyramid stage of the NEXT training forward (trainer: teacher start point)
+
+
+def _mark_stage(name, t):
+    if STAGE_EVENTS is not None and t.is_cuda and t.requires_grad:
+        import torch
+        e = torch.cuda.Event()
+        e.record()
+        STAGE_EVENTS[name] = e
+
+
 class YoloV5BackBone(nn.Module):
     def __init__(self, cfg):
         super(YoloV5BackBone, self).__init__()
@@ -38,13 +49,17 @@ class YoloV5BackBone(nn.Module):
     def forward(self, x, dst_c3=None, dst_c4=None):
         """dst_c3 / dst_c4 = (buffer, channel offset): produce C3 / C4 in place inside the neck's concat buffers"""
         x1 = self.stage1(x)        # P1/2
+        _mark_stage("p1", x1)
         x21 = self.stage2_1(x1)    # P2/4
         x22 = self.stage2_2(x21)
+        _mark_stage("p2", x22)
         x31 = self.stage3_1(x22)   # P3/8
         # C3 / C4 feed the next stage AND the neck: the stride-2 conv adds its input gradient into the neck's (autograd.GradFork)
         c3, c3n, f3 = GradFork.split(self.stage3_2(x31, dst=dst_c3))
+        _mark_stage("p3", c3)
         x41 = self.stage4_1(c3, acc=f3)    # P4/16
         c4, c4n, f4 = GradFork.split(self.stage4_2(x41, dst=dst_c4))
+        _mark_stage("p4", c4)
         x51 = self.stage5_1(c4, acc=f4)    # P5/32
         x5 = self.stage5_2(x51)
         return GradFork.tap(c3n, f3), GradFork.tap(c4n, f4), self.sppf(x5)

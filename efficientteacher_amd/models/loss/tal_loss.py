@@ -102,10 +102,15 @@ class ComputeTalLoss:
         feats, pred_scores, pred_distri = outputs
         dev = pred_scores.device
         B, A, nc = pred_scores.shape
-        tg, num_gts = self.preprocess(targets, B)
-        tg = tg.to(dev)
-        gt_labels, gt_bboxes = tg[..., :1], tg[..., 1:]
-        mask_gt = (gt_bboxes.sum(-1, keepdim=True) > 0).float()
+        if targets.is_cuda or (dev.type == "cpu" and targets.device.type == "cpu" and ops._lib.is_emulated()):
+            # device-resident targets: the padded table is built by a kernel (no .cpu() round trip = no host synchronisation)
+            gt_labels, gt_bboxes, mask_gt = ops.tal_targets_pad(targets.to(dev), B, self.ori_img_size, self.ori_img_size)
+            num_gts = int(targets.shape[0]) + B              # the reference counts its dummy row per image (:133-137)
+        else:
+            tg, num_gts = self.preprocess(targets, B)
+            tg = tg.to(dev)
+            gt_labels, gt_bboxes = tg[..., :1], tg[..., 1:]
+            mask_gt = (gt_bboxes.sum(-1, keepdim=True) > 0).float()
         scores, pd_xyxy, anchor_points, anchor_points_s, stride_tensor = self.assigner_inputs(feats, pred_scores, pred_distri)
         with torch.no_grad():
             tl, tb, ts, fg = ops.tal_assign(scores, pd_xyxy, anchor_points, gt_labels, gt_bboxes, mask_gt, topk=13, alpha=1.0, beta=6.0)

@@ -53,7 +53,7 @@ class FamilyTimer:
         "et_nms": "nms_loss_pl", "et_nms_ssod": "nms_loss_pl", "et_detect_decode": "nms_loss_pl", "et_pseudo_label_transform": "nms_loss_pl",
         "et_select_targets": "nms_loss_pl", "et_yolo_loss": "nms_loss_pl", "et_ota_assign": "nms_loss_pl", "et_score_log_append": "nms_loss_pl",
         "et_scale_cast": "nms_loss_pl", "et_domain_focal": "nms_loss_pl", "et_scale_inplace": "nms_loss_pl", "et_v8_decode": "nms_loss_pl",
-        "et_tal_loss": "nms_loss_pl", "et_tal_assign": "nms_loss_pl", "et_colsum": "nms_loss_pl", "et_tal_pseudo_split": "nms_loss_pl",
+        "et_tal_loss": "nms_loss_pl", "et_tal_assign": "nms_loss_pl", "et_colsum": "nms_loss_pl", "et_tal_pseudo_split": "nms_loss_pl", "et_tal_targets_pad": "nms_loss_pl",
         "et_tal_assigned_gt": "nms_loss_pl", "et_tal_merge_pseudo": "nms_loss_pl",
         "et_sgd_nesterov": "optimizer_ema", "et_sgd_nesterov_dev": "optimizer_ema", "et_adamw": "optimizer_ema", "et_ema_update": "optimizer_ema",
         "et_ema_update_dev": "optimizer_ema", "et_cast_f32_to_bf16": "optimizer_ema", "et_weight_transpose": "optimizer_ema",
@@ -209,7 +209,7 @@ class WgradQueue:
         self.last = {}
         self.tick = 0
         self._cb_armed = False
-        self.use_side = os.environ.get("ET_WGRAD_STREAM", "0") == "1"
+        self.use_side = int(os.environ.get("ET_WGRAD_STREAM", "0") or 0)     # 0 off, 1 every group, 2 only the 1x1 layers, 3 only k > 1
         self._side = {}              # device -> side stream
         self._dirty = set()          # devices whose side stream holds work the launching stream has not joined yet
 
@@ -260,7 +260,7 @@ class WgradQueue:
             return
         xs, dys, ksize, stride, pad, dev = key
         items = [(a, b, c) for a, b, c, _ in lst]
-        if self.use_side and dev.type == "cuda":
+        if dev.type == "cuda" and (self.use_side == 1 or (self.use_side == 2 and ksize == 1) or (self.use_side == 3 and ksize > 1)):
             main, side = torch.cuda.current_stream(dev), self.side_stream(dev)
             side.wait_stream(main)               # every x / dy of the group is complete on the launching stream
             with torch.cuda.stream(side):
@@ -854,6 +854,19 @@ def tal_assign(pd_scores, pd_bboxes, anc_points, gt_labels, gt_bboxes, mask_gt, 
         _lib.check(lib.et_tal_assigned_gt(_lib.ptr(ws), B, A, G, _lib.ptr(idx), _lib.stream(ps)), "et_tal_assigned_gt")
         return tl, tb, ts, fg.bool(), idx
     return tl, tb, ts, fg.bool()
+
+
+def tal_targets_pad(targets, B, img_w, img_h):
+    """ComputeTalLoss.preprocess on the device: (n,6) [img, cls, x, y, w, h] normalised -> gt_labels (B,G,1), gt_bboxes (B,G,4) xyxy
+    pixels, mask_gt (B,G,1) with G = max(n, 1): no host synchronisation (the reference loops over targets.cpu())"""
+    t = targets[:, :6].to(torch.float32).contiguous()
+    n = int(t.shape[0])
+    G = max(n, 1)
+    out = torch.empty((B, G, 5), dtype=torch.float32, device=t.device)
+    mask = torch.empty((B, G, 1), dtype=torch.float32, device=t.device)
+    _lib.check(_lib.load().et_tal_targets_pad(_lib.ptr(t) if n else None, n, B, G, float(img_w), float(img_h), _lib.ptr(out), _lib.ptr(mask),
+                                              _lib.stream(out)), "et_tal_targets_pad")
+    return out[..., :1], out[..., 1:], mask
 
 
 def tal_pseudo_split(targets9, valid, thr, B, nc, with_obj, with_bbox, with_cls, img_w, img_h):

@@ -313,6 +313,7 @@ class _SsodHotPath(_HotPath):
         return self._side
 
     overlap_teacher = True
+    teacher_after = "p2"
 
 
 def hot_path_trainers(ref_trainer=None, ref_ssod_trainer=None):

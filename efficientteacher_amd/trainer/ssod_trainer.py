@@ -58,6 +58,9 @@ class SSODTrainer(Trainer):
         self.extra_teacher_models = []
         self.teacher_pred_hook = None      # optional callable(teacher_pred) -> teacher_pred (bench: synthetic scores)
         self.overlap_teacher = True        # teacher forward + pseudo labels on a second stream
+        import os as _os
+        ta = _os.environ.get("ET_TEACHER_AFTER", "p2")                 # "start" | "p1" | "p2" | "p3" | "p4" (see _train_instance_eager)
+        self.teacher_after = "" if ta in ("", "start", "0") else ta
         self._side = None
         # the step as one captured HIP graph (trainer/graph_step.py), opt-in: ET_STEP_GRAPH=1 or use_graph=True.  Measured on
         # MI355X (profiles/r02_graph_step_timing.txt): issuing the ~750 launches of an eager step takes the host 18-24 ms, a
@@ -167,26 +170,54 @@ class SSODTrainer(Trainer):
         # filled last waves interleave with the student's MFMA-bound kernels.
         side = self._side_stream() if self.cuda and self.overlap_teacher else None
         cur = torch.cuda.current_stream(self.device) if side is not None else None
-        if side is not None:
-            side.wait_stream(cur)
         if self.cfg.SSOD.pseudo_label_type == 'LabelMatch':         # ssod_trainer.py:616-617
             self.pseudo_label_creator.update(targets, n_img, unlabeled_imgs.shape[0])
-        with torch.no_grad(), (torch.cuda.stream(side) if side is not None else _nullcontext()):
-            from .. import ops as _ops
-            _ops.SCOPE = "teacher"
-            try:
-                (teacher_pred, _), _ = self.ema.ema(unlabeled_imgs_ori, augment=False)
-            finally:
-                _ops.SCOPE = None
-            if self.teacher_pred_hook is not None:
-                teacher_pred = self.teacher_pred_hook(teacher_pred)
-            t9, valid = self.pseudo_label_creator.create_pseudo_label_padded(teacher_pred, unlabeled_M, width, height)
-            has_targets = valid.any().float()        # == not invalid_target_shape, as a device flag
+
+        def teacher(start_event=None):
+            if side is not None:
+                side.wait_stream(cur) if start_event is None else side.wait_event(start_event)
+            with torch.no_grad(), (torch.cuda.stream(side) if side is not None else _nullcontext()):
+                from .. import ops as _ops
+                _ops.SCOPE = "teacher"
+                try:
+                    (teacher_pred, _), _ = self.ema.ema(unlabeled_imgs_ori, augment=False)
+                finally:
+                    _ops.SCOPE = None
+                if self.teacher_pred_hook is not None:
+                    teacher_pred = self.teacher_pred_hook(teacher_pred)
+                t9, valid = self.pseudo_label_creator.create_pseudo_label_padded(teacher_pred, unlabeled_M, width, height)
+                return t9, valid, valid.any().float()        # has_targets == not invalid_target_shape, as a device flag
+
+        # The teacher stream starts when the student's forward has passed its stride-4 stage (ET_TEACHER_AFTER=p2, the default;
+        # p1 / p3 / p4 / "start" are the other measured settings), not at the start of the step: both networks begin with their
+        # large, HBM-bound maps, and running those side by side only makes both slower.  Same-box A/B, three alternations
+        # (profiles/r03_teacher_start_ab.txt): 58.64 / 58.74 / 58.74 ms against 59.06 / 58.78 / 59.00 ms, and the dominant
+        # gather-GEMM's in-step roofline fraction 0.240 / 0.242 / 0.240 against 0.232 / 0.229 / 0.232.
+        after = self.teacher_after if side is not None else ""
+        if after:
+            from ..models.backbone.yolov5_backbone import YoloV5BackBone
+            inner = self.model.module if isinstance(self.model, FlatDataParallel) else self.model
+            if not isinstance(inner.backbone, YoloV5BackBone):
+                after = ""                                    # only this backbone marks its stages
+        if not after:
+            t9, valid, has_targets = teacher()
         # 3 student forward on the concatenated batch (:623-627)
         # the reference concatenates the two batches (:623); here they are packed into one NHWC buffer directly
         same = imgs.shape[1:] == unlabeled_imgs.shape[1:] and imgs.dtype == unlabeled_imgs.dtype
         total_imgs = [imgs, unlabeled_imgs] if same else torch.cat([imgs, unlabeled_imgs.to(imgs.dtype)], 0)
-        total_pred, total_feature = self.model(total_imgs)
+        if after:
+            from ..models.backbone import yolov5_backbone as _bb
+            if side is not None:
+                side.wait_stream(cur)                         # inputs / weights of this step are ready on the main stream
+            _bb.STAGE_EVENTS = {}
+            try:
+                total_pred, total_feature = self.model(total_imgs)
+                ev = _bb.STAGE_EVENTS.get(after)
+            finally:
+                _bb.STAGE_EVENTS = None
+            t9, valid, has_targets = teacher(ev)
+        else:
+            total_pred, total_feature = self.model(total_imgs)
         if side is not None:
             cur.wait_stream(side)
             for t in (t9, valid, has_targets):

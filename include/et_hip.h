@@ -337,6 +337,12 @@ int et_tal_assign(const float* pd_scores, const float* pd_bboxes, const float* a
                   const float* gt_bboxes, const float* mask_gt, int B, int A, int G, int nc, int topk, float alpha, float beta,
                   float eps, int64_t* target_labels, float* target_bboxes, float* target_scores, uint8_t* fg_mask,
                   void* workspace, size_t ws_bytes, et_stream_t stream);
+/* et_tal_targets_pad: ComputeTalLoss.preprocess (models/loss/tal_loss.py:131-143) without the host loop: targets (n,6) fp32
+ *   [img, cls, x, y, w, h] normalised -> out (B,G,5) [cls, x1, y1, x2, y2] pixels (padded rows: cls -1, zero box) and mask (B,G)
+ *   = (x1 + y1 + x2 + y2 > 0), a row's slot = the number of earlier rows of its image.  G >= the largest per-image count (G = n is
+ *   always enough). */
+int et_tal_targets_pad(const float* targets, int n, int B, int G, float img_w, float img_h, float* out, float* mask, et_stream_t stream);
+
 /* ---- EXTENSION (no counterpart in the reference): pseudo labels on the anchor-free head.  The reference's
  * ComputeStudentMatchLoss needs det.anchors (models/loss/ssod/ssod_loss.py:69) and its SSOD trainer raises for model types other
  * than yolov5 (trainer/ssod_trainer.py:598-606), although update_train_logger anticipates a 'tal' variant (:271-272).  These three

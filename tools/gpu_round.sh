@@ -47,6 +47,7 @@ first16) run first16; for K in "--graph" "--graph" "--no-graph"; do timeout 600 
 ab_fork) run ab_fork; for K in "X=0" "ET_GRAD_FORK=0" "X=0" "ET_GRAD_FORK=0"; do env $K timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); k=d['kernel_ms_by_family']; print('$K', round(d['ms_per_step'],2), k['main_stream'], k['aten_and_gaps_ms'])"; done ;;
 ab_lib) run ab_lib; for L in base new base new; do if [ $L = base ]; then export ET_HIP_LIB=$PWD/tools/probe/libet_base.so; else unset ET_HIP_LIB; fi; MB_REF=0 timeout 600 python tools/microbench.py conv 2>&1 | tail -1 | cut -c1-230; timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); k=d['kernel_ms_by_family']; print('$L', round(d['ms_per_step'],2), k['main_stream'], k['teacher_stream_ms'], round(d['roofline']['frac'],4))"; done; unset ET_HIP_LIB ;;
 launches) run launches; timeout 900 python bench.py --steps 12 --warmup 4 --no-cpu-baseline --dump-launches $OUT/launches_one_step.json > $OUT/bench_launches.json 2> $OUT/launches.err; python tools/launch_table.py $OUT/launches_one_step.json > $OUT/launch_table.txt 2>&1; tail -25 $OUT/launch_table.txt ;;
+ab_teacher) run ab_teacher; for K in ${AB_TEACHER:-"X=0" "ET_TEACHER_AFTER=p2" "ET_TEACHER_AFTER=p1" "X=0" "ET_TEACHER_AFTER=p2" "ET_TEACHER_AFTER=p1" "X=0" "ET_TEACHER_AFTER=p2"}; do env $K timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); k=d['kernel_ms_by_family']; print('$K', round(d['ms_per_step'],2), round(d['roofline']['frac'],4), round(d['roofline']['all_conv_kernels']['tflops']), k['main_stream'], k['teacher_stream_ms'])"; done ;;
 smoke) run smoke; timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -3 $OUT/smoke.log ;;
 prof) run prof; (cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/bench_under_rocprof.json 2> $GRAFT_REPO_ROOT/$OUT/prof.err); find $OUT/prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv; find $OUT/prof -name "*kernel_trace.csv" | head -1 | xargs -I{} python tools/trace_streams.py {} > $OUT/trace_streams.txt 2>&1; cat $OUT/trace_streams.txt; find $OUT/prof -name "*.db" -delete; find $OUT/prof -name "*kernel_trace.csv" -size +20M -delete; head -8 $OUT/kernel_stats.csv | cut -c1-160 ;;
 pmc) run pmc; for C in FETCH_SIZE WRITE_SIZE; do (cd /tmp && timeout 900 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmc_$C -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/bench_pmc_$C.json 2> $GRAFT_REPO_ROOT/$OUT/pmc_$C.err); done; python tools/pmc_summarize.py $OUT > $OUT/pmc_bench_summary.csv; find $OUT -name "*.db" -delete; find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*kernel_trace.csv" -delete; head -12 $OUT/pmc_bench_summary.csv ;;
