@@ -373,9 +373,12 @@ def measure(a, wl_name, per_rank, device, rank, world, dev_index, full=True):
     n_extra = 0
     if ssod and getattr(tr, "use_graph", False):
         # the captured step graph is instantiated after `graph_warmup` eager steps; its first replays carry one-off costs (graph
-        # upload; measured ~0.3 s in the first process on a fresh box) -- keep them out of the timed region: at least four replays
-        # happen untimed, whatever W is
-        while (getattr(getattr(tr, "_graph", None), "replays", 0) < 4 and not getattr(tr, "graph_error", None)) and n_extra < 12:
+        # upload; measured ~0.3 s in the first process on a fresh box) and the next ones are the trainer's slow-replay probe
+        # (trainer/graph_step.py: a graph that replays slower than the eager step is captured once more, then dropped).  All of
+        # that stays out of the timed region -- a FIXED number of steps (every rank issues the same collectives), whatever W is
+        from efficientteacher_amd.trainer.graph_step import StepGraph
+        need = tr.graph_warmup + 2 * (1 + StepGraph.REPLAY_PROBE) + 1
+        while a.warmup + n_extra < need:
             step(a.warmup + n_extra)
             n_extra += 1
         torch.cuda.synchronize()
@@ -420,6 +423,8 @@ def measure(a, wl_name, per_rank, device, rank, world, dev_index, full=True):
                t_ar=t_ar, grad_bytes=int(tr.model.flat_state().grads.numel() * 4), graph_default=bool(graph_default),
                graph_replays=(getattr(tr._graph, "replays", 0) if getattr(tr, "_graph", None) else 0),
                graph_recaptures=(getattr(tr._graph, "recaptures", 0) if getattr(tr, "_graph", None) else 0),
+               graph_probe=((getattr(tr._graph, "probe_ms", None), tr.eager_step_ms(), getattr(tr._graph, "slow_captures", 0))
+                            if getattr(tr, "_graph", None) else None),
                graph_error=getattr(tr, "graph_error", None), graph_requested=bool(a.graph and ssod), graph_extra_warmup=n_extra,
                n_timed=len(timed), timer=timer, S=S)
     if not full:
@@ -648,6 +653,8 @@ def main():
                        "step_graph": dict(enabled=res["graph_default"], requested=res["graph_requested"], error=res["graph_error"],
                                           replays=res["graph_replays"], recaptures=res["graph_recaptures"],
                                           extra_untimed_warmup_steps=res["graph_extra_warmup"],
+                                          replay_probe=(dict(zip(("replay_ms", "eager_ms", "slow_captures"), res["graph_probe"]))
+                                                        if res.get("graph_probe") else None),
                                           eager_instrumented_steps=res["n_timed"]),
                        "inputs": "host uint8 (PCIe inclusive)" if a.host_inputs else "resident in HBM"},
             "roofline": roof,

@@ -54,8 +54,14 @@ class HostStager:
         return self.dev
 
 
+class SlowReplay(RuntimeError):
+    """both captures of the step replayed slower than the eager step: the trainer continues eagerly"""
+
+
 class StepGraph:
     TARGET_CAPACITY = 4096          # rows of the padded supervised target table (32 mosaic images stay far below)
+    REPLAY_PROBE = 3                # replays timed after each capture (the first replay of a capture is not one of them)
+    SLOW_FACTOR = 1.10              # replay / eager step above this = the slow mode (normal: 0.92-1.003 measured)
 
     def __init__(self, trainer):
         self.t = trainer
@@ -64,6 +70,12 @@ class StepGraph:
         self.replays = 0
         self.recaptures = 0
         self.sig = None
+        import os
+        self.slow_factor = float(os.environ.get("ET_GRAPH_SLOW_FACTOR", self.SLOW_FACTOR))
+        self._probe = []                # (start, end) events of the timed replays of the current capture
+        self._since_capture = 0
+        self.slow_captures = 0
+        self.probe_ms = None            # median replay ms of the current capture (None until measured)
 
     # ---- eligibility ------------------------------------------------------------------------------------------
     def _signature(self, imgs):
@@ -140,6 +152,26 @@ class StepGraph:
                 e.capturing = False
         self.graph = g
         self.sig = self._signature(imgs)
+        self._probe, self._since_capture, self.probe_ms = [], 0, None
+
+    def _check_probe(self):
+        """after the timed replays of a capture: compare their median with the last eager step (both HIP-event spans on the step's
+        stream).  Returns False when the trainer has to go back to eager steps."""
+        t = self.t
+        self._probe[-1][1].synchronize()
+        ms = sorted(a.elapsed_time(b) for a, b in self._probe)
+        self.probe_ms = ms[len(ms) // 2]
+        self._probe = []
+        eager = t.eager_step_ms()
+        if eager is None or self.probe_ms <= self.slow_factor * eager:
+            return True
+        self.slow_captures += 1
+        torch.cuda.synchronize(t.device)
+        self.graph, self.items = None, None
+        if self.slow_captures >= 2:
+            raise SlowReplay(f"captured step replays in {self.probe_ms:.1f} ms, the eager step takes {eager:.1f} ms (twice)")
+        self.recaptures += 1
+        return True
 
     def _scalars(self, advance=True):
         vals = self.t.optimizer.hp_values()
@@ -151,6 +183,8 @@ class StepGraph:
     # ---- one step -------------------------------------------------------------------------------------------------
     def run(self, imgs, targets, u_str, u_ori, M_s, ni):
         t = self.t
+        if self.graph is not None and len(self._probe) == self.REPLAY_PROBE:
+            self._check_probe()
         if self.graph is None:
             self._capture(imgs, u_str, u_ori, M_s)
         # host side of update_optimizer (trainer/ssod_trainer.py:458-488), in its order: warm-up, then the step's scalars
@@ -181,7 +215,16 @@ class StepGraph:
                 tb[:n, :6] = targets[:, :6].detach().to(torch.float32)
                 tb[:n, 7] = 1.0                            # flags bit 0: labelled target (pass 0); 0 = padding row
             self.tbl.push(tb.view(-1))
+        timed = self.probe_ms is None and 1 <= self._since_capture <= self.REPLAY_PROBE
+        if timed:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
         self.graph.replay()
+        if timed:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self._probe.append((e0, e1))
+        self._since_capture += 1
         self.replays += 1
         t.last_opt_step = ni
         return self.items

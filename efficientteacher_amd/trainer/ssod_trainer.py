@@ -149,16 +149,34 @@ class SSODTrainer(Trainer):
                 try:
                     return self._graph.run(imgs, targets, unlabeled_imgs, unlabeled_imgs_ori, unlabeled_M, ni)
                 except Exception as e:                 # a capture the runtime rejects (e.g. a collective library that cannot be
-                    if self._graph.graph is not None:  # captured): this step and all later ones are issued eagerly, loudly
-                        raise                          # (a failure of an already captured graph is a real error)
+                    if self._graph.graph is not None:  # captured) or two captures that replay slower than the eager step: this
+                        raise                          # step and all later ones are issued eagerly, loudly (a failure of an
+                                                       # already captured graph is a real error)
                     import logging
-                    logging.getLogger(__name__).warning("step-graph capture failed (%s: %s): falling back to eager steps", type(e).__name__, e)
+                    logging.getLogger(__name__).warning("step graph dropped (%s: %s): falling back to eager steps", type(e).__name__, e)
                     self.graph_error = f"{type(e).__name__}: {e}"
                     self.use_graph = False
                     torch.cuda.synchronize(self.device)
         self._eager_steps += 1
-        return self._train_instance_eager(imgs, targets, paths, unlabeled_imgs, unlabeled_imgs_ori, unlabeled_gt, unlabeled_M, ni,
-                                          pbar, callbacks)
+        time_it = self.use_graph and self.cuda and self._eager_steps == self.graph_warmup    # the graph's yardstick (graph_step.py)
+        if time_it:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+        out = self._train_instance_eager(imgs, targets, paths, unlabeled_imgs, unlabeled_imgs_ori, unlabeled_gt, unlabeled_M, ni,
+                                         pbar, callbacks)
+        if time_it:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self._eager_events = (e0, e1)
+        return out
+
+    def eager_step_ms(self):
+        """HIP-event span of the last eager step before the capture (None when it was not timed)"""
+        ev = getattr(self, "_eager_events", None)
+        if ev is None:
+            return None
+        ev[1].synchronize()
+        return ev[0].elapsed_time(ev[1])
 
     def _train_instance_eager(self, imgs, targets, paths, unlabeled_imgs, unlabeled_imgs_ori, unlabeled_gt, unlabeled_M, ni,
                               pbar=None, callbacks=None, sup_table=None):
