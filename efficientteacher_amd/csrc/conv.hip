@@ -32,6 +32,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;   // 16-byte reg
 __device__ __forceinline__ u32x4 mk4(unsigned a, unsigned b, unsigned c, unsigned d) { u32x4 v = {a, b, c, d}; return v; }
 
 #define CONV_MAX_TAPS 36
+#define RS_A_ROWS(BM) ((BM) + 16)    // LDS rows of conv_gemm_rs_kernel's activation unit: BM + 2 pixels + one pad slot per image row
 
 struct FastDiv {
     uint32_t magic, shift, d;
@@ -61,7 +62,7 @@ struct GatherGeom {
     int tap_inner;               // K-chunk order: 1 = channel-chunk outer / tap inner (L2-friendly), 0 = tap outer
     int xcd_swz;                 // 1 = remap blockIdx.x so that neighbouring pixel tiles share an XCD (L2)
     int ntm, ntn, nfast;         // tile grid (1-D launch, decoded in-kernel); nfast: channel tiles of a pixel tile adjacent
-    FastDiv dQW, dQH, dCV;
+    FastDiv dQW, dQH, dCV, dW1;  // dW1: by QW + 1 (conv_gemm_rs_kernel's padded raster)
     signed char dy[CONV_MAX_TAPS], dx[CONV_MAX_TAPS];
     unsigned char wt[CONV_MAX_TAPS];
     int tapinfo[CONV_MAX_TAPS];  // (dy & 0xff) | (dx & 0xff) << 8 | wt << 16 : one scalar load per chunk
@@ -741,6 +742,183 @@ __global__ __launch_bounds__(64 * WM * WN, (NS == 3 && BKV == 4 && BM == 128) ? 
     }
     __syncthreads();                               // the epilogue reuses the ring as its staging area
 #undef ET_ADVANCE_CURSOR
+    conv_epilogue<T, BM, BN, WM, WN>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn);
+}
+
+// ---- 3x3 stride-1 gather-GEMM with the activation rows shared by the three taps of a kernel row ("row shift") --------------
+// conv_gemm_glds_kernel stages the activation operand once per TAP: nine times per 64-channel chunk, although the three taps
+// of one kernel row (dx = -1, 0, +1 at the same dy) read the SAME pixels shifted by one raster position.  Here one unit =
+// (channel chunk, kernel row) stages the tile's pixels ONCE, in a PADDED raster: LDS row index = Yg * (W + 1) + x (Yg = image
+// row counted through the batch), i.e. one extra slot after every image row, staged from the zero page.  The three steps of the
+// unit (dx) read their A fragments from LDS rows rr + (0 | 1 | 2), rr = this lane's padded row: x - 1 of a row's first pixel
+// and x + 1 of its last one land on a pad slot, rows beyond M on zero-page rows -- no masks, no branches (a first version ANDed
+// the fragments of row-end pixels with zero in registers: +18 % on the whole kernel, profiles/r03_row_shift_ablation.txt).
+// Only the weight tile is staged per step: (BM + 16) + 3 * BN instead of 3 * (BM + BN) rows per unit of L2->LDS traffic.
+// Ring: two A-unit slots + two B-step slots; B(s+1) is issued at the start of step s, A(u+1) at the first step of unit u, BEHIND
+// that step's B so that the counted vmcnt wait of the next step releases B while A is still in flight.
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, BN <= 64 ? 3 : 2) void conv_gemm_rs_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W,
+                                                                       uint16_t* __restrict__ Y, const uint16_t* __restrict__ ZERO,
+                                                                       GatherGeom g, Epilogue ep) {
+    using T = uint16_t;
+    constexpr int VEC = 8, BKV = 8;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int NW = WM * WN, NT = 64 * NW;
+    constexpr int RPT = NT / BKV;                        // rows per full staging pass (8 per wave)
+    constexpr int CAP = RS_A_ROWS(BM);                   // LDS rows of an A unit: BM + 2 + pad slots (host: rs_eligible)
+    constexpr int RAF = CAP / RPT;                       // full passes ...
+    constexpr int XW = (CAP - RAF * RPT) / 8;            // ... and one more for the first XW waves
+    constexpr int RA = RAF + (XW ? 1 : 0);
+    constexpr int RB = BN / RPT;
+    constexpr int A_VEC = CAP * BKV, B_VEC = BN * BKV;
+    constexpr int RING_VEC = 2 * A_VEC + 2 * B_VEC;
+    constexpr int EPI_VEC = EpiLds<BM, BN, WM, WN>::VEC16;
+    constexpr int LDS_VEC = RING_VEC > EPI_VEC ? RING_VEC : EPI_VEC;
+    static_assert(CAP % 8 == 0 && RA < 16 && XW < NW, "A unit = whole wave instructions; vmcnt immediate");
+    __shared__ __attribute__((aligned(16))) u32x4 lds_raw[LDS_VEC];
+    u32x4* const slotA = lds_raw;                        // [2][A_VEC]
+    u32x4* const slotB = lds_raw + 2 * A_VEC;            // [2][B_VEC]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    int bx, by;
+    tile_of_block(g, bx, by);
+    const int m0 = bx * BM, n0 = by * BN;
+    const int lvec = tid % BKV, lrow = tid / BKV;
+    const int W1 = g.QW + 1;
+    // padded index of the tile's first pixel; LDS row rho <-> padded index P0 - 1 + rho
+    const uint32_t yg0 = fdiv((uint32_t)m0, g.dQW);
+    const int P0 = (int)(yg0 * W1 + ((uint32_t)m0 - yg0 * g.QW));
+
+    int a_off[RA], a_iy[RA], a_lv[RA];
+    bool a_ok[RA];
+#pragma unroll
+    for (int q = 0; q < RA; ++q) {
+        const int rho = lrow + q * RPT;
+        const int P = P0 - 1 + rho;
+        const uint32_t Pp = P < 0 ? 0 : P;
+        const uint32_t yg = fdiv(Pp, g.dW1), xp = Pp - yg * W1;
+        const uint32_t pix = yg * g.QW + xp;
+        a_ok[q] = rho < CAP && P >= 0 && (int)xp < g.QW && pix < (uint32_t)g.M;
+        const uint32_t ygc = a_ok[q] ? yg : 0;
+        a_iy[q] = ygc - fdiv(ygc, g.dQH) * g.QH;        // image row
+        a_off[q] = (a_ok[q] ? pix : 0) * g.ldx;
+        a_lv[q] = lvec ^ lds_swz<BKV>(rho);
+    }
+    int b_off[RB], b_lv[RB];
+    bool b_ok[RB];
+#pragma unroll
+    for (int q = 0; q < RB; ++q) {
+        const int rl = lrow + q * RPT;
+        const int co = n0 + rl;
+        b_ok[q] = co < g.Cout;
+        b_off[q] = (b_ok[q] ? co : 0) * g.TT * g.Cin;
+        b_lv[q] = lvec ^ lds_swz<BKV>(rl);
+    }
+    // padded LDS row (of the dx = -1 step) of this lane's output rows
+    int rr[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        const uint32_t p = m0 + wm * (BM / WM) + tm * 32 + (lane & 31);
+        const uint32_t yg = fdiv(p, g.dQW);
+        rr[tm] = (int)(yg * W1 + (p - yg * g.QW)) - P0;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+    // taps in kernel-row order (rs_eligible): tap = 3*j + k has dy = sgn*(j-1), dx = sgn*(k-1), weight slot tap; sgn = -1 for dgrad.
+    // Arithmetic instead of the tap table: a scalar load in the loop waits lgkmcnt(0) in front of every burst.
+    const int sgn = g.dy[0] < 0 ? 1 : -1;                // uniform (kernel argument)
+    auto stage_a = [&](u32x4* dst, int j, int cv_c) {    // unit (channel chunk cv_c, kernel row j)
+        u32x4* const wbase = dst + wave * 64;
+        const int dy = sgn * (j - 1);
+        const int roff = dy * g.IW * g.ldx + cv_c * VEC;
+#pragma unroll
+        for (int q = 0; q < RA; ++q) {
+            if (q == RAF && wave >= XW) continue;        // wave-uniform: the short last pass
+            const bool ok = a_ok[q] && (unsigned)(a_iy[q] + dy) < (unsigned)g.IH;
+            const T* src = ok ? X + (a_off[q] + roff + a_lv[q] * VEC) : ZERO;
+            et_glds16(src, wbase + q * NT);
+        }
+    };
+    auto stage_b = [&](u32x4* dst, int tap, int cv_c) {
+        u32x4* const wbase = dst + wave * 64;
+        const int woff = tap * g.Cin + cv_c * VEC;
+#pragma unroll
+        for (int q = 0; q < RB; ++q) {
+            const T* src = b_ok[q] ? W + (b_off[q] + woff + b_lv[q] * VEC) : ZERO;
+            et_glds16(src, wbase + q * NT);
+        }
+    };
+    // one step: TM x TN x 4 MFMAs, A fragments from LDS rows rr + shift of the unit
+    auto mma_step = [&](const u32x4* __restrict__ sa, const u32x4* __restrict__ sb, int shift) {
+        const int l31 = lane & 31, gh = lane >> 5;
+        u32x4 af[2][TM], bf[2][TN];
+        auto fetch = [&](int kk, int set) {
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                const int r = rr[tm] + shift;
+                af[set][tm] = sa[r * BKV + ((kk * 2 + gh) ^ lds_swz<BKV>(r))];
+            }
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const int r = wn * (BN / WN) + tn * 32 + l31;
+                bf[set][tn] = sb[r * BKV + ((kk * 2 + gh) ^ lds_swz<BKV>(r))];
+            }
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int kk = 0; kk < BKV / 2; ++kk) {
+            const int cur = kk & 1;
+            if (kk + 1 < BKV / 2) {
+                fetch(kk + 1, cur ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        __builtin_bit_cast(bf16x8, af[cur][tm]), __builtin_bit_cast(bf16x8, bf[cur][tn]), acc[tm][tn], 0, 0, 0);
+        }
+    };
+
+    const int nunits = 3 * (g.CV / BKV);                 // (channel chunk outer, kernel row inner)
+    const int nsteps = 3 * nunits;
+    // prologue: A(0) then B(0): both awaited together
+    stage_a(slotA, 0, 0);
+    stage_b(slotB, 0, 0);
+    // one rolled loop over the steps (k = step inside the unit is a run-time counter: unrolling the three steps of a unit let the
+    // compiler keep three sets of fragment addresses alive -- 256 VGPRs and spills)
+    int u = 0, k = 0, j = 0, cv_u = 0;                   // unit, step in the unit, kernel row and channel cursor of the unit
+#pragma unroll 1
+    for (int s = 0; s < nsteps; ++s) {
+        const bool more_units = u + 1 < nunits;
+        int nj = j + 1, ncv = cv_u;                      // the next unit
+        if (nj == 3) { nj = 0; ncv += BKV; }
+        // B(s) has landed (and A(u) at k == 0); at k == 1 the A unit issued behind B(s) may still be in flight
+        if (k == 1 && more_units) {
+            if (wave < XW) et_wait_vmem_le<RA>(); else et_wait_vmem_le<RAF>();
+        } else {
+            et_wait_vmem();
+        }
+        __builtin_amdgcn_s_barrier();                    // ... for every wave; all reads of the slots rewritten below are done
+        if (k < 2) stage_b(slotB + ((s + 1) & 1) * B_VEC, j * 3 + k + 1, cv_u);
+        else if (more_units) stage_b(slotB + ((s + 1) & 1) * B_VEC, nj * 3, ncv);
+#if !defined(RS_ABL) || !(RS_ABL & 4)
+        if (k == 0 && more_units) stage_a(slotA + ((u + 1) & 1) * A_VEC, nj, ncv);
+#endif
+        const int shift = 1 + sgn * (k - 1);             // uniform
+        mma_step(slotA + (u & 1) * A_VEC, slotB + (s & 1) * B_VEC, shift);
+        if (++k == 3) { k = 0; ++u; j = nj; cv_u = ncv; }
+    }
+    __syncthreads();                                     // the epilogue reuses the ring as its staging area
     conv_epilogue<T, BM, BN, WM, WN>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn);
 }
 
@@ -1634,7 +1812,7 @@ static int fill_common(GatherGeom& g, int N, int IH, int IW, int Cin, int ldx, i
     g.QH = QH; g.QW = QW; g.M = N * QH * QW;
     g.OH = OH; g.OW = OW; g.Cout = Cout; g.ldy = ldy;
     g.CV = Cin / vec; g.KV = g.T * g.CV;
-    g.dQW = make_fastdiv(QW); g.dQH = make_fastdiv(QH); g.dCV = make_fastdiv(g.CV);
+    g.dQW = make_fastdiv(QW); g.dQH = make_fastdiv(QH); g.dCV = make_fastdiv(g.CV); g.dW1 = make_fastdiv(QW + 1);
     // K-chunk order: channel chunk outer / tap inner; XCD-contiguous tile ranges (both were knobs in r01 / r02; two single-knob
     // sweeps of the step showed no other setting within noise of these: profiles/r02_step_knob_sweep*_same_box.log)
     const int tap_inner = 1, xcd_swz = 1;
@@ -1643,10 +1821,64 @@ static int fill_common(GatherGeom& g, int N, int IH, int IW, int Cin, int ldx, i
     return 0;
 }
 
+// ---- launch geometry of the two gather-GEMM uses (ONE copy: the launchers and et_conv2d_kernel_name both call these) -----------
+static int fwd_geom(GatherGeom& g, int N, int IH, int IW, int Cin, int ldx, int Cout, int KH, int KW, int stride, int pad, int ldy,
+                    int vec) {
+    const int OH = (IH + 2 * pad - KH) / stride + 1, OW = (IW + 2 * pad - KW) / stride + 1;
+    g.T = g.TT = KH * KW;
+    for (int ky = 0; ky < KH; ++ky)
+        for (int kx = 0; kx < KW; ++kx) {
+            const int t = ky * KW + kx;
+            g.dy[t] = (signed char)(ky - pad); g.dx[t] = (signed char)(kx - pad); g.wt[t] = (unsigned char)t;
+        }
+    for (int t = 0; t < g.T; ++t) g.tapinfo[t] = (g.dy[t] & 0xff) | ((g.dx[t] & 0xff) << 8) | ((int)g.wt[t] << 16);
+    g.isy = g.isx = stride; g.osy = g.osx = 1; g.ooy = g.oox = 0;
+    return fill_common(g, N, IH, IW, Cin, ldx, OH, OW, OH, OW, Cout, ldy, vec);
+}
+
+// dgrad of output-parity class (py, px): returns 1 when the class has no pixel, 0 on success (g.T may be 0: no tap reaches it)
+static int dgrad_geom(GatherGeom& g, int py, int px, int N, int IH, int IW, int Cin, int ldx, int Cout, int KH, int KW, int stride,
+                      int pad, int ldy, int vec) {
+    const int OH = (IH + 2 * pad - KH) / stride + 1, OW = (IW + 2 * pad - KW) / stride + 1;
+    g.TT = KH * KW;
+    int t = 0;
+    for (int ky = 0; ky < KH; ++ky) {
+        if ((py + pad - ky) % stride) continue;
+        for (int kx = 0; kx < KW; ++kx) {
+            if ((px + pad - kx) % stride) continue;
+            // floor division is exact here (remainder checked above, also for negatives)
+            g.dy[t] = (signed char)((py + pad - ky) / stride);
+            g.dx[t] = (signed char)((px + pad - kx) / stride);
+            g.wt[t] = (unsigned char)(ky * KW + kx);
+            ++t;
+        }
+    }
+    g.T = t;
+    for (int q = 0; q < t; ++q) g.tapinfo[q] = (g.dy[q] & 0xff) | ((g.dx[q] & 0xff) << 8) | ((int)g.wt[q] << 16);
+    g.isy = g.isx = 1; g.osy = g.osx = stride; g.ooy = py; g.oox = px;
+    const int QH = (IH - py + stride - 1) / stride, QW = (IW - px + stride - 1) / stride;
+    if (QH <= 0 || QW <= 0) return 1;              // a 1-pixel-high / -wide input has no pixel in this parity class
+    // the "gathered" tensor of dgrad is dy (OH x OW x Cout), the written one is dx (IH x IW x Cin)
+    return fill_common(g, N, OH, OW, Cout, ldy, QH, QW, IH, IW, Cin, ldx, vec);
+}
+
 // ---- kernel selection ---------------------------------------------------------------------------------
 // ONE place decides which instantiation runs; et_conv2d_kernel_name() reports the same decision to the tests and
 // to bench.py's roofline tags (there is no second copy of this logic on the Python side).
-enum { GEMM_REG = 0, GEMM_GLDS = 1, GEMM_PP = 2 };
+enum { GEMM_REG = 0, GEMM_GLDS = 1, GEMM_PP = 2, GEMM_RS = 3 };
+
+// conv_gemm_rs_kernel's contract: 3x3 taps in kernel-row order (three consecutive taps share dy, dx in [-1, 1]), stride 1,
+// output lattice = the gathered tensor's own pixels, whole 64-channel chunks
+static bool rs_eligible(const GatherGeom& g) {
+    if (g.T != 9 || g.isy != 1 || g.isx != 1 || g.osy != 1 || g.osx != 1 || g.ooy || g.oox) return false;
+    if (g.QH != g.IH || g.QW != g.IW || g.OH != g.QH || g.OW != g.QW || g.CV % 8 || g.QW < 2) return false;
+    if (128 + 2 + (128 + 2 + g.QW - 1) / g.QW + 1 > RS_A_ROWS(128)) return false;      // pad slots of a 128-pixel tile fit the unit
+    if ((long long)(g.N * g.QH + 1) * (g.QW + 1) >= (1ll << 31)) return false;
+    const int sgn = g.dy[0] < 0 ? 1 : -1;
+    for (int t = 0; t < 9; ++t)
+        if (g.dy[t] != sgn * (t / 3 - 1) || g.dx[t] != sgn * (t % 3 - 1) || g.wt[t] != t) return false;
+    return true;
+}
 struct GemmPlan { int kind, BM, BN, WM, WN, BKV, NS; bool utap; };
 
 static GemmPlan plan_gemm(const GatherGeom& g, int elem_bytes, bool have_zero_page) {
@@ -1682,6 +1914,9 @@ static GemmPlan plan_gemm(const GatherGeom& g, int elem_bytes, bool have_zero_pa
         const bool enough = blocks * 100 >= (long long)minfill * n_cu;
         if (enough && (g.TT > 1 || (g.T * g.Cin >= 512 && fills))) ring = use_pp ? 25680 : 25682;
     }
+    // 3x3 stride-1 layers on the 128-row tiles: activation rows shared by the three taps of a kernel row (ET_CONV_RS=0: off)
+    static const int use_rs = env_int("ET_CONV_RS", 1);
+    if (use_rs && ring == 12882 && rs_eligible(g)) return GemmPlan{GEMM_RS, 128, wide ? 128 : 64, 2, 2, 8, 2, true};
     switch (ring) {
         case 25680: p = GemmPlan{GEMM_PP, 256, 256, 2, 4, 8, 2, true}; break;
         case 25682: p = GemmPlan{GEMM_GLDS, 256, 256, 2, 4, 8, 2, true}; break;
@@ -1695,6 +1930,7 @@ static GemmPlan plan_gemm(const GatherGeom& g, int elem_bytes, bool have_zero_pa
 static void plan_name(const GemmPlan& p, int elem_bytes, char* buf, int n) {
     const char* t = elem_bytes == 2 ? "unsigned short" : "float";
     if (p.kind == GEMM_PP) snprintf(buf, n, "conv_gemm_pp_kernel");
+    else if (p.kind == GEMM_RS) snprintf(buf, n, "conv_gemm_rs_kernel<%d, %d, %d, %d>", p.BM, p.BN, p.WM, p.WN);
     else if (p.kind == GEMM_GLDS) snprintf(buf, n, "conv_gemm_glds_kernel<%s, %d, %d, %d, %d, %d, %d, %s>", t, p.BM, p.BN, p.WM, p.WN, p.BKV, p.NS, p.utap ? "true" : "false");
     else snprintf(buf, n, "conv_gemm_kernel<%s, %d, %d, %d, %d, %d, %s>", t, p.BM, p.BN, p.WM, p.WN, p.BKV, p.utap ? "true" : "false");
 }
@@ -1718,6 +1954,15 @@ static int launch_gemm(const void* X, const void* W, void* Y, const void* zero16
     if (p.kind == GEMM_PP) {
         if constexpr (sizeof(T) == 2) {
             hipLaunchKernelGGL(conv_gemm_pp_kernel, grid, block, 0, s, (const uint16_t*)x, (const uint16_t*)w, (uint16_t*)y, (const uint16_t*)z, g, ep);
+            return 0;
+        }
+        return -2;
+    }
+    if (p.kind == GEMM_RS) {
+        if constexpr (sizeof(T) == 2) {
+            const uint16_t *xs = (const uint16_t*)x, *ws = (const uint16_t*)w, *zs = (const uint16_t*)z;
+            if (p.BN == 128) hipLaunchKernelGGL((conv_gemm_rs_kernel<128, 128, 2, 2>), grid, block, 0, s, xs, ws, (uint16_t*)y, zs, g, ep);
+            else hipLaunchKernelGGL((conv_gemm_rs_kernel<128, 64, 2, 2>), grid, block, 0, s, xs, ws, (uint16_t*)y, zs, g, ep);
             return 0;
         }
         return -2;
@@ -1768,17 +2013,8 @@ extern "C" int et_conv2d_fwd(const void* x, const void* w, void* y, int dtype, i
         return 0;
     }
     GatherGeom g;
-    const int OH = (IH + 2 * pad - KH) / stride + 1, OW = (IW + 2 * pad - KW) / stride + 1;
-    g.T = g.TT = KH * KW;
-    for (int ky = 0; ky < KH; ++ky)
-        for (int kx = 0; kx < KW; ++kx) {
-            const int t = ky * KW + kx;
-            g.dy[t] = (signed char)(ky - pad); g.dx[t] = (signed char)(kx - pad); g.wt[t] = (unsigned char)t;
-        }
-    for (int t = 0; t < g.T; ++t) g.tapinfo[t] = (g.dy[t] & 0xff) | ((g.dx[t] & 0xff) << 8) | ((int)g.wt[t] << 16);
-    g.isy = g.isx = stride; g.osy = g.osx = 1; g.ooy = g.oox = 0;
     const int vec = dtype == ET_F32 ? 4 : 8;
-    int rc = fill_common(g, N, IH, IW, Cin, ldx, OH, OW, OH, OW, Cout, ldy, vec);
+    int rc = fwd_geom(g, N, IH, IW, Cin, ldx, Cout, KH, KW, stride, pad, ldy, vec);
     if (rc) return rc;
     Epilogue ep{scale, bias, act, residual, ldr, stats_partial, 0};
     if (dtype == ET_F32) rc = launch_gemm<float>(x, w, y, zero16, g, ep, (hipStream_t)stream);
@@ -1813,32 +2049,14 @@ static int conv2d_dgrad_impl(const void* dy, const void* wT, void* dx, int dtype
     if (KH * KW > CONV_MAX_TAPS || stride < 1 || stride > 2 || N <= 0) return -2;
     if (residual && stride != 1) return -2;        // the fused shortcut-gradient add is a stride-1 (Bottleneck) feature
     if (bn_y && (stride != 1 || !bn_scale || !bn_shift || !bn_stats || Cin % 8)) return -2;   // one launch, whole channel groups
-    const int OH = (IH + 2 * pad - KH) / stride + 1, OW = (IW + 2 * pad - KW) / stride + 1;
     const int vec = dtype == ET_F32 ? 4 : 8;
     for (int py = 0; py < stride; ++py)
         for (int px = 0; px < stride; ++px) {
             GatherGeom g;
-            g.TT = KH * KW;
-            int t = 0;
-            for (int ky = 0; ky < KH; ++ky) {
-                if ((py + pad - ky) % stride) continue;
-                for (int kx = 0; kx < KW; ++kx) {
-                    if ((px + pad - kx) % stride) continue;
-                    // floor division is exact here (remainder checked above, also for negatives)
-                    g.dy[t] = (signed char)((py + pad - ky) / stride);
-                    g.dx[t] = (signed char)((px + pad - kx) / stride);
-                    g.wt[t] = (unsigned char)(ky * KW + kx);
-                    ++t;
-                }
-            }
-            g.T = t;
-            for (int q = 0; q < t; ++q) g.tapinfo[q] = (g.dy[q] & 0xff) | ((g.dx[q] & 0xff) << 8) | ((int)g.wt[q] << 16);
-            g.isy = g.isx = 1; g.osy = g.osx = stride; g.ooy = py; g.oox = px;
-            const int QH = (IH - py + stride - 1) / stride, QW = (IW - px + stride - 1) / stride;
-            if (QH <= 0 || QW <= 0) continue;      // a 1-pixel-high / -wide input has no pixel in this parity class
-            // the "gathered" tensor of dgrad is dy (OH x OW x Cout), the written one is dx (IH x IW x Cin)
-            int rc = fill_common(g, N, OH, OW, Cout, ldy, QH, QW, IH, IW, Cin, ldx, vec);
+            int rc = dgrad_geom(g, py, px, N, IH, IW, Cin, ldx, Cout, KH, KW, stride, pad, ldy, vec);
+            if (rc == 1) continue;
             if (rc) return rc;
+            const int t = g.T, QH = g.QH, QW = g.QW;
             Epilogue ep{nullptr, nullptr, ACT_NONE, residual, ldr, bn_y ? bn_stats : nullptr, accumulate,
                         bn_y, ld_bn, bn_scale, bn_shift, bn_act};   // dx = dgrad (+ residual) (+ BN-backward sums)
             if (t == 0) {            // no tap reaches this class (k < stride): zero gradient unless the caller accumulates
@@ -2059,7 +2277,6 @@ extern "C" int et_conv2d_kernel_name(int op, int dtype, int N, int IH, int IW, i
     if (!buf || buflen < 8) return -1;
     if (KH * KW > CONV_MAX_TAPS || stride < 1 || N <= 0) return -2;
     const int eb = dtype == ET_F32 ? 4 : 2, vec = dtype == ET_F32 ? 4 : 8;
-    const int OH = (IH + 2 * pad - KH) / stride + 1, OW = (IW + 2 * pad - KW) / stride + 1;
     if (op == 2) {
         WgradGeom g;
         g.Cout = Cout; g.T = KH * KW; g.NC = g.T * Cin; g.isy = g.isx = stride;
@@ -2073,21 +2290,12 @@ extern "C" int et_conv2d_kernel_name(int op, int dtype, int N, int IH, int IW, i
             snprintf(buf, buflen, "conv_stem_kernel");       // rocprofv3: "void conv_stem_kernel<ACT>(StemArgs)"
             return 0;
         }
-        g.T = g.TT = KH * KW;
-        if (Cin % vec) return -2;
-        g.Cin = Cin; g.Cout = Cout; g.CV = Cin / vec; g.KV = g.T * g.CV; g.M = N * OH * OW;
+        if (fwd_geom(g, N, IH, IW, Cin, Cin, Cout, KH, KW, stride, pad, Cout, vec)) return -2;
     } else if (op == 1) {
         if (stride > 2 || Cout % vec) return -2;
         const int py = parity_class / stride, px = parity_class % stride;
         if (py >= stride) return -2;
-        int t = 0;
-        for (int ky = 0; ky < KH; ++ky) {
-            if ((py + pad - ky) % stride) continue;
-            for (int kx = 0; kx < KW; ++kx) if (!((px + pad - kx) % stride)) ++t;
-        }
-        g.T = t; g.TT = KH * KW;
-        const int QH = (IH - py + stride - 1) / stride, QW = (IW - px + stride - 1) / stride;
-        g.Cin = Cout; g.Cout = Cin; g.CV = Cout / vec; g.KV = g.T * g.CV; g.M = N * QH * QW;
+        if (dgrad_geom(g, py, px, N, IH, IW, Cin, Cin, Cout, KH, KW, stride, pad, Cout, vec)) return -2;
     } else return -2;
     plan_name(plan_gemm(g, eb, have_zero_page != 0), eb, buf, buflen);
     return 0;
@@ -2095,7 +2303,7 @@ extern "C" int et_conv2d_kernel_name(int op, int dtype, int N, int IH, int IW, i
 
 extern "C" int et_env_knobs(char* buf, int buflen) {
     // every ET_* tuning knob that is SET in this process's environment, as "NAME=value;..." (bench.py records it)
-    static const char* names[] = {"ET_CONV_GLDS", "ET_CONV_BIG", "ET_CONV_BIG_MINFILL", "ET_CONV_PP", "ET_CONV_STEM", "ET_CONV_STEM_WGS",
+    static const char* names[] = {"ET_CONV_GLDS", "ET_CONV_BIG", "ET_CONV_BIG_MINFILL", "ET_CONV_PP", "ET_CONV_RS", "ET_CONV_STEM", "ET_CONV_STEM_WGS",
                                   "ET_WGRAD_TR", "ET_WGRAD_BIG", "ET_WGRAD_GROUP", "ET_WGRAD_STALE", "ET_WGRAD_STREAM", "ET_FUSE_BN_BWD",
                                   "ET_STEP_GRAPH", "ET_ALLREDUCE_CHUNK_MB", "ET_RCCL_CHANNELS", "ET_DP_SINGLE_RANK", "ET_HIP_LIB"};
     if (!buf || buflen < 1) return -1;
