@@ -815,13 +815,16 @@ __global__ __launch_bounds__(64 * WM * WN, BN <= 64 ? 3 : 2) void conv_gemm_rs_k
         b_off[q] = (b_ok[q] ? co : 0) * g.TT * g.Cin;
         b_lv[q] = lvec ^ lds_swz<BKV>(rl);
     }
-    // padded LDS row (of the dx = -1 step) of this lane's output rows
-    int rr[TM];
+    // byte offset (inside an A unit) of this lane's k-step-0 fragment of row tile tm at step shift s; a k-step XORs bits 5-6 of it
+    // (the swizzle is an XOR on the K-vector slot): one v_xor per fragment read instead of a swizzle computation
+    int abase[TM][3];
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
         const uint32_t p = m0 + wm * (BM / WM) + tm * 32 + (lane & 31);
         const uint32_t yg = fdiv(p, g.dQW);
-        rr[tm] = (int)(yg * W1 + (p - yg * g.QW)) - P0;
+        const int r0 = (int)(yg * W1 + (p - yg * g.QW)) - P0;
+#pragma unroll
+        for (int sft = 0; sft < 3; ++sft) abase[tm][sft] = ((r0 + sft) * BKV + ((lane >> 5) ^ lds_swz<BKV>(r0 + sft))) * 16;
     }
 
     f32x16 acc[TM][TN];
@@ -856,16 +859,14 @@ __global__ __launch_bounds__(64 * WM * WN, BN <= 64 ? 3 : 2) void conv_gemm_rs_k
             et_glds16(src, wbase + q * NT);
         }
     };
-    // one step: TM x TN x 4 MFMAs, A fragments from LDS rows rr + shift of the unit
-    auto mma_step = [&](const u32x4* __restrict__ sa, const u32x4* __restrict__ sb, int shift) {
+    // one step: TM x TN x 4 MFMAs, A fragments from the unit at row offset SFT
+    auto mma_step = [&](const u32x4* __restrict__ sa, const u32x4* __restrict__ sb, auto shift_tag) {
+        constexpr int SFT = decltype(shift_tag)::value;
         const int l31 = lane & 31, gh = lane >> 5;
         u32x4 af[2][TM], bf[2][TN];
         auto fetch = [&](int kk, int set) {
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm) {
-                const int r = rr[tm] + shift;
-                af[set][tm] = sa[r * BKV + ((kk * 2 + gh) ^ lds_swz<BKV>(r))];
-            }
+            for (int tm = 0; tm < TM; ++tm) af[set][tm] = *(const u32x4*)((const char*)sa + (abase[tm][SFT] ^ (kk * 32)));
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) {
                 const int r = wn * (BN / WN) + tn * 32 + l31;
@@ -890,33 +891,38 @@ __global__ __launch_bounds__(64 * WM * WN, BN <= 64 ? 3 : 2) void conv_gemm_rs_k
     };
 
     const int nunits = 3 * (g.CV / BKV);                 // (channel chunk outer, kernel row inner)
-    const int nsteps = 3 * nunits;
-    // prologue: A(0) then B(0): both awaited together
+    // prologue: A(0) then B(0): both awaited together.  Step k of a unit reads the unit at row offset k (dx = k - 1); its weights
+    // are tap 3j + k (forward) or 3j + 2 - k (dgrad: sgn < 0)
     stage_a(slotA, 0, 0);
-    stage_b(slotB, 0, 0);
-    // one rolled loop over the steps (k = step inside the unit is a run-time counter: unrolling the three steps of a unit let the
-    // compiler keep three sets of fragment addresses alive -- 256 VGPRs and spills)
-    int u = 0, k = 0, j = 0, cv_u = 0;                   // unit, step in the unit, kernel row and channel cursor of the unit
+    stage_b(slotB, sgn > 0 ? 0 : 2, 0);
+    int j = 0, cv_u = 0, bs = 0;                         // kernel row and channel cursor of the unit; B slot of the current step
 #pragma unroll 1
-    for (int s = 0; s < nsteps; ++s) {
+    for (int u = 0; u < nunits; ++u) {
         const bool more_units = u + 1 < nunits;
         int nj = j + 1, ncv = cv_u;                      // the next unit
         if (nj == 3) { nj = 0; ncv += BKV; }
-        // B(s) has landed (and A(u) at k == 0); at k == 1 the A unit issued behind B(s) may still be in flight
-        if (k == 1 && more_units) {
-            if (wave < XW) et_wait_vmem_le<RA>(); else et_wait_vmem_le<RAF>();
-        } else {
-            et_wait_vmem();
-        }
-        __builtin_amdgcn_s_barrier();                    // ... for every wave; all reads of the slots rewritten below are done
-        if (k < 2) stage_b(slotB + ((s + 1) & 1) * B_VEC, j * 3 + k + 1, cv_u);
-        else if (more_units) stage_b(slotB + ((s + 1) & 1) * B_VEC, nj * 3, ncv);
+        const u32x4* const sa = slotA + (u & 1) * A_VEC;
+        auto step = [&](auto ktag) {
+            constexpr int k = decltype(ktag)::value;
+            // B(s) has landed (and A(u) at k == 0); at k == 1 the A unit issued behind B(s) may still be in flight
+            if (k == 1 && more_units) {
+                if (wave < XW) et_wait_vmem_le<RA>(); else et_wait_vmem_le<RAF>();
+            } else {
+                et_wait_vmem();
+            }
+            __builtin_amdgcn_s_barrier();                // ... for every wave; all reads of the slots rewritten below are done
+            constexpr int kn = k < 2 ? k + 1 : 0;
+            if (k < 2 || more_units) stage_b(slotB + (bs ^ 1) * B_VEC, (k < 2 ? j : nj) * 3 + (sgn > 0 ? kn : 2 - kn), k < 2 ? cv_u : ncv);
 #if !defined(RS_ABL) || !(RS_ABL & 4)
-        if (k == 0 && more_units) stage_a(slotA + ((u + 1) & 1) * A_VEC, nj, ncv);
+            if (k == 0 && more_units) stage_a(slotA + ((u + 1) & 1) * A_VEC, nj, ncv);
 #endif
-        const int shift = 1 + sgn * (k - 1);             // uniform
-        mma_step(slotA + (u & 1) * A_VEC, slotB + (s & 1) * B_VEC, shift);
-        if (++k == 3) { k = 0; ++u; j = nj; cv_u = ncv; }
+            mma_step(sa, slotB + bs * B_VEC, ktag);
+            bs ^= 1;
+        };
+        step(std::integral_constant<int, 0>{});
+        step(std::integral_constant<int, 1>{});
+        step(std::integral_constant<int, 2>{});
+        j = nj; cv_u = ncv;
     }
     __syncthreads();                                     // the epilogue reuses the ring as its staging area
     conv_epilogue<T, BM, BN, WM, WN>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn);
@@ -1030,6 +1036,9 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_pp_kernel(const uint16_t* __
     auto stage_piece = [&](int k, int buf, int jj) {
         u32x4* const wbase = lds_raw + (2 * k + buf) * HALF_VEC + wave * 64;
         if (k < 2) {
+#if defined(RS_ABL) && (RS_ABL & 8)
+            if (udx != 0) return;                      // timing probe: the activation half-tiles of one tap per kernel row only
+#endif
             const int i = k;
             const int doff = (udy * g.IW + udx) * g.ldx + (cv_u + lv) * VEC;
             const bool ok = (bool)((a_okm >> (i * 2 + jj)) & 1u) & ((unsigned)(a_iy[i][jj] + udy) < (unsigned)g.IH) &
@@ -1141,6 +1150,205 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_pp_kernel(const uint16_t* __
     conv_epilogue<uint16_t, BM, BN, WM, WN>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn);
 #undef ET_PP_DECODE
 #undef ET_PP_ADVANCE
+#undef ET_PP_BAR
+#undef ET_PP_WAIT
+}
+
+// ---- the ping-pong tile with the activation rows shared by the three taps of a kernel row --------------------------------
+// conv_gemm_pp_kernel's schedule (two wave groups half a phase apart, four phases per K-chunk, weight half-tiles B0 / B1 double
+// buffered and issued in ph1 / ph2 for the next chunk) with conv_gemm_rs_kernel's activation operand: one unit = (channel chunk,
+// kernel row) = three chunks (dx) stages the tile's 256 pixels ONCE, as a padded raster of PPRS_ROWS LDS rows (one zero slot after
+// every image row), in five 64-row pieces -- one per phase 0 and phase 3 of the unit's chunks, two units deep; the fragment reads of
+// a chunk take rows rr + (0 | 1 | 2).  17 LDS-DMA pieces per thread and unit instead of 24, -30 % of the L2->LDS bytes; measured
+// bound with the activation pieces of two taps simply dropped (timing only): -11 % on 256->256 @40^2, -8 % on 512->512 @20^2.
+// In-order vmcnt accounting per wave (steady state; B1' = the two youngest pieces at every phase-3 wait):
+//   ph0: [A piece]   ph1: [B0' B0']   ph2: [B1' B1']   ph3: [A piece | none in the unit's last chunk]
+//   end of ph3's load section: vmcnt(2)  -> B0' (next chunk's ph0) and everything older, i.e. all activation pieces, have landed
+//   end of ph0's load section: vmcnt(1) if the previous phase 3 issued a piece, else vmcnt(0) -> B1 of this chunk has landed
+// RAW / WAR as in conv_gemm_pp_kernel (its header): the weight schedule is unchanged, the activation unit is written two
+// units before... no: ONE unit before it is read (buffer (u+1)&1 during unit u; its last reader was unit u-1).
+#define PPRS_ROWS 320
+__global__ __launch_bounds__(512, 2) void conv_gemm_pprs_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W,
+                                                                uint16_t* __restrict__ Y, const uint16_t* __restrict__ ZERO,
+                                                                GatherGeom g, Epilogue ep) {
+    constexpr int BM = 256, BN = 256, WM = 2, WN = 4, BKV = 8, VEC = 8;
+    constexpr int HALF_VEC = 128 * BKV;            // one weight half-tile in 16-byte vectors (16 KB)
+    constexpr int A_VEC = PPRS_ROWS * BKV;         // one activation unit (40 KB)
+    constexpr int NPIECE = PPRS_ROWS / 64;         // 5
+    constexpr int RING_VEC = 2 * A_VEC + 4 * HALF_VEC;
+    constexpr int EPI_VEC = EpiLds<BM, BN, WM, WN>::VEC16;
+    constexpr int LDS_VEC = RING_VEC > EPI_VEC ? RING_VEC : EPI_VEC;
+    static_assert(NPIECE == 5, "one activation piece per phase 0 / phase 3 of a unit's three chunks");
+    __shared__ __attribute__((aligned(16))) u32x4 lds_raw[LDS_VEC];
+    u32x4* const slotA = lds_raw;                  // [2][A_VEC]
+    u32x4* const slotB = lds_raw + 2 * A_VEC;      // weight half-tile j, buffer b at slotB + (2*j + b) * HALF_VEC
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;       // wm = the wave group (waves w and w+4 share a SIMD)
+    int bx, by;
+    tile_of_block(g, bx, by);
+    const int m0 = bx * BM, n0 = by * BN;
+    const int lvec = tid & 7, lrow = tid >> 3;     // staging: 64 rows x 8 K-vectors per instruction of the workgroup
+    const int lv = lvec ^ lds_swz<BKV>(lrow);      // logical K-vector this lane stages (64-row pieces: the swizzle only sees lrow)
+    const int W1 = g.QW + 1;
+    const uint32_t yg0 = fdiv((uint32_t)m0, g.dQW);
+    const int P0 = (int)(yg0 * W1 + ((uint32_t)m0 - yg0 * g.QW));   // padded index of the tile's first pixel
+
+    int a_off[NPIECE];
+    unsigned a_okm = 0u, b_okm = 0u;               // a_okm: bit 3q+1 = piece q's pixel exists, bits 3q / 3q+2 = and so does its row above / below
+#pragma unroll
+    for (int q = 0; q < NPIECE; ++q) {
+        const int P = P0 - 1 + q * 64 + lrow;      // LDS row q*64 + lrow <-> padded index P
+        const uint32_t Pp = P < 0 ? 0 : P;
+        const uint32_t yg = fdiv(Pp, g.dW1), xp = Pp - yg * W1;
+        const uint32_t pix = yg * g.QW + xp;
+        const bool ok = P >= 0 && (int)xp < g.QW && pix < (uint32_t)g.M;
+        const uint32_t ygc = ok ? yg : 0;
+        const int iy = ygc - fdiv(ygc, g.dQH) * g.QH;
+        a_off[q] = (ok ? pix : 0) * g.ldx;
+        a_okm |= ok ? ((iy > 0 ? 1u : 0u) | 2u | (iy + 1 < g.IH ? 4u : 0u)) << (3 * q) : 0u;
+    }
+    // weight rows: half-tile j, piece jj, LDS row jj*64 + lrow <-> output channel co0 + jj*128 + j*32 (one base + uniform steps)
+    const int co0 = n0 + (lrow >> 5) * 64 + (lrow & 31);
+    const int wrow = g.TT * g.Cin;                 // elements per weight row (uniform)
+    const int b_off0 = co0 * wrow;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) b_okm |= (co0 + jj * 128 + j * 32 < g.Cout) ? (1u << (j * 2 + jj)) : 0u;
+    const int l31 = lane & 31, gk = lane >> 5;
+    // byte offset (inside an activation unit) of this lane's k-step-0 fragment: half i, row tile t, step shift s.  The k-step only
+    // XORs bits 5-6 of it (the swizzle is an XOR on the K-vector slot), so a fragment address costs one v_xor, not a swizzle
+    int abase[2][2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const uint32_t p = m0 + wm * 128 + i * 64 + t * 32 + l31;
+            const uint32_t yg = fdiv(p, g.dQW);
+            const int r0 = (int)(yg * W1 + (p - yg * g.QW)) - P0;
+#pragma unroll
+            for (int sft = 0; sft < 3; ++sft) abase[i][t][sft] = ((r0 + sft) * BKV + (gk ^ lds_swz<BKV>(r0 + sft))) * 16;
+        }
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+    const int sgn = g.dy[0] < 0 ? 1 : -1;          // taps in kernel-row order: tap 3j+k has dy = sgn*(j-1), dx = sgn*(k-1) (rs_eligible)
+    // activation piece q of unit (kernel row j, channel cursor cv) into unit buffer ub
+    auto stage_a_piece = [&](int q, int ub, int j, int cv) {
+        u32x4* const wbase = slotA + ub * A_VEC + q * 512 + wave * 64;
+        const int dy = sgn * (j - 1);
+        const bool ok = (a_okm >> (3 * q + 1 + dy)) & 1u;
+        et_glds16(ok ? X + (a_off[q] + dy * g.IW * g.ldx + (cv + lv) * VEC) : ZERO, wbase);
+    };
+    // piece jj (rows 0-63 / 64-127) of weight half-tile j of chunk (tap, cv) into buffer b
+    auto stage_b_piece = [&](int j, int b, int jj, int tap, int cv) {
+        u32x4* const wbase = slotB + (2 * j + b) * HALF_VEC + wave * 64;
+        const bool ok = (b_okm >> (j * 2 + jj)) & 1u;
+        et_glds16(ok ? W + (b_off0 + (jj * 128 + j * 32) * wrow + tap * g.Cin + (cv + lv) * VEC) : ZERO, wbase + jj * 512);
+    };
+
+    u32x4 af[2][4], bf[4];                         // A fragments of one half (2 row tiles x 4 k-steps), B of one half
+    auto load_a = [&](int i, int ub, auto shift_tag) {
+        constexpr int SFT = decltype(shift_tag)::value;
+        const char* sm = (const char*)(slotA + ub * A_VEC);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) af[t][kk] = *(const u32x4*)(sm + (abase[i][t][SFT] ^ (kk * 32)));
+    };
+    auto load_b = [&](int j, int b) {
+        const u32x4* sm = slotB + (2 * j + b) * HALF_VEC;
+        const int r = wn * 32 + l31;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) bf[kk] = sm[r * BKV + ((kk * 2 + gk) ^ lds_swz<BKV>(r))];
+    };
+    // 8 MFMAs of one phase with up to two LDS-DMA pieces issued between them (after the 2nd and the 5th: conv_gemm_pp_kernel)
+    auto mfma8 = [&](int i, int j, auto&& piece0, auto&& piece1) {
+        __builtin_amdgcn_s_setprio(1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                acc[2 * i + t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[t][kk]),
+                                                                           __builtin_bit_cast(bf16x8, bf[kk]), acc[2 * i + t][j], 0, 0, 0);
+                const int n = kk * 2 + t;
+                if (n == 1) { __builtin_amdgcn_sched_barrier(0); piece0(); __builtin_amdgcn_sched_barrier(0); }
+                if (n == 4) { __builtin_amdgcn_sched_barrier(0); piece1(); __builtin_amdgcn_sched_barrier(0); }
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto nothing = [] {};
+
+    const int nunits = 3 * (g.CV / BKV);           // (channel chunk outer, kernel row inner); host: Cin % 64 == 0
+    // prologue: unit 0 and the weight half-tiles of chunk 0
+#pragma unroll
+    for (int q = 0; q < NPIECE; ++q) stage_a_piece(q, 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { stage_b_piece(j, 0, 0, sgn > 0 ? 0 : 2, 0); stage_b_piece(j, 0, 1, sgn > 0 ? 0 : 2, 0); }
+    et_wait_vmem();
+    __builtin_amdgcn_s_barrier();
+#define ET_PP_BAR() __builtin_amdgcn_s_barrier()
+#define ET_PP_WAIT(n) et_wait_vmem_le_pp<n>()
+    if (wm == 1) __builtin_amdgcn_s_barrier();     // group 1 runs one barrier (half a phase) behind group 0
+
+    int jrow = 0, cv_u = 0, bbuf = 0;              // kernel row / channel cursor of the current unit; weight buffer of the current chunk
+#pragma unroll 1
+    for (int u = 0; u < nunits; ++u) {
+        const bool more = u + 1 < nunits;          // uniform: a next unit exists (its activation pieces are staged during this one)
+        int nj = jrow + 1, ncv = cv_u;
+        if (nj == 3) { nj = 0; ncv += BKV; }
+        const int ub = u & 1, nub = ub ^ 1;
+        // (compile-time k: a lambda per chunk)
+        auto chunk = [&](auto ktag) {
+            constexpr int k = decltype(ktag)::value;
+            // chunk k reads the unit at row offset k (dx = k - 1); its weights are tap 3j + k (forward) or 3j + 2 - k (dgrad: sgn < 0)
+            const bool stage_b = k < 2 || more;    // a next chunk exists
+            const int kn = k < 2 ? k + 1 : 0;
+            const int ntap = (k < 2 ? jrow : nj) * 3 + (sgn > 0 ? kn : 2 - kn), nbcv = k < 2 ? cv_u : ncv;
+            const int nb = bbuf ^ 1;
+            const std::integral_constant<int, k> shift{};
+            // ---- ph0: (A0, B0); issues activation piece 2k of the next unit
+            load_a(0, ub, shift); load_b(0, bbuf);
+            if (k > 0 && more) ET_PP_WAIT(1); else ET_PP_WAIT(0);          // B1 of this chunk has landed
+            ET_PP_BAR();
+            mfma8(0, 0, [&] { if (more) stage_a_piece(2 * k, nub, nj, ncv); }, nothing);
+            ET_PP_BAR();
+            // ---- ph1: (A0, B1); issues B0 of the next chunk
+            load_b(1, bbuf);
+            ET_PP_BAR();
+            mfma8(0, 1, [&] { if (stage_b) stage_b_piece(0, nb, 0, ntap, nbcv); }, [&] { if (stage_b) stage_b_piece(0, nb, 1, ntap, nbcv); });
+            ET_PP_BAR();
+            // ---- ph2: (A1, B1); issues B1 of the next chunk
+            load_a(1, ub, shift);
+            ET_PP_BAR();
+            mfma8(1, 1, [&] { if (stage_b) stage_b_piece(1, nb, 0, ntap, nbcv); }, [&] { if (stage_b) stage_b_piece(1, nb, 1, ntap, nbcv); });
+            ET_PP_BAR();
+            // ---- ph3: (A1, B0); issues activation piece 2k+1 of the next unit (k < 2)
+            load_b(0, bbuf);
+            if (stage_b) ET_PP_WAIT(2); else ET_PP_WAIT(0);                // B0 of the next chunk and every activation piece have landed
+            ET_PP_BAR();
+            mfma8(1, 0, [&] { if (k < 2 && more) stage_a_piece(2 * k + 1, nub, nj, ncv); }, nothing);
+            ET_PP_BAR();
+            bbuf = nb;
+        };
+        chunk(std::integral_constant<int, 0>{});
+        chunk(std::integral_constant<int, 1>{});
+        chunk(std::integral_constant<int, 2>{});
+        jrow = nj; cv_u = ncv;
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();     // balances group 1's extra barrier
+    __syncthreads();                               // the epilogue reuses the ring as its staging area
+    conv_epilogue<uint16_t, BM, BN, WM, WN>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn);
 #undef ET_PP_BAR
 #undef ET_PP_WAIT
 }
@@ -1865,14 +2073,14 @@ static int dgrad_geom(GatherGeom& g, int py, int px, int N, int IH, int IW, int 
 // ---- kernel selection ---------------------------------------------------------------------------------
 // ONE place decides which instantiation runs; et_conv2d_kernel_name() reports the same decision to the tests and
 // to bench.py's roofline tags (there is no second copy of this logic on the Python side).
-enum { GEMM_REG = 0, GEMM_GLDS = 1, GEMM_PP = 2, GEMM_RS = 3 };
+enum { GEMM_REG = 0, GEMM_GLDS = 1, GEMM_PP = 2, GEMM_RS = 3, GEMM_PPRS = 4 };
 
 // conv_gemm_rs_kernel's contract: 3x3 taps in kernel-row order (three consecutive taps share dy, dx in [-1, 1]), stride 1,
 // output lattice = the gathered tensor's own pixels, whole 64-channel chunks
-static bool rs_eligible(const GatherGeom& g) {
+static bool rs_eligible(const GatherGeom& g, int BM, int unit_rows) {
     if (g.T != 9 || g.isy != 1 || g.isx != 1 || g.osy != 1 || g.osx != 1 || g.ooy || g.oox) return false;
     if (g.QH != g.IH || g.QW != g.IW || g.OH != g.QH || g.OW != g.QW || g.CV % 8 || g.QW < 2) return false;
-    if (128 + 2 + (128 + 2 + g.QW - 1) / g.QW + 1 > RS_A_ROWS(128)) return false;      // pad slots of a 128-pixel tile fit the unit
+    if (BM + 2 + (BM + 2 + g.QW - 1) / g.QW + 1 > unit_rows) return false;             // the pad slots of a BM-pixel tile fit the unit
     if ((long long)(g.N * g.QH + 1) * (g.QW + 1) >= (1ll << 31)) return false;
     const int sgn = g.dy[0] < 0 ? 1 : -1;
     for (int t = 0; t < 9; ++t)
@@ -1916,7 +2124,9 @@ static GemmPlan plan_gemm(const GatherGeom& g, int elem_bytes, bool have_zero_pa
     }
     // 3x3 stride-1 layers on the 128-row tiles: activation rows shared by the three taps of a kernel row (ET_CONV_RS=0: off)
     static const int use_rs = env_int("ET_CONV_RS", 1);
-    if (use_rs && ring == 12882 && rs_eligible(g)) return GemmPlan{GEMM_RS, 128, wide ? 128 : 64, 2, 2, 8, 2, true};
+    if (use_rs && ring == 12882 && rs_eligible(g, 128, RS_A_ROWS(128))) return GemmPlan{GEMM_RS, 128, wide ? 128 : 64, 2, 2, 8, 2, true};
+    static const int use_pprs = env_int("ET_CONV_PPRS", 1);
+    if (use_pprs && ring == 25680 && rs_eligible(g, 256, PPRS_ROWS)) return GemmPlan{GEMM_PPRS, 256, 256, 2, 4, 8, 2, true};
     switch (ring) {
         case 25680: p = GemmPlan{GEMM_PP, 256, 256, 2, 4, 8, 2, true}; break;
         case 25682: p = GemmPlan{GEMM_GLDS, 256, 256, 2, 4, 8, 2, true}; break;
@@ -1930,6 +2140,7 @@ static GemmPlan plan_gemm(const GatherGeom& g, int elem_bytes, bool have_zero_pa
 static void plan_name(const GemmPlan& p, int elem_bytes, char* buf, int n) {
     const char* t = elem_bytes == 2 ? "unsigned short" : "float";
     if (p.kind == GEMM_PP) snprintf(buf, n, "conv_gemm_pp_kernel");
+    else if (p.kind == GEMM_PPRS) snprintf(buf, n, "conv_gemm_pprs_kernel");
     else if (p.kind == GEMM_RS) snprintf(buf, n, "conv_gemm_rs_kernel<%d, %d, %d, %d>", p.BM, p.BN, p.WM, p.WN);
     else if (p.kind == GEMM_GLDS) snprintf(buf, n, "conv_gemm_glds_kernel<%s, %d, %d, %d, %d, %d, %d, %s>", t, p.BM, p.BN, p.WM, p.WN, p.BKV, p.NS, p.utap ? "true" : "false");
     else snprintf(buf, n, "conv_gemm_kernel<%s, %d, %d, %d, %d, %d, %s>", t, p.BM, p.BN, p.WM, p.WN, p.BKV, p.utap ? "true" : "false");
@@ -1954,6 +2165,13 @@ static int launch_gemm(const void* X, const void* W, void* Y, const void* zero16
     if (p.kind == GEMM_PP) {
         if constexpr (sizeof(T) == 2) {
             hipLaunchKernelGGL(conv_gemm_pp_kernel, grid, block, 0, s, (const uint16_t*)x, (const uint16_t*)w, (uint16_t*)y, (const uint16_t*)z, g, ep);
+            return 0;
+        }
+        return -2;
+    }
+    if (p.kind == GEMM_PPRS) {
+        if constexpr (sizeof(T) == 2) {
+            hipLaunchKernelGGL(conv_gemm_pprs_kernel, grid, block, 0, s, (const uint16_t*)x, (const uint16_t*)w, (uint16_t*)y, (const uint16_t*)z, g, ep);
             return 0;
         }
         return -2;
@@ -2303,7 +2521,7 @@ extern "C" int et_conv2d_kernel_name(int op, int dtype, int N, int IH, int IW, i
 
 extern "C" int et_env_knobs(char* buf, int buflen) {
     // every ET_* tuning knob that is SET in this process's environment, as "NAME=value;..." (bench.py records it)
-    static const char* names[] = {"ET_CONV_GLDS", "ET_CONV_BIG", "ET_CONV_BIG_MINFILL", "ET_CONV_PP", "ET_CONV_RS", "ET_CONV_STEM", "ET_CONV_STEM_WGS",
+    static const char* names[] = {"ET_CONV_GLDS", "ET_CONV_BIG", "ET_CONV_BIG_MINFILL", "ET_CONV_PP", "ET_CONV_RS", "ET_CONV_PPRS", "ET_CONV_STEM", "ET_CONV_STEM_WGS",
                                   "ET_WGRAD_TR", "ET_WGRAD_BIG", "ET_WGRAD_GROUP", "ET_WGRAD_STALE", "ET_WGRAD_STREAM", "ET_FUSE_BN_BWD",
                                   "ET_STEP_GRAPH", "ET_ALLREDUCE_CHUNK_MB", "ET_RCCL_CHANNELS", "ET_DP_SINGLE_RANK", "ET_HIP_LIB"};
     if (!buf || buflen < 1) return -1;

@@ -38,6 +38,15 @@ __device__ __forceinline__ uint32_t et_pack_bf2(float lo, float hi) {
 }
 #endif
 
+// a wave-uniform value the optimiser must treat as unknown from here on (keeps address arithmetic that depends on it where it is
+// written instead of hoisted and kept alive across phases)
+__device__ __forceinline__ int et_opaque_uniform(int v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+s"(v));
+#endif
+    return v;
+}
+
 // element-type traits: T = float (parity mode) or uint16_t holding bf16 (performance mode)
 template <typename T> struct et_elem;
 template <> struct et_elem<float> {

@@ -151,7 +151,7 @@ GLDS = "conv_gemm_glds_kernel<unsigned short, "
 RS128, RS64 = "conv_gemm_rs_kernel<128, 128, 2, 2>", "conv_gemm_rs_kernel<128, 64, 2, 2>"
 SELECT = [
     # N, H, W, Cin, Cout, k, s, p, fwd kernel, dgrad kernels (per parity class), wgrad kernel
-    ((2, 20, 20, 256, 256, 3, 1, 1), "conv_gemm_pp_kernel", ["conv_gemm_pp_kernel"], "conv_wgrad_tr_kernel<256, 256, 2, 4>"),
+    ((2, 20, 20, 256, 256, 3, 1, 1), "conv_gemm_pprs_kernel", ["conv_gemm_pprs_kernel"], "conv_wgrad_tr_kernel<256, 256, 2, 4>"),
     ((2, 20, 20, 128, 256, 3, 2, 1), "conv_gemm_pp_kernel",
      [GLDS + "128, 128, 2, 2, 4, 3, true>", GLDS + "128, 128, 2, 2, 8, 2, true>", GLDS + "128, 128, 2, 2, 8, 2, true>",
       GLDS + "128, 128, 2, 2, 8, 2, true>"], "conv_wgrad_tr_kernel<256, 256, 2, 4>"),
@@ -166,9 +166,9 @@ SELECT = [
     ((2, 12, 12, 64, 64, 1, 1, 0), GLDS + "128, 64, 2, 2, 4, 3, true>", [GLDS + "128, 64, 2, 2, 4, 3, true>"],
      "conv_wgrad_tr_kernel<64, 64, 2, 2>"),
     ((1, 16, 16, 8, 32, 6, 2, 2), "conv_stem_kernel", None, None),                            # the stem (no dgrad in the net)
-    ((1, 5, 5, 64, 264, 3, 1, 1), "conv_gemm_pp_kernel", [GLDS + "128, 64, 2, 2, 4, 2, false>"],
+    ((1, 5, 5, 64, 264, 3, 1, 1), "conv_gemm_pprs_kernel", [GLDS + "128, 64, 2, 2, 4, 2, false>"],
      "conv_wgrad_tr_kernel<256, 256, 2, 4>"),                                                  # ragged M and Cout on the 256^2 tiles
-    ((3, 14, 14, 192, 320, 3, 1, 1), "conv_gemm_pp_kernel", [RS128], "conv_wgrad_tr_kernel<256, 256, 2, 4>"),
+    ((3, 14, 14, 192, 320, 3, 1, 1), "conv_gemm_pprs_kernel", [RS128], "conv_wgrad_tr_kernel<256, 256, 2, 4>"),
     # YOLOv8 head: its 68 (-> 72) channel DFL branch is not a multiple of the 32-wide K chunk: per-lane tap decode (UTAP false)
     ((1, 9, 11, 256, 72, 3, 1, 1), RS128, [GLDS + "128, 128, 2, 2, 4, 2, false>"],
      "conv_wgrad_tr_kernel<128, 128, 2, 2>"),
@@ -190,12 +190,12 @@ def test_bench_instantiations_elementwise(hip, case, kf, kd, kw):
 
 @pytest.mark.parametrize("dma_late,seed", [(1, 3), (0, 5), (1, 11)])
 def test_lds_dma_pipelines_under_adversarial_schedules(emu, dma_late, seed):
-    """The counted-vmcnt LDS-DMA pipelines (ping-pong 256x256 gather-GEMM, the 3-deep short-K ring, the two-ring row-shift
-    3x3 kernel, the wgrad double buffer) under the emulator's race-exposing modes: DMA landing as late / as early as the hardware may, waves run
+    """The counted-vmcnt LDS-DMA pipelines (the ping-pong 256x256 gather-GEMM with per-tap and with shared activation rows, the 3-deep
+    short-K ring, the two-ring row-shift 3x3 kernel, the wgrad double buffer) under the emulator's race-exposing modes: DMA landing as late / as early as the hardware may, waves run
     one at a time in random order between barriers.  A wait that is one half-tile too weak, or a half-tile staged
     into a buffer that is still being read, fails here (checked by mutation when the kernel was written)."""
     emu.configure(dma_late, seed)
-    for case, kf, kd, kw in (SELECT[0], SELECT[4], SELECT[8], SELECT[3], SELECT[5]):     # [3], [5]: the row-shift 3x3 tiles
+    for case, kf, kd, kw in (SELECT[0], SELECT[1], SELECT[4], SELECT[8], SELECT[3], SELECT[5]):     # [3], [5]: the row-shift 3x3 tiles
         _check_instantiation(emu, case, kf, kd, kw)
     import os
     os.environ["ET_CONV_STEM_WGS"] = "2"          # 6 tiles on 2 persistent workgroups: the single patch buffer is re-staged

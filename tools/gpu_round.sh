@@ -66,7 +66,7 @@ for l in sys.stdin:
         d = json.loads(l)
         if d['s'] == 1 and d['cin'] < 256: print(d['cin'], d['cout'], d['h'], 'fwd %.1f us %.0f TF  dgrad %.1f us %.0f TF' % (d['fwd_ms'] * 1e3, d['fwd_tf'], d['dgrad_ms'] * 1e3, d['dgrad_tf']), d['fwd_kernel'][:34])
 " | tee -a $OUT/mb_rs.txt; done ;;
-mb_rs_abl) run mb_rs_abl; for L in ${RS_LIBS:-base new rs4 base new}; do if [ $L = new ]; then unset ET_HIP_LIB; export ET_CONV_RS=1; elif [ $L = base ]; then unset ET_HIP_LIB; export ET_CONV_RS=0; else export ET_HIP_LIB=$PWD/tools/probe/libet_$L.so; export ET_CONV_RS=1; fi; echo "--- $L"; MB_REF=0 MB_K=3 MB_ROTATE=4 timeout 600 python tools/microbench.py conv 2>&1 | python -c "
+mb_rs_abl) run mb_rs_abl; for L in ${RS_LIBS:-base new base new}; do if [ $L = new ]; then unset ET_HIP_LIB; export ET_CONV_RS=1; elif [ $L = base ]; then unset ET_HIP_LIB; export ET_CONV_RS=0; else export ET_HIP_LIB=$PWD/tools/probe/libet_$L.so; export ET_CONV_RS=1; fi; echo "--- $L"; MB_REF=0 MB_K=3 MB_ROTATE=4 timeout 600 python tools/microbench.py conv 2>&1 | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
@@ -74,6 +74,20 @@ for l in sys.stdin:
         if d['s'] == 1 and d['cin'] < 256: print(d['cin'], d['cout'], d['h'], 'fwd %.1f us %.0f TF  dgrad %.1f us %.0f TF' % (d['fwd_ms'] * 1e3, d['fwd_tf'], d['dgrad_ms'] * 1e3, d['dgrad_tf']), d['fwd_kernel'][:34])
 " | tee -a $OUT/mb_rs_abl.txt; done ;;
 ab_rs_step) run ab_rs_step; for R in 0 1 0 1 0 1; do ET_CONV_RS=$R timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('ET_CONV_RS=$R', round(d['ms_per_step'],2), round(d['roofline']['frac'],4), round(d['roofline']['all_conv_kernels']['tflops'],1), d['kernel_ms_by_family']['main_stream'], d['kernel_ms_by_family']['teacher_stream_ms'])" | tee -a $OUT/ab_rs_step.txt; done ;;
+mb_pp_abl) run mb_pp_abl; for L in base rs8 base rs8; do if [ $L = base ]; then unset ET_HIP_LIB; else export ET_HIP_LIB=$PWD/tools/probe/libet_$L.so; fi; echo "--- $L"; MB_REF=0 MB_K=3 MB_ROTATE=4 timeout 600 python tools/microbench.py conv 2>&1 | python -c "
+import sys, json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d = json.loads(l)
+        if d['s'] == 1 and d['cin'] >= 256: print(d['cin'], d['cout'], d['h'], 'fwd %.1f us %.0f TF  dgrad %.1f us %.0f TF' % (d['fwd_ms'] * 1e3, d['fwd_tf'], d['dgrad_ms'] * 1e3, d['dgrad_tf']), d['fwd_kernel'][:34])
+" | tee -a $OUT/mb_pp_abl.txt; done ;;
+ab_pprs) run ab_pprs; for R in 0 1 0 1; do echo "--- ET_CONV_PPRS=$R"; ET_CONV_PPRS=$R MB_REF=0 MB_K=3 MB_ROTATE=4 timeout 600 python tools/microbench.py conv 2>&1 | python -c "
+import sys, json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d = json.loads(l)
+        if d['s'] == 1 and d['cin'] >= 256: print(d['cin'], d['cout'], d['h'], 'fwd %.1f us %.0f TF  dgrad %.1f us %.0f TF' % (d['fwd_ms'] * 1e3, d['fwd_tf'], d['dgrad_ms'] * 1e3, d['dgrad_tf']), d['fwd_kernel'][:34])
+" | tee -a $OUT/ab_pprs_mb.txt; done; for R in 0 1 0 1 0 1; do ET_CONV_PPRS=$R timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('ET_CONV_PPRS=$R', round(d['ms_per_step'],2), d['roofline']['kernel'], round(d['roofline']['frac'],4), round(d['roofline']['all_conv_kernels']['tflops'],1), d['kernel_ms_by_family']['main_stream'], d['kernel_ms_by_family']['teacher_stream_ms'])" | tee -a $OUT/ab_pprs_step.txt; done ;;
 smoke) run smoke; timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -3 $OUT/smoke.log ;;
 prof) run prof; (cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/bench_under_rocprof.json 2> $GRAFT_REPO_ROOT/$OUT/prof.err); find $OUT/prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv; find $OUT/prof -name "*kernel_trace.csv" | head -1 | xargs -I{} python tools/trace_streams.py {} > $OUT/trace_streams.txt 2>&1; cat $OUT/trace_streams.txt; find $OUT/prof -name "*.db" -delete; find $OUT/prof -name "*kernel_trace.csv" -size +20M -delete; head -8 $OUT/kernel_stats.csv | cut -c1-160 ;;
 pmc) run pmc; for C in FETCH_SIZE WRITE_SIZE; do (cd /tmp && timeout 900 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmc_$C -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/bench_pmc_$C.json 2> $GRAFT_REPO_ROOT/$OUT/pmc_$C.err); done; python tools/pmc_summarize.py $OUT > $OUT/pmc_bench_summary.csv; find $OUT -name "*.db" -delete; find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*kernel_trace.csv" -delete; head -12 $OUT/pmc_bench_summary.csv ;;
