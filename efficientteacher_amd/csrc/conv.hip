@@ -1584,7 +1584,8 @@ struct WgradGeom {
     int xcd;                     // 1 = remap the linear workgroup id so that one K-split's tiles share an XCD
     int Pper;                    // pixels per split-K slice (multiple of the K-chunk)
     int ntn, ntm, nsk;           // tile grid: column tiles, cout tiles, K splits (1-D launch, decoded in-kernel)
-    FastDiv dQW, dQH, dCin;
+    FastDiv dQW, dQH, dCin, dW1; // dW1: by QW + 1 (conv_wgrad_rs_kernel's padded raster)
+    int PP;                      // padded slots N*QH*(QW+1) (conv_wgrad_rs_kernel's GEMM-K)
     signed char dy[CONV_MAX_TAPS], dx[CONV_MAX_TAPS];
 };
 
@@ -1960,6 +1961,186 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_tr_kernel(WgradGroup 
     }
 }
 
+// ---- weight gradient of the 3x3 stride-1 layers with BOTH operands shared by the three taps of a kernel row ------------------
+// conv_wgrad_tr_kernel computes one (cout tile, tap, cin tile) per workgroup: dY is staged nine times and X nine times per pixel
+// chunk of a layer.  The three taps of a kernel row multiply the SAME dY rows with X rows shifted by one pixel, so here a
+// workgroup owns (cout tile) x (kernel row j) x (cin tile) = three dW tiles (accumulator sets) and stages per K-chunk ONE dY
+// tile and ONE X tile with two extra rows; tap k reads its B fragments k rows further down.  GEMM-K runs over the PADDED raster
+// (index Yg * (W + 1) + x, one zero slot after every image row, in BOTH operands): a dY pad row contributes nothing, and
+// x - 1 / x + 1 of a row's first / last pixel is the X pad slot -- no masks (conv_gemm_rs_kernel's layout).  Per 64-slot chunk:
+// 64 + 72 rows staged for three taps instead of 3 * (64 + 64); fragment bases per (tap, lane) are precomputed, the k-step and the
+// row half are immediates (the swizzle only depends on the row modulo 4, which 16*ks + 4*r does not change).
+template <int BM, int BNC, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) ET_WAVES_PER_EU(4) void conv_wgrad_rs_kernel(WgradGroup grp, const uint16_t* __restrict__ ZERO, WgradGeom g) {
+    constexpr int NT = 64 * WM * WN, BKP = 64, BROWS = 72;      // threads; padded slots per chunk; X rows per chunk (66 used)
+    constexpr int TM = BM / WM / 32, TN = BNC / WN / 32;
+    constexpr int SA = BM / 8, SB = BNC / 8;                     // 16-byte slots per row of the A / B tile
+    constexpr int RPA = NT / SA, RPB = NT / SB;                  // rows staged per pass of the workgroup
+    constexpr int RA = BKP / RPA, RB = (BROWS + RPB - 1) / RPB;  // LDS-DMA instructions per thread per chunk (the last B pass partial)
+    constexpr int A_VEC = BKP * SA, B_VEC = BROWS * SB;          // (the partial last B pass only writes rows < BROWS)
+    static_assert(BKP % RPA == 0 && RPA >= 1 && RPB >= 8 && TM >= 1 && TN >= 1 && (BROWS * SB) % 64 == 0, "staging passes");
+    __shared__ __attribute__((aligned(16))) u32x4 lds_raw[2 * (A_VEC + B_VEC)];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    int bid = blockIdx.x;
+    if (g.xcd) {
+        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bid & 7, k = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    const int per_layer = g.ntn * g.ntm * g.nsk;
+    const int layer = __builtin_amdgcn_readfirstlane(bid / per_layer);
+    bid -= layer * per_layer;
+    const uint16_t* __restrict__ X = grp.it[layer].x;
+    const uint16_t* __restrict__ DY = grp.it[layer].dy;
+    float* __restrict__ DW = grp.it[layer].dw;
+    const int ldx = grp.it[layer].ldx, ldy = grp.it[layer].ldy;
+    const int tx = bid % g.ntn, ty = (bid / g.ntn) % g.ntm, tz = bid / (g.ntn * g.ntm);
+    const int nci = g.ntn / 3;                       // column tiles = 3 kernel rows x cin tiles
+    const int jrow = tx / nci, c0 = (tx - jrow * nci) * BNC, m0 = ty * BM;
+    const int dyr = jrow - 1;                        // image-row offset of this kernel row (pad 1)
+    const int W1 = g.QW + 1;
+    const int k_begin = tz * g.Pper;                 // padded slots [k_begin, k_end)
+    const int k_end = min(g.PP, k_begin + g.Pper);
+
+    int a_pl[RA], a_co[RA];
+    bool a_ok[RA];
+#pragma unroll
+    for (int j = 0; j < RA; ++j) {
+        a_pl[j] = tid / SA + j * RPA;
+        const int ls = (tid % SA) ^ tr_swz<SA>(a_pl[j]);
+        a_co[j] = m0 + ls * 8;
+        a_ok[j] = a_co[j] < g.Cout;
+    }
+    int b_pl[RB], b_ci[RB];
+    bool b_ok[RB];
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+        b_pl[j] = tid / SB + j * RPB;
+        const int ls = (tid % SB) ^ tr_swz<SB>(b_pl[j]);
+        b_ci[j] = c0 + ls * 8;
+        b_ok[j] = b_ci[j] < g.Cin && b_pl[j] < BROWS;
+    }
+
+    f32x16 acc[3][TM][TN];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[k][tm][tn][r] = 0.f;
+
+    auto stage = [&](u32x4* dstA, u32x4* dstB, int k0) {
+        u32x4* const wa = dstA + wave * 64;
+        u32x4* const wb = dstB + wave * 64;
+#pragma unroll
+        for (int j = 0; j < RA; ++j) {
+            const int sl = k0 + a_pl[j];                                     // padded slot of this dY row
+            const uint32_t ss = min(sl, g.PP - 1);
+            const uint32_t yg = fdiv(ss, g.dW1), xp = ss - yg * W1;
+            const bool ok = a_ok[j] && sl < k_end && (int)xp < g.QW;
+            const uint16_t* src = ok ? DY + ((long long)(yg * g.QW + xp) * ldy + a_co[j]) : ZERO;
+            et_glds16(src, wa + j * NT);
+        }
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+            if (j * RPB >= BROWS) continue;
+            if (RB * RPB > BROWS && j == RB - 1 && wave * 64 >= (BROWS - j * RPB) * SB) continue;   // wave-uniform: the partial pass
+            const int sl = k0 - 1 + b_pl[j];                                 // padded slot of this X row (LDS row b_pl)
+            const uint32_t ss = sl < 0 ? 0 : min(sl, g.PP - 1);
+            const uint32_t yg = fdiv(ss, g.dW1), xp = ss - yg * W1;
+            const uint32_t n = fdiv(yg, g.dQH), qy = yg - n * g.QH;
+            const bool ok = b_ok[j] && sl >= 0 && sl < g.PP && (int)xp < g.QW && (unsigned)((int)qy + dyr) < (unsigned)g.IH;
+            const uint16_t* src = ok ? X + ((long long)((int)(yg * g.QW + xp) + dyr * g.IW) * ldx + b_ci[j]) : ZERO;
+            et_glds16(src, wb + j * NT);
+        }
+    };
+
+    // fragment bases (bytes inside an operand tile); k-step ks and row half r add (16*ks + 4*r) rows as an immediate
+    const int fp = 8 * (lane >> 5) + ((lane & 15) >> 2);
+    const int fc = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    int abase[TM], bbase[3][TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        const int ch = wm * (BM / WM) + tm * 32 + fc;
+        abase[tm] = (fp * SA + ((ch >> 3) ^ tr_swz<SA>(fp))) * 16 + (ch & 4) * 2;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int ch = wn * (BNC / WN) + tn * 32 + fc;
+            bbase[k][tn] = ((fp + k) * SB + ((ch >> 3) ^ tr_swz<SB>(fp + k))) * 16 + (ch & 4) * 2;
+        }
+    auto frag = [&](const char* tile, int base, int row_bytes, int ks) -> s16x8 {
+        s16x8 o;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) s16x4*)(tile + base + (16 * ks + 4 * r) * row_bytes));
+            o[4 * r + 0] = v[0]; o[4 * r + 1] = v[1]; o[4 * r + 2] = v[2]; o[4 * r + 3] = v[3];
+        }
+        return o;
+    };
+    auto mma = [&](const u32x4* bufA, const u32x4* bufB) {
+        const char* ta = (const char*)bufA;
+        const char* tb = (const char*)bufB;
+#pragma unroll
+        for (int ks = 0; ks < BKP / 16; ++ks) {
+            s16x8 af[TM], bf[3][TN];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) af[tm] = frag(ta, abase[tm], SA * 16, ks);
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) bf[k][tn] = frag(tb, bbase[k][tn], SB * 16, ks);
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        acc[k][tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[tm]),
+                                                                                __builtin_bit_cast(bf16x8, bf[k][tn]), acc[k][tm][tn], 0, 0, 0);
+        }
+    };
+
+    u32x4* const A0 = lds_raw;
+    u32x4* const B0 = lds_raw + A_VEC;
+    u32x4* const A1 = lds_raw + A_VEC + B_VEC;
+    u32x4* const B1 = A1 + A_VEC;
+    const int nchunks = (k_end - k_begin + BKP - 1) / BKP;
+    if (nchunks <= 0) return;
+    stage(A0, B0, k_begin);
+    et_wait_vmem();
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const bool odd = c & 1;
+        if (c + 1 < nchunks) stage(odd ? A0 : A1, odd ? B0 : B1, k_begin + (c + 1) * BKP);
+        mma(odd ? A1 : A0, odd ? B1 : B0);
+        et_wait_vmem();
+        __syncthreads();
+    }
+    const int l31 = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float* const tapbase = DW + (size_t)(jrow * 3 + k) * g.Cin + c0;      // dW[co][tap][ci]: row pitch NC = 9 * Cin
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = m0 + wm * (BM / WM) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    const int ci = wn * (BNC / WN) + tn * 32 + l31;
+                    if (co < g.Cout && c0 + ci < g.Cin) atomicAdd(tapbase + (size_t)co * g.NC + ci, acc[k][tm][tn][r]);
+                }
+            }
+    }
+}
+
 // ---- small helpers ---------------------------------------------------------------------------------
 // W [Cout][TT][Cin] -> WT [Cin][TT][Cout]  (operand of dgrad)
 template <typename T>
@@ -2311,11 +2492,26 @@ extern "C" int et_conv2d_dgrad_bn(const void* dy, const void* wT, void* dx, int 
                              bn_scale, bn_shift, bn_act, bn_stats_partial, zero16, stream);
 }
 
-struct WgradPlan { bool tr; int bm, bn; };
+// launch geometry of the weight gradient (ONE copy: the launcher and et_conv2d_kernel_name both call this)
+static void wgrad_geom(WgradGeom& g, int N, int IH, int IW, int Cin, int ldx, int Cout, int KH, int KW, int stride, int pad, int ldy) {
+    const int OH = (IH + 2 * pad - KH) / stride + 1, OW = (IW + 2 * pad - KW) / stride + 1;
+    g.N = N; g.IH = IH; g.IW = IW; g.Cin = Cin; g.ldx = ldx;
+    g.QH = OH; g.QW = OW; g.P = N * OH * OW; g.Cout = Cout; g.ldy = ldy;
+    g.isy = g.isx = stride; g.T = KH * KW; g.NC = g.T * Cin;
+    g.dQW = make_fastdiv(OW); g.dQH = make_fastdiv(OH); g.dCin = make_fastdiv(Cin); g.dW1 = make_fastdiv(OW + 1);
+    g.PP = N * OH * (OW + 1);
+    for (int ky = 0; ky < KH; ++ky)
+        for (int kx = 0; kx < KW; ++kx) {
+            g.dy[ky * KW + kx] = (signed char)(ky - pad);
+            g.dx[ky * KW + kx] = (signed char)(kx - pad);
+        }
+}
+
+struct WgradPlan { bool tr; int bm, bn; bool rs; };
 static WgradPlan plan_wgrad(const WgradGeom& g, int elem_bytes, bool have_zero_page) {
     const bool wideN = g.NC > 64;
     const bool tallM = g.Cout > 64;            // Cout <= 64 layers: a 64-row tile wastes no MFMA rows
-    WgradPlan p{false, tallM ? 128 : 64, wideN ? 128 : 64};
+    WgradPlan p{false, tallM ? 128 : 64, wideN ? 128 : 64, false};
     // bf16 + zero page: LDS-DMA staging with transposing LDS reads (ET_WGRAD_TR=0 forces the register path)
     static const int use_tr = env_int("ET_WGRAD_TR", 1);
     p.tr = elem_bytes == 2 && use_tr && have_zero_page;
@@ -2329,10 +2525,20 @@ static WgradPlan plan_wgrad(const WgradGeom& g, int elem_bytes, bool have_zero_p
         else if (g.T > 1 && g.isy == 1 && g.NC >= 256 && g.Cout == 128 && (big & 1)) p.bn = 256;
         if (big & 2) { if (g.NC >= 256) p.bn = 256; if (g.Cout >= 256) p.bm = 256; }   // experiment: always
     }
+    // 3x3 stride-1 pad-1 layers: the three taps of a kernel row share both staged operands (conv_wgrad_rs_kernel).
+    // ET_WGRAD_RS bits: 1 = layers below 256 output channels, 2 = the others (0: the per-tap kernel everywhere)
+    static const int use_rs = env_int("ET_WGRAD_RS", 3);
+    if (p.tr && g.T == 9 && g.isy == 1 && g.isx == 1 && g.dy[0] == -1 && g.dx[0] == -1 && g.dy[8] == 1 && g.dx[8] == 1 &&
+        g.QH == g.IH && g.QW == g.IW && g.QW >= 2 && (use_rs & (g.Cout >= 256 ? 2 : 1))) {
+        if (g.Cout >= 128 && g.Cin >= 128) { p.rs = true; p.bm = 128; p.bn = 128; }
+        else if (g.Cout <= 64 && g.Cin <= 64) { p.rs = true; p.bm = 64; p.bn = 64; }
+    }
     return p;
 }
 static void wgrad_plan_name(const WgradPlan& p, int elem_bytes, char* buf, int n) {
-    if (p.tr) {
+    if (p.rs) {
+        snprintf(buf, n, "conv_wgrad_rs_kernel<%d, %d, %d, %d>", p.bm, p.bn, 2, p.bm == 128 ? 4 : 2);
+    } else if (p.tr) {
         const int wm = p.bm == 256 ? (p.bn == 256 ? 2 : 4) : (p.bm == 128 ? 2 : (p.bn == 256 ? 1 : 2));
         const int wn = p.bm == 256 ? (p.bn == 256 ? 4 : (p.bn == 128 ? 2 : 1)) : (p.bn == 256 ? 4 : 2);
         snprintf(buf, n, "conv_wgrad_tr_kernel<%d, %d, %d, %d>", p.bm, p.bn, wm, wn);
@@ -2348,6 +2554,33 @@ static void launch_wgrad(const WgradGroup& grp, const void* zero16, WgradGeom& g
     const WgradPlan wp = plan_wgrad(g, (int)sizeof(T), zero16 != nullptr);
     const bool tr = wp.tr, wideN = g.NC > 64, tallM = g.Cout > 64;
     const int bm = wp.bm, bn = wp.bn;
+    if (wp.rs) {
+        if constexpr (sizeof(T) == 2) {
+            // same split policy as below, over the padded raster: one round of co-resident workgroups, >= ~25 chunks each
+            const int nci = (g.Cin + bn - 1) / bn;
+            g.ntn = 3 * nci; g.ntm = (g.Cout + bm - 1) / bm;
+            const int tiles = grp.n * g.ntn * g.ntm;
+            const int n_cu = device_cus();
+            const int slots = bm == 128 ? 2 : 4;               // 68 KB / 34 KB of LDS; 8 / 4 waves, <= 128 VGPRs
+            const int cap = slots * n_cu;
+            const int max_sk = max(1, g.PP / (64 * 25));
+            auto eff = [&](int k) { const int b = tiles * k; return (double)b / ((double)((b + cap - 1) / cap) * cap); };
+            int sk = max(1, min(cap / tiles, max_sk));
+            if (eff(sk) < 0.8)
+                for (int k = sk + 1; k <= min(max_sk, max(4, 2 * cap / tiles)); ++k)
+                    if (eff(k) > eff(sk) + 0.1) sk = k;
+            sk = max(1, min(sk, max_sk));
+            int per = (g.PP + sk - 1) / sk;
+            per = ((per + 63) / 64) * 64;
+            sk = (g.PP + per - 1) / per;
+            g.xcd = 1; g.Pper = per; g.nsk = sk;
+            const dim3 grid(grp.n * g.ntn * g.ntm * sk);
+            const uint16_t* z = (const uint16_t*)zero16;
+            if (bm == 128) hipLaunchKernelGGL((conv_wgrad_rs_kernel<128, 128, 2, 4>), grid, dim3(512), 0, s, grp, z, g);
+            else hipLaunchKernelGGL((conv_wgrad_rs_kernel<64, 64, 2, 2>), grid, dim3(256), 0, s, grp, z, g);
+            return;
+        }
+    }
     const int tiles = grp.n * ((g.NC + bn - 1) / bn) * ((g.Cout + bm - 1) / bm);   // the whole group shares the split
     // Split K so that the grid is a whole number of residency rounds: `slots` workgroups of this tile fit on
     // a CU (LDS- or register-limited), so up to slots*CUs run at once and a grid a little OVER a multiple of
@@ -2419,16 +2652,7 @@ extern "C" int et_conv2d_wgrad_grouped(const et_wgrad_item* items, int n_items, 
     }
     for (int i = n_items; i < WGRAD_MAX_GROUP; ++i) grp.it[i] = grp.it[0];
     WgradGeom g;
-    const int OH = (IH + 2 * pad - KH) / stride + 1, OW = (IW + 2 * pad - KW) / stride + 1;
-    g.N = N; g.IH = IH; g.IW = IW; g.Cin = Cin; g.ldx = items[0].ldx;
-    g.QH = OH; g.QW = OW; g.P = N * OH * OW; g.Cout = Cout; g.ldy = items[0].ldy;
-    g.isy = g.isx = stride; g.T = KH * KW; g.NC = g.T * Cin;
-    g.dQW = make_fastdiv(OW); g.dQH = make_fastdiv(OH); g.dCin = make_fastdiv(Cin);
-    for (int ky = 0; ky < KH; ++ky)
-        for (int kx = 0; kx < KW; ++kx) {
-            g.dy[ky * KW + kx] = (signed char)(ky - pad);
-            g.dx[ky * KW + kx] = (signed char)(kx - pad);
-        }
+    wgrad_geom(g, N, IH, IW, Cin, items[0].ldx, Cout, KH, KW, stride, pad, items[0].ldy);
     if (g.P <= 0) return 0;
     if (dtype == ET_F32) launch_wgrad<float>(grp, zero16, g, (hipStream_t)stream);
     else if (dtype == ET_BF16) launch_wgrad<uint16_t>(grp, zero16, g, (hipStream_t)stream);
@@ -2497,7 +2721,7 @@ extern "C" int et_conv2d_kernel_name(int op, int dtype, int N, int IH, int IW, i
     const int eb = dtype == ET_F32 ? 4 : 2, vec = dtype == ET_F32 ? 4 : 8;
     if (op == 2) {
         WgradGeom g;
-        g.Cout = Cout; g.T = KH * KW; g.NC = g.T * Cin; g.isy = g.isx = stride;
+        wgrad_geom(g, N, IH, IW, Cin, Cin, Cout, KH, KW, stride, pad, Cout);
         wgrad_plan_name(plan_wgrad(g, eb, have_zero_page != 0), eb, buf, buflen);
         return 0;
     }
@@ -2522,7 +2746,7 @@ extern "C" int et_conv2d_kernel_name(int op, int dtype, int N, int IH, int IW, i
 extern "C" int et_env_knobs(char* buf, int buflen) {
     // every ET_* tuning knob that is SET in this process's environment, as "NAME=value;..." (bench.py records it)
     static const char* names[] = {"ET_CONV_GLDS", "ET_CONV_BIG", "ET_CONV_BIG_MINFILL", "ET_CONV_PP", "ET_CONV_RS", "ET_CONV_PPRS", "ET_CONV_STEM", "ET_CONV_STEM_WGS",
-                                  "ET_WGRAD_TR", "ET_WGRAD_BIG", "ET_WGRAD_GROUP", "ET_WGRAD_STALE", "ET_WGRAD_STREAM", "ET_FUSE_BN_BWD",
+                                  "ET_WGRAD_TR", "ET_WGRAD_BIG", "ET_WGRAD_RS", "ET_WGRAD_GROUP", "ET_WGRAD_STALE", "ET_WGRAD_STREAM", "ET_FUSE_BN_BWD",
                                   "ET_STEP_GRAPH", "ET_ALLREDUCE_CHUNK_MB", "ET_RCCL_CHANNELS", "ET_DP_SINGLE_RANK", "ET_HIP_LIB"};
     if (!buf || buflen < 1) return -1;
     int off = 0;

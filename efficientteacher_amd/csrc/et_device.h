@@ -38,6 +38,13 @@ __device__ __forceinline__ uint32_t et_pack_bf2(float lo, float hi) {
 }
 #endif
 
+// register budget of a kernel as "n waves per SIMD" (device pass only: the host pass and the CPU emulator see a plain function)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ET_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n, n)))
+#else
+#define ET_WAVES_PER_EU(n)
+#endif
+
 // a wave-uniform value the optimiser must treat as unknown from here on (keeps address arithmetic that depends on it where it is
 // written instead of hoisted and kept alive across phases)
 __device__ __forceinline__ int et_opaque_uniform(int v) {

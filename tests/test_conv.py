@@ -151,24 +151,24 @@ GLDS = "conv_gemm_glds_kernel<unsigned short, "
 RS128, RS64 = "conv_gemm_rs_kernel<128, 128, 2, 2>", "conv_gemm_rs_kernel<128, 64, 2, 2>"
 SELECT = [
     # N, H, W, Cin, Cout, k, s, p, fwd kernel, dgrad kernels (per parity class), wgrad kernel
-    ((2, 20, 20, 256, 256, 3, 1, 1), "conv_gemm_pprs_kernel", ["conv_gemm_pprs_kernel"], "conv_wgrad_tr_kernel<256, 256, 2, 4>"),
+    ((2, 20, 20, 256, 256, 3, 1, 1), "conv_gemm_pprs_kernel", ["conv_gemm_pprs_kernel"], "conv_wgrad_rs_kernel<128, 128, 2, 4>"),
     ((2, 20, 20, 128, 256, 3, 2, 1), "conv_gemm_pp_kernel",
      [GLDS + "128, 128, 2, 2, 4, 3, true>", GLDS + "128, 128, 2, 2, 8, 2, true>", GLDS + "128, 128, 2, 2, 8, 2, true>",
       GLDS + "128, 128, 2, 2, 8, 2, true>"], "conv_wgrad_tr_kernel<256, 256, 2, 4>"),
     ((2, 20, 20, 512, 512, 1, 1, 0), GLDS + "128, 128, 2, 2, 8, 2, true>", [GLDS + "128, 128, 2, 2, 8, 2, true>"],
      "conv_wgrad_tr_kernel<128, 128, 2, 2>"),
     ((1, 9, 11, 64, 40, 3, 1, 1), RS64, [GLDS + "128, 64, 2, 2, 4, 2, false>"],                # ragged M, 11-pixel rows
-     "conv_wgrad_tr_kernel<64, 128, 2, 2>"),
+     "conv_wgrad_rs_kernel<64, 64, 2, 2>"),
     ((2, 12, 12, 64, 128, 1, 1, 0), GLDS + "128, 64, 2, 2, 4, 3, true>", [GLDS + "128, 64, 2, 2, 4, 3, true>"],
      "conv_wgrad_tr_kernel<128, 64, 2, 2>"),
     ((2, 12, 12, 128, 128, 3, 1, 1), RS128, [RS128],
-     "conv_wgrad_tr_kernel<128, 256, 2, 4>"),
+     "conv_wgrad_rs_kernel<128, 128, 2, 4>"),
     ((2, 12, 12, 64, 64, 1, 1, 0), GLDS + "128, 64, 2, 2, 4, 3, true>", [GLDS + "128, 64, 2, 2, 4, 3, true>"],
      "conv_wgrad_tr_kernel<64, 64, 2, 2>"),
     ((1, 16, 16, 8, 32, 6, 2, 2), "conv_stem_kernel", None, None),                            # the stem (no dgrad in the net)
     ((1, 5, 5, 64, 264, 3, 1, 1), "conv_gemm_pprs_kernel", [GLDS + "128, 64, 2, 2, 4, 2, false>"],
      "conv_wgrad_tr_kernel<256, 256, 2, 4>"),                                                  # ragged M and Cout on the 256^2 tiles
-    ((3, 14, 14, 192, 320, 3, 1, 1), "conv_gemm_pprs_kernel", [RS128], "conv_wgrad_tr_kernel<256, 256, 2, 4>"),
+    ((3, 14, 14, 192, 320, 3, 1, 1), "conv_gemm_pprs_kernel", [RS128], "conv_wgrad_rs_kernel<128, 128, 2, 4>"),       # ragged cout / cin tiles
     # YOLOv8 head: its 68 (-> 72) channel DFL branch is not a multiple of the 32-wide K chunk: per-lane tap decode (UTAP false)
     ((1, 9, 11, 256, 72, 3, 1, 1), RS128, [GLDS + "128, 128, 2, 2, 4, 2, false>"],
      "conv_wgrad_tr_kernel<128, 128, 2, 2>"),
