@@ -1978,7 +1978,7 @@ __global__ __launch_bounds__(64 * WM * WN) ET_WAVES_PER_EU(4) void conv_wgrad_rs
     constexpr int RPA = NT / SA, RPB = NT / SB;                  // rows staged per pass of the workgroup
     constexpr int RA = BKP / RPA, RB = (BROWS + RPB - 1) / RPB;  // LDS-DMA instructions per thread per chunk (the last B pass partial)
     constexpr int A_VEC = BKP * SA, B_VEC = BROWS * SB;          // (the partial last B pass only writes rows < BROWS)
-    static_assert(BKP % RPA == 0 && RPA >= 1 && RPB >= 8 && TM >= 1 && TN >= 1 && (BROWS * SB) % 64 == 0, "staging passes");
+    static_assert(RPA >= 1 && RPB >= 8 && TM >= 1 && TN >= 1 && (BROWS * SB) % 64 == 0 && RB * RPB > BKP, "staging passes");
     __shared__ __attribute__((aligned(16))) u32x4 lds_raw[2 * (A_VEC + B_VEC)];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -2003,23 +2003,29 @@ __global__ __launch_bounds__(64 * WM * WN) ET_WAVES_PER_EU(4) void conv_wgrad_rs
     const int k_begin = tz * g.Pper;                 // padded slots [k_begin, k_end)
     const int k_end = min(g.PP, k_begin + g.Pper);
 
-    int a_pl[RA], a_co[RA];
-    bool a_ok[RA];
-#pragma unroll
-    for (int j = 0; j < RA; ++j) {
-        a_pl[j] = tid / SA + j * RPA;
-        const int ls = (tid % SA) ^ tr_swz<SA>(a_pl[j]);
-        a_co[j] = m0 + ls * 8;
-        a_ok[j] = a_co[j] < g.Cout;
-    }
-    int b_pl[RB], b_ci[RB];
-    bool b_ok[RB];
-#pragma unroll
-    for (int j = 0; j < RB; ++j) {
-        b_pl[j] = tid / SB + j * RPB;
-        const int ls = (tid % SB) ^ tr_swz<SB>(b_pl[j]);
-        b_ci[j] = c0 + ls * 8;
-        b_ok[j] = b_ci[j] < g.Cin && b_pl[j] < BROWS;
+    static_assert(BKP % RPA == 0 && BKP % RPB == 0 && RPA % 4 == 0 && RPB % 4 == 0, "pieces are whole row groups; the swizzle repeats every 4 rows");
+    // this lane's rows: A piece j = LDS row a_pl0 + j*RPA, B piece j = row b_pl0 + j*RPB; the 8-channel group is the same for all of them
+    const int a_pl0 = tid / SA, b_pl0 = tid / SB;
+    const int a_co = m0 + ((tid % SA) ^ tr_swz<SA>(a_pl0)) * 8;
+    const int b_ci = c0 + ((tid % SB) ^ tr_swz<SB>(b_pl0)) * 8;
+    const bool a_okc = a_co < g.Cout, b_okc = b_ci < g.Cin;
+
+    // Padded coordinates (image row counted through the batch, column) of piece 0's row, kept across chunks: the pieces of a chunk
+    // are RPA / RPB slots apart and a chunk is a whole number of pieces, so stepping piece to piece IS the advance to the next chunk
+    // -- no division in the loop (two per staged row and chunk were ~100 of the ~170 staging instructions of a chunk, four waves per
+    // SIMD deep: as much VALU time as the MFMAs take).  Host guarantees 64 / (QW + 1) + 2 <= QH: one subtraction wraps the image row.
+    const int qa = RPA / W1, ra = RPA - qa * W1, qb = RPB / W1, rb = RPB - qb * W1;   // uniform
+    int a_yg, a_xp, b_yg, b_xp, b_qy;              // b_yg = -1 for the slot before the first (X row r <-> slot k0 - 1 + r)
+    {
+        const uint32_t sl = k_begin + a_pl0;
+        a_yg = fdiv(sl, g.dW1);
+        a_xp = sl - a_yg * W1;
+        const uint32_t s1 = k_begin - 1 + b_pl0 + W1;                   // one padded row further down: never negative
+        const uint32_t yg1 = fdiv(s1, g.dW1);
+        b_xp = s1 - yg1 * W1;
+        b_yg = (int)yg1 - 1;
+        const int q1 = yg1 - fdiv(yg1, g.dQH) * g.QH;
+        b_qy = q1 == 0 ? g.QH - 1 : q1 - 1;
     }
 
     f32x16 acc[3][TM][TN];
@@ -2032,29 +2038,32 @@ __global__ __launch_bounds__(64 * WM * WN) ET_WAVES_PER_EU(4) void conv_wgrad_rs
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[k][tm][tn][r] = 0.f;
 
+    // stage the chunk the row coordinates currently point at (k0 = its first slot) and leave them at the next chunk
     auto stage = [&](u32x4* dstA, u32x4* dstB, int k0) {
         u32x4* const wa = dstA + wave * 64;
         u32x4* const wb = dstB + wave * 64;
 #pragma unroll
         for (int j = 0; j < RA; ++j) {
-            const int sl = k0 + a_pl[j];                                     // padded slot of this dY row
-            const uint32_t ss = min(sl, g.PP - 1);
-            const uint32_t yg = fdiv(ss, g.dW1), xp = ss - yg * W1;
-            const bool ok = a_ok[j] && sl < k_end && (int)xp < g.QW;
-            const uint16_t* src = ok ? DY + ((long long)(yg * g.QW + xp) * ldy + a_co[j]) : ZERO;
+            const bool ok = a_okc && k0 + a_pl0 + j * RPA < k_end && a_xp < g.QW;
+            const uint16_t* src = ok ? DY + ((size_t)(unsigned)((a_yg * g.QW + a_xp) * ldy + a_co)) : ZERO;   // host: tensors < 2^31 elements
             et_glds16(src, wa + j * NT);
+            a_xp += ra; a_yg += qa;
+            if (a_xp >= W1) { a_xp -= W1; a_yg += 1; }
         }
+        int yg = b_yg, xp = b_xp, qy = b_qy;
 #pragma unroll
         for (int j = 0; j < RB; ++j) {
-            if (j * RPB >= BROWS) continue;
+            if (j * RPB == BKP) { b_yg = yg; b_xp = xp; b_qy = qy; }                                 // piece 0 of the next chunk
             if (RB * RPB > BROWS && j == RB - 1 && wave * 64 >= (BROWS - j * RPB) * SB) continue;   // wave-uniform: the partial pass
-            const int sl = k0 - 1 + b_pl[j];                                 // padded slot of this X row (LDS row b_pl)
-            const uint32_t ss = sl < 0 ? 0 : min(sl, g.PP - 1);
-            const uint32_t yg = fdiv(ss, g.dW1), xp = ss - yg * W1;
-            const uint32_t n = fdiv(yg, g.dQH), qy = yg - n * g.QH;
-            const bool ok = b_ok[j] && sl >= 0 && sl < g.PP && (int)xp < g.QW && (unsigned)((int)qy + dyr) < (unsigned)g.IH;
-            const uint16_t* src = ok ? X + ((long long)((int)(yg * g.QW + xp) + dyr * g.IW) * ldx + b_ci[j]) : ZERO;
+            const bool ok = b_okc && yg >= 0 && k0 - 1 + b_pl0 + j * RPB < g.PP && b_pl0 + j * RPB < BROWS && xp < g.QW &&
+                            (unsigned)(qy + dyr) < (unsigned)g.IH;
+            const uint16_t* src = ok ? X + ((size_t)(unsigned)((yg * g.QW + xp + dyr * g.IW) * ldx + b_ci)) : ZERO;
             et_glds16(src, wb + j * NT);
+            int dq = qb;
+            xp += rb;
+            if (xp >= W1) { xp -= W1; dq += 1; }
+            yg += dq; qy += dq;
+            if (qy >= g.QH) qy -= g.QH;
         }
     };
 
@@ -2529,7 +2538,8 @@ static WgradPlan plan_wgrad(const WgradGeom& g, int elem_bytes, bool have_zero_p
     // ET_WGRAD_RS bits: 1 = layers below 256 output channels, 2 = the others (0: the per-tap kernel everywhere)
     static const int use_rs = env_int("ET_WGRAD_RS", 3);
     if (p.tr && g.T == 9 && g.isy == 1 && g.isx == 1 && g.dy[0] == -1 && g.dx[0] == -1 && g.dy[8] == 1 && g.dx[8] == 1 &&
-        g.QH == g.IH && g.QW == g.IW && g.QW >= 2 && (use_rs & (g.Cout >= 256 ? 2 : 1))) {
+        g.QH == g.IH && g.QW == g.IW && g.QW >= 2 && 64 / (g.QW + 1) + 2 <= g.QH && (use_rs & (g.Cout >= 256 ? 2 : 1)) &&
+        (long long)g.N * g.IH * g.IW * (g.ldx > g.ldy ? g.ldx : g.ldy) < (1ll << 31)) {          // 32-bit element offsets in the kernel
         if (g.Cout >= 128 && g.Cin >= 128) { p.rs = true; p.bm = 128; p.bn = 128; }
         else if (g.Cout <= 64 && g.Cin <= 64) { p.rs = true; p.bm = 64; p.bn = 64; }
     }

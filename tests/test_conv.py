@@ -258,22 +258,25 @@ def _check_instantiation(hip, case, kf, kd, kw):
     assert (dw.cpu() - wref).abs().max().item() <= 1e-4 * max(1.0, wref.abs().max().item())
 
 
-def test_wgrad_grouped_eight_layers_256_tile(hip):
-    """the bench's grouped launch: 8 same-shaped 3x3 layers share one K-split on the 256x256 wgrad tile"""
+@pytest.mark.parametrize("stride,kernel", [(1, "conv_wgrad_rs_kernel<128, 128, 2, 4>"), (2, "conv_wgrad_tr_kernel<256, 256, 2, 4>")])
+def test_wgrad_grouped_eight_layers(hip, stride, kernel):
+    """the bench's grouped launch: 8 same-shaped 3x3 layers share one K-split -- on the row-sharing kernel (stride 1) and on the
+    256x256 per-tap tile (stride 2)"""
     from efficientteacher_amd import ops
     N, H, W, C, k = 1, 10, 10, 256, 3
     dt = torch.bfloat16
-    assert ops.kernel_name("wgrad", dt, N, H, W, C, C, k, 1, 1) == "conv_wgrad_tr_kernel<256, 256, 2, 4>"
+    assert ops.kernel_name("wgrad", dt, N, H, W, C, C, k, stride, 1) == kernel
+    OH, OW = ops.conv_out_hw(H, W, k, stride, 1)
     items, refs = [], []
     for i in range(8):
         x = _mk(hip, (N, H, W, C), dt, 60 + i)
-        dy = _mk(hip, (N, H, W, C), dt, 70 + i)
+        dy = _mk(hip, (N, OH, OW, C), dt, 70 + i)
         dw = torch.zeros((C, k, k, C), dtype=torch.float32, device=hip.device)
         items.append((x, dy, dw))
         wr = torch.zeros((C, C, k, k), requires_grad=True)
-        F.conv2d(x.float().cpu().permute(0, 3, 1, 2), wr, padding=1).backward(dy.float().cpu().permute(0, 3, 1, 2))
+        F.conv2d(x.float().cpu().permute(0, 3, 1, 2), wr, stride=stride, padding=1).backward(dy.float().cpu().permute(0, 3, 1, 2))
         refs.append(wr.grad.permute(0, 2, 3, 1))
-    ops.conv2d_wgrad_grouped(items, k, 1, 1)
+    ops.conv2d_wgrad_grouped(items, k, stride, 1)
     for (_, _, dw), ref in zip(items, refs):
         assert (dw.cpu() - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item())
 
