@@ -381,6 +381,15 @@ def measure(a, wl_name, per_rank, device, rank, world, dev_index, full=True):
         while a.warmup + n_extra < need:
             step(a.warmup + n_extra)
             n_extra += 1
+        # ... and ONE eager step after the capture: torch.cuda.graph() empties the caching allocator when it starts capturing, so the
+        # instrumented eager step of the timed region would otherwise re-allocate every activation with hipMalloc inside the timed
+        # region -- seen as a constant ~0.6 s (32+32) / ~0.2 s (16+16) added to some processes' timed regions (86 ms per step
+        # with every replay at 54 ms by its own HIP events; NOTEBOOK.md "slow replay mode", second entry)
+        if getattr(tr, "use_graph", False):
+            tr.use_graph = False
+            step(a.warmup + n_extra)
+            n_extra += 1
+            tr.use_graph = True
         torch.cuda.synchronize()
     timer = ops.KernelTimer()
 
@@ -397,6 +406,7 @@ def measure(a, wl_name, per_rank, device, rank, world, dev_index, full=True):
     ddp = tr.model if hasattr(tr.model, "collect_timing") else None
     graph_default = getattr(tr, "use_graph", False)
     items = None
+    step_walls = [t0] if os.environ.get("ET_BENCH_STEP_TIMES") else None     # debugging aid: host wall clock after every enqueue
     for i in range(a.steps):
         ops.TIMER = timer if (i in timed and full) else None
         if ssod:
@@ -404,6 +414,8 @@ def measure(a, wl_name, per_rank, device, rank, world, dev_index, full=True):
         if ddp is not None:                                              # the instrumented step(s) of the timed region run eagerly
             ddp.timing = i in timed
         items = step(a.warmup + i)
+        if step_walls is not None:
+            step_walls.append(time.perf_counter())
         if graph_default and getattr(tr, "graph_error", None):
             graph_default = False                                        # capture was rejected: the trainer fell back to eager steps
     ops.TIMER = None
@@ -411,6 +423,9 @@ def measure(a, wl_name, per_rank, device, rank, world, dev_index, full=True):
         tr.use_graph = graph_default
     t_enq = time.perf_counter() - t0          # host time to enqueue the K steps (no device sync inside a step)
     sync()
+    if step_walls is not None:
+        print("[step enqueue ms]", [round((b - a_) * 1e3, 1) for a_, b in zip(step_walls, step_walls[1:])],
+              "drain", round((time.perf_counter() - step_walls[-1]) * 1e3, 1), file=sys.stderr)
     dt = time.perf_counter() - t0
     t_ar = ddp.collect_timing() if ddp is not None else None
     if world > 1:

@@ -102,6 +102,15 @@ for l in sys.stdin:
         d = json.loads(l)
         if d['s'] == 1: print(d['cin'], d['cout'], d['h'], 'wgrad %.1f us %.0f TF' % (d['wgrad_ms'] * 1e3, d['wgrad_tf']))
 " | tee -a $OUT/ab_wlib_mb.txt; done; for L in base new base new; do if [ $L = base ]; then export ET_HIP_LIB=$PWD/tools/probe/libet_base.so; else unset ET_HIP_LIB; fi; timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('$L', round(d['ms_per_step'],2), round(d['roofline']['frac'],4), round(d['roofline']['all_conv_kernels']['tflops'],1), d['kernel_ms_by_family']['main_stream'], d['kernel_ms_by_family']['teacher_stream_ms'])" | tee -a $OUT/ab_wlib_step.txt; done ;;
+mb_k1) run mb_k1; MB_REF=0 MB_K=1 MB_ROTATE=3 timeout 600 python tools/microbench.py conv 2>&1 | python -c "
+import sys, json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d = json.loads(l); B=64; px=B*(d['h']//d['s'])**2
+        byt=px*(d['cin']+d['cout'])*2
+        print('%4d->%4d @%3d x%2d  fwd %6.1f us %5.2f TB/s %4.0f TF | dgrad %6.1f us %5.2f TB/s | wgrad %6.1f us %5.2f TB/s' % (d['cin'], d['cout'], d['h'], d['count'], d['fwd_ms']*1e3, byt/d['fwd_ms']/1e9, d['fwd_tf'], d['dgrad_ms']*1e3, byt/d['dgrad_ms']/1e9, d['wgrad_ms']*1e3, byt/d['wgrad_ms']/1e9), d['fwd_kernel'][22:60])
+" | tee $OUT/mb_k1.txt ;;
+graph_seq) run graph_seq; for C in "--force-dp --graph --per-rank 16" "--graph" "--graph" "--force-dp --per-rank 16" "--graph" "" "--graph"; do echo "--- bench.py $C"; ET_BENCH_STEP_TIMES=1 timeout 600 python bench.py $C --steps 20 --warmup 5 --no-cpu-baseline 2> $OUT/gs.err | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print(round(d['ms_per_step'],2), d['config']['step_graph'].get('replay_probe'))"; grep "step enqueue" $OUT/gs.err; done 2>&1 | tee $OUT/graph_seq.txt ;;
 smoke) run smoke; timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -3 $OUT/smoke.log ;;
 prof) run prof; (cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/bench_under_rocprof.json 2> $GRAFT_REPO_ROOT/$OUT/prof.err); find $OUT/prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv; find $OUT/prof -name "*kernel_trace.csv" | head -1 | xargs -I{} python tools/trace_streams.py {} > $OUT/trace_streams.txt 2>&1; cat $OUT/trace_streams.txt; find $OUT/prof -name "*.db" -delete; find $OUT/prof -name "*kernel_trace.csv" -size +20M -delete; head -8 $OUT/kernel_stats.csv | cut -c1-160 ;;
 pmc) run pmc; for C in FETCH_SIZE WRITE_SIZE; do (cd /tmp && timeout 900 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmc_$C -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/bench_pmc_$C.json 2> $GRAFT_REPO_ROOT/$OUT/pmc_$C.err); done; python tools/pmc_summarize.py $OUT > $OUT/pmc_bench_summary.csv; find $OUT -name "*.db" -delete; find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*kernel_trace.csv" -delete; head -12 $OUT/pmc_bench_summary.csv ;;
