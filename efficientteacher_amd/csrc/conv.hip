@@ -132,7 +132,7 @@ template <int BKV> __device__ __forceinline__ int lds_swz(int r) {
 
 // ---- one K-chunk of MFMAs from LDS --------------------------------------------------------------
 struct NoBetween { __device__ __forceinline__ void operator()(int) const {} };
-template <typename T, int BM, int BN, int WM, int WN, int BKV, typename BETWEEN = NoBetween, bool SWP = false>
+template <typename T, int BM, int BN, int WM, int WN, int BKV, typename BETWEEN = NoBetween>
 __device__ __forceinline__ void mma_chunk(const u32x4* __restrict__ sm, f32x16 (&acc)[BM / WM / 32][BN / WN / 32],
                                           int wm, int wn, int lane, BETWEEN between = BETWEEN()) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -166,11 +166,7 @@ __device__ __forceinline__ void mma_chunk(const u32x4* __restrict__ sm, f32x16 (
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) {
-                if constexpr (sizeof(T) == 2 && SWP) {
-                    // swapped operands: the tile comes out transposed (lane = pixel), see conv_epilogue_swp_act
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                        __builtin_bit_cast(bf16x8, bf[cur][tn]), __builtin_bit_cast(bf16x8, af[cur][tm]), acc[tm][tn], 0, 0, 0);
-                } else if constexpr (sizeof(T) == 2) {
+                if constexpr (sizeof(T) == 2) {
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                         __builtin_bit_cast(bf16x8, af[cur][tm]), __builtin_bit_cast(bf16x8, bf[cur][tn]), acc[tm][tn], 0, 0, 0);
                 } else {
@@ -434,245 +430,6 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BM / WM / 32][BN / W
     else conv_epilogue_act<T, BM, BN, WM, WN, ACT_NONE>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn);
 }
 
-// ---- epilogue of the SWAPPED operand order: stores straight from the accumulator registers ---------------------------------
-// With the MFMA operands exchanged (A = weight fragment, B = pixel fragment) a 32x32 accumulator tile is the TRANSPOSED
-// result: lane (l31, hi) owns output PIXEL l31 of the tile and register r is output channel 8*(r>>2) + 4*hi + (r&3).  The two
-// lanes of a pixel each hold one half of every channel octet; one v_permlane32_swap per dword trades the halves (et_device.h),
-// after which lane hi = 0 holds octets 0 and 2 of the 32 channels and lane hi = 1 octets 1 and 3: two 16-byte stores per lane
-// and tile, no LDS transposition, no slab waits (cdna_hip_programming.md T21; conv_stem_kernel does the same for the stem).
-// Everything the LDS epilogue does per (pixel, channel octet) -- residual, accumulate, BN-backward sums -- happens in that
-// layout unchanged.  Statistics (forward sums of the raw accumulators, or the BN-backward sums) are accumulated per lane over
-// the wave tile and reduced ONCE across the 32 pixels of a half-wave with a reduce-scatter (31 exchanges for 32 values).
-template <int BM, int BN, int WM, int WN, int ACT, bool LEAN>
-__device__ __forceinline__ void conv_epilogue_swp_act(f32x16 (&acc)[BM / WM / 32][BN / WN / 32], uint16_t* __restrict__ Y,
-                                                      const GatherGeom& g, const Epilogue& ep, int m0, int n0, int lane, int wm,
-                                                      int wn) {
-    constexpr int TM = BM / WM / 32, TN = BN / WN / 32, WCOLS = BN / WN;
-    constexpr int PF = TM == 2 ? 2 : 1;                  // row tiles whose epilogue operands (residual / accumulate, BN y) are in flight together
-    const int l31 = lane & 31, hi = lane >> 5;
-    const int cw0 = n0 + wn * WCOLS;                     // first channel of this wave's tile
-    const bool ident = (g.osy == 1 && g.osx == 1 && g.ooy == 0 && g.oox == 0 && g.QH == g.OH && g.QW == g.OW);
-    const bool bnb = ep.bn_y != nullptr;
-    const bool fstats = ep.stats != nullptr && !bnb;
-    // LEAN (a template constant: two kernels): a plain layer -- no per-channel affine, no residual / accumulate, no BN-backward
-    // sums (the student's forward convs and the plain dgrads).  Compiled together, the two forms cost the lean one 60 VGPRs (103 ->
-    // 166 on the 128x64 tile: a wave of occupancy) because the compiler hoists the general form's operands above the branch.
-    constexpr bool lean = LEAN;
-    // Channel tiles outermost: the statistics of ONE 32-channel tile are live at a time (32 registers beside the accumulators).
-    //   forward statistics  st[r] = sum, st[16 + r] = sum of squares of accumulator register r (channel as above);
-    //   BN-backward sums    st[8*m + e] = sum du, st[16 + 8*m + e] = sum du*y of channel 16*m + 8*hi + e
-    constexpr int RPW = (BM / WM) / 64;                  // 64-row blocks (partial-statistics rows) per wave tile
-    static_assert((BM / WM) % 64 == 0 && TM % PF == 0, "wave tiles are whole 64-row blocks");
-    const int nrows = (g.M + 63) / 64;
-    const int rw = (m0 + wm * (BM / WM)) / 64;
-    // pixel of every row tile (one per lane); lanes beyond M point at pixel 0 (valid memory: their loads are harmless, their
-    // stores are masked)
-    uint32_t pixs[TM];                                   // pixel INDEX (32 bits; host: tensors below 2^31 elements), widened at each use
-    unsigned pokm = 0u;
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-        const int p = m0 + wm * (BM / WM) + tm * 32 + l31;
-        const bool pok = p < g.M;
-        pokm |= pok ? (1u << tm) : 0u;
-        const uint32_t pp = pok ? p : 0;
-        uint32_t pix = pp;
-        if (!ident) {
-            const uint32_t t1 = fdiv(pp, g.dQW), qx = pp - t1 * g.QW;
-            const uint32_t n = fdiv(t1, g.dQH), qy = t1 - n * g.QH;
-            pix = (n * g.OH + (qy * g.osy + g.ooy)) * g.OW + (qx * g.osx + g.oox);
-        }
-        pixs[tm] = pix;
-    }
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-        float st[32];
-#pragma unroll
-        for (int i = 0; i < 32; ++i) st[i] = 0.f;
-        auto flush_fstats = [&]() {
-            // one partial row per 64 output rows (et_conv2d_stats_rows), as in the LDS epilogue: this wave's sums go to its first
-            // row, the other rows it covers are zeroed
-            const float tot = et_half_reduce_scatter32(st, l31);
-            const int which = l31 >> 4, j = l31 & 15;
-            const int ch = cw0 + tn * 32 + 8 * (j >> 2) + 4 * hi + (j & 3);
-            if (ch < g.Cout) {
-#pragma unroll
-                for (int r = 0; r < RPW; ++r) {
-                    if (rw + r >= nrows) break;
-                    ep.stats[((size_t)(rw + r) * 2 + which) * g.Cout + ch] = r == 0 ? tot : 0.f;
-                }
-            }
-        };
-        if (lean) {
-            // plain layer (the student's forward convs): activation, bf16 packing, ONE swap per packed pair, store
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm) {
-                const bool pok = (pokm >> tm) & 1u;
-                uint16_t* const yrow = Y + (long long)pixs[tm] * g.ldy;
-                if (fstats) {
-                    // rows beyond M were zero-filled operands: they add nothing
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) { const float raw = acc[tm][tn][r]; st[r] += raw; st[16 + r] += raw * raw; }
-                }
-#pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    const int co = cw0 + tn * 32 + 16 * m + 8 * hi;
-                    float a[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        float v = acc[tm][tn][8 * m + e];
-                        if constexpr (ACT == ACT_SILU) v = v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
-                        else if constexpr (ACT == ACT_RELU) v = fmaxf(v, 0.f);
-                        a[e] = v;
-                    }
-                    unsigned p0 = et_pack_bf2(a[0], a[1]), p1 = et_pack_bf2(a[2], a[3]);
-                    unsigned q0 = et_pack_bf2(a[4], a[5]), q1 = et_pack_bf2(a[6], a[7]);
-                    et_permlane32_swap(p0, q0);
-                    et_permlane32_swap(p1, q1);
-                    if (pok && co + 8 <= g.Cout) {
-                        *(u32x4*)(yrow + co) = mk4(p0, p1, q0, q1);
-                    } else if (pok && co < g.Cout) {
-                        const unsigned w4[4] = {p0, p1, q0, q1};
-#pragma unroll
-                        for (int e = 0; e < 8; ++e)          // static indices: a run-time index would put the array in scratch memory
-                            if (co + e < g.Cout) yrow[co + e] = (uint16_t)((w4[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
-                    }
-                }
-            }
-            if (fstats) flush_fstats();
-        } else {
-            // general form, one channel OCTET at a time (m outermost): live beside the accumulators are 16 per-channel constants,
-            // 16 statistics and the prefetched operands of PF row tiles -- the order keeps this form inside the register budget
-            // of the main loop (with both octets in flight the 128x128 tiles lost a wave of occupancy to their epilogue)
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                const int co = cw0 + tn * 32 + 16 * m + 8 * hi;
-                const bool cfull = co + 8 <= g.Cout;
-                const int cl = cfull ? co : 0;           // an octet beyond Cout reads octet 0 of the row instead (valid memory, never used)
-                // per-channel constants: the folded BatchNorm affine of an eval-mode forward (scale, bias) or the producer's
-                // BatchNorm affine of a BN-backward-sums dgrad (never both)
-                const float* const pcs = bnb ? ep.bn_scale : ep.scale;
-                const float* const pcb = bnb ? ep.bn_shift : ep.bias;
-                float cs[8], cb[8], sb[16];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const bool cok = co + e < g.Cout;
-                    cs[e] = (pcs && cok) ? pcs[co + e] : 1.0f;
-                    cb[e] = (pcb && cok) ? pcb[co + e] : 0.0f;
-                    sb[e] = 0.f; sb[8 + e] = 0.f;
-                }
-#pragma unroll
-                for (int t0 = 0; t0 < TM; t0 += PF) {
-                    // epilogue operands of PF row tiles, requested together (one memory latency, not one per tile): the addend
-                    // (residual, or the old value of an accumulating launch) and the BatchNorm y.  The scheduling barriers bound
-                    // the live ranges: without them the scheduler hoists the operands of EVERY tile.
-                    u32x4 radd[PF], rby[PF];
-#pragma unroll
-                    for (int t = 0; t < PF; ++t) {
-                        const long long pix = pixs[t0 + t];
-                        radd[t] = ep.res ? *(const u32x4*)((const uint16_t*)ep.res + pix * ep.ldr + cl)
-                                         : (ep.accumulate ? *(const u32x4*)(Y + pix * g.ldy + cl) : mk4(0, 0, 0, 0));
-                        rby[t] = bnb ? *(const u32x4*)((const uint16_t*)ep.bn_y + pix * ep.ld_bn + cl) : mk4(0, 0, 0, 0);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int t = 0; t < PF; ++t) {
-                        const int tm = t0 + t;
-                        const bool pok = (pokm >> tm) & 1u;
-                        const long long pix = pixs[tm];
-                        float v[8];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            unsigned x = __float_as_uint(acc[tm][tn][8 * m + e]), y = __float_as_uint(acc[tm][tn][8 * m + 4 + e]);
-                            et_permlane32_swap(x, y);
-                            v[e] = __uint_as_float(x); v[4 + e] = __uint_as_float(y);
-                        }
-                        if (!bnb) {
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) v[e] = v[e] * cs[e] + cb[e];
-                        }
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            if constexpr (ACT == ACT_SILU) v[e] = v[e] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[e]));
-                            else if constexpr (ACT == ACT_RELU) v[e] = fmaxf(v[e], 0.f);
-                        }
-                        if (pok && cfull) {
-                            uint16_t* const yp = Y + pix * g.ldy + co;
-                            const unsigned rw4[4] = {radd[t].x, radd[t].y, radd[t].z, radd[t].w};
-#pragma unroll
-                            for (int e = 0; e < 8; ++e)          // zeros when there is neither a residual nor an accumulate
-                                v[e] += __uint_as_float((e & 1) ? (rw4[e >> 1] & 0xffff0000u) : (rw4[e >> 1] << 16));
-                            if (ep.res && ep.accumulate) {       // both: the second addend is fetched here
-                                const u32x4 rr = *(const u32x4*)yp;
-                                const unsigned aw4[4] = {rr.x, rr.y, rr.z, rr.w};
-#pragma unroll
-                                for (int e = 0; e < 8; ++e) v[e] += __uint_as_float((e & 1) ? (aw4[e >> 1] & 0xffff0000u) : (aw4[e >> 1] << 16));
-                            }
-                            const u32x4 packed = mk4(et_pack_bf2(v[0], v[1]), et_pack_bf2(v[2], v[3]), et_pack_bf2(v[4], v[5]), et_pack_bf2(v[6], v[7]));
-                            *(u32x4*)yp = packed;
-                            if (bnb) {
-                                // statistics of exactly what the apply pass will read back: the bf16-ROUNDED dz
-                                const unsigned pw[4] = {packed.x, packed.y, packed.z, packed.w};
-                                const unsigned yw[4] = {rby[t].x, rby[t].y, rby[t].z, rby[t].w};
-                                auto body = [&](auto act_tag) {
-                                    constexpr int BACT = decltype(act_tag)::value;
-#pragma unroll
-                                    for (int e = 0; e < 8; ++e) {
-                                        const float dz = __uint_as_float((e & 1) ? (pw[e >> 1] & 0xffff0000u) : (pw[e >> 1] << 16));
-                                        const float yv = __uint_as_float((e & 1) ? (yw[e >> 1] & 0xffff0000u) : (yw[e >> 1] << 16));
-                                        const float u = yv * cs[e] + cb[e];
-                                        float gact = 1.f;
-                                        if constexpr (BACT == ACT_SILU) { const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-u)); gact = sg * (1.0f + u * (1.0f - sg)); }
-                                        else if constexpr (BACT == ACT_RELU) gact = u > 0.f ? 1.f : 0.f;
-                                        const float du = dz * gact;
-                                        sb[e] += du;
-                                        sb[8 + e] += du * yv;
-                                    }
-                                };
-                                if (ep.bn_act == ACT_SILU) body(std::integral_constant<int, ACT_SILU>{});
-                                else if (ep.bn_act == ACT_RELU) body(std::integral_constant<int, ACT_RELU>{});
-                                else body(std::integral_constant<int, ACT_NONE>{});
-                            }
-                        } else if (pok && co < g.Cout) {
-                            uint16_t* const yp = Y + pix * g.ldy + co;
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) {
-                                if (co + e >= g.Cout) continue;
-                                float x = v[e];
-                                if (ep.res) x += et_bf2f(((const uint16_t*)ep.res)[pix * ep.ldr + co + e]);
-                                if (ep.accumulate) x += et_bf2f(yp[e]);
-                                yp[e] = et_f2bf(x);
-                            }
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-                if (bnb) {
-                    // BN-backward sums of this octet: reduce-scatter the 16 values over the half-wave (each ends up on two lanes)
-                    const float tot = et_half_reduce_scatter16(sb, l31);
-                    const int which = (l31 >> 3) & 1, e = l31 & 7;
-                    if (!(l31 & 16) && cfull) {
-#pragma unroll
-                        for (int r = 0; r < RPW; ++r) {
-                            if (rw + r >= nrows) break;
-                            ep.stats[((size_t)(rw + r) * 2 + which) * g.Cout + co + e] = r == 0 ? tot : 0.f;
-                        }
-                    }
-                }
-            }
-        }
-    }
-}
-
-template <int BM, int BN, int WM, int WN, bool LEAN>
-__device__ __forceinline__ void conv_epilogue_swp(f32x16 (&acc)[BM / WM / 32][BN / WN / 32], uint16_t* __restrict__ Y,
-                                                  const GatherGeom& g, const Epilogue& ep, int m0, int n0, int lane, int wm, int wn) {
-    if (ep.act == ACT_SILU) conv_epilogue_swp_act<BM, BN, WM, WN, ACT_SILU, LEAN>(acc, Y, g, ep, m0, n0, lane, wm, wn);
-    else if (ep.act == ACT_RELU) conv_epilogue_swp_act<BM, BN, WM, WN, ACT_RELU, LEAN>(acc, Y, g, ep, m0, n0, lane, wm, wn);
-    else conv_epilogue_swp_act<BM, BN, WM, WN, ACT_NONE, LEAN>(acc, Y, g, ep, m0, n0, lane, wm, wn);
-}
-// which of the two swapped-order kernels a launch needs (host)
-static bool epilogue_is_lean(const Epilogue& ep) { return !ep.scale && !ep.bias && !ep.res && !ep.accumulate && !ep.bn_y; }
-
 // ---- forward / dgrad gather-GEMM ----------------------------------------------------------------
 template <typename T, int BM, int BN, int WM, int WN, int BKV, bool UTAP>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const T* __restrict__ X, const T* __restrict__ W,
@@ -841,10 +598,10 @@ template <int N> __device__ __forceinline__ void et_wait_vmem_le() {
 // over the loaded L2/fabric latency (measured: ~10 TB/s of L2->LDS traffic with 2 x 32 KB bursts per CU,
 // MFMA busy ~30 %), not LDS or MFMA issue -- hence deeper rings and, where the layer has the rows, a
 // 256-row tile (1.33x the flops per staged byte).
-template <typename T, int BM, int BN, int WM, int WN, int BKV, int NS, bool UTAP, bool SWP, bool LEAN>
-__device__ __forceinline__ void conv_gemm_glds_body(const T* __restrict__ X, const T* __restrict__ W,
-                                                    T* __restrict__ Y, const T* __restrict__ ZERO,
-                                                    const GatherGeom& g, const Epilogue& ep) {
+template <typename T, int BM, int BN, int WM, int WN, int BKV, int NS, bool UTAP>
+__global__ __launch_bounds__(64 * WM * WN, (NS == 3 && BKV == 4 && BM == 128) ? 3 : 1) void conv_gemm_glds_kernel(const T* __restrict__ X, const T* __restrict__ W,
+                                                             T* __restrict__ Y, const T* __restrict__ ZERO,
+                                                             GatherGeom g, Epilogue ep) {
     constexpr int VEC = et_elem<T>::VEC;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int NT = 64 * WM * WN;             // 4 waves (2x2) or 8 waves (2x4) per workgroup
@@ -979,30 +736,13 @@ __device__ __forceinline__ void conv_gemm_glds_body(const T* __restrict__ X, con
         // the very LDS-DMA the ring keeps in flight
         if constexpr (NS > 2) __builtin_amdgcn_s_barrier(); else __syncthreads();
         if (c + NS - 1 < nchunks) { stage(lds_raw + wr * STAGE_VEC, c + NS - 1, tap_u, cv_u); ET_ADVANCE_CURSOR(); }
-        mma_chunk<T, BM, BN, WM, WN, BKV, NoBetween, SWP>(lds_raw + rd * STAGE_VEC, acc, wm, wn, lane);
+        mma_chunk<T, BM, BN, WM, WN, BKV>(lds_raw + rd * STAGE_VEC, acc, wm, wn, lane);
         rd = rd + 1 == NS ? 0 : rd + 1;
         wr = wr + 1 == NS ? 0 : wr + 1;
     }
+    __syncthreads();                               // the epilogue reuses the ring as its staging area
 #undef ET_ADVANCE_CURSOR
-    if constexpr (SWP) {
-        conv_epilogue_swp<BM, BN, WM, WN, LEAN>(acc, Y, g, ep, m0, n0, lane, wm, wn);      // registers only: no LDS, no barrier
-    } else {
-        __syncthreads();                           // the epilogue reuses the ring as its staging area
-        conv_epilogue<T, BM, BN, WM, WN>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn);
-    }
-}
-template <typename T, int BM, int BN, int WM, int WN, int BKV, int NS, bool UTAP>
-__global__ __launch_bounds__(64 * WM * WN, (NS == 3 && BKV == 4 && BM == 128) ? 3 : 1) void conv_gemm_glds_kernel(const T* __restrict__ X, const T* __restrict__ W,
-                                                             T* __restrict__ Y, const T* __restrict__ ZERO,
-                                                             GatherGeom g, Epilogue ep) {
-    conv_gemm_glds_body<T, BM, BN, WM, WN, BKV, NS, UTAP, false, false>(X, W, Y, ZERO, g, ep);
-}
-// the same gather-GEMM with the MFMA operands swapped and the register epilogue (bf16 only)
-template <int BM, int BN, int WM, int WN, int BKV, int NS, bool UTAP, bool LEAN>
-__global__ __launch_bounds__(64 * WM * WN, (NS == 3 && BKV == 4 && BM == 128) ? 3 : 1) void conv_gemm_glds_swp_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W,
-                                                             uint16_t* __restrict__ Y, const uint16_t* __restrict__ ZERO,
-                                                             GatherGeom g, Epilogue ep) {
-    conv_gemm_glds_body<uint16_t, BM, BN, WM, WN, BKV, NS, UTAP, true, LEAN>(X, W, Y, ZERO, g, ep);
+    conv_epilogue<T, BM, BN, WM, WN>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn);
 }
 
 // ---- 3x3 stride-1 gather-GEMM with the activation rows shared by the three taps of a kernel row ("row shift") --------------
@@ -1016,10 +756,10 @@ __global__ __launch_bounds__(64 * WM * WN, (NS == 3 && BKV == 4 && BM == 128) ? 
 // Only the weight tile is staged per step: (BM + 16) + 3 * BN instead of 3 * (BM + BN) rows per unit of L2->LDS traffic.
 // Ring: two A-unit slots + two B-step slots; B(s+1) is issued at the start of step s, A(u+1) at the first step of unit u, BEHIND
 // that step's B so that the counted vmcnt wait of the next step releases B while A is still in flight.
-template <int BM, int BN, int WM, int WN, bool SWP, bool LEAN>
-__device__ __forceinline__ void conv_gemm_rs_body(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W,
-                                                  uint16_t* __restrict__ Y, const uint16_t* __restrict__ ZERO,
-                                                  const GatherGeom& g, const Epilogue& ep) {
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, BN <= 64 ? 3 : 2) void conv_gemm_rs_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W,
+                                                                       uint16_t* __restrict__ Y, const uint16_t* __restrict__ ZERO,
+                                                                       GatherGeom g, Epilogue ep) {
     using T = uint16_t;
     constexpr int VEC = 8, BKV = 8;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -1144,14 +884,9 @@ __device__ __forceinline__ void conv_gemm_rs_body(const uint16_t* __restrict__ X
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-                for (int tn = 0; tn < TN; ++tn) {
-                    if constexpr (SWP)
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                            __builtin_bit_cast(bf16x8, bf[cur][tn]), __builtin_bit_cast(bf16x8, af[cur][tm]), acc[tm][tn], 0, 0, 0);
-                    else
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                            __builtin_bit_cast(bf16x8, af[cur][tm]), __builtin_bit_cast(bf16x8, bf[cur][tn]), acc[tm][tn], 0, 0, 0);
-                }
+                for (int tn = 0; tn < TN; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        __builtin_bit_cast(bf16x8, af[cur][tm]), __builtin_bit_cast(bf16x8, bf[cur][tn]), acc[tm][tn], 0, 0, 0);
         }
     };
 
@@ -1189,24 +924,8 @@ __device__ __forceinline__ void conv_gemm_rs_body(const uint16_t* __restrict__ X
         step(std::integral_constant<int, 2>{});
         j = nj; cv_u = ncv;
     }
-    if constexpr (SWP) {
-        conv_epilogue_swp<BM, BN, WM, WN, LEAN>(acc, Y, g, ep, m0, n0, lane, wm, wn);
-    } else {
-        __syncthreads();                                 // the epilogue reuses the ring as its staging area
-        conv_epilogue<T, BM, BN, WM, WN>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn);
-    }
-}
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN, BN <= 64 ? 3 : 2) void conv_gemm_rs_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W,
-                                                                       uint16_t* __restrict__ Y, const uint16_t* __restrict__ ZERO,
-                                                                       GatherGeom g, Epilogue ep) {
-    conv_gemm_rs_body<BM, BN, WM, WN, false, false>(X, W, Y, ZERO, g, ep);
-}
-template <int BM, int BN, int WM, int WN, bool LEAN>
-__global__ __launch_bounds__(64 * WM * WN, BN <= 64 ? 3 : 2) void conv_gemm_rs_swp_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W,
-                                                                       uint16_t* __restrict__ Y, const uint16_t* __restrict__ ZERO,
-                                                                       GatherGeom g, Epilogue ep) {
-    conv_gemm_rs_body<BM, BN, WM, WN, true, LEAN>(X, W, Y, ZERO, g, ep);
+    __syncthreads();                                     // the epilogue reuses the ring as its staging area
+    conv_epilogue<T, BM, BN, WM, WN>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn);
 }
 
 // ---- forward / dgrad gather-GEMM, 256x256 tile, two wave groups in anti-phase ("ping-pong") ----------------
@@ -1237,10 +956,9 @@ template <int N> __device__ __forceinline__ void et_wait_vmem_le_pp() {
     __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 0xF) | ((N >> 4) << 14));
 }
 
-template <bool SWP, bool LEAN>
-__device__ __forceinline__ void conv_gemm_pp_body(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W,
-                                                  uint16_t* __restrict__ Y, const uint16_t* __restrict__ ZERO,
-                                                  const GatherGeom& g, const Epilogue& ep) {
+__global__ __launch_bounds__(512, 2) void conv_gemm_pp_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W,
+                                                              uint16_t* __restrict__ Y, const uint16_t* __restrict__ ZERO,
+                                                              GatherGeom g, Epilogue ep) {
     constexpr int BM = 256, BN = 256, WM = 2, WN = 4, BKV = 8, VEC = 8;
     constexpr int HALF_VEC = 128 * BKV;            // one half-tile in 16-byte vectors (16 KB)
     constexpr int EPI_VEC = EpiLds<BM, BN, WM, WN>::VEC16;
@@ -1364,12 +1082,8 @@ __device__ __forceinline__ void conv_gemm_pp_body(const uint16_t* __restrict__ X
         for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                if constexpr (SWP)
-                    acc[2 * i + t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bf[kk]),
-                                                                               __builtin_bit_cast(bf16x8, af[t][kk]), acc[2 * i + t][j], 0, 0, 0);
-                else
-                    acc[2 * i + t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[t][kk]),
-                                                                               __builtin_bit_cast(bf16x8, bf[kk]), acc[2 * i + t][j], 0, 0, 0);
+                acc[2 * i + t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[t][kk]),
+                                                                           __builtin_bit_cast(bf16x8, bf[kk]), acc[2 * i + t][j], 0, 0, 0);
                 const int n = kk * 2 + t;
                 if (sk >= 0 && (n == 1 || n == 4)) {
                     __builtin_amdgcn_sched_barrier(0);
@@ -1432,27 +1146,12 @@ __device__ __forceinline__ void conv_gemm_pp_body(const uint16_t* __restrict__ X
     }
     chunk(buf, std::true_type{});
     if (wm == 0) __builtin_amdgcn_s_barrier();     // balances group 1's extra barrier
-    if constexpr (SWP) {
-        conv_epilogue_swp<BM, BN, WM, WN, LEAN>(acc, Y, g, ep, m0, n0, lane, wm, wn);
-    } else {
-        __syncthreads();                           // the epilogue reuses the half-tile buffers as its staging area
-        conv_epilogue<uint16_t, BM, BN, WM, WN>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn);
-    }
+    __syncthreads();                               // the epilogue reuses the half-tile buffers as its staging area
+    conv_epilogue<uint16_t, BM, BN, WM, WN>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn);
 #undef ET_PP_DECODE
 #undef ET_PP_ADVANCE
 #undef ET_PP_BAR
 #undef ET_PP_WAIT
-}
-__global__ __launch_bounds__(512, 2) void conv_gemm_pp_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W,
-                                                              uint16_t* __restrict__ Y, const uint16_t* __restrict__ ZERO,
-                                                              GatherGeom g, Epilogue ep) {
-    conv_gemm_pp_body<false, false>(X, W, Y, ZERO, g, ep);
-}
-template <bool LEAN>
-__global__ __launch_bounds__(512, 2) void conv_gemm_pp_swp_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W,
-                                                                  uint16_t* __restrict__ Y, const uint16_t* __restrict__ ZERO,
-                                                                  GatherGeom g, Epilogue ep) {
-    conv_gemm_pp_body<true, LEAN>(X, W, Y, ZERO, g, ep);
 }
 
 // ---- the ping-pong tile with the activation rows shared by the three taps of a kernel row --------------------------------
@@ -1469,10 +1168,9 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_pp_swp_kernel(const uint16_t
 // RAW / WAR as in conv_gemm_pp_kernel (its header): the weight schedule is unchanged, the activation unit is written two
 // units before... no: ONE unit before it is read (buffer (u+1)&1 during unit u; its last reader was unit u-1).
 #define PPRS_ROWS 320
-template <bool SWP, bool LEAN>
-__device__ __forceinline__ void conv_gemm_pprs_body(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W,
-                                                    uint16_t* __restrict__ Y, const uint16_t* __restrict__ ZERO,
-                                                    const GatherGeom& g, const Epilogue& ep) {
+__global__ __launch_bounds__(512, 2) void conv_gemm_pprs_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W,
+                                                                uint16_t* __restrict__ Y, const uint16_t* __restrict__ ZERO,
+                                                                GatherGeom g, Epilogue ep) {
     constexpr int BM = 256, BN = 256, WM = 2, WN = 4, BKV = 8, VEC = 8;
     constexpr int HALF_VEC = 128 * BKV;            // one weight half-tile in 16-byte vectors (16 KB)
     constexpr int A_VEC = PPRS_ROWS * BKV;         // one activation unit (40 KB)
@@ -1580,12 +1278,8 @@ __device__ __forceinline__ void conv_gemm_pprs_body(const uint16_t* __restrict__
         for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                if constexpr (SWP)
-                    acc[2 * i + t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bf[kk]),
-                                                                               __builtin_bit_cast(bf16x8, af[t][kk]), acc[2 * i + t][j], 0, 0, 0);
-                else
-                    acc[2 * i + t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[t][kk]),
-                                                                               __builtin_bit_cast(bf16x8, bf[kk]), acc[2 * i + t][j], 0, 0, 0);
+                acc[2 * i + t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[t][kk]),
+                                                                           __builtin_bit_cast(bf16x8, bf[kk]), acc[2 * i + t][j], 0, 0, 0);
                 const int n = kk * 2 + t;
                 if (n == 1) { __builtin_amdgcn_sched_barrier(0); piece0(); __builtin_amdgcn_sched_barrier(0); }
                 if (n == 4) { __builtin_amdgcn_sched_barrier(0); piece1(); __builtin_amdgcn_sched_barrier(0); }
@@ -1653,25 +1347,10 @@ __device__ __forceinline__ void conv_gemm_pprs_body(const uint16_t* __restrict__
         jrow = nj; cv_u = ncv;
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();     // balances group 1's extra barrier
-    if constexpr (SWP) {
-        conv_epilogue_swp<BM, BN, WM, WN, LEAN>(acc, Y, g, ep, m0, n0, lane, wm, wn);
-    } else {
-        __syncthreads();                           // the epilogue reuses the ring as its staging area
-        conv_epilogue<uint16_t, BM, BN, WM, WN>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn);
-    }
+    __syncthreads();                               // the epilogue reuses the ring as its staging area
+    conv_epilogue<uint16_t, BM, BN, WM, WN>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn);
 #undef ET_PP_BAR
 #undef ET_PP_WAIT
-}
-__global__ __launch_bounds__(512, 2) void conv_gemm_pprs_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W,
-                                                                uint16_t* __restrict__ Y, const uint16_t* __restrict__ ZERO,
-                                                                GatherGeom g, Epilogue ep) {
-    conv_gemm_pprs_body<false, false>(X, W, Y, ZERO, g, ep);
-}
-template <bool LEAN>
-__global__ __launch_bounds__(512, 2) void conv_gemm_pprs_swp_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W,
-                                                                    uint16_t* __restrict__ Y, const uint16_t* __restrict__ ZERO,
-                                                                    GatherGeom g, Epilogue ep) {
-    conv_gemm_pprs_body<true, LEAN>(X, W, Y, ZERO, g, ep);
 }
 
 // ---- the stem: 6x6 stride-2 pad-2 convolution of the packed image (8 channels, 3 used) ----------------------------
@@ -2598,23 +2277,9 @@ static bool rs_eligible(const GatherGeom& g, int BM, int unit_rows) {
         if (g.dy[t] != sgn * (t / 3 - 1) || g.dx[t] != sgn * (t % 3 - 1) || g.wt[t] != t) return false;
     return true;
 }
-struct GemmPlan { int kind, BM, BN, WM, WN, BKV, NS; bool utap; bool swp = false; };
+struct GemmPlan { int kind, BM, BN, WM, WN, BKV, NS; bool utap; };
 
-static GemmPlan plan_gemm_tiles(const GatherGeom& g, int elem_bytes, bool have_zero_page);
-// tile plan + operand order.  bf16 LDS-DMA kernels run with the MFMA operands swapped and the register epilogue
-// (conv_epilogue_swp_act); ET_CONV_SWP is a bit mask of kernel families for A/B runs: 1 = the lockstep 128-row tiles,
-// 2 = the row-sharing 128-row tiles, 4 = the ping-pong 256x256 tiles (0: the LDS-transposing epilogue everywhere)
 static GemmPlan plan_gemm(const GatherGeom& g, int elem_bytes, bool have_zero_page) {
-    GemmPlan p = plan_gemm_tiles(g, elem_bytes, have_zero_page);
-    const int swp = env_int("ET_CONV_SWP", 7);          // read per call (not cached): the tests run both operand orders in one process
-    if (elem_bytes == 2) {
-        if (p.kind == GEMM_GLDS) p.swp = (swp & 1) != 0;
-        else if (p.kind == GEMM_RS) p.swp = (swp & 2) != 0;
-        else if (p.kind == GEMM_PP || p.kind == GEMM_PPRS) p.swp = (swp & 4) != 0;
-    }
-    return p;
-}
-static GemmPlan plan_gemm_tiles(const GatherGeom& g, int elem_bytes, bool have_zero_page) {
     // Build-time constants that were tuning knobs in r01 / r02 (swept on the step, profiles/r02_step_knob_sweep*_same_box.log, and
     // per layer, profiles/r02_microbench_narrow_k.log): GEMMs with K <= 128 elements use the 128x64 tile (3 workgroups per CU for
     // the HBM-bound short-K 1x1 layers; at K = 256 the 128-wide tile re-reads the activations half as often: 150 -> 124 us on
@@ -2664,10 +2329,9 @@ static GemmPlan plan_gemm_tiles(const GatherGeom& g, int elem_bytes, bool have_z
 // the name rocprofv3 prints for the plan's kernel (template arguments spelled as the demangler does)
 static void plan_name(const GemmPlan& p, int elem_bytes, char* buf, int n) {
     const char* t = elem_bytes == 2 ? "unsigned short" : "float";
-    if (p.kind == GEMM_PP) snprintf(buf, n, p.swp ? "conv_gemm_pp_swp_kernel" : "conv_gemm_pp_kernel");
-    else if (p.kind == GEMM_PPRS) snprintf(buf, n, p.swp ? "conv_gemm_pprs_swp_kernel" : "conv_gemm_pprs_kernel");
-    else if (p.kind == GEMM_RS) snprintf(buf, n, "conv_gemm_rs%s_kernel<%d, %d, %d, %d>", p.swp ? "_swp" : "", p.BM, p.BN, p.WM, p.WN);
-    else if (p.kind == GEMM_GLDS && p.swp) snprintf(buf, n, "conv_gemm_glds_swp_kernel<%d, %d, %d, %d, %d, %d, %s>", p.BM, p.BN, p.WM, p.WN, p.BKV, p.NS, p.utap ? "true" : "false");
+    if (p.kind == GEMM_PP) snprintf(buf, n, "conv_gemm_pp_kernel");
+    else if (p.kind == GEMM_PPRS) snprintf(buf, n, "conv_gemm_pprs_kernel");
+    else if (p.kind == GEMM_RS) snprintf(buf, n, "conv_gemm_rs_kernel<%d, %d, %d, %d>", p.BM, p.BN, p.WM, p.WN);
     else if (p.kind == GEMM_GLDS) snprintf(buf, n, "conv_gemm_glds_kernel<%s, %d, %d, %d, %d, %d, %d, %s>", t, p.BM, p.BN, p.WM, p.WN, p.BKV, p.NS, p.utap ? "true" : "false");
     else snprintf(buf, n, "conv_gemm_kernel<%s, %d, %d, %d, %d, %d, %s>", t, p.BM, p.BN, p.WM, p.WN, p.BKV, p.utap ? "true" : "false");
 }
@@ -2678,46 +2342,26 @@ static int launch_gemm(const void* X, const void* W, void* Y, const void* zero16
     if (g.M <= 0) return 0;
     const int nfast = 1;
     g.nfast = nfast;
-    const GemmPlan p0 = plan_gemm(g, (int)sizeof(T), zero16 != nullptr);
-    g.ntm = (g.M + p0.BM - 1) / p0.BM;
-    g.ntn = (g.Cout + p0.BN - 1) / p0.BN;
+    const GemmPlan p = plan_gemm(g, (int)sizeof(T), zero16 != nullptr);
+    g.ntm = (g.M + p.BM - 1) / p.BM;
+    g.ntn = (g.Cout + p.BN - 1) / p.BN;
     const T* x = (const T*)X; const T* w = (const T*)W; T* y = (T*)Y; const T* z = (const T*)zero16;
-    const dim3 grid(g.ntm * g.ntn), block(64 * p0.WM * p0.WN);
-    const bool lean = epilogue_is_lean(ep);
-    // forward statistics together with an affine / residual epilogue (no caller in the training step): the swapped-order kernels
-    // do not carry that combination, the LDS-epilogue kernels do
-    GemmPlan p = p0;
-    if (p.swp && !lean && ep.stats && !ep.bn_y) p.swp = false;
-#define ET_GLDS(BM_, BN_, WM_, WN_, BKV_, NS_, UT_)                                                                                  \
-    do {                                                                                                                             \
-        if constexpr (sizeof(T) == 2) {                                                                                              \
-            if (p.swp) {                                                                                                             \
-                if (lean) hipLaunchKernelGGL((conv_gemm_glds_swp_kernel<BM_, BN_, WM_, WN_, BKV_, NS_, UT_, true>), grid, block, 0, s, \
-                                   (const uint16_t*)x, (const uint16_t*)w, (uint16_t*)y, (const uint16_t*)z, g, ep);                 \
-                else hipLaunchKernelGGL((conv_gemm_glds_swp_kernel<BM_, BN_, WM_, WN_, BKV_, NS_, UT_, false>), grid, block, 0, s,   \
-                                   (const uint16_t*)x, (const uint16_t*)w, (uint16_t*)y, (const uint16_t*)z, g, ep);                 \
-                break;                                                                                                               \
-            }                                                                                                                        \
-        }                                                                                                                            \
-        hipLaunchKernelGGL((conv_gemm_glds_kernel<T, BM_, BN_, WM_, WN_, BKV_, NS_, UT_>), grid, block, 0, s, x, w, y, z, g, ep);    \
-    } while (0)
+    const dim3 grid(g.ntm * g.ntn), block(64 * p.WM * p.WN);
+#define ET_GLDS(BM_, BN_, WM_, WN_, BKV_, NS_, UT_) \
+    hipLaunchKernelGGL((conv_gemm_glds_kernel<T, BM_, BN_, WM_, WN_, BKV_, NS_, UT_>), grid, block, 0, s, x, w, y, z, g, ep)
 #define ET_REG(BN_, BKV_, UT_) \
     hipLaunchKernelGGL((conv_gemm_kernel<T, 128, BN_, 2, 2, BKV_, UT_>), grid, block, 0, s, x, w, y, g, ep)
     const int key = p.BM * 100000 + p.BN * 100 + p.BKV * 10 + p.NS;
     if (p.kind == GEMM_PP) {
         if constexpr (sizeof(T) == 2) {
-            if (p.swp && lean) hipLaunchKernelGGL(conv_gemm_pp_swp_kernel<true>, grid, block, 0, s, (const uint16_t*)x, (const uint16_t*)w, (uint16_t*)y, (const uint16_t*)z, g, ep);
-            else if (p.swp) hipLaunchKernelGGL(conv_gemm_pp_swp_kernel<false>, grid, block, 0, s, (const uint16_t*)x, (const uint16_t*)w, (uint16_t*)y, (const uint16_t*)z, g, ep);
-            else hipLaunchKernelGGL(conv_gemm_pp_kernel, grid, block, 0, s, (const uint16_t*)x, (const uint16_t*)w, (uint16_t*)y, (const uint16_t*)z, g, ep);
+            hipLaunchKernelGGL(conv_gemm_pp_kernel, grid, block, 0, s, (const uint16_t*)x, (const uint16_t*)w, (uint16_t*)y, (const uint16_t*)z, g, ep);
             return 0;
         }
         return -2;
     }
     if (p.kind == GEMM_PPRS) {
         if constexpr (sizeof(T) == 2) {
-            if (p.swp && lean) hipLaunchKernelGGL(conv_gemm_pprs_swp_kernel<true>, grid, block, 0, s, (const uint16_t*)x, (const uint16_t*)w, (uint16_t*)y, (const uint16_t*)z, g, ep);
-            else if (p.swp) hipLaunchKernelGGL(conv_gemm_pprs_swp_kernel<false>, grid, block, 0, s, (const uint16_t*)x, (const uint16_t*)w, (uint16_t*)y, (const uint16_t*)z, g, ep);
-            else hipLaunchKernelGGL(conv_gemm_pprs_kernel, grid, block, 0, s, (const uint16_t*)x, (const uint16_t*)w, (uint16_t*)y, (const uint16_t*)z, g, ep);
+            hipLaunchKernelGGL(conv_gemm_pprs_kernel, grid, block, 0, s, (const uint16_t*)x, (const uint16_t*)w, (uint16_t*)y, (const uint16_t*)z, g, ep);
             return 0;
         }
         return -2;
@@ -2725,16 +2369,8 @@ static int launch_gemm(const void* X, const void* W, void* Y, const void* zero16
     if (p.kind == GEMM_RS) {
         if constexpr (sizeof(T) == 2) {
             const uint16_t *xs = (const uint16_t*)x, *ws = (const uint16_t*)w, *zs = (const uint16_t*)z;
-            if (p.swp && lean) {
-                if (p.BN == 128) hipLaunchKernelGGL((conv_gemm_rs_swp_kernel<128, 128, 2, 2, true>), grid, block, 0, s, xs, ws, (uint16_t*)y, zs, g, ep);
-                else hipLaunchKernelGGL((conv_gemm_rs_swp_kernel<128, 64, 2, 2, true>), grid, block, 0, s, xs, ws, (uint16_t*)y, zs, g, ep);
-            } else if (p.swp) {
-                if (p.BN == 128) hipLaunchKernelGGL((conv_gemm_rs_swp_kernel<128, 128, 2, 2, false>), grid, block, 0, s, xs, ws, (uint16_t*)y, zs, g, ep);
-                else hipLaunchKernelGGL((conv_gemm_rs_swp_kernel<128, 64, 2, 2, false>), grid, block, 0, s, xs, ws, (uint16_t*)y, zs, g, ep);
-            } else {
-                if (p.BN == 128) hipLaunchKernelGGL((conv_gemm_rs_kernel<128, 128, 2, 2>), grid, block, 0, s, xs, ws, (uint16_t*)y, zs, g, ep);
-                else hipLaunchKernelGGL((conv_gemm_rs_kernel<128, 64, 2, 2>), grid, block, 0, s, xs, ws, (uint16_t*)y, zs, g, ep);
-            }
+            if (p.BN == 128) hipLaunchKernelGGL((conv_gemm_rs_kernel<128, 128, 2, 2>), grid, block, 0, s, xs, ws, (uint16_t*)y, zs, g, ep);
+            else hipLaunchKernelGGL((conv_gemm_rs_kernel<128, 64, 2, 2>), grid, block, 0, s, xs, ws, (uint16_t*)y, zs, g, ep);
             return 0;
         }
         return -2;
@@ -3119,7 +2755,7 @@ extern "C" int et_conv2d_kernel_name(int op, int dtype, int N, int IH, int IW, i
 
 extern "C" int et_env_knobs(char* buf, int buflen) {
     // every ET_* tuning knob that is SET in this process's environment, as "NAME=value;..." (bench.py records it)
-    static const char* names[] = {"ET_CONV_GLDS", "ET_CONV_BIG", "ET_CONV_BIG_MINFILL", "ET_CONV_PP", "ET_CONV_RS", "ET_CONV_PPRS", "ET_CONV_SWP", "ET_CONV_STEM", "ET_CONV_STEM_WGS",
+    static const char* names[] = {"ET_CONV_GLDS", "ET_CONV_BIG", "ET_CONV_BIG_MINFILL", "ET_CONV_PP", "ET_CONV_RS", "ET_CONV_PPRS", "ET_CONV_STEM", "ET_CONV_STEM_WGS",
                                   "ET_WGRAD_TR", "ET_WGRAD_BIG", "ET_WGRAD_RS", "ET_WGRAD_GROUP", "ET_WGRAD_STALE", "ET_WGRAD_STREAM", "ET_FUSE_BN_BWD",
                                   "ET_STEP_GRAPH", "ET_ALLREDUCE_CHUNK_MB", "ET_RCCL_CHANNELS", "ET_DP_SINGLE_RANK", "ET_HIP_LIB"};
     if (!buf || buflen < 1) return -1;

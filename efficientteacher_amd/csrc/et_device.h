@@ -2,7 +2,6 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <type_traits>
 
 #define ET_WAVE 64
 
@@ -96,56 +95,3 @@ __device__ __forceinline__ void et_glds16(const void* g, void* lds_wave_base) {
 }
 // s_waitcnt vmcnt(0): all of this wave's LDS-DMA writes have landed (expcnt / lgkmcnt left at max)
 __device__ __forceinline__ void et_wait_vmem() { __builtin_amdgcn_s_waitcnt(0x0F70); }
-
-// ---- half-wave exchange (gfx950 v_permlane32_swap_b32 vdst, src): lanes 32-63 of `vdst` trade places with lanes 0-31 of `src`,
-// the other two halves stay put (cdna_hip_programming.md T21).  After it lane i < 32 holds {its vdst, lane i+32's vdst} and
-// lane i+32 holds {lane i's src, its src}, in (vdst, src).  The host form is what the CPU emulator runs: same result.
-__device__ __forceinline__ void et_permlane32_swap(unsigned& vdst, unsigned& src) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    const auto r = __builtin_amdgcn_permlane32_swap(vdst, src, false, false);
-    vdst = r[0]; src = r[1];
-#else
-    const bool up = (threadIdx.x & 63) >= 32;
-    const unsigned t = __shfl_xor(up ? vdst : src, 32);
-    if (up) vdst = t; else src = t;
-#endif
-}
-
-// reduce-scatter over the 32 lanes of a half-wave: on return lane (l & 31) == j holds the sum over its half-wave of v[j]
-// (31 exchanges for 32 values; a plain xor-reduction of every value would take 160).  The step width is a template constant:
-// with a run-time shift in the loop header the compiler does not unroll and puts v[] into scratch memory.
-template <int S> __device__ __forceinline__ void et_half_reduce_scatter_step(float (&v)[32], int l31) {
-    const bool up = (l31 & S) != 0;
-#pragma unroll
-    for (int i = 0; i < S; ++i) {
-        const float keep = up ? v[S + i] : v[i];
-        const float send = up ? v[i] : v[S + i];
-        v[i] = keep + __shfl_xor(send, S);
-    }
-}
-__device__ __forceinline__ float et_half_reduce_scatter32(float (&v)[32], int l31) {
-    et_half_reduce_scatter_step<16>(v, l31);
-    et_half_reduce_scatter_step<8>(v, l31);
-    et_half_reduce_scatter_step<4>(v, l31);
-    et_half_reduce_scatter_step<2>(v, l31);
-    et_half_reduce_scatter_step<1>(v, l31);
-    return v[0];
-}
-// the same for 16 values: lane (l & 15) == j -- and lane j + 16 -- hold the sum over the half-wave of v[j]
-__device__ __forceinline__ float et_half_reduce_scatter16(float (&v)[16], int l31) {
-    auto step = [&](auto s_tag) {
-        constexpr int S = decltype(s_tag)::value;
-        const bool up = (l31 & S) != 0;
-#pragma unroll
-        for (int i = 0; i < S; ++i) {
-            const float keep = up ? v[S + i] : v[i];
-            const float send = up ? v[i] : v[S + i];
-            v[i] = keep + __shfl_xor(send, S);
-        }
-    };
-    step(std::integral_constant<int, 8>{});
-    step(std::integral_constant<int, 4>{});
-    step(std::integral_constant<int, 2>{});
-    step(std::integral_constant<int, 1>{});
-    return v[0] + __shfl_xor(v[0], 16);
-}

@@ -181,40 +181,10 @@ SELECT = [
 ]
 
 
-def _swp_name(name, mask=None):
-    """SELECT spells the LDS-epilogue (operand order A = pixels) kernel names; the library runs the bf16 LDS-DMA kernels with the
-    operands swapped and the register epilogue by default (ET_CONV_SWP bit mask: 1 lockstep 128-row tiles, 2 row-sharing tiles,
-    4 ping-pong 256x256 tiles) under these names."""
-    import os
-    mask = int(os.environ.get("ET_CONV_SWP", "7")) if mask is None else mask
-    if name is None:
-        return None
-    if name.startswith("conv_gemm_glds_kernel<unsigned short, ") and mask & 1:
-        return "conv_gemm_glds_swp_kernel<" + name[len("conv_gemm_glds_kernel<unsigned short, "):]
-    if name.startswith("conv_gemm_rs_kernel<") and mask & 2:
-        return name.replace("conv_gemm_rs_kernel<", "conv_gemm_rs_swp_kernel<")
-    if name in ("conv_gemm_pp_kernel", "conv_gemm_pprs_kernel") and mask & 4:
-        return name.replace("_kernel", "_swp_kernel")
-    return name
-
-
-@pytest.fixture(params=[7, 0], ids=["swapped-operands", "lds-epilogue"])
-def operand_order(request):
-    import os
-    old = os.environ.get("ET_CONV_SWP")
-    os.environ["ET_CONV_SWP"] = str(request.param)
-    yield request.param
-    if old is None:
-        del os.environ["ET_CONV_SWP"]
-    else:
-        os.environ["ET_CONV_SWP"] = old
-
-
 @pytest.mark.parametrize("case,kf,kd,kw", SELECT, ids=[str(c[0]) for c in SELECT])
-def test_bench_instantiations_elementwise(hip, operand_order, case, kf, kd, kw):
+def test_bench_instantiations_elementwise(hip, case, kf, kd, kw):
     """bf16 fwd (+ stats, scale/bias/SiLU/residual epilogue, output slice), dgrad (+ residual, accumulate) and wgrad of
-    the named instantiation, element-wise against F.conv2d (fp32) on the bf16-rounded operands -- in both operand orders
-    (the default: MFMA operands swapped + register epilogue; ET_CONV_SWP=0: the LDS-transposing epilogue)."""
+    the named instantiation, element-wise against F.conv2d (fp32) on the bf16-rounded operands."""
     _check_instantiation(hip, case, kf, kd, kw)
 
 
@@ -239,7 +209,7 @@ def _check_instantiation(hip, case, kf, kd, kw):
     from efficientteacher_amd import ops
     N, H, W, Cin, Cout, k, s, p = case
     dt = torch.bfloat16
-    assert ops.kernel_name("fwd", dt, N, H, W, Cin, Cout, k, s, p) == _swp_name(kf)
+    assert ops.kernel_name("fwd", dt, N, H, W, Cin, Cout, k, s, p) == kf
     x = _mk(hip, (N, H, W, Cin), dt, 41)
     w = (_mk(hip, (Cout, k, k, Cin), dt, 42) * (1.0 / (k * k * Cin) ** 0.5)).to(dt)
     OH, OW = ops.conv_out_hw(H, W, k, s, p)
@@ -264,7 +234,7 @@ def _check_instantiation(hip, case, kf, kd, kw):
         return
     # dgrad (the operand roles swap: K = taps * Cout)
     names = [ops.kernel_name("dgrad", dt, N, H, W, Cin, Cout, k, s, p, parity_class=c) for c in range(s * s)]
-    assert names == [_swp_name(n) for n in kd], names
+    assert names == kd, names
     dy = _mk(hip, (N, OH, OW, Cout), dt, 46)
     w2 = (_mk(hip, (Cout, k, k, Cin), dt, 47) * (1.0 / (k * k * Cout) ** 0.5)).to(dt)
     wT = ops.weight_transpose(w2)
@@ -314,13 +284,11 @@ def test_wgrad_grouped_eight_layers(hip, stride, kernel):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("case", [(2, 12, 12, 64, 40, 3), (2, 20, 20, 256, 256, 3), (3, 10, 10, 32, 128, 1)],
                          ids=["128x64 tile", "256x256 tile", "1x1"])
-def test_dgrad_with_fused_bn_backward_sums(hip, operand_order, case, dtype):
+def test_dgrad_with_fused_bn_backward_sums(hip, case, dtype):
     """et_conv2d_dgrad_bn + et_bn_act_bwd_from_partials == et_conv2d_dgrad + et_bn_act_bwd (the separate reduce pass),
     with and without the shortcut-gradient residual; and both equal torch autograd of act(BN(y)) on the same tensors."""
     from efficientteacher_amd import ops
     N, H, W, Cin, Cout, k = case
-    if dtype == torch.float32 and operand_order == 0:
-        pytest.skip("fp32 (parity mode) has one operand order: covered by the other parameter value")
     if hip.emulated and Cin >= 256:      # one ragged 256-row tile pair is enough for the CPU tier (the GPU tier runs the full case)
         N, H, W = 1, 17, 17
         if dtype == torch.float32:
@@ -461,8 +429,8 @@ def test_bench_workloads_launch_only_covered_instantiations(hip_lib_path, wl_nam
     _lib._use_library_for_tests(None, False)
     covered = set()
     for _, kf, kd, kw in SELECT:
-        covered.add(_swp_name(kf))
-        covered.update(_swp_name(n) for n in (kd or []))
+        covered.add(kf)
+        covered.update(kd or [])
         if kw:
             covered.add(kw)
     missing = {}

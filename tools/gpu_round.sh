@@ -10,6 +10,22 @@ run() { echo "=== $1 ($(date +%T))" | tee -a $OUT/log.txt; }
 for s in $SECTIONS; do
 case $s in
 conv_tests) run conv_tests; timeout 900 python -m pytest tests/test_conv.py -x -q -m gpu > $OUT/pytest_conv.log 2>&1; tail -3 $OUT/pytest_conv.log ;;
+ab_swp) run ab_swp; for R in ${AB_SWP_MB:-0 7 0 7}; do echo "--- ET_CONV_SWP=$R"; ET_CONV_SWP=$R MB_REF=0 MB_WGRAD=0 MB_ROTATE=4 timeout 600 python tools/microbench.py conv 2>&1 | python -c "
+import sys, json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d = json.loads(l)
+        print(d['cin'], d['cout'], d['k'], d['s'], d['h'], 'x%d' % d['count'], 'fwd %.1f us %.0f TF  dgrad %.1f us %.0f TF' % (d['fwd_ms'] * 1e3, d['fwd_tf'], d['dgrad_ms'] * 1e3, d['dgrad_tf']), d['fwd_kernel'][:40])
+    elif l.startswith('SUMMARY'): print(l.strip()[:200])
+" | tee -a $OUT/ab_swp_mb.txt; done; for R in ${AB_SWP_STEP:-0 7 0 7 1 2 4}; do ET_CONV_SWP=$R timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('ET_CONV_SWP=$R', round(d['ms_per_step'],2), round(d['roofline']['frac'],4), d['roofline']['kernel'], round(d['roofline']['all_conv_kernels']['tflops'],1), d['kernel_ms_by_family']['main_stream'], d['kernel_ms_by_family']['teacher_stream'])" | tee -a $OUT/ab_swp_step.txt; done ;;
+ab_swp_abl) run ab_swp_abl; for R in ${AB_SWP_ABL:-0: 7: 7:swpabl1 0: 7: 7:swpabl1}; do M=${R%%:*}; L=${R#*:}; if [ -n "$L" ]; then export ET_HIP_LIB=$PWD/tools/probe/libet_$L.so; else unset ET_HIP_LIB; fi; echo "--- ET_CONV_SWP=$M lib=$L" | tee -a $OUT/ab_swp_abl.txt; ET_CONV_SWP=$M MB_REF=0 MB_WGRAD=0 MB_ROTATE=4 timeout 600 python tools/microbench.py conv 2>&1 | python -c "
+import sys, json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d = json.loads(l)
+        print(d['cin'], d['cout'], d['k'], d['s'], d['h'], 'x%d' % d['count'], 'fwd %.1f us %.0f TF  dgrad %.1f us %.0f TF' % (d['fwd_ms'] * 1e3, d['fwd_tf'], d['dgrad_ms'] * 1e3, d['dgrad_tf']), d['fwd_kernel'][:40])
+    elif l.startswith('SUMMARY'): print(l.strip()[:200])
+" | tee -a $OUT/ab_swp_abl.txt; done; unset ET_HIP_LIB ;;
 all_tests) run all_tests; timeout 2400 python -m pytest tests -x -q -m gpu > $OUT/pytest_gpu.log 2>&1; tail -5 $OUT/pytest_gpu.log ;;
 mb_pp) run mb_pp; MB_REF=0 MB_ONLY=${MB_ONLY:-pp} timeout 600 python tools/microbench.py conv > $OUT/mb_pp1.log 2>&1; tail -1 $OUT/mb_pp1.log ;;
 mb_lock) run mb_lock; ET_CONV_PP=0 MB_REF=0 MB_ONLY=${MB_ONLY:-"256, 256"} timeout 600 python tools/microbench.py conv > $OUT/mb_pp0.log 2>&1; tail -1 $OUT/mb_pp0.log ;;

@@ -80,7 +80,7 @@ def bench_conv(B=64, dtype=torch.bfloat16, with_ref=True):
         else:
             t_f = timeit(lambda: ops.conv2d_fwd(x, w, s, p, out=y))
             t_d = timeit(lambda: ops.conv2d_dgrad(dy, wT, (h, h), s, p, out=dx)) if k != 6 else 0.0
-        t_w = timeit(lambda: ops.conv2d_wgrad(x, dy, dw, k, s, p))
+        t_w = timeit(lambda: ops.conv2d_wgrad(x, dy, dw, k, s, p)) if os.environ.get("MB_WGRAD", "1") == "1" else 1e-9
         r = dict(cin=cin, cout=cout, k=k, s=s, h=h, count=cnt, gflop=flop / 1e9, fwd_kernel=kname,
                  fwd_ms=t_f * 1e3, dgrad_ms=t_d * 1e3, wgrad_ms=t_w * 1e3,
                  fwd_tf=flop / t_f / 1e12, dgrad_tf=(flop / t_d / 1e12 if t_d else 0), wgrad_tf=flop / t_w / 1e12)
