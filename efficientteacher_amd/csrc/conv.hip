@@ -1417,6 +1417,20 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(StemArgs a) {
     for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { ssum[cb][r] = 0.f; ssq[cb][r] = 0.f; }
+    // folded-BatchNorm scale / bias (eval-mode teacher) of the channel octets this lane stores: (cb, m) -> channels cb*32 + 8*(2m + hi) .. +7.
+    // Loaded ONCE per (persistent) workgroup: read inside the store loop they were 128 extra vector-memory instructions per tile,
+    // in front of 72 MFMAs (the teacher's stem ran at half the student's rate per image)
+    float esc[2][2][8], ebi[2][2][8];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int ch = cb * 32 + 8 * (2 * m + hi) + e;
+                esc[cb][m][e] = (a.scale && ch < a.Cout) ? a.scale[ch] : 1.0f;
+                ebi[cb][m][e] = (a.bias && ch < a.Cout) ? a.bias[ch] : 0.0f;
+            }
 
     const u32x4* const wbase = wl + l31 * STEM_WPITCH + hi;                          // + cb * 32 * 37 + 2 * ks
     const u32x4* const pbase = pl + (2 * wave) * STEM_PITCH + 2 * l31 + hi;          // + pb * 64 + (ks/3) * PITCH + 2 * (ks%3)
@@ -1497,8 +1511,7 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(StemArgs a) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         float u = e < 4 ? lo4[e] : hi4[e - 4];
-                        if (a.scale) u = u * a.scale[ch + e];
-                        if (a.bias) u = u + a.bias[ch + e];
+                        u = u * esc[cb][m][e] + ebi[cb][m][e];
                         if constexpr (ACT == ACT_SILU) u = u * __builtin_amdgcn_rcpf(1.0f + __expf(-u));
                         else if constexpr (ACT == ACT_RELU) u = fmaxf(u, 0.f);
                         v[e] = u;
@@ -1586,6 +1599,7 @@ struct WgradGeom {
     int ntn, ntm, nsk;           // tile grid: column tiles, cout tiles, K splits (1-D launch, decoded in-kernel)
     FastDiv dQW, dQH, dCin, dW1; // dW1: by QW + 1 (conv_wgrad_rs_kernel's padded raster)
     int PP;                      // padded slots N*QH*(QW+1) (conv_wgrad_rs_kernel's GEMM-K)
+    int ident;                   // 1 = every tap reads X at the dY pixel itself (1x1, stride 1, pad 0): X row = dY row, no decode
     signed char dy[CONV_MAX_TAPS], dx[CONV_MAX_TAPS];
 };
 
@@ -1868,6 +1882,18 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_tr_kernel(WgradGroup 
             const bool ok = a_ok[j] && p < pk_end;
             const uint16_t* src = ok ? DY + ((long long)p * ldy + a_co[j]) : ZERO;
             et_glds16(src, wa + j * NT);
+        }
+        if (g.ident) {
+            // 1x1 stride-1 layers (half of the model's weight-gradient launches, all HBM-bound): the X row IS the dY row -- no pixel
+            // decode (two divisions by multiplication and four compares per staged row sat in front of every chunk's loads)
+#pragma unroll
+            for (int j = 0; j < RB; ++j) {
+                const int p = pk0 + b_pl[j];
+                const bool ok = b_ok[j] && p < pk_end;
+                const uint16_t* src = ok ? X + ((long long)p * ldx + b_ci[j]) : ZERO;
+                et_glds16(src, wb + j * NT);
+            }
+            return;
         }
 #pragma unroll
         for (int j = 0; j < RB; ++j) {
@@ -2509,6 +2535,7 @@ static void wgrad_geom(WgradGeom& g, int N, int IH, int IW, int Cin, int ldx, in
     g.isy = g.isx = stride; g.T = KH * KW; g.NC = g.T * Cin;
     g.dQW = make_fastdiv(OW); g.dQH = make_fastdiv(OH); g.dCin = make_fastdiv(Cin); g.dW1 = make_fastdiv(OW + 1);
     g.PP = N * OH * (OW + 1);
+    g.ident = (KH == 1 && KW == 1 && stride == 1 && pad == 0 && OH == IH && OW == IW) ? 1 : 0;
     for (int ky = 0; ky < KH; ++ky)
         for (int kx = 0; kx < KW; ++kx) {
             g.dy[ky * KW + kx] = (signed char)(ky - pad);
@@ -2757,7 +2784,7 @@ extern "C" int et_env_knobs(char* buf, int buflen) {
     // every ET_* tuning knob that is SET in this process's environment, as "NAME=value;..." (bench.py records it)
     static const char* names[] = {"ET_CONV_GLDS", "ET_CONV_BIG", "ET_CONV_BIG_MINFILL", "ET_CONV_PP", "ET_CONV_RS", "ET_CONV_PPRS", "ET_CONV_STEM", "ET_CONV_STEM_WGS",
                                   "ET_WGRAD_TR", "ET_WGRAD_BIG", "ET_WGRAD_RS", "ET_WGRAD_GROUP", "ET_WGRAD_STALE", "ET_WGRAD_STREAM", "ET_FUSE_BN_BWD",
-                                  "ET_STEP_GRAPH", "ET_ALLREDUCE_CHUNK_MB", "ET_RCCL_CHANNELS", "ET_DP_SINGLE_RANK", "ET_HIP_LIB"};
+                                  "ET_BN_FIN_SMALL", "ET_STEP_GRAPH", "ET_ALLREDUCE_CHUNK_MB", "ET_RCCL_CHANNELS", "ET_DP_SINGLE_RANK", "ET_HIP_LIB"};
     if (!buf || buflen < 1) return -1;
     int off = 0;
     buf[0] = 0;

@@ -126,8 +126,49 @@ __global__ __launch_bounds__(256) void rows_reduce_finalize_kernel(const float* 
     }
 }
 
+// Few partial rows (the 40x40 and 20x20 maps: <= 1600 rows): one 1024-thread block per 16 channels walks ALL rows (64 row groups,
+// four rows in flight per thread) and finalizes -- no fp64 atomics, no fences, no ticket.  The distributed form above spends most of
+// its 10-14 us in four dependent L2 round trips (atomic, fence, ticket, exchange); on these sizes there is nothing to distribute.
+template <typename FIN>
+__global__ __launch_bounds__(1024) void rows_reduce_finalize_small_kernel(const float* __restrict__ part, int rows, int C, FIN fin) {
+    __shared__ double red[2][64][16];
+    const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    double s = 0.0, q = 0.0;
+    if (c < C) {
+        int r = rg;
+        for (; r + 192 < rows; r += 256) {
+            const float s0 = part[((size_t)r * 2 + 0) * C + c], q0 = part[((size_t)r * 2 + 1) * C + c];
+            const float s1 = part[((size_t)(r + 64) * 2 + 0) * C + c], q1 = part[((size_t)(r + 64) * 2 + 1) * C + c];
+            const float s2 = part[((size_t)(r + 128) * 2 + 0) * C + c], q2 = part[((size_t)(r + 128) * 2 + 1) * C + c];
+            const float s3 = part[((size_t)(r + 192) * 2 + 0) * C + c], q3 = part[((size_t)(r + 192) * 2 + 1) * C + c];
+            s += ((double)s0 + (double)s1) + ((double)s2 + (double)s3);
+            q += ((double)q0 + (double)q1) + ((double)q2 + (double)q3);
+        }
+        for (; r < rows; r += 64) {
+            s += (double)part[((size_t)r * 2 + 0) * C + c];
+            q += (double)part[((size_t)r * 2 + 1) * C + c];
+        }
+    }
+    red[0][rg][cl] = s; red[1][rg][cl] = q;
+    __syncthreads();
+    if (rg < 2 && c < C) {                                  // rg 0: the sums, rg 1: the second totals; 64 partials each
+        double t = 0.0;
+        for (int k = 0; k < 64; ++k) t += red[rg][k][cl];
+        red[rg][0][cl] = t;
+    }
+    __syncthreads();
+    if (rg == 0 && c < C) bn_finalize_channel(fin, c, red[0][0][cl], red[1][0][cl]);
+}
+
 template <typename FIN>
 static void launch_rows_reduce_finalize(const float* part, int rows, int C, double* ws, const FIN& fin, hipStream_t s) {
+    const char* const fe = getenv("ET_BN_FIN_SMALL");         // threshold in partial rows (0: always the distributed form); read per call: tests run both
+    const int small_rows = fe ? atoi(fe) : 2048;
+    if (rows <= small_rows) {
+        hipLaunchKernelGGL((rows_reduce_finalize_small_kernel<FIN>), dim3((C + 15) / 16), dim3(1024), 0, s, part, rows, C, fin);
+        return;
+    }
     int rb = rows / 64;
     rb = rb < 1 ? 1 : (rb > 64 ? 64 : rb);
     const int per = (rows + rb - 1) / rb;

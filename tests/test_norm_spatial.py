@@ -14,9 +14,24 @@ def _tol(dtype):
     return 3e-5 if dtype == torch.float32 else 3e-2
 
 
+@pytest.fixture(params=["single-block finalize", "distributed finalize"])
+def finalize_form(request):
+    """the statistics finalize has two forms (csrc/norm.hip): one block per 16 channels for few partial rows (the default below
+    2048 rows), fp64 atomics + ticket over many blocks above; ET_BN_FIN_SMALL=0 forces the second on these small tensors"""
+    import os
+    old = os.environ.get("ET_BN_FIN_SMALL")
+    if request.param.startswith("distributed"):
+        os.environ["ET_BN_FIN_SMALL"] = "0"
+    yield request.param
+    if old is None:
+        os.environ.pop("ET_BN_FIN_SMALL", None)
+    else:
+        os.environ["ET_BN_FIN_SMALL"] = old
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("shape", [(2, 7, 9, 32), (1, 5, 5, 48), (3, 4, 4, 8)])
-def test_bn_silu_fwd_bwd(hip, shape, dtype):
+@pytest.mark.parametrize("shape", [(2, 7, 9, 32), (1, 5, 5, 48), (3, 4, 4, 8), (2, 40, 40, 24), (4, 72, 72, 8)])
+def test_bn_silu_fwd_bwd(hip, finalize_form, shape, dtype):
     from efficientteacher_amd import ops
     N, H, W, C = shape
     # conv in front so that the stats come from the conv epilogue exactly as in the model

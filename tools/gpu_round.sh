@@ -26,6 +26,7 @@ for l in sys.stdin:
         print(d['cin'], d['cout'], d['k'], d['s'], d['h'], 'x%d' % d['count'], 'fwd %.1f us %.0f TF  dgrad %.1f us %.0f TF' % (d['fwd_ms'] * 1e3, d['fwd_tf'], d['dgrad_ms'] * 1e3, d['dgrad_tf']), d['fwd_kernel'][:40])
     elif l.startswith('SUMMARY'): print(l.strip()[:200])
 " | tee -a $OUT/ab_swp_abl.txt; done; unset ET_HIP_LIB ;;
+ab_fin) run ab_fin; for R in ${AB_FIN:-base: new:0 new:2048 new:8192 base: new:0 new:2048 new:8192}; do L=${R%%:*}; F=${R#*:}; if [ $L = base ]; then export ET_HIP_LIB=$PWD/tools/probe/libet_base.so; else unset ET_HIP_LIB; fi; if [ -n "$F" ]; then export ET_BN_FIN_SMALL=$F; else unset ET_BN_FIN_SMALL; fi; timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); k=d['kernel_ms_by_family']; print('$R', round(d['ms_per_step'],2), round(d['roofline']['frac'],4), round(d['roofline']['all_conv_kernels']['tflops'],1), k['main_stream'], k['teacher_stream'])" | tee -a $OUT/ab_fin.txt; done; unset ET_HIP_LIB ET_BN_FIN_SMALL ;;
 all_tests) run all_tests; timeout 2400 python -m pytest tests -x -q -m gpu > $OUT/pytest_gpu.log 2>&1; tail -5 $OUT/pytest_gpu.log ;;
 mb_pp) run mb_pp; MB_REF=0 MB_ONLY=${MB_ONLY:-pp} timeout 600 python tools/microbench.py conv > $OUT/mb_pp1.log 2>&1; tail -1 $OUT/mb_pp1.log ;;
 mb_lock) run mb_lock; ET_CONV_PP=0 MB_REF=0 MB_ONLY=${MB_ONLY:-"256, 256"} timeout 600 python tools/microbench.py conv > $OUT/mb_pp0.log 2>&1; tail -1 $OUT/mb_pp0.log ;;
