@@ -27,6 +27,15 @@ for l in sys.stdin:
     elif l.startswith('SUMMARY'): print(l.strip()[:200])
 " | tee -a $OUT/ab_swp_abl.txt; done; unset ET_HIP_LIB ;;
 ab_fin) run ab_fin; for R in ${AB_FIN:-base: new:0 new:2048 new:8192 base: new:0 new:2048 new:8192}; do L=${R%%:*}; F=${R#*:}; if [ $L = base ]; then export ET_HIP_LIB=$PWD/tools/probe/libet_base.so; else unset ET_HIP_LIB; fi; if [ -n "$F" ]; then export ET_BN_FIN_SMALL=$F; else unset ET_BN_FIN_SMALL; fi; timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); k=d['kernel_ms_by_family']; print('$R', round(d['ms_per_step'],2), round(d['roofline']['frac'],4), round(d['roofline']['all_conv_kernels']['tflops'],1), k['main_stream'], k['teacher_stream'])" | tee -a $OUT/ab_fin.txt; done; unset ET_HIP_LIB ET_BN_FIN_SMALL ;;
+ab_wgroup) run ab_wgroup; for K in ${AB_WGROUP:-8 4 2 1 8 4 2 1}; do ET_WGRAD_GROUP=$K timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); k=d['kernel_ms_by_family']; print('ET_WGRAD_GROUP=$K', round(d['ms_per_step'],2), round(d['roofline']['frac'],4), round(d['roofline']['all_conv_kernels']['tflops'],1), k['main_stream'], k['teacher_stream'])" | tee -a $OUT/ab_wgroup.txt; done ;;
+mb_wgrad_ident) run mb_wgrad_ident; for L in base new base new; do if [ $L = base ]; then export ET_HIP_LIB=$PWD/tools/probe/libet_base.so; else unset ET_HIP_LIB; fi; echo "--- $L" | tee -a $OUT/mb_wgrad_ident.txt; MB_REF=0 MB_K=1 timeout 600 python tools/microbench.py conv 2>&1 | python -c "
+import sys, json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d = json.loads(l)
+        print(d['cin'], d['cout'], d['k'], d['s'], d['h'], 'x%d' % d['count'], 'wgrad %.1f us %.0f TF' % (d['wgrad_ms'] * 1e3, d['wgrad_tf']))
+    elif l.startswith('SUMMARY'): print(l.strip()[:160])
+" | tee -a $OUT/mb_wgrad_ident.txt; done; unset ET_HIP_LIB ;;
 all_tests) run all_tests; timeout 2400 python -m pytest tests -x -q -m gpu > $OUT/pytest_gpu.log 2>&1; tail -5 $OUT/pytest_gpu.log ;;
 mb_pp) run mb_pp; MB_REF=0 MB_ONLY=${MB_ONLY:-pp} timeout 600 python tools/microbench.py conv > $OUT/mb_pp1.log 2>&1; tail -1 $OUT/mb_pp1.log ;;
 mb_lock) run mb_lock; ET_CONV_PP=0 MB_REF=0 MB_ONLY=${MB_ONLY:-"256, 256"} timeout 600 python tools/microbench.py conv > $OUT/mb_pp0.log 2>&1; tail -1 $OUT/mb_pp0.log ;;
