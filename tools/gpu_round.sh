@@ -36,6 +36,15 @@ for l in sys.stdin:
         print(d['cin'], d['cout'], d['k'], d['s'], d['h'], 'x%d' % d['count'], 'wgrad %.1f us %.0f TF' % (d['wgrad_ms'] * 1e3, d['wgrad_tf']))
     elif l.startswith('SUMMARY'): print(l.strip()[:160])
 " | tee -a $OUT/mb_wgrad_ident.txt; done; unset ET_HIP_LIB ;;
+ab_s2slice) run ab_s2slice; for K in ${AB_S2SLICE:-0 49152 24576 98304 0 49152 24576 98304}; do ET_DGRAD_S2_SLICE_KB=$K timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); k=d['kernel_ms_by_family']; print('ET_DGRAD_S2_SLICE_KB=$K', round(d['ms_per_step'],2), round(d['roofline']['frac'],4), round(d['roofline']['all_conv_kernels']['tflops'],1), k['main_stream'], k['teacher_stream'])" | tee -a $OUT/ab_s2slice.txt; done; for K in 0 49152 0 49152; do echo "--- slice $K" | tee -a $OUT/ab_s2slice.txt; ET_DGRAD_S2_SLICE_KB=$K MB_REF=0 MB_WGRAD=0 MB_K=3 MB_ROTATE=4 timeout 600 python tools/microbench.py conv 2>&1 | python -c "
+import sys, json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d = json.loads(l)
+        if d['s'] == 2: print(d['cin'], d['cout'], d['k'], d['s'], d['h'], 'x%d' % d['count'], 'fwd %.1f us  dgrad %.1f us %.0f TF' % (d['fwd_ms'] * 1e3, d['dgrad_ms'] * 1e3, d['dgrad_tf']))
+" | tee -a $OUT/ab_s2slice.txt; done ;;
+ab_bnrev) run ab_bnrev; for K in ${AB_BNREV:-0 1 3 7 0 1 3 7}; do ET_BN_REVERSE=$K timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); k=d['kernel_ms_by_family']; print('ET_BN_REVERSE=$K', round(d['ms_per_step'],2), round(d['roofline']['frac'],4), round(d['roofline']['all_conv_kernels']['tflops'],1), k['main_stream'], k['teacher_stream'])" | tee -a $OUT/ab_bnrev.txt; done ;;
+ab_minfill) run ab_minfill; for K in ${AB_MINFILL:-0 45 80 0 45 80}; do ET_CONV_BIG_MINFILL=$K timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); k=d['kernel_ms_by_family']; print('ET_CONV_BIG_MINFILL=$K', round(d['ms_per_step'],2), round(d['roofline']['frac'],4), d['roofline']['kernel'], round(d['roofline']['all_conv_kernels']['tflops'],1), k['main_stream'], k['teacher_stream'])" | tee -a $OUT/ab_minfill.txt; done ;;
 all_tests) run all_tests; timeout 2400 python -m pytest tests -x -q -m gpu > $OUT/pytest_gpu.log 2>&1; tail -5 $OUT/pytest_gpu.log ;;
 mb_pp) run mb_pp; MB_REF=0 MB_ONLY=${MB_ONLY:-pp} timeout 600 python tools/microbench.py conv > $OUT/mb_pp1.log 2>&1; tail -1 $OUT/mb_pp1.log ;;
 mb_lock) run mb_lock; ET_CONV_PP=0 MB_REF=0 MB_ONLY=${MB_ONLY:-"256, 256"} timeout 600 python tools/microbench.py conv > $OUT/mb_pp0.log 2>&1; tail -1 $OUT/mb_pp0.log ;;
