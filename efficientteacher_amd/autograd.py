@@ -14,6 +14,19 @@ ACT_CODE = {"silu": ops.ACT_SILU, "relu": ops.ACT_RELU, "none": ops.ACT_NONE}
 # (et_conv2d_dgrad_bn); ET_FUSE_BN_BWD=0 restores the separate reduce pass everywhere (A/B knob)
 import os as _os
 FUSE_BN_BWD = _os.environ.get("ET_FUSE_BN_BWD", "1") != "0"
+# ... and which dgrads carry those sums: bit 1 = the 1x1 layers, bit 2 = the k > 1 layers.  Measured on the YOLOv5l SSOD step, same box,
+# alternating (profiles/r03_fuse_bn_bwd_by_kernel_size_ab.txt): 3 / 1 / 2 / 0 = 54.70 / 54.78 / 55.00 / 54.74 ms -- the fusion moves the
+# reduce pass's time between the BatchNorm family and the dgrads, the step does not change.  Default 1: the HBM-bound 1x1 dgrads carry
+# the sums (one y read instead of a dz + y pass), the MFMA-bound 3x3 dgrads keep a pure GEMM epilogue (their launches were 160 us
+# with the sums against 125 us without; the separate reduce pass of the same tensor is ~19 us).
+FUSE_BN_BWD_K = int(_os.environ.get("ET_FUSE_BN_BWD_K", "1"))
+
+
+def _fuse_into(cs, bn):
+    """bn (a BnBwdSums or None) if the dgrad of conv slot `cs` may carry it, else None (-> the separate reduce pass)"""
+    if bn is None or not (FUSE_BN_BWD_K & (1 if cs.k == 1 else 2)):
+        return None
+    return bn
 # two-consumer tensors: the later consumer's backward adds into the earlier one's gradient in its own kernel (GradFork below);
 # ET_GRAD_FORK=0 leaves the sum to autograd (a torch bf16 add per tensor: A/B knob)
 GRAD_FORK = _os.environ.get("ET_GRAD_FORK", "1") != "0"
@@ -164,7 +177,7 @@ class ConvBnActFn(Function):
                 dx = ops.conv2d_dgrad(dy, wT, (x.shape[1], x.shape[2]), cs.stride, cs.pad, out=into, accumulate=True)
                 ctx.acc.merged = True
             else:
-                dx = ops.conv2d_dgrad(dy, wT, (x.shape[1], x.shape[2]), cs.stride, cs.pad, bn=ctx.bn_in)
+                dx = ops.conv2d_dgrad(dy, wT, (x.shape[1], x.shape[2]), cs.stride, cs.pad, bn=_fuse_into(cs, ctx.bn_in))
         return dx, (dz if ctx.has_res else None), None, None, None, None, None, None, None, None, None
 
 
@@ -210,7 +223,7 @@ class BottleneckFn(Function):
             _wgrad(h, dy2, cs2)
         # h = act(BN1(y1)) has exactly one consumer (cv2, inside this node): the reduce pass of BN1's backward rides
         # the epilogue of cv2's dgrad
-        inner = ops.BnBwdSums(y1, s1, b1, act1) if FUSE_BN_BWD else None
+        inner = _fuse_into(cs2, ops.BnBwdSums(y1, s1, b1, act1)) if FUSE_BN_BWD else None
         dh = ops.conv2d_dgrad(dy2, cs2.transposed(), (h.shape[1], h.shape[2]), cs2.stride, cs2.pad, bn=inner)
         dy1 = ops.bn_act_bwd(dh, y1, bs1.gamma, s1, b1, m1, i1, act1, bs1.ggamma, bs1.gbeta,
                              partial=inner.take(dh) if inner is not None else None)
@@ -219,7 +232,7 @@ class BottleneckFn(Function):
         dx = None
         if ctx.x_needs_grad:
             dx = ops.conv2d_dgrad(dy1, cs1.transposed(), (x.shape[1], x.shape[2]), cs1.stride, cs1.pad,
-                                  residual=dz, bn=ctx.bn_in)
+                                  residual=dz, bn=_fuse_into(cs1, ctx.bn_in))
         return (dx,) + (None,) * 13
 
 
