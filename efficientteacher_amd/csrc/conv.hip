@@ -2216,6 +2216,37 @@ __global__ __launch_bounds__(256) void weight_transpose_all_kernel(const T* __re
     wt[off + j] = w[off + ((long long)co * TT + t) * Cin + ci];
 }
 
+// bf16 form of the same operation in 8x8 register blocks: one thread reads eight 16-byte rows of w (8 input channels of 8
+// consecutive output channels), transposes the block in registers and writes eight 16-byte rows of wt.  A wave covers a 64 x 64
+// tile (lane = 8 * (cout block) + (cin block): every read instruction is eight 128-byte segments); a workgroup takes four tiles
+// per iteration, workgroup (bx, layer) walks tiles bx, bx + gridDim.x, ... of its layer.  The element-per-thread kernel above
+// gathers 2-byte values at a stride of a whole weight row: 240 us per step for the 92 MB of YOLOv5l against ~40 us of traffic.
+__global__ __launch_bounds__(256) void weight_transpose_all_tiled_kernel(const uint16_t* __restrict__ w, uint16_t* __restrict__ wt,
+                                                                         const int* __restrict__ table, int nlayers) {
+    const int layer = blockIdx.y;
+    const long long off = (unsigned)table[layer * 4];
+    const int Cout = table[layer * 4 + 1], TT = table[layer * 4 + 2], Cin = table[layer * 4 + 3];
+    if ((Cout | Cin) & 7) return;                              // (host: such a layer takes the element-wise kernel)
+    const int tco = (Cout + 63) >> 6, tci = (Cin + 63) >> 6;
+    const int ntiles = TT * tco * tci;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int a = lane >> 3, b = lane & 7;
+    const uint16_t* const wl = w + off;
+    uint16_t* const wtl = wt + off;
+    for (int tile = (blockIdx.x * 4 + wave); tile < ntiles; tile += gridDim.x * 4) {
+        const int ic = tile % tci, r1 = tile / tci;
+        const int oc = r1 % tco, t = r1 / tco;
+        const int co = oc * 64 + a * 8, ci = ic * 64 + b * 8;
+        if (co >= Cout || ci >= Cin) continue;                 // whole 8x8 blocks are in or out (channels are multiples of 8)
+        u32x4 in[8], out[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) in[r] = *(const u32x4*)(wl + ((long long)(co + r) * TT + t) * Cin + ci);
+        Transposer<uint16_t>::run(in, out);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) *(u32x4*)(wtl + ((long long)(ci + c) * TT + t) * Cout + co) = out[c];
+    }
+}
+
 // column sums of a [P][C] (pixel stride ld) tensor into fp32 out[C] (atomicAdd): bias gradients
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int P, int C, int ld, int rows_per_block,
@@ -2229,6 +2260,46 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
 }
 
 // ---- host side -------------------------------------------------------------------------------------
+// bf16 column sums with 16-byte loads: a thread owns one 8-channel vector and every (256 / CV)-th row of its block's rows (the
+// element-per-thread kernel above moves 128 bytes per wave instruction: 88 us for the 210 MB of the stride-8 Detect gradient)
+__global__ __launch_bounds__(256) void colsum_vec8_kernel(const uint16_t* __restrict__ x, int P, int CV, int ld, int rows_per_block,
+                                                          float* __restrict__ out) {
+    __shared__ float red[256][9];
+    const int rgs = 256 / CV;                                // row groups per block (CV divides 256: host)
+    const int cv = threadIdx.x % CV, rg = threadIdx.x / CV;
+    const int p0 = blockIdx.x * rows_per_block, p1 = min(P, p0 + rows_per_block);
+    float s[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = 0.f;
+    if (rg < rgs) {
+        int p = p0 + rg;
+        for (; p + rgs < p1; p += 2 * rgs) {                 // two rows in flight
+            const u32x4 a = *(const u32x4*)(x + (long long)p * ld + cv * 8), b = *(const u32x4*)(x + (long long)(p + rgs) * ld + cv * 8);
+            const unsigned wa[4] = {a.x, a.y, a.z, a.w}, wb[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s[2 * j] += __uint_as_float(wa[j] << 16) + __uint_as_float(wb[j] << 16);
+                s[2 * j + 1] += __uint_as_float(wa[j] & 0xffff0000u) + __uint_as_float(wb[j] & 0xffff0000u);
+            }
+        }
+        for (; p < p1; p += rgs) {
+            const u32x4 a = *(const u32x4*)(x + (long long)p * ld + cv * 8);
+            const unsigned wa[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s[2 * j] += __uint_as_float(wa[j] << 16); s[2 * j + 1] += __uint_as_float(wa[j] & 0xffff0000u); }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[threadIdx.x][e] = rg < rgs ? s[e] : 0.f;
+    __syncthreads();
+    // thread t < 8 * CV: channel t, summed over the row groups
+    for (int c = threadIdx.x; c < CV * 8; c += 256) {
+        float t = 0.f;
+        for (int g = 0; g < rgs; ++g) t += red[g * CV + (c >> 3)][c & 7];
+        atomicAdd(out + c, t);
+    }
+}
+
 static int fill_common(GatherGeom& g, int N, int IH, int IW, int Cin, int ldx, int QH, int QW, int OH, int OW,
                        int Cout, int ldy, int vec) {
     if (Cin % vec) return -2;
@@ -2727,10 +2798,17 @@ extern "C" int et_weight_transpose_all(const void* w_arena, void* wT_arena, int 
     if (dtype == ET_F32)
         hipLaunchKernelGGL((weight_transpose_all_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)w_arena,
                            (float*)wT_arena, table, n_layers, total_elems);
-    else if (dtype == ET_BF16)
-        hipLaunchKernelGGL((weight_transpose_all_kernel<uint16_t>), grid, block, 0, (hipStream_t)stream,
-                           (const uint16_t*)w_arena, (uint16_t*)wT_arena, table, n_layers, total_elems);
-    else return -2;
+    else if (dtype == ET_BF16) {
+        // layer offsets are multiples of 16 elements and bf16 channel counts multiples of 8 (flat_state.py): 16-byte rows.  The tiled
+        // kernel skips a layer whose channels are not (none in the models here); ET_WT_TILED=0 keeps the element-wise kernel
+        static const int tiled = env_int("ET_WT_TILED", 1);
+        if (tiled && (((uintptr_t)w_arena | (uintptr_t)wT_arena) & 15) == 0)
+            hipLaunchKernelGGL(weight_transpose_all_tiled_kernel, dim3(96, n_layers), block, 0, (hipStream_t)stream,
+                               (const uint16_t*)w_arena, (uint16_t*)wT_arena, table, n_layers);
+        else
+            hipLaunchKernelGGL((weight_transpose_all_kernel<uint16_t>), grid, block, 0, (hipStream_t)stream,
+                               (const uint16_t*)w_arena, (uint16_t*)wT_arena, table, n_layers, total_elems);
+    } else return -2;
     ET_CHECK_LAUNCH();
     return 0;
 }
@@ -2741,7 +2819,15 @@ extern "C" int et_colsum(const void* x, int dtype, int P, int C, int ld, float* 
     const int rpb = 256;
     const dim3 grid((C + 255) / 256, (P + rpb - 1) / rpb), block(256);
     if (dtype == ET_F32) hipLaunchKernelGGL((colsum_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)x, P, C, ld, rpb, out);
-    else if (dtype == ET_BF16) hipLaunchKernelGGL((colsum_kernel<uint16_t>), grid, block, 0, (hipStream_t)stream, (const uint16_t*)x, P, C, ld, rpb, out);
+    else if (dtype == ET_BF16) {
+        const int CV = C / 8;
+        if (C % 8 == 0 && ld % 8 == 0 && CV >= 1 && CV <= 256 && 256 % CV == 0 && (((uintptr_t)x) & 15) == 0) {
+            const int rpb2 = 256;                              // rows per block: 8-256 rows per row group, two in flight per thread
+            hipLaunchKernelGGL(colsum_vec8_kernel, dim3((P + rpb2 - 1) / rpb2), block, 0, (hipStream_t)stream, (const uint16_t*)x, P, CV, ld, rpb2, out);
+        } else {
+            hipLaunchKernelGGL((colsum_kernel<uint16_t>), grid, block, 0, (hipStream_t)stream, (const uint16_t*)x, P, C, ld, rpb, out);
+        }
+    }
     else return -2;
     ET_CHECK_LAUNCH();
     return 0;

@@ -99,6 +99,43 @@ def test_conv_dgrad(hip, case, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 9, 11, 256), (1, 7, 5, 24), (3, 20, 20, 64)])
+def test_colsum_bias_gradient(hip, shape, dtype):
+    """et_colsum: out[c] += sum over pixels (the bias gradient of the Detect convs), on a channel slice of a wider buffer; bf16 with
+    whole 8-channel vectors takes the 16-byte-load kernel, 24 channels (3 vectors: not a divisor of 256) the element-wise one"""
+    from efficientteacher_amd import ops
+    N, H, W, C = shape
+    wide = _mk(hip, (N, H, W, C + 16), dtype, 71)
+    x = wide[..., 8:8 + C]
+    out = torch.full((C,), 0.5, dtype=torch.float32, device=hip.device)
+    ops.colsum(x, out)
+    ref = x.float().cpu().reshape(-1, C).sum(0) + 0.5
+    assert torch.allclose(out.cpu(), ref, rtol=1e-4, atol=1e-3 * (N * H * W) ** 0.5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_weight_transpose_all_layers(hip, dtype):
+    """et_weight_transpose_all: every layer of a flat weight arena [Cout][KH][KW][Cin] -> [Cin][KH][KW][Cout] in one launch
+    (bf16: the tiled 8x8-register-block kernel; fp32: one element per thread), ragged 64-tiles, gaps between layers untouched"""
+    from efficientteacher_amd import ops
+    layers = [(72, 9, 40), (8, 1, 136), (128, 9, 64), (200, 1, 8)]          # (Cout, taps, Cin), multiples of 8
+    offs, total = [], 0
+    for co, tt, ci in layers:
+        offs.append(total)
+        total += (co * tt * ci + 15) // 16 * 16 + 16                          # 16-element alignment + a gap
+    g = torch.Generator().manual_seed(5)
+    arena = torch.randn(total, generator=g).to(dtype).to(hip.device)
+    out = torch.full((total,), 7.0, dtype=dtype, device=hip.device)
+    table = torch.tensor([[o, co, tt, ci] for o, (co, tt, ci) in zip(offs, layers)], dtype=torch.int32, device=hip.device)
+    ops.weight_transpose_all(arena, out, table, total)
+    for o, (co, tt, ci) in zip(offs, layers):
+        n = co * tt * ci
+        ref = arena[o:o + n].view(co, tt, ci).permute(2, 1, 0).contiguous().view(-1)
+        assert torch.equal(out[o:o + n].cpu(), ref.cpu()), (co, tt, ci)
+        assert (out[o + n:o + n + 16].float().cpu() == 7.0).all()           # the gap behind the layer is not written
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("case", [c for c in CASES if c[4] % 8 == 0])
 def test_conv_wgrad(hip, case, dtype):
     from efficientteacher_amd import ops
