@@ -75,10 +75,12 @@ def test_bn_silu_fwd_bwd(hip, finalize_form, shape, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_sppf_pool_chain(hip, dtype):
-    """x -> y1 -> y2 -> y3 written into slices of one concat buffer; backward through the chain."""
+@pytest.mark.parametrize("shape", [(2, 9, 7, 16), (1, 20, 20, 32), (1, 3, 2, 8)])
+def test_sppf_pool_chain(hip, shape, dtype):
+    """x -> y1 -> y2 -> y3 written into slices of one concat buffer; backward through the chain (the pooled maps have plateaus:
+    the gradient routing checks the first-maximum tie rule against torch)."""
     from efficientteacher_amd import ops
-    N, H, W, C = 2, 9, 7, 16
+    N, H, W, C = shape
     cat = torch.zeros((N, H, W, 4 * C), dtype=dtype, device=hip.device)
     x = _mk(hip, (N, H, W, C), dtype, 11)
     cat[..., :C].copy_(x)

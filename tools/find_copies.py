@@ -29,3 +29,13 @@ for e in prof.key_averages(group_by_input_shape=True, group_by_stack_n=6):
 rows.sort(reverse=True)
 for r in rows[:40]:
     print("%8.0f us  x%-3d %-28s %s\n            %s" % r)
+# the many SMALL ones: every aten / memcpy entry by call count
+print("---- by count")
+small = []
+for e in prof.key_averages(group_by_stack_n=8):
+    if e.count >= 8 and (e.key.startswith("aten::") or "emcpy" in e.key or "emset" in e.key):
+        st = [s for s in e.stack if "efficientteacher_amd" in s or "bench.py" in s]
+        small.append((e.count, e.device_time_total, e.key, st[:3]))
+small.sort(reverse=True)
+for r in small[:40]:
+    print("x%-4d %8.0f us  %-30s %s" % r)
