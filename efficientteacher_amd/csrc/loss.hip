@@ -707,6 +707,18 @@ __global__ __launch_bounds__(256) void scale_cast_kernel(const float* __restrict
     if (i < n) d[i] = et_elem<T>::st(s[i] * f);
 }
 
+// bf16 destination, eight elements per thread (two 16-byte loads, one 16-byte store; the element-per-thread form moves 128 bytes
+// per wave instruction: 2.7 TB/s on the head gradients).  Same arithmetic per element: one multiplication, round to nearest even.
+__global__ __launch_bounds__(256) void scale_cast_bf16_vec8_kernel(const float* __restrict__ s, uint16_t* __restrict__ d, long long n8,
+                                                                   float scale, const float* __restrict__ dev_scale) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    const float f = dev_scale ? scale * dev_scale[0] : scale;
+    const float4 a = *(const float4*)(s + i * 8), b = *(const float4*)(s + i * 8 + 4);
+    *(uint4*)(d + i * 8) = make_uint4(et_pack_bf2(a.x * f, a.y * f), et_pack_bf2(a.z * f, a.w * f), et_pack_bf2(b.x * f, b.y * f),
+                                      et_pack_bf2(b.z * f, b.w * f));
+}
+
 // ---- host -------------------------------------------------------------------------------------------------
 extern "C" int et_yolo_loss(const et_loss_desc* d, et_stream_t stream) {
     if (!d || !d->targets || !d->acc_ws || !d->out) return -1;
@@ -774,8 +786,17 @@ extern "C" int et_scale_cast(const float* src, void* dst, int dtype, int64_t n, 
     if (n <= 0) return n == 0 ? 0 : -2;
     const dim3 grid(et_cdiv(n, 256));
     if (dtype == ET_F32) hipLaunchKernelGGL((scale_cast_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, src, (float*)dst, (long long)n, scale, dev_scale);
-    else if (dtype == ET_BF16) hipLaunchKernelGGL((scale_cast_kernel<uint16_t>), grid, dim3(256), 0, (hipStream_t)stream, src, (uint16_t*)dst, (long long)n, scale, dev_scale);
-    else return -2;
+    else if (dtype == ET_BF16) {
+        long long done = 0;
+        if (((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0 && n >= 8) {
+            const long long n8 = n / 8;
+            hipLaunchKernelGGL(scale_cast_bf16_vec8_kernel, dim3(et_cdiv(n8, 256)), dim3(256), 0, (hipStream_t)stream, src, (uint16_t*)dst, n8, scale, dev_scale);
+            done = n8 * 8;
+        }
+        if (done < n)
+            hipLaunchKernelGGL((scale_cast_kernel<uint16_t>), dim3(et_cdiv(n - done, 256)), dim3(256), 0, (hipStream_t)stream, src + done,
+                               (uint16_t*)dst + done, (long long)(n - done), scale, dev_scale);
+    } else return -2;
     ET_CHECK_LAUNCH();
     return 0;
 }

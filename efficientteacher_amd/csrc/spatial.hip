@@ -41,6 +41,38 @@ __global__ __launch_bounds__(256) void pack_input_u8_kernel(const uint8_t* __res
     for (int c = 0; c < 8; ++c) d[c] = v[c];
 }
 
+// bf16 output, FOUR consecutive pixels per thread: one 16-byte (fp32 image) or 4-byte (uint8 image) load per channel and 64
+// contiguous bytes stored, instead of a 4- / 1-byte load per channel and pixel (the fp32 pack ran at 3.7 TB/s, the uint8 one issues
+// 64-byte wave loads).  Same arithmetic: fp32 value rounded to bf16; uint8 value / norm_scale (IEEE division), then rounded.
+template <typename IN>
+__global__ __launch_bounds__(256) void pack_input4_bf16_kernel(const IN* __restrict__ x, uint16_t* __restrict__ y, int C, int HW4,
+                                                               long long total4, float scale) {
+    const unsigned qu = blockIdx.x * 256u + threadIdx.x;               // quad index over B*HW/4 (host: < 2^31)
+    if (qu >= total4) return;
+    const unsigned b = qu / (unsigned)HW4, h4 = qu - b * (unsigned)HW4;
+    float v[4][4];                                                      // [channel][pixel]; channels >= C stay zero (C <= 4 here)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[c][j] = 0.f;
+        if (c < C) {
+            const long long off = ((long long)b * C + c) * HW4 * 4 + (long long)h4 * 4;
+            if constexpr (sizeof(IN) == 4) {
+                const float4 t = *(const float4*)((const float*)x + off);
+                v[c][0] = t.x; v[c][1] = t.y; v[c][2] = t.z; v[c][3] = t.w;
+            } else {
+                const unsigned w = *(const unsigned*)((const uint8_t*)x + off);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[c][j] = (float)((w >> (8 * j)) & 0xffu) / scale;
+            }
+        }
+    }
+    uint16_t* const d = y + ((long long)b * HW4 * 4 + (long long)h4 * 4) * 8;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        *(uint4*)(d + j * 8) = make_uint4(et_pack_bf2(v[0][j], v[1][j]), et_pack_bf2(v[2][j], v[3][j]), 0u, 0u);
+}
+
 template <typename T> struct PV;   // 16-byte vector <-> floats
 template <> struct PV<float> {
     static constexpr int N = 4;
@@ -190,8 +222,13 @@ extern "C" int et_pack_input(const float* x_nchw, void* y_nhwc8, int dtype, int 
     if (total >= (1ll << 31)) return -2;               // the kernels index with 32-bit arithmetic
     const dim3 grid(et_cdiv(total, 256));
     if (dtype == ET_F32) hipLaunchKernelGGL((pack_input_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, x_nchw, (float*)y_nhwc8, C, H * W, total);
-    else if (dtype == ET_BF16) hipLaunchKernelGGL((pack_input_kernel<uint16_t>), grid, dim3(256), 0, (hipStream_t)stream, x_nchw, (uint16_t*)y_nhwc8, C, H * W, total);
-    else return -2;
+    else if (dtype == ET_BF16) {
+        if (C <= 4 && (H * W) % 4 == 0 && ((((uintptr_t)x_nchw) | ((uintptr_t)y_nhwc8)) & 15) == 0)
+            hipLaunchKernelGGL((pack_input4_bf16_kernel<float>), dim3(et_cdiv(total / 4, 256)), dim3(256), 0, (hipStream_t)stream, x_nchw,
+                               (uint16_t*)y_nhwc8, C, H * W / 4, total / 4, 1.0f);
+        else
+            hipLaunchKernelGGL((pack_input_kernel<uint16_t>), grid, dim3(256), 0, (hipStream_t)stream, x_nchw, (uint16_t*)y_nhwc8, C, H * W, total);
+    } else return -2;
     ET_CHECK_LAUNCH();
     return 0;
 }
@@ -204,8 +241,13 @@ extern "C" int et_pack_input_u8(const uint8_t* x_nchw, void* y_nhwc8, int dtype,
     if (total >= (1ll << 31)) return -2;               // the kernels index with 32-bit arithmetic
     const dim3 grid(et_cdiv(total, 256));
     if (dtype == ET_F32) hipLaunchKernelGGL((pack_input_u8_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, x_nchw, (float*)y_nhwc8, C, H * W, total, norm_scale);
-    else if (dtype == ET_BF16) hipLaunchKernelGGL((pack_input_u8_kernel<uint16_t>), grid, dim3(256), 0, (hipStream_t)stream, x_nchw, (uint16_t*)y_nhwc8, C, H * W, total, norm_scale);
-    else return -2;
+    else if (dtype == ET_BF16) {
+        if (C <= 4 && (H * W) % 4 == 0 && (((uintptr_t)x_nchw) & 3) == 0 && (((uintptr_t)y_nhwc8) & 15) == 0)
+            hipLaunchKernelGGL((pack_input4_bf16_kernel<uint8_t>), dim3(et_cdiv(total / 4, 256)), dim3(256), 0, (hipStream_t)stream, x_nchw,
+                               (uint16_t*)y_nhwc8, C, H * W / 4, total / 4, norm_scale);
+        else
+            hipLaunchKernelGGL((pack_input_u8_kernel<uint16_t>), grid, dim3(256), 0, (hipStream_t)stream, x_nchw, (uint16_t*)y_nhwc8, C, H * W, total, norm_scale);
+    } else return -2;
     ET_CHECK_LAUNCH();
     return 0;
 }

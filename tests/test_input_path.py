@@ -9,15 +9,18 @@ from tests.test_ssod_step import make_trainer
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_pack_input_uint8_equals_float_division(hip, dtype):
+@pytest.mark.parametrize("hw", [(20, 24), (5, 3)], ids=["four pixels per thread (bf16)", "one pixel per thread"])
+def test_pack_input_uint8_equals_float_division(hip, hw, dtype):
     """(float)x / 255 in the kernel is bit-identical to the IEEE division `imgs.float() / 255.0` (what torch computes on the CPU --
     the oracle's arithmetic; torch's GPU kernel multiplies by the rounded reciprocal instead, 1 ulp away) followed by the fp32 pack"""
     from efficientteacher_amd import ops
     rng = np.random.default_rng(1)
-    x = torch.from_numpy(rng.integers(0, 256, (2, 3, 20, 24), dtype=np.uint8))
+    x = torch.from_numpy(rng.integers(0, 256, (2, 3) + hw, dtype=np.uint8))
     a = ops.pack_input(hip.t(x), dtype)
     b = ops.pack_input(hip.t(x.float() / 255.0), dtype)
-    assert a.shape == (2, 20, 24, 8) and torch.equal(a.cpu(), b.cpu())
+    assert a.shape == (2,) + hw + (8,) and torch.equal(a.cpu(), b.cpu())
+    ref = (x.float() / 255.0).permute(0, 2, 3, 1).to(dtype)
+    assert torch.equal(a[..., :3].cpu(), ref)
     assert (a[..., 3:] == 0).all()
 
 

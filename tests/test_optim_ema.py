@@ -93,3 +93,32 @@ def test_adamw_matches_torch(hip):
     opt2 = FlatAdamW(model, lr=0.01, betas=(0.937, 0.999), weight_decay=5e-4)
     opt2.load_state_dict(sd)
     assert opt2.steps == 3 and torch.equal(opt2.exp_avg, opt.exp_avg)
+
+
+def test_cast_f32_to_bf16_is_torch_rounding(hip):
+    """et_cast_f32_to_bf16 (the bf16 weight shadow): round-to-nearest-even like torch, for aligned arenas (eight elements per
+    thread + a scalar tail) and for an unaligned slice (scalar kernel)"""
+    from efficientteacher_amd import ops
+    g = torch.Generator().manual_seed(3)
+    src = (torch.randn(4099, generator=g) * torch.logspace(-20, 20, 4099)).to(hip.device)
+    src[5] = float("inf"); src[6] = -0.0; src[7] = 1.00390625          # a tie: rounds to even
+    for sl in (slice(0, 4099), slice(0, 4096), slice(1, 1000), slice(8, 13)):
+        s = src[sl]
+        d = torch.empty(s.numel(), dtype=torch.bfloat16, device=hip.device)
+        ops.cast_f32_to_bf16(s, d)
+        assert torch.equal(d.cpu(), s.cpu().to(torch.bfloat16)), sl
+
+
+def test_scale_cast_bf16_vector_and_tail(hip):
+    """et_scale_cast to bf16 (the loss gradients handed to the head's backward): src * scale [* dev_scale], rounded like torch,
+    for a length that is not a multiple of eight (vector kernel + scalar tail) and an unaligned slice"""
+    from efficientteacher_amd import ops
+    g = torch.Generator().manual_seed(4)
+    src = torch.randn(2051, generator=g).to(hip.device)
+    dev_scale = torch.tensor([0.37], device=hip.device)
+    for s in (src, src[3:1500]):
+        out = ops.scale_cast(s, torch.bfloat16, scale=1.7, dev_scale=dev_scale)
+        ref = (s.cpu() * (torch.tensor(1.7) * dev_scale.cpu()[0])).to(torch.bfloat16)
+        assert torch.equal(out.cpu(), ref)
+        out2 = ops.scale_cast(s, torch.bfloat16, scale=-2.0)
+        assert torch.equal(out2.cpu(), (s.cpu() * -2.0).to(torch.bfloat16))
