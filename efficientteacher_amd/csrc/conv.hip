@@ -2226,7 +2226,15 @@ __global__ __launch_bounds__(256) void weight_transpose_all_tiled_kernel(const u
     const int layer = blockIdx.y;
     const long long off = (unsigned)table[layer * 4];
     const int Cout = table[layer * 4 + 1], TT = table[layer * 4 + 2], Cin = table[layer * 4 + 3];
-    if ((Cout | Cin) & 7) return;                              // (host: such a layer takes the element-wise kernel)
+    if ((Cout | Cin) & 7) {
+        // channels that are not whole 16-byte rows (no layer of the models here: bf16 slots are padded to 8): element by element
+        const long long n = (long long)Cout * TT * Cin;
+        for (long long j = (long long)blockIdx.x * 256 + threadIdx.x; j < n; j += (long long)gridDim.x * 256) {
+            const int co = (int)(j % Cout), t = (int)((j / Cout) % TT), ci = (int)(j / ((long long)Cout * TT));
+            wt[off + j] = w[off + ((long long)co * TT + t) * Cin + ci];
+        }
+        return;
+    }
     const int tco = (Cout + 63) >> 6, tci = (Cin + 63) >> 6;
     const int ntiles = TT * tco * tci;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -2799,8 +2807,8 @@ extern "C" int et_weight_transpose_all(const void* w_arena, void* wT_arena, int 
         hipLaunchKernelGGL((weight_transpose_all_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)w_arena,
                            (float*)wT_arena, table, n_layers, total_elems);
     else if (dtype == ET_BF16) {
-        // layer offsets are multiples of 16 elements and bf16 channel counts multiples of 8 (flat_state.py): 16-byte rows.  The tiled
-        // kernel skips a layer whose channels are not (none in the models here); ET_WT_TILED=0 keeps the element-wise kernel
+        // layer offsets are multiples of 16 elements and bf16 channel counts multiples of 8 (flat_state.py): 16-byte rows (a layer
+        // whose channels are not is copied element by element inside the same launch); ET_WT_TILED=0 keeps the element-wise kernel
         static const int tiled = env_int("ET_WT_TILED", 1);
         if (tiled && (((uintptr_t)w_arena | (uintptr_t)wT_arena) & 15) == 0)
             hipLaunchKernelGGL(weight_transpose_all_tiled_kernel, dim3(96, n_layers), block, 0, (hipStream_t)stream,
@@ -2870,7 +2878,7 @@ extern "C" int et_env_knobs(char* buf, int buflen) {
     // every ET_* tuning knob that is SET in this process's environment, as "NAME=value;..." (bench.py records it)
     static const char* names[] = {"ET_CONV_GLDS", "ET_CONV_BIG", "ET_CONV_BIG_MINFILL", "ET_CONV_PP", "ET_CONV_RS", "ET_CONV_PPRS", "ET_CONV_STEM", "ET_CONV_STEM_WGS",
                                   "ET_WGRAD_TR", "ET_WGRAD_BIG", "ET_WGRAD_RS", "ET_WGRAD_GROUP", "ET_WGRAD_STALE", "ET_WGRAD_STREAM", "ET_FUSE_BN_BWD",
-                                  "ET_BN_FIN_SMALL", "ET_STEP_GRAPH", "ET_ALLREDUCE_CHUNK_MB", "ET_RCCL_CHANNELS", "ET_DP_SINGLE_RANK", "ET_HIP_LIB"};
+                                  "ET_BN_FIN_SMALL", "ET_WT_TILED", "ET_FUSE_BN_BWD_K", "ET_STEP_GRAPH", "ET_ALLREDUCE_CHUNK_MB", "ET_RCCL_CHANNELS", "ET_DP_SINGLE_RANK", "ET_HIP_LIB"};
     if (!buf || buflen < 1) return -1;
     int off = 0;
     buf[0] = 0;

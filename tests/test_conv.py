@@ -118,7 +118,7 @@ def test_weight_transpose_all_layers(hip, dtype):
     """et_weight_transpose_all: every layer of a flat weight arena [Cout][KH][KW][Cin] -> [Cin][KH][KW][Cout] in one launch
     (bf16: the tiled 8x8-register-block kernel; fp32: one element per thread), ragged 64-tiles, gaps between layers untouched"""
     from efficientteacher_amd import ops
-    layers = [(72, 9, 40), (8, 1, 136), (128, 9, 64), (200, 1, 8)]          # (Cout, taps, Cin), multiples of 8
+    layers = [(72, 9, 40), (8, 1, 136), (128, 9, 64), (200, 1, 8), (20, 4, 12)]   # (Cout, taps, Cin); the last one is not whole 16-byte rows
     offs, total = [], 0
     for co, tt, ci in layers:
         offs.append(total)
