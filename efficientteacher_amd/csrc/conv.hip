@@ -32,6 +32,12 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;   // 16-byte reg
 __device__ __forceinline__ u32x4 mk4(unsigned a, unsigned b, unsigned c, unsigned d) { u32x4 v = {a, b, c, d}; return v; }
 
 #define CONV_MAX_TAPS 36
+// workgroups per CU the short-K 128x64 tile (32-wide chunks, 3-deep ring, 36 KB of LDS) is compiled for: 3 = 129 VGPRs, 4 = 128 + two spilled
+// dwords.  Four resident workgroups keep more bytes in flight on these HBM-bound 1x1 layers: step 53.70 -> 53.38 ms, same box, two
+// alternations (profiles/r03_shortk_four_workgroups_ab.txt)
+#ifndef ET_GLDS_SHORTK_WGS
+#define ET_GLDS_SHORTK_WGS 4
+#endif
 #define RS_A_ROWS(BM) ((BM) + 16)    // LDS rows of conv_gemm_rs_kernel's activation unit: BM + 2 pixels + one pad slot per image row
 
 struct FastDiv {
@@ -599,7 +605,7 @@ template <int N> __device__ __forceinline__ void et_wait_vmem_le() {
 // MFMA busy ~30 %), not LDS or MFMA issue -- hence deeper rings and, where the layer has the rows, a
 // 256-row tile (1.33x the flops per staged byte).
 template <typename T, int BM, int BN, int WM, int WN, int BKV, int NS, bool UTAP>
-__global__ __launch_bounds__(64 * WM * WN, (NS == 3 && BKV == 4 && BM == 128) ? 3 : 1) void conv_gemm_glds_kernel(const T* __restrict__ X, const T* __restrict__ W,
+__global__ __launch_bounds__(64 * WM * WN, (NS == 3 && BKV == 4 && BM == 128) ? (BN == 64 ? ET_GLDS_SHORTK_WGS : 3) : 1) void conv_gemm_glds_kernel(const T* __restrict__ X, const T* __restrict__ W,
                                                              T* __restrict__ Y, const T* __restrict__ ZERO,
                                                              GatherGeom g, Epilogue ep) {
     constexpr int VEC = et_elem<T>::VEC;

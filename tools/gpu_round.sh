@@ -47,6 +47,7 @@ ab_bnrev) run ab_bnrev; for K in ${AB_BNREV:-0 1 3 7 0 1 3 7}; do ET_BN_REVERSE=
 ab_minfill) run ab_minfill; for K in ${AB_MINFILL:-0 45 80 0 45 80}; do ET_CONV_BIG_MINFILL=$K timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); k=d['kernel_ms_by_family']; print('ET_CONV_BIG_MINFILL=$K', round(d['ms_per_step'],2), round(d['roofline']['frac'],4), d['roofline']['kernel'], round(d['roofline']['all_conv_kernels']['tflops'],1), k['main_stream'], k['teacher_stream'])" | tee -a $OUT/ab_minfill.txt; done ;;
 ab_fusek) run ab_fusek; for K in ${AB_FUSEK:-3 1 2 0 3 1 2 0}; do ET_FUSE_BN_BWD_K=$K timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); k=d['kernel_ms_by_family']; print('ET_FUSE_BN_BWD_K=$K', round(d['ms_per_step'],2), round(d['roofline']['frac'],4), round(d['roofline']['all_conv_kernels']['tflops'],1), k['main_stream'], k['teacher_stream'])" | tee -a $OUT/ab_fusek.txt; done ;;
 ab_env) run ab_env; for K in ${AB_ENV:-"X=0"}; do env $K timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); k=d['kernel_ms_by_family']; print('$K', round(d['ms_per_step'],2), round(d['roofline']['frac'],4), round(d['roofline']['all_conv_kernels']['tflops'],1), k['main_stream'], k['teacher_stream'])" | tee -a $OUT/ab_env.txt; done ;;
+ab_libs) run ab_libs; for L in ${AB_LIBS:-base new base new}; do if [ $L = new ]; then unset ET_HIP_LIB; else export ET_HIP_LIB=$PWD/tools/probe/libet_$L.so; fi; timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); k=d['kernel_ms_by_family']; print('$L', round(d['ms_per_step'],2), round(d['roofline']['frac'],4), round(d['roofline']['all_conv_kernels']['tflops'],1), k['main_stream'], k['teacher_stream'])" | tee -a $OUT/ab_libs.txt; done; unset ET_HIP_LIB ;;
 all_tests) run all_tests; timeout 2400 python -m pytest tests -x -q -m gpu > $OUT/pytest_gpu.log 2>&1; tail -5 $OUT/pytest_gpu.log ;;
 mb_pp) run mb_pp; MB_REF=0 MB_ONLY=${MB_ONLY:-pp} timeout 600 python tools/microbench.py conv > $OUT/mb_pp1.log 2>&1; tail -1 $OUT/mb_pp1.log ;;
 mb_lock) run mb_lock; ET_CONV_PP=0 MB_REF=0 MB_ONLY=${MB_ONLY:-"256, 256"} timeout 600 python tools/microbench.py conv > $OUT/mb_pp0.log 2>&1; tail -1 $OUT/mb_pp0.log ;;
