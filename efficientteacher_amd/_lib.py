@@ -139,11 +139,29 @@ class EtHipError(RuntimeError):
     pass
 
 
+def _header_abi_version():
+    """ET_ABI_VERSION of include/et_hip.h -- the contract SIGNATURES above was written against"""
+    import re
+    with open(os.path.join(os.path.dirname(_HERE), "include", "et_hip.h")) as f:
+        m = re.search(r"^#define\s+ET_ABI_VERSION\s+(\d+)", f.read(), re.M)
+    if m is None:
+        raise EtHipError("include/et_hip.h does not define ET_ABI_VERSION")
+    return int(m.group(1))
+
+
+ABI_VERSION = _header_abi_version()
+
+
 def _declare(dll):
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(dll, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    got = dll.et_abi_version()
+    if got != ABI_VERSION:
+        # a stale build: argument lists differ (an added int would be read as the stream, kernels would run unordered on the null stream)
+        raise EtHipError(f"{getattr(dll, '_name', 'libet_hip.so')} has ABI version {got}, this binding needs {ABI_VERSION}: "
+                         f"rebuild it (python -m efficientteacher_amd.csrc.build)")
     return dll
 
 

@@ -488,11 +488,12 @@ class UpsampleCatFn(Function):
     the upsampled rows are written straight into the concat buffer."""
 
     @staticmethod
-    def forward(ctx, a, b, acc=None):
-        """acc: the GradFork of `a` when `a` has a second consumer (the neck's lateral outputs also sit in a bottom-up concat)"""
+    def forward(ctx, a, b, acc=None, buf=None):
+        """acc: the GradFork of `a` when `a` has a second consumer (the neck's lateral outputs also sit in a bottom-up concat).
+        buf: the concat buffer `b` was produced in (YoloV5Neck.concat_slots), handed over explicitly by the caller"""
         N, H, W, Ca = a.shape
         Cb = b.shape[3]
-        cat = in_place_concat_buffer(b, Ca)
+        cat = in_place_concat_buffer(b, Ca, buf)
         if cat is None or cat.shape != (N, 2 * H, 2 * W, Ca + Cb):
             cat = torch.empty((N, 2 * H, 2 * W, Ca + Cb), dtype=a.dtype, device=a.device)
             cat[..., Ca:].copy_(b)
@@ -512,13 +513,12 @@ class UpsampleCatFn(Function):
             ctx.acc.merged = True
         else:
             da = ops.upsample2x_bwd(da_src)
-        return da, dcat[..., ctx.Ca:], None
+        return da, dcat[..., ctx.Ca:], None, None
 
 
-def in_place_concat_buffer(b, Ca):
-    """`b` was produced IN PLACE as channels [Ca, Ca + Cb) of a wider NHWC buffer (YoloV5Neck.concat_slots: the backbone's C3 / C4
-    blocks wrote P3 / P4 there): return that buffer, else None.  The producer tags the slice (`_et_cat_buf`)."""
-    buf = getattr(b, "_et_cat_buf", None)
+def in_place_concat_buffer(b, Ca, buf):
+    """`b` was produced IN PLACE as channels [Ca, Ca + Cb) of the wider NHWC buffer `buf` (YoloV5Neck.concat_slots: the backbone's
+    C3 / C4 blocks wrote P3 / P4 there): return `buf` if the geometry confirms it, else None (the caller then copies)."""
     if buf is None:
         return None
     es = buf.element_size()

@@ -3,4 +3,4 @@
 #include "../../include/et_hip.h"
 
 extern "C" const char* et_build_arch(void) { return "gfx950"; }
-extern "C" int et_abi_version(void) { return 1; }
+extern "C" int et_abi_version(void) { return ET_ABI_VERSION; }

@@ -19,6 +19,8 @@ def _mark_stage(name, t):
 
 
 class YoloV5BackBone(nn.Module):
+    supports_concat_dst = True       # forward(dst_c3=, dst_c4=): C3 / C4 written straight into the neck's concat buffers (detector/yolo.py)
+
     def __init__(self, cfg):
         super(YoloV5BackBone, self).__init__()
         self.gd = cfg.Model.depth_multiple

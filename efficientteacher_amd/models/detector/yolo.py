@@ -171,14 +171,16 @@ class Model(nn.Module):
         # uint8 batches (what the loaders deliver) are normalised inside the pack kernel: x / 255 (ssod_trainer.py:694-696)
         x8 = ops.pack_input(x, self._compute_dtype, norm_scale=getattr(self, "input_norm_scale", 255.0))
         slots = None
-        if hasattr(self.neck, "concat_slots") and x8.shape[1] % 32 == 0 and x8.shape[2] % 32 == 0:
+        # in-place P3 / P4: only a backbone that can write its C3 / C4 outputs into a destination slice (YoloV5BackBone) together
+        # with a neck that lays out the concat buffers (YoloV5Neck); any other registered pairing takes the plain path
+        if (hasattr(self.neck, "concat_slots") and getattr(self.backbone, "supports_concat_dst", False)
+                and x8.shape[1] % 32 == 0 and x8.shape[2] % 32 == 0):
             slots = self.neck.concat_slots(x8.shape[0], x8.shape[1] // 8, x8.shape[2] // 8, x8.dtype, x8.device)
         if slots is None:
             return self.neck(self.backbone(x8))
         (b3, o3), (b4, o4) = slots
         c3, c4, c5 = self.backbone(x8, dst_c3=(b3, o3), dst_c4=(b4, o4))
-        c3._et_cat_buf, c4._et_cat_buf = b3, b4          # UpsampleCatFn finds P3 / P4 already in place
-        return self.neck((c3, c4, c5))
+        return self.neck((c3, c4, c5), cat_bufs=(b3, b4))     # UpsampleCatFn finds P3 / P4 already in place
 
     def _forward_once(self, x, profile=False, visualize=False):
         return self.head(self._features(x))

@@ -58,8 +58,10 @@ class YoloV5Neck(nn.Module):
         cat1 = torch.empty((N, H3 // 2, W3 // 2, c1o + self.input_p4), dtype=dtype, device=device)
         return (cat2, c2o), (cat1, c1o)
 
-    def forward(self, inputs):
+    def forward(self, inputs, cat_bufs=None):
+        """cat_bufs = (buffer holding P3, buffer holding P4) from concat_slots() when the backbone produced them in place"""
         P3, P4, P5 = inputs
+        b3, b4 = cat_bufs if cat_bufs is not None else (None, None)
         # the two bottom-up concats [conv3(x2) | xp_2] and [conv4(x3) | xp_1] are produced IN PLACE: the lateral
         # convs write xp_1 / xp_2 into the second half of the concat buffer when they run, the stride-2 convs
         # later fill the first half (JoinSlicesFn is the differentiable "cat" of the filled buffer)
@@ -67,9 +69,9 @@ class YoloV5Neck(nn.Module):
         c1o = self.conv1.conv.out_channels
         if c1o % 8 or self.conv4.conv.out_channels % 8 or self.conv2.conv.out_channels % 8 or self.conv3.conv.out_channels % 8:
             xp_1 = self.conv1(P5)
-            x1 = self.C1(UpsampleCatFn.apply(xp_1, P4))
+            x1 = self.C1(UpsampleCatFn.apply(xp_1, P4, None, b4))
             xp_2 = self.conv2(x1)
-            x2 = self.C2(UpsampleCatFn.apply(xp_2, P3))
+            x2 = self.C2(UpsampleCatFn.apply(xp_2, P3, None, b3))
             x3 = self.C3(self.concat([self.conv3(x2), xp_2]))
             x4 = self.C4(self.concat([self.conv4(x3), xp_1]))
             return x2, x3, x4
@@ -78,12 +80,12 @@ class YoloV5Neck(nn.Module):
         # xp_1 / xp_2 (lateral outputs) and x2 / x3 (pyramid outputs) have two consumers each; the one that runs its backward LAST
         # (upsample-concat, stride-2 conv) adds its gradient into the other's in place (autograd.GradFork) instead of a torch add
         xp_1u, xp_1, f1 = GradFork.split(self.conv1(P5, dst=(buf4, c4o)))
-        x1 = self.C1(UpsampleCatFn.apply(xp_1u, P4, f1))     # upsample1 + concat, no intermediate tensor
+        x1 = self.C1(UpsampleCatFn.apply(xp_1u, P4, f1, b4))     # upsample1 + concat, no intermediate tensor
         xp_1 = GradFork.tap(xp_1, f1)
         c2o, c3o = self.conv2.conv.out_channels, self.conv3.conv.out_channels
         buf3 = torch.empty((N, x1.shape[1], x1.shape[2], c3o + c2o), dtype=x1.dtype, device=x1.device)
         xp_2u, xp_2, f2 = GradFork.split(self.conv2(x1, dst=(buf3, c3o)))
-        x2c, x2, g2 = GradFork.split(self.C2(UpsampleCatFn.apply(xp_2u, P3, f2)))     # upsample2 + concat
+        x2c, x2, g2 = GradFork.split(self.C2(UpsampleCatFn.apply(xp_2u, P3, f2, b3)))     # upsample2 + concat
         xp_2 = GradFork.tap(xp_2, f2)
         t3 = self.conv3(x2c, dst=(buf3, 0), acc=g2)
         x2 = GradFork.tap(x2, g2)

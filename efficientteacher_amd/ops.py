@@ -618,6 +618,10 @@ class DeviceThresholds:
         if st[1] != key:
             if st[0].shape[1] != len(key[0]):
                 raise ValueError("the number of classes of the threshold lists changed")
+            if dev.type == "cuda" and torch.cuda.is_current_stream_capturing():
+                # a pageable host-to-device copy would invalidate the capture with an opaque error: say what went wrong instead
+                raise RuntimeError("pseudo-label thresholds changed inside a step-graph capture: refresh_thresholds() must run "
+                                   "before the capture starts (trainer/graph_step.py::StepGraph.run does)")
             st[0].copy_(torch.tensor([key[0], key[1]], dtype=torch.float64))
             st[1] = key
         return st[0]
@@ -856,12 +860,21 @@ def tal_assign(pd_scores, pd_bboxes, anc_points, gt_labels, gt_bboxes, mask_gt, 
     return tl, tb, ts, fg.bool()
 
 
+TAL_PAD_SYNC_FREE_ROWS = 32     # up to this many target rows per image ON AVERAGE the padded table is sized by n without a host sync
+
+
 def tal_targets_pad(targets, B, img_w, img_h):
     """ComputeTalLoss.preprocess on the device: (n,6) [img, cls, x, y, w, h] normalised -> gt_labels (B,G,1), gt_bboxes (B,G,4) xyxy
-    pixels, mask_gt (B,G,1) with G = max(n, 1): no host synchronisation (the reference loops over targets.cpu())"""
+    pixels, mask_gt (B,G,1).  G = max(n, 1) without a host synchronisation while n <= 32 * B (the reference loops over
+    targets.cpu()); beyond that G = the largest per-image count (one host read)"""
     t = targets[:, :6].to(torch.float32).contiguous()
     n = int(t.shape[0])
     G = max(n, 1)
+    if n > TAL_PAD_SYNC_FREE_ROWS * B:
+        # crowded batch (mosaic: thousands of boxes): G = n would make the assigner's B*G*A workspace and its B*G workgroups grow with the
+        # BATCH total instead of the per-image maximum the reference pads to (tal_loss.py:131-143).  One host read of the per-image
+        # maximum -- the reference's own preprocess synchronises on targets.cpu() at this point anyway.
+        G = max(int(torch.bincount(t[:, 0].long().clamp_(0, B - 1), minlength=B).max()), 1)
     out = torch.empty((B, G, 5), dtype=torch.float32, device=t.device)
     mask = torch.empty((B, G, 1), dtype=torch.float32, device=t.device)
     _lib.check(_lib.load().et_tal_targets_pad(_lib.ptr(t) if n else None, n, B, G, float(img_w), float(img_h), _lib.ptr(out), _lib.ptr(mask),

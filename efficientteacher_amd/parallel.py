@@ -61,6 +61,7 @@ class FlatDataParallel(nn.Module):
         self.active = self.world > 1 or (bool(single_rank_collectives) and dist.is_initialized())
         self._works = []
         self._launched = set()
+        self._dirty = False              # a backward has moved the per-chunk counters since the last reduce_gradients()
         self.timing = False              # bench.py: HIP events around the collective phase of a step
         self.last_timing = None          # (first launch -> all complete, exposed wait after backward) in ms
         self._ev0 = None
@@ -121,6 +122,7 @@ class FlatDataParallel(nn.Module):
         ci = self._slot_chunk.get(slot.index)
         if ci is None or ci in self._launched:
             return
+        self._dirty = True                    # counters no longer at their start values (cleared by reduce_gradients)
         self._remaining[ci] -= 1
         if self._remaining[ci] == 0:
             o, n, _ = self._chunks[ci]
@@ -128,9 +130,12 @@ class FlatDataParallel(nn.Module):
             self._all_reduce(self.module.flat_state().grads[o:o + n])
 
     def forward(self, *a, **k):
-        if self._works or self._launched:
+        if self._works or self._launched or self._dirty:
             # a backward whose collectives nobody finished (an exception between backward and reduce_gradients, or a caller
-            # that skipped it): never let an all-reduce in flight overlap the next backward's writes into the same arena
+            # that skipped it): never let an all-reduce in flight overlap the next backward's writes into the same arena.
+            # _dirty covers a backward that aborted after some wgrad hooks had counted down but before any chunk was complete:
+            # with stale counters the next backward would launch a chunk's all-reduce before all of its layers had accumulated,
+            # and the late layers' gradients would never be averaged (ranks diverge silently).
             self.reduce_gradients()
         if self.active and self.broadcast_buffers and self.module.training:
             # DDP broadcast_buffers=True: rank 0's BN running stats / anchors at every forward
@@ -173,6 +178,7 @@ class FlatDataParallel(nn.Module):
         self._works = []
         self._launched = set()
         self._remaining = [c[2] for c in self._chunks]
+        self._dirty = False
 
     def collect_timing(self):
         """(ms from the first all-reduce launch to the completion of the last, ms the compute stream waited for the

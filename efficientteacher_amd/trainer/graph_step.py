@@ -185,18 +185,20 @@ class StepGraph:
         t = self.t
         if self.graph is not None and len(self._probe) == self.REPLAY_PROBE:
             self._check_probe()
+        # host-side bookkeeping the eager step does between its launches (ssod_trainer.py:616-617) and the loss thresholds:
+        # LabelMatch's after_epoch rewrites the per-class lists; the captured select_targets reads them from ONE persistent
+        # device tensor that is refreshed in place here (stream-ordered before the replay).  BEFORE a capture: the refresh is a
+        # pageable host-to-device copy when the lists changed, which is illegal inside a capturing stream -- a (re-)capture after an
+        # epoch boundary would be invalidated and the trainer would stay eager for the rest of the run.
+        if t.cfg.SSOD.pseudo_label_type == 'LabelMatch':
+            t.pseudo_label_creator.update(targets, imgs.shape[0], u_str.shape[0])
+        t.compute_un_sup_loss.refresh_thresholds(t.device)
         if self.graph is None:
             self._capture(imgs, u_str, u_ori, M_s)
         # host side of update_optimizer (trainer/ssod_trainer.py:458-488), in its order: warm-up, then the step's scalars
         t.accumulate = 1
         t._warmup(ni, 1 if t.fixed_accumulate else 64 / t.batch_size)
         self.hp.push(self._scalars())
-        # host-side bookkeeping the eager step does between its launches (ssod_trainer.py:616-617) and the loss thresholds:
-        # LabelMatch's after_epoch rewrites the per-class lists; the captured select_targets reads them from ONE persistent
-        # device tensor that is refreshed in place here (stream-ordered before the replay)
-        if t.cfg.SSOD.pseudo_label_type == 'LabelMatch':
-            t.pseudo_label_creator.update(targets, imgs.shape[0], u_str.shape[0])
-        t.compute_un_sup_loss.refresh_thresholds(t.device)
         # inputs
         for dst, src in ((self.s_imgs, imgs), (self.s_ustr, u_str), (self.s_uori, u_ori)):
             if src.data_ptr() != dst.data_ptr():

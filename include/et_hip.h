@@ -27,7 +27,10 @@ typedef void* et_stream_t; /* hipStream_t */
 enum { ET_F32 = 0, ET_BF16 = 1 };
 
 /* Library / device identification (host side). Returns the gfx arch the code objects were built
- * for ("gfx950") and the ABI version. */
+ * for ("gfx950") and the ABI version.  ET_ABI_VERSION changes whenever an entry point is added or a signature / workspace
+ * contract changes; a binding must refuse a library whose et_abi_version() differs from the header it was written against
+ * (efficientteacher_amd/_lib.py does): a stale libet_hip.so would otherwise read e.g. a new int argument as the stream. */
+#define ET_ABI_VERSION 2
 const char* et_build_arch(void);
 int et_abi_version(void);
 

@@ -19,12 +19,13 @@ def _declared():
 
 
 def test_library_exports_every_declared_symbol(hip_lib_path):
+    from efficientteacher_amd import _lib
     lib = ctypes.CDLL(hip_lib_path)
     missing = [n for n in _declared() if not hasattr(lib, n)]
     assert not missing, missing
     lib.et_build_arch.restype = ctypes.c_char_p
     assert lib.et_build_arch() == b"gfx950"
-    assert lib.et_abi_version() >= 1
+    assert lib.et_abi_version() == _lib.ABI_VERSION        # _lib._declare refuses any other library
 
 
 def test_ctypes_table_binds_every_symbol():
@@ -33,6 +34,16 @@ def test_ctypes_table_binds_every_symbol():
     bound = set(_lib.SIGNATURES)
     assert decl - bound == set(), sorted(decl - bound)
     assert bound - decl == set(), sorted(bound - decl)
+
+
+def test_stale_library_is_refused(hip_lib_path, monkeypatch):
+    """a library whose et_abi_version() differs from include/et_hip.h's ET_ABI_VERSION does not bind (a stale .so would
+    read a newly added int argument as the stream and launch unordered on the null stream)"""
+    from efficientteacher_amd import _lib
+    monkeypatch.setattr(_lib, "ABI_VERSION", _lib.ABI_VERSION + 1)
+    with pytest.raises(_lib.EtHipError) as e:
+        _lib._declare(ctypes.CDLL(hip_lib_path))
+    assert "rebuild" in str(e.value)
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

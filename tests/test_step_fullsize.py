@@ -52,8 +52,11 @@ def _canon(a):
     return a[np.lexsort((np.round(a[:, 3], 5), np.round(a[:, 2], 5), a[:, 1], a[:, 0]))]
 
 
-def run_ssod_step_parity(dev, dtype, width=1.0, depth=1.0, S=640, Bl=1, Bu=1):
-    """shared by the two dtype tests (and importable by tools): returns the measured deviations"""
+def run_ssod_step_parity(dev, dtype, width=1.0, depth=1.0, S=640, Bl=1, Bu=1, with_oracle=True, amp_calibration=True, all_grads=None):
+    """shared by the dtype tests (and importable by tools): returns the measured deviations.
+    with_oracle=False: only the HIP step (items, decoded teacher output, gradients) -- tests/test_step_benchbatch.py compares two HIP
+    modes with it.  all_grads: a dict that receives {"hip": {name: grad}, "ref": {name: grad}} of EVERY parameter (the HIP ones
+    recovered from the first SGD update)."""
     from efficientteacher_amd.configs import get_cfg
     from efficientteacher_amd.trainer import SSODTrainer
     from efficientteacher_amd.utils.torch_utils import ModelEMA
@@ -87,10 +90,26 @@ def run_ssod_step_parity(dev, dtype, width=1.0, depth=1.0, S=640, Bl=1, Bu=1):
     items = tr.train_instance(imgs.to(dev), targets.to(dev), None, u_str.to(dev), u_ori.to(dev), None, M_s.to(dev), ni)
     torch.cuda.synchronize()
     torch.set_num_threads(min(32, os.cpu_count() or 1))
-    ref = o_step.ssod_step(student, teacher, imgs, targets, u_str, u_ori, M_s, cfg, synth_scores=synth)
     out = {}
+    gp = dict(tr.model.named_parameters())
+    groups = {id(p): g for g in tr.optimizer.param_groups for p in g["params"]}
+
+    def hip_grad(name):
+        # recovered from the first SGD-nesterov update: dp = -lr*(1+m)*(g + wd*p)  (buf = g on step 1)
+        g = groups[id(gp[name])]
+        lr, m, wd = float(g["lr"]), float(g["momentum"]), float(g["weight_decay"])
+        return -(gp[name].detach().cpu() - p0[name]) / (lr * (1.0 + m)) - wd * p0[name]
+    if all_grads is not None:
+        all_grads["hip"] = {n: hip_grad(n) for n in gp if id(gp[n]) in groups}
+    if not with_oracle:
+        out["items"] = {k: float(v) for k, v in items.items()}
+        out["teacher_pred"] = captured["tp"]
+        return out
+    ref = o_step.ssod_step(student, teacher, imgs, targets, u_str, u_ori, M_s, cfg, synth_scores=synth)
+    if all_grads is not None:
+        all_grads["ref"] = {n: p.grad.detach().clone() for n, p in student.named_parameters() if p.grad is not None}
     amp = None
-    if dtype != torch.float32:
+    if dtype != torch.float32 and amp_calibration:
         # calibration: the reference's own mixed-precision recipe (autocast, trainer.py:348) on the oracle, bf16 instead
         # of fp16 -- how far reduced-precision activations move THIS step's gradients at all
         st16 = copy.deepcopy(student)
@@ -116,21 +135,17 @@ def run_ssod_step_parity(dev, dtype, width=1.0, depth=1.0, S=640, Bl=1, Bu=1):
         out["pseudo_box_abs"] = float(np.abs(mine[:, 2:6] - theirs[:, 2:6]).max()) if mine.size else 0.0
     # 4 losses
     mine_items = {k: float(v) for k, v in items.items()}
+    out["items"] = mine_items
     out["loss_rel"] = {k: abs(mine_items[k] - r) / max(abs(r), 1e-12) for k, r in
                        {**{k: ref["sup_items"][k] for k in ("box", "obj", "cls")}, **ref["un_items"]}.items()}
     out["loss_values"] = {k: (mine_items[k], r) for k, r in {**{k: ref["sup_items"][k] for k in ("box", "obj", "cls")}, **ref["un_items"]}.items()}
-    # 5 gradients, recovered from the first SGD-nesterov update: dp = -lr*(1+m)*(g + wd*p)  (buf = g on step 1)
-    gp = dict(tr.model.named_parameters())
+    # 5 gradients (five named tensors here; every conv weight at the benchmarked batch: tests/test_step_benchbatch.py)
     rp = dict(student.named_parameters())
-    groups = {id(p): g for g in tr.optimizer.param_groups for p in g["params"]}
     out["grad_rel"], out["grad_l2"], out["grad_cos"], out["amp_l2"], out["amp_cos"] = {}, {}, {}, {}, {}
     for name in GRADS:
         if name not in gp:
             continue
-        g = groups[id(gp[name])]
-        lr, m, wd = float(g["lr"]), float(g["momentum"]), float(g["weight_decay"])
-        upd = gp[name].detach().cpu() - p0[name]
-        grad = -upd / (lr * (1.0 + m)) - wd * p0[name]
+        grad = hip_grad(name)
         rg = rp[name].grad
         out["grad_rel"][name] = ((grad - rg).abs().max() / rg.abs().max().clamp_min(1e-12)).item()
         out["grad_l2"][name] = ((grad - rg).norm() / rg.norm().clamp_min(1e-20)).item()
