@@ -35,6 +35,7 @@ SIGNATURES = {
     "et_ema_update_dev": (c_int, [P, P, c_int64, P, P]),
     "et_sgd_nesterov_dev": (c_int, [P, P, P, P, c_int64, P, c_int, P]),
     "et_conv2d_stats_rows": (c_int, [c_int, c_int, c_int]),
+    "et_conv2d_stats_rows_for": (c_int, [c_int] * 12),
     "et_conv2d_fwd": (c_int, [P, P, P, c_int] + [c_int] * 11 + [P, P, c_int, P, c_int, P, P, P]),
     "et_conv2d_dgrad": (c_int, [P, P, P, c_int] + [c_int] * 11 + [c_int, P, c_int, P, P]),
     "et_conv2d_dgrad_bn": (c_int, [P, P, P, c_int] + [c_int] * 10 + [P, c_int, P, c_int, P, P, c_int, P, P, P]),
@@ -107,7 +108,7 @@ _emulated = False
 # the launching stream.  None (always, outside that one instrumented step) = the library object itself, no wrapper.
 CALL_TIMER = None
 _NO_LAUNCH = frozenset(n for n in (
-    "et_build_arch", "et_abi_version", "et_nms_ssod_workspace_bytes", "et_nms_workspace_bytes", "et_conv2d_stats_rows",
+    "et_build_arch", "et_abi_version", "et_nms_ssod_workspace_bytes", "et_nms_workspace_bytes", "et_conv2d_stats_rows", "et_conv2d_stats_rows_for",
     "et_conv2d_kernel_name", "et_env_knobs", "et_bn_reduce_rows", "et_ota_workspace_bytes", "et_tal_assign_workspace_bytes"))
 
 

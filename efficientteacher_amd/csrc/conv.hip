@@ -30,6 +30,13 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;   // 16-byte register vector (SSA, no struct)
 __device__ __forceinline__ u32x4 mk4(unsigned a, unsigned b, unsigned c, unsigned d) { u32x4 v = {a, b, c, d}; return v; }
+// "this register is defined HERE": whatever load produced it has completed in front of this point, and later uses depend on
+// this (empty) instruction instead of the load
+__device__ __forceinline__ void et_pin_loaded(u32x4& v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(v));
+#endif
+}
 
 #define CONV_MAX_TAPS 36
 // workgroups per CU the short-K 128x64 tile (32-wide chunks, 3-deep ring, 36 KB of LDS) is compiled for: 3 = 129 VGPRs, 4 = 128 + two spilled
@@ -188,8 +195,8 @@ __device__ __forceinline__ void mma_chunk(const u32x4* __restrict__ sm, f32x16 (
 
 // ---- shared epilogue of the gather-GEMM kernels -----------------------------------------------------
 // LDS floats the epilogue needs: one private [32][BN/WN + 4] fp32 slab per wave
-template <int BM, int BN, int WM, int WN> struct EpiLds {
-    static constexpr int WCOLS = BN / WN, SLD = WCOLS + 4, SLAB = 32 * SLD;
+template <int BM, int BN, int WM, int WN, int SROWS = 32> struct EpiLds {
+    static constexpr int WCOLS = BN / WN, SLD = WCOLS + 4, SLAB = SROWS * SLD;
     static constexpr int FLOATS = WM * WN * SLAB;
     static constexpr int VEC16 = (FLOATS * 4 + 15) / 16;
 };
@@ -201,41 +208,124 @@ template <int BM, int BN, int WM, int WN> struct EpiLds {
 // staged half the block tile per __syncthreads round with a run-time activation switch per element, spent
 // 12.5 k cycles on a 128x64 tile and 23 k on 128x128 -- 22 % of a 3x3 and 45-60 % of a 1x1 layer's
 // workgroup lifetime).  residual / accumulate are vector loads.
-template <typename T, int BM, int BN, int WM, int WN, int ACT>
+// SROWS = rows of the private slab: 32 (one MFMA tile per round) or 16 (two rounds per tile, half the LDS: the persistent 1x1
+// kernel keeps its operand ring resident beside the slabs).
+// The per-lane statistics live in an EpiSums the caller owns: the tiled kernels pass a fresh one per tile and let the epilogue write
+// it out (DEFER = false); the persistent 1x1 kernel accumulates over ALL its tiles and writes one partial row per workgroup at the
+// end (DEFER = true, conv_epilogue_write_stats).  MODE 0: every feature behind run-time flags; MODE 1: plain layer only -- no
+// residual, no accumulate, no BN-backward sums (their code and registers are compiled out: the caller guarantees the flags are off).
+template <int TN> struct EpiSums {
+    float ssum[TN], ssq[TN];        // forward: per-lane sums of the raw accumulators / their squares (lane owns one channel per column tile)
+    float bs1[8], bs2[8];           // BN-backward: sums of du and du * y over this lane's 8 channels of the store phase
+    // per-channel constants staged in LDS by the caller: [scale | bias | bn_scale | bn_shift], `cstride` floats each, indexed by the
+    // channel inside the workgroup's column range (DEFER callers only; the tiled kernels read global memory once per tile).  A
+    // persistent kernel must not read them from global memory per tile: the wait for such a load sits behind every LDS-DMA piece
+    // the ring has in flight (vector-memory loads retire in order)
+    const float* cst = nullptr;
+    int cstride = 0;
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) { ssum[tn] = 0.f; ssq[tn] = 0.f; }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { bs1[e] = 0.f; bs2[e] = 0.f; }
+    }
+};
+
+// one partial row (rows, 2, Cout) of this WAVE's sums: channels n0 + wn * WCOLS ..., row `row`; `zero_rows` further rows are zeroed
+template <int BN, int WN, int MODE>
+__device__ __forceinline__ void conv_epilogue_write_stats(EpiSums<BN / WN / 32>& st, const GatherGeom& g, const Epilogue& ep, int n0, int lane,
+                                                          int wn, int row, int zero_rows, int nrows) {
+    constexpr int TN = BN / WN / 32, WCOLS = BN / WN, CVN = WCOLS / 8;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int scv = lane % CVN;
+    const int co = n0 + wn * WCOLS + scv * 8;
+    const bool bnb = MODE == 1 ? false : ep.bn_y != nullptr;
+    if (bnb) {
+        // BN-backward sums: lanes of a wave that share a channel group (same scv, different srow) are CVN apart: xor-reduce over
+        // the srow bits, lane scv then holds the sums of its 8 channels
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            for (int m = CVN; m < 64; m <<= 1) { st.bs1[e] += __shfl_xor(st.bs1[e], m); st.bs2[e] += __shfl_xor(st.bs2[e], m); }
+        if (lane < CVN && co + 8 <= g.Cout) {
+            for (int r = 0; r <= zero_rows; ++r) {
+                if (row + r >= nrows) break;
+                float* d0 = ep.stats + ((size_t)(row + r) * 2 + 0) * g.Cout + co;
+                float* d1 = ep.stats + ((size_t)(row + r) * 2 + 1) * g.Cout + co;
+                if (r == 0) {
+                    *(float4*)d0 = make_float4(st.bs1[0], st.bs1[1], st.bs1[2], st.bs1[3]); *(float4*)(d0 + 4) = make_float4(st.bs1[4], st.bs1[5], st.bs1[6], st.bs1[7]);
+                    *(float4*)d1 = make_float4(st.bs2[0], st.bs2[1], st.bs2[2], st.bs2[3]); *(float4*)(d1 + 4) = make_float4(st.bs2[4], st.bs2[5], st.bs2[6], st.bs2[7]);
+                } else {
+                    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                    *(float4*)d0 = z; *(float4*)(d0 + 4) = z; *(float4*)d1 = z; *(float4*)(d1 + 4) = z;
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const float sv = st.ssum[tn] + __shfl_xor(st.ssum[tn], 32);   // the two lane halves hold the two row halves of a channel
+            const float qv = st.ssq[tn] + __shfl_xor(st.ssq[tn], 32);
+            const int cc = n0 + wn * WCOLS + tn * 32 + l31;
+            if (hi == 0 && cc < g.Cout) {
+                for (int r = 0; r <= zero_rows; ++r) {
+                    if (row + r >= nrows) break;
+                    ep.stats[((size_t)(row + r) * 2 + 0) * g.Cout + cc] = r == 0 ? sv : 0.f;
+                    ep.stats[((size_t)(row + r) * 2 + 1) * g.Cout + cc] = r == 0 ? qv : 0.f;
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int ACT, int SROWS = 32, int MODE = 0, bool DEFER = false>
 __device__ __forceinline__ void conv_epilogue_act(f32x16 (&acc)[BM / WM / 32][BN / WN / 32], u32x4* lds_raw, T* __restrict__ Y,
                                                   const GatherGeom& g, const Epilogue& ep, int bx, int m0, int n0, int tid,
-                                                  int lane, int wm, int wn) {
+                                                  int lane, int wm, int wn, EpiSums<BN / WN / 32>& st) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    using L = EpiLds<BM, BN, WM, WN>;
+    static_assert(SROWS == 32 || SROWS == 16, "slab rows");
+    constexpr int NH = 32 / SROWS;                 // slab rounds per 32-row MFMA tile
+    using L = EpiLds<BM, BN, WM, WN, SROWS>;
     constexpr int WCOLS = L::WCOLS, SLD = L::SLD;
     constexpr int CVN = WCOLS / 8;                 // 8-channel groups per slab row
     constexpr int RPI = 64 / CVN;                  // slab rows stored per wave iteration
+    static_assert(RPI <= SROWS, "a store iteration covers at most one slab");
     const int l31 = lane & 31, hi = lane >> 5;
     const int wave = wm * WN + wn;
     float* const stg = (float*)lds_raw + wave * L::SLAB;
-    float ssum[TN], ssq[TN];
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) { ssum[tn] = 0.f; ssq[tn] = 0.f; }
+    float (&ssum)[TN] = st.ssum;
+    float (&ssq)[TN] = st.ssq;
+    float (&bs1)[8] = st.bs1;
+    float (&bs2)[8] = st.bs2;
     const bool ident = (g.osy == 1 && g.osx == 1 && g.ooy == 0 && g.oox == 0 && g.QH == g.OH && g.QW == g.OW);
     float csc[TN], cbi[TN];
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
         const int co = n0 + wn * WCOLS + tn * 32 + l31;
         const bool cok = co < g.Cout;
-        csc[tn] = (ep.scale && cok) ? ep.scale[co] : 1.0f;
-        cbi[tn] = (ep.bias && cok) ? ep.bias[co] : 0.0f;
+        if constexpr (DEFER) {           // (a persistent caller: compile-time, so that the LDS address space is inferred)
+            csc[tn] = st.cst[co - n0];
+            cbi[tn] = st.cst[st.cstride + co - n0];
+        } else {
+            csc[tn] = (ep.scale && cok) ? ep.scale[co] : 1.0f;
+            cbi[tn] = (ep.bias && cok) ? ep.bias[co] : 0.0f;
+        }
     }
     const int srow = lane / CVN, scv = lane % CVN;  // this lane's (row, channel group) in the store phase
     const int co = n0 + wn * WCOLS + scv * 8;
     // BN-backward statistics mode: this lane owns 8 channels in the store phase; per-channel affine in registers
-    const bool bnb = ep.bn_y != nullptr;
-    const bool lean = ident && !bnb && ep.res == nullptr && !ep.accumulate && m0 + BM <= g.M && n0 + BN <= g.Cout;   // uniform
-    float bsc[8], bsh[8], bs1[8], bs2[8];
+    const bool bnb = MODE == 1 ? false : ep.bn_y != nullptr;
+    const void* const ep_res = MODE == 1 ? nullptr : ep.res;
+    const bool ep_accumulate = MODE == 1 ? false : (bool)ep.accumulate;
+    const bool lean = ident && !bnb && ep_res == nullptr && !ep_accumulate && m0 + BM <= g.M && n0 + BN <= g.Cout;   // uniform
+    float bsc[8], bsh[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { bsc[e] = 1.f; bsh[e] = 0.f; bs1[e] = 0.f; bs2[e] = 0.f; }
+    for (int e = 0; e < 8; ++e) { bsc[e] = 1.f; bsh[e] = 0.f; }
     if (bnb && co + 8 <= g.Cout) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { bsc[e] = ep.bn_scale[co + e]; bsh[e] = ep.bn_shift[co + e]; }
+        for (int e = 0; e < 8; ++e) {
+            if constexpr (DEFER) { bsc[e] = st.cst[2 * st.cstride + co - n0 + e]; bsh[e] = st.cst[3 * st.cstride + co - n0 + e]; }
+            else { bsc[e] = ep.bn_scale[co + e]; bsh[e] = ep.bn_shift[co + e]; }
+        }
     }
     // sums of du = dz * act'(y*s + b) and du*y over 8 channels of one pixel; the activation kind is resolved by ONE uniform
     // branch per call (it used to be a scalar compare-and-branch chain per element: ~25 instructions each)
@@ -258,10 +348,12 @@ __device__ __forceinline__ void conv_epilogue_act(f32x16 (&acc)[BM / WM / 32][BN
         else body(std::integral_constant<int, ACT_NONE>{});
     };
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
+    for (int tmh = 0; tmh < TM * NH; ++tmh) {
+        const int tm = tmh / NH, hoff = (tmh % NH) * SROWS;      // accumulator tile, first tile row of this slab round
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        for (int rr = 0; rr < 16 / NH; ++rr) {
+            const int r = (tmh % NH) * (16 / NH) + rr;
+            const int row = (rr & 3) + 8 * (rr >> 2) + 4 * hi;   // row inside the slab (accumulator register r <-> tile row hoff + row)
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) {
                 float v = acc[tm][tn][r];
@@ -282,9 +374,9 @@ __device__ __forceinline__ void conv_epilogue_act(f32x16 (&acc)[BM / WM / 32][BN
                 // interior tile of a plain bf16 layer (no residual / accumulate / BN-backward sums, identity pixel map): the store
                 // pass without a single guard or branch, so that the compiler can overlap the slab reads of the four iterations
 #pragma unroll
-                for (int it = 0; it < 32 / RPI; ++it) {
+                for (int it = 0; it < SROWS / RPI; ++it) {
                     const int row = it * RPI + srow;
-                    const long long p = m0 + wm * (BM / WM) + tm * 32 + row;
+                    const long long p = m0 + wm * (BM / WM) + tm * 32 + hoff + row;
                     const float4 a = *(const float4*)(stg + row * SLD + scv * 8);
                     const float4 b = *(const float4*)(stg + row * SLD + scv * 8 + 4);
                     *(u32x4*)(Y + p * g.ldy + co) = mk4(et_pack_bf2(a.x, a.y), et_pack_bf2(a.z, a.w), et_pack_bf2(b.x, b.y), et_pack_bf2(b.z, b.w));
@@ -295,9 +387,9 @@ __device__ __forceinline__ void conv_epilogue_act(f32x16 (&acc)[BM / WM / 32][BN
             }
         }
 #pragma unroll
-        for (int it = 0; it < 32 / RPI; ++it) {
+        for (int it = 0; it < SROWS / RPI; ++it) {
             const int row = it * RPI + srow;
-            const int p = m0 + wm * (BM / WM) + tm * 32 + row;
+            const int p = m0 + wm * (BM / WM) + tm * 32 + hoff + row;
             if (p < g.M && co < g.Cout) {
                 long long pix;
                 if (ident) {
@@ -314,14 +406,14 @@ __device__ __forceinline__ void conv_epilogue_act(f32x16 (&acc)[BM / WM / 32][BN
                 T* yp = Y + pix * g.ldy + co;
                 if (co + 8 <= g.Cout) {
                     if constexpr (sizeof(T) == 2) {
-                        if (ep.res) {
-                            const u32x4 rr = *(const u32x4*)((const T*)ep.res + pix * ep.ldr + co);
+                        if (ep_res) {
+                            const u32x4 rr = *(const u32x4*)((const T*)ep_res + pix * ep.ldr + co);
                             v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
                             v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
                             v[4] += __uint_as_float(rr.z << 16); v[5] += __uint_as_float(rr.z & 0xffff0000u);
                             v[6] += __uint_as_float(rr.w << 16); v[7] += __uint_as_float(rr.w & 0xffff0000u);
                         }
-                        if (ep.accumulate) {
+                        if (ep_accumulate) {
                             const u32x4 rr = *(const u32x4*)yp;
                             v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
                             v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
@@ -344,12 +436,12 @@ __device__ __forceinline__ void conv_epilogue_act(f32x16 (&acc)[BM / WM / 32][BN
                             bn_bwd_sums(dz8, y8);
                         }
                     } else {
-                        if (ep.res) {
-                            const float* rp = (const float*)ep.res + pix * ep.ldr + co;
+                        if (ep_res) {
+                            const float* rp = (const float*)ep_res + pix * ep.ldr + co;
                             const float4 r0 = *(const float4*)rp, r1 = *(const float4*)(rp + 4);
                             v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
                         }
-                        if (ep.accumulate) {
+                        if (ep_accumulate) {
                             const float4 r0 = *(const float4*)yp, r1 = *(const float4*)((const float*)yp + 4);
                             v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
                         }
@@ -365,8 +457,8 @@ __device__ __forceinline__ void conv_epilogue_act(f32x16 (&acc)[BM / WM / 32][BN
                 } else {
                     for (int e = 0; e < 8 && co + e < g.Cout; ++e) {
                         float x = v[e];
-                        if (ep.res) x += et_elem<T>::ld(((const T*)ep.res)[pix * ep.ldr + co + e]);
-                        if (ep.accumulate) x += et_elem<T>::ld(yp[e]);
+                        if (ep_res) x += et_elem<T>::ld(((const T*)ep_res)[pix * ep.ldr + co + e]);
+                        if (ep_accumulate) x += et_elem<T>::ld(yp[e]);
                         yp[e] = et_elem<T>::st(x);
                     }
                 }
@@ -375,65 +467,38 @@ __device__ __forceinline__ void conv_epilogue_act(f32x16 (&acc)[BM / WM / 32][BN
         __builtin_amdgcn_s_waitcnt(0xC07F);        // slab reads done before the next 32 rows overwrite it
         __builtin_amdgcn_wave_barrier();
     }
-    if (ep.stats) {
-        // Partial statistics, one row of the (rows, 2, Cout) buffer per 64 output rows (et_conv2d_stats_rows).  Every wave writes
-        // the sums of ITS rows and channels straight to global memory -- no LDS hop, no workgroup barrier: the barrier made every
-        // wave of the tile wait for the slowest one's store passes (measured with s_memtime stamps, profiles/r03_epilogue_stamps.txt:
-        // 1.0 k of the 10.1 k cycles of a short-K 1x1 tile, 3.6 k of the 130 k of a 256x256 3x3 tile).  A wave whose tile part is
-        // taller than 64 rows writes its sums into its first row and zeros the others it covers; rows beyond M were zero-filled
-        // operands, so they add nothing.
-        constexpr int RPW = (BM / WM) / 64;                      // 64-row blocks per wave
-        static_assert((BM / WM) % 64 == 0, "wave tiles are whole 64-row blocks");
-        const int nrows = (g.M + 63) / 64;
-        const int rw = (m0 + wm * (BM / WM)) / 64;
-        if (bnb) {
-            // BN-backward sums: lanes of a wave that share a channel group (same scv, different srow) are CVN apart: xor-reduce over
-            // the srow bits, lane scv then holds the sums of its 8 channels
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-                for (int m = CVN; m < 64; m <<= 1) { bs1[e] += __shfl_xor(bs1[e], m); bs2[e] += __shfl_xor(bs2[e], m); }
-            if (lane < CVN && co + 8 <= g.Cout) {
-#pragma unroll
-                for (int r = 0; r < RPW; ++r) {
-                    if (rw + r >= nrows) break;
-                    float* d0 = ep.stats + ((size_t)(rw + r) * 2 + 0) * g.Cout + co;
-                    float* d1 = ep.stats + ((size_t)(rw + r) * 2 + 1) * g.Cout + co;
-                    if (r == 0) {
-                        *(float4*)d0 = make_float4(bs1[0], bs1[1], bs1[2], bs1[3]); *(float4*)(d0 + 4) = make_float4(bs1[4], bs1[5], bs1[6], bs1[7]);
-                        *(float4*)d1 = make_float4(bs2[0], bs2[1], bs2[2], bs2[3]); *(float4*)(d1 + 4) = make_float4(bs2[4], bs2[5], bs2[6], bs2[7]);
-                    } else {
-                        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-                        *(float4*)d0 = z; *(float4*)(d0 + 4) = z; *(float4*)d1 = z; *(float4*)(d1 + 4) = z;
-                    }
-                }
-            }
-        } else {
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn) {
-                const float sv = ssum[tn] + __shfl_xor(ssum[tn], 32);   // the two lane halves hold the two row halves of a channel
-                const float qv = ssq[tn] + __shfl_xor(ssq[tn], 32);
-                const int cc = n0 + wn * WCOLS + tn * 32 + l31;
-                if (hi == 0 && cc < g.Cout) {
-#pragma unroll
-                    for (int r = 0; r < RPW; ++r) {
-                        if (rw + r >= nrows) break;
-                        ep.stats[((size_t)(rw + r) * 2 + 0) * g.Cout + cc] = r == 0 ? sv : 0.f;
-                        ep.stats[((size_t)(rw + r) * 2 + 1) * g.Cout + cc] = r == 0 ? qv : 0.f;
-                    }
-                }
-            }
+    if constexpr (!DEFER) {
+        if (ep.stats) {
+            // Partial statistics, one row of the (rows, 2, Cout) buffer per 64 output rows (et_conv2d_stats_rows).  Every wave writes
+            // the sums of ITS rows and channels straight to global memory -- no LDS hop, no workgroup barrier: the barrier made every
+            // wave of the tile wait for the slowest one's store passes (measured with s_memtime stamps, profiles/r03_epilogue_stamps.txt:
+            // 1.0 k of the 10.1 k cycles of a short-K 1x1 tile, 3.6 k of the 130 k of a 256x256 3x3 tile).  A wave whose tile part is
+            // taller than 64 rows writes its sums into its first row and zeros the others it covers; rows beyond M were zero-filled
+            // operands, so they add nothing.
+            constexpr int RPW = (BM / WM) / 64;                      // 64-row blocks per wave
+            static_assert((BM / WM) % 64 == 0, "wave tiles are whole 64-row blocks");
+            conv_epilogue_write_stats<BN, WN, MODE>(st, g, ep, n0, lane, wn, (m0 + wm * (BM / WM)) / 64, RPW - 1, (g.M + 63) / 64);
         }
     }
 }
 
+template <typename T, int BM, int BN, int WM, int WN, int SROWS = 32, int MODE = 0, bool DEFER = false>
+__device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN / 32], u32x4* lds_raw, T* __restrict__ Y,
+                                              const GatherGeom& g, const Epilogue& ep, int bx, int m0, int n0, int tid,
+                                              int lane, int wm, int wn, EpiSums<BN / WN / 32>& st) {
+    // one uniform branch per workgroup instead of one per element
+    if (ep.act == ACT_SILU) conv_epilogue_act<T, BM, BN, WM, WN, ACT_SILU, SROWS, MODE, DEFER>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn, st);
+    else if (ep.act == ACT_RELU) conv_epilogue_act<T, BM, BN, WM, WN, ACT_RELU, SROWS, MODE, DEFER>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn, st);
+    else conv_epilogue_act<T, BM, BN, WM, WN, ACT_NONE, SROWS, MODE, DEFER>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn, st);
+}
+// the tiled kernels: one tile per workgroup, statistics written by the epilogue itself
 template <typename T, int BM, int BN, int WM, int WN>
 __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN / 32], u32x4* lds_raw, T* __restrict__ Y,
                                               const GatherGeom& g, const Epilogue& ep, int bx, int m0, int n0, int tid,
                                               int lane, int wm, int wn) {
-    // one uniform branch per workgroup instead of one per element
-    if (ep.act == ACT_SILU) conv_epilogue_act<T, BM, BN, WM, WN, ACT_SILU>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn);
-    else if (ep.act == ACT_RELU) conv_epilogue_act<T, BM, BN, WM, WN, ACT_RELU>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn);
-    else conv_epilogue_act<T, BM, BN, WM, WN, ACT_NONE>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn);
+    EpiSums<BN / WN / 32> st;
+    st.clear();
+    conv_epilogue<T, BM, BN, WM, WN, 32, 0, false>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn, st);
 }
 
 // ---- forward / dgrad gather-GEMM ----------------------------------------------------------------
@@ -1357,6 +1422,190 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_pprs_kernel(const uint16_t* 
     conv_epilogue<uint16_t, BM, BN, WM, WN>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn);
 #undef ET_PP_BAR
 #undef ET_PP_WAIT
+}
+
+// ---- 1x1 stride-1 layers with <= 256 input and <= 256 output channels: persistent streaming GEMM ---------------------------
+// These layers (every Bottleneck.cv1, the C3 stems and cv3 of the stride-4 / 8 / 16 stages: 60 % of the model's BatchNorm layers)
+// are HBM-bound: 64-128 flop per byte of activation traffic against the chip's ~400.  As tiles of the generic gather-GEMM they ran
+// at 1.3-2.9 TB/s of algorithmic traffic (profiles/r03_launch_table.txt): a workgroup lives for ONE 128 x 64|128 tile -- index
+// arithmetic, a cold start of the load pipeline, four short K-chunks, an epilogue during which it has no load in flight, exit --
+// and a layer is 1600-12800 such workgroups; with N = 128 output channels on a 64-wide tile every activation row is also fetched
+// twice.  Here the layer is a STREAM:
+//   * a workgroup is persistent (grid = resident workgroups) and walks row tiles  t = blockIdx.x, + gridDim.x, ...
+//   * one tile spans ALL output channels, so every activation row is read from HBM exactly once
+//   * the weights (<= 256 x 256 bf16 = 128 KB per layer) never touch LDS: each wave loads the MFMA B fragments of ITS 64 output
+//     channels once, at kernel start, and keeps them in registers (KC * 32 VGPRs) for the lifetime of the workgroup
+//   * the activation tile goes global -> LDS by LDS-DMA in 64-channel chunks through an NS-deep ring that runs ACROSS tile
+//     boundaries: while a wave is in the epilogue of tile i the chunks of tile i + 1 (and beyond) are already in flight
+//   * the epilogue is the shared one (scale / bias / activation, BN partial sums, residual, BN-backward sums, 16-byte stores) on
+//     16-row slabs, so that ring + slabs of two to four workgroups fit a CU
+// vmcnt accounting: a wave's outstanding vector-memory operations are its LDS-DMA pieces (in order among themselves) and the
+// epilogue's stores / residual loads.  Loads retire in order, so "at most Y operations outstanding", Y = the pieces issued AFTER
+// chunk q, implies chunk q has landed whatever the stores are doing (they can only make the wait conservative, never early).
+// RAW: a wave waits for its own pieces of chunk q, then the workgroup barrier publishes every wave's pieces.  WAR: the slot that
+// chunk q + NS - 1 overwrites held chunk q - 1, whose last reads precede that same barrier in every wave's program order.
+// Register budget (two waves per SIMD, 256 VGPRs each): a wave keeps the weights of its TN * 32 output channels (KC * TN * 16
+// VGPRs) and TMW * TN accumulator tiles (16 VGPRs each), and the epilogue's optional features are compiled per kernel: FULL = false
+// is the plain forward layer (scale / bias / activation, forward statistics; ~70 VGPRs beside weights and accumulators), FULL = true
+// adds residual, accumulate and the BN-backward sums of the dgrads (~150).  Hence the shapes (plan_gemm): plain layers run two
+// workgroups of four waves per CU with 64-channel wave tiles (K = 256: 32 rows per wave, else 64); the FULL K = 256 layers run ONE
+// workgroup of eight waves with 32-channel wave tiles (64 VGPRs of weights), the ring twice as deep instead of a second workgroup.
+// Statistics: a lane's sums run over ALL tiles of its (persistent) workgroup and are written ONCE, as partial row
+// blockIdx.x * WM + wm of a (gridDim.x * WM, 2, Cout) buffer (et_conv2d_stats_rows_for reports that row count to the caller): the
+// finalize then reads a few hundred rows instead of one per 64 pixels.
+template <int KC, int WN, int TN, int WM, int TMW, int NS, int WGS, bool FULL>
+__global__ __launch_bounds__(64 * WM * WN, WGS) void conv1x1_stream_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W,
+                                                                          uint16_t* __restrict__ Y, const uint16_t* __restrict__ ZERO,
+                                                                          GatherGeom g, Epilogue ep) {
+    using T = uint16_t;
+    constexpr int BN = 32 * TN * WN, BM = 32 * TMW * WM, BKV = 8, VEC = 8;
+    constexpr int TM = TMW;                              // a wave owns 32 * TMW rows x 32 * TN output channels
+    constexpr int NT = 64 * WM * WN;
+    constexpr int CH_VEC = BM * BKV;                     // one chunk (BM rows x 64 channels) in 16-byte vectors
+    constexpr int DT = CH_VEC < NT ? CH_VEC : NT;        // threads that stage (a 32-row chunk is 256 pieces: four waves of eight)
+    constexpr int PER = CH_VEC / DT;                     // LDS-DMA instructions per staging thread per chunk
+    constexpr int MODE = FULL ? 0 : 1;
+    using L = EpiLds<BM, BN, WM, WN, 16>;
+    static_assert(KC == 1 || KC == 2 || KC == 4, "K = 64 * KC");
+    static_assert(CH_VEC % DT == 0 && DT % 64 == 0 && PER >= 1 && (NS - 1) * PER < 64 && NS >= 2 && NS <= 16, "ring");
+    __shared__ __attribute__((aligned(16))) u32x4 lds_raw[NS * CH_VEC + L::VEC16 + BN];
+    u32x4* const ring = lds_raw;
+    u32x4* const slabs = lds_raw + NS * CH_VEC;
+    float* const cst = (float*)(lds_raw + NS * CH_VEC + L::VEC16);      // [scale | bias | bn_scale | bn_shift][BN]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, gk = lane >> 5;
+    const int lvec = tid % BKV, lrow = tid / BKV;
+    constexpr int RPT = DT / BKV;                        // rows per staging pass
+    const bool stager = wave * 64 < DT;                  // wave-uniform
+
+    // ---- per-channel epilogue constants -> LDS, once (EpiSums::cst)
+    for (int c = tid; c < BN; c += NT) {
+        const bool cok = c < g.Cout;
+        cst[c] = (ep.scale && cok) ? ep.scale[c] : 1.0f;
+        cst[BN + c] = (ep.bias && cok) ? ep.bias[c] : 0.0f;
+        cst[2 * BN + c] = (FULL && ep.bn_y && cok) ? ep.bn_scale[c] : 1.0f;
+        cst[3 * BN + c] = (FULL && ep.bn_y && cok) ? ep.bn_shift[c] : 0.0f;
+    }
+
+    // ---- staging: piece j of a chunk = LDS rows lrow + j * RPT; the swizzle is applied to the SOURCE (conv_gemm_glds_kernel)
+    int a_row[PER], a_lv[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        a_row[j] = lrow + j * RPT;
+        a_lv[j] = (lvec ^ lds_swz<BKV>(a_row[j])) * VEC;
+    }
+    const int ntiles = g.ntm;
+    const int my_tiles = ((int)blockIdx.x < ntiles) ? (ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const int total = my_tiles * KC;                     // chunks this workgroup consumes
+    int is_tile = blockIdx.x, is_kc = 0, is_slot = 0, issued = 0;     // cursor of the next chunk to ISSUE (uniform)
+    auto issue = [&]() {
+        if (stager) {
+            u32x4* const wbase = ring + is_slot * CH_VEC + wave * 64;
+            const int m0i = is_tile * BM;
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                const int p = m0i + a_row[j];
+                const T* src = p < g.M ? X + ((size_t)p * g.ldx + is_kc * 64 + a_lv[j]) : ZERO;
+                et_glds16(src, wbase + j * DT);
+            }
+        }
+        ++issued;
+        if (++is_kc == KC) { is_kc = 0; is_tile += gridDim.x; }
+        is_slot = is_slot + 1 == NS ? 0 : is_slot + 1;
+    };
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (issued < total) issue();
+
+    // ---- this wave's weights -> registers: B fragment (column tile tn, k-step ks) = 8 consecutive K elements of output channel co
+    u32x4 bw[TN][KC * 4];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int co = wn * (32 * TN) + tn * 32 + l31;
+        const bool cok = co < g.Cout;
+        const uint16_t* wr = W + (size_t)(cok ? co : 0) * g.Cin + gk * VEC;
+#pragma unroll
+        for (int ks = 0; ks < KC * 4; ++ks) {
+            bw[tn][ks] = *(const u32x4*)(wr + ks * 16);          // unconditional load (row 0 for a channel beyond Cout), zeroed below
+            if (!cok) bw[tn][ks] = mk4(0, 0, 0, 0);
+        }
+    }
+    // The weights (and with them the ring's first chunks, issued just above) must have LANDED before the tile loop starts, so
+    // that the loop's MFMAs read registers with no load pending on them: left to the compiler, the wait for these loads is a
+    // vmcnt(0) in front of the first MFMA of EVERY tile -- it drains the ring once per tile (seen in the ISA of the first
+    // version; a plain s_waitcnt here does not help, the loads are sunk below it into the loop preheader).  et_pin_loaded is an
+    // empty asm that redefines the register: the loads complete in front of it, the loop depends on its output.
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int ks = 0; ks < KC * 4; ++ks) et_pin_loaded(bw[tn][ks]);
+    __syncthreads();                                     // ... and the constants are visible to every wave
+
+    // byte offset of this lane's k-step-0 fragment inside a chunk: row tile tm; a k-step XORs bits 5-6 of it (the swizzle is an XOR
+    // on the K-vector slot)
+    int abase[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        const int r = wm * (32 * TMW) + tm * 32 + l31;
+        abase[tm] = (r * BKV + (gk ^ lds_swz<BKV>(r))) * 16;
+    }
+
+    EpiSums<TN> st;
+    st.clear();
+    st.cst = cst;
+    st.cstride = BN;
+    int rd = 0, q = 0;
+    for (int i = 0; i < my_tiles; ++i) {
+        const int m0 = ((int)blockIdx.x + i * (int)gridDim.x) * BM;
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc, ++q) {
+            // chunk q has landed once at most `ahead` younger chunks of this wave are outstanding (see the header); a wave that
+            // stages nothing has nothing to wait for
+            const int ahead = min(NS - 2, total - 1 - q);
+            switch (ahead) {             // uniform; NS <= 16
+#define ET_S1_WAIT(A) case A: et_wait_vmem_le<((A) <= NS - 2 ? (A) : 0) * PER>(); break;
+                ET_S1_WAIT(1) ET_S1_WAIT(2) ET_S1_WAIT(3) ET_S1_WAIT(4) ET_S1_WAIT(5) ET_S1_WAIT(6) ET_S1_WAIT(7)
+                ET_S1_WAIT(8) ET_S1_WAIT(9) ET_S1_WAIT(10) ET_S1_WAIT(11) ET_S1_WAIT(12) ET_S1_WAIT(13) ET_S1_WAIT(14)
+#undef ET_S1_WAIT
+                default: et_wait_vmem(); break;
+            }
+            __builtin_amdgcn_s_barrier();
+            if (issued < total) issue();
+            const char* const sa = (const char*)(ring + rd * CH_VEC);
+            u32x4 af[2][TM];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) af[0][tm] = *(const u32x4*)(sa + abase[tm]);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int cur = kk & 1;
+                if (kk + 1 < 4) {
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm) af[cur ^ 1][tm] = *(const u32x4*)(sa + (abase[tm] ^ ((kk + 1) * 32)));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[cur][tm]),
+                                                                              __builtin_bit_cast(bf16x8, bw[tn][kc * 4 + kk]), acc[tm][tn], 0, 0, 0);
+            }
+            rd = rd + 1 == NS ? 0 : rd + 1;
+        }
+        conv_epilogue<T, BM, BN, WM, WN, 16, MODE, true>(acc, slabs, Y, g, ep, 0, m0, 0, tid, lane, wm, wn, st);
+    }
+    // every workgroup of the grid writes its row (also one that had no tile: zeros), so the consumer may sum all gridDim.x * WM rows
+    if (ep.stats) conv_epilogue_write_stats<BN, WN, MODE>(st, g, ep, 0, lane, wn, (int)blockIdx.x * WM + wm, 0, (int)gridDim.x * WM);
 }
 
 // ---- the stem: 6x6 stride-2 pad-2 convolution of the packed image (8 channels, 3 used) ----------------------------
@@ -2374,7 +2623,18 @@ static int dgrad_geom(GatherGeom& g, int py, int px, int N, int IH, int IW, int 
 // ---- kernel selection ---------------------------------------------------------------------------------
 // ONE place decides which instantiation runs; et_conv2d_kernel_name() reports the same decision to the tests and
 // to bench.py's roofline tags (there is no second copy of this logic on the Python side).
-enum { GEMM_REG = 0, GEMM_GLDS = 1, GEMM_PP = 2, GEMM_RS = 3, GEMM_PPRS = 4 };
+enum { GEMM_REG = 0, GEMM_GLDS = 1, GEMM_PP = 2, GEMM_RS = 3, GEMM_PPRS = 4, GEMM_S1 = 5 };
+
+// conv1x1_stream_kernel's contract: one tap at the pixel itself (1x1, stride 1, pad 0: forward and dgrad alike), whole 64-channel
+// chunks with K = 64 | 128 | 256, all output channels in one tile (<= 256, whole 8-channel groups), identity pixel map
+static bool s1_eligible(const GatherGeom& g) {
+    if (g.T != 1 || g.TT != 1 || g.dy[0] || g.dx[0] || g.isy != 1 || g.isx != 1 || g.osy != 1 || g.osx != 1 || g.ooy || g.oox) return false;
+    if (g.QH != g.IH || g.QW != g.IW || g.OH != g.QH || g.OW != g.QW) return false;
+    if (g.Cin != 64 && g.Cin != 128 && g.Cin != 256) return false;
+    if (g.Cout > 256 || g.Cout % 8 || g.ldx % 8 || g.ldy % 8) return false;
+    if (g.Cin == 256 && g.Cout <= 64) return false;                       // no instantiation (no such layer)
+    return true;
+}
 
 // conv_gemm_rs_kernel's contract: 3x3 taps in kernel-row order (three consecutive taps share dy, dx in [-1, 1]), stride 1,
 // output lattice = the gathered tensor's own pixels, whole 64-channel chunks
@@ -2388,9 +2648,28 @@ static bool rs_eligible(const GatherGeom& g, int BM, int unit_rows) {
         if (g.dy[t] != sgn * (t / 3 - 1) || g.dx[t] != sgn * (t % 3 - 1) || g.wt[t] != t) return false;
     return true;
 }
-struct GemmPlan { int kind, BM, BN, WM, WN, BKV, NS; bool utap; };
+struct GemmPlan { int kind, BM, BN, WM, WN, BKV, NS; bool utap; int wgs, kc, tn, full; };   // wgs / kc / tn / full: conv1x1_stream_kernel only
 
-static GemmPlan plan_gemm(const GatherGeom& g, int elem_bytes, bool have_zero_page) {
+// conv1x1_stream_kernel's shape table (its header explains the register budget behind it).  full = the launch needs residual /
+// accumulate / BN-backward sums in the epilogue.
+static GemmPlan plan_s1(const GatherGeom& g, bool full) {
+    const int BN = g.Cout > 128 ? 256 : (g.Cout > 64 ? 128 : 64);
+    const int kc = g.Cin / 64;
+    GemmPlan p{GEMM_S1, 0, BN, 0, 0, 8, 0, true, 2, kc, 2, full ? 1 : 0};
+    if (full && kc == 4) {               // eight waves, 32-channel wave tiles, one workgroup per CU
+        p.tn = 1; p.WN = BN / 32; p.WM = BN == 256 ? 1 : (BN == 128 ? 2 : 4); p.BM = 32 * p.WM; p.wgs = 1;
+        p.NS = p.BM == 32 ? 16 : (p.BM == 64 ? 10 : 5);
+        return p;
+    }
+    p.WN = BN / 64;
+    p.WM = BN == 256 ? 1 : (BN == 128 ? 2 : 4);                              // four waves
+    const int tmw = (kc == 4 || full || BN == 64) ? 1 : 2;                   // rows per wave = 32 * tmw
+    p.BM = 32 * tmw * p.WM;
+    p.NS = p.BM == 32 ? 8 : (p.BM == 64 ? 6 : 3);                            // ring: 8 x 4 KB / 6 x 8 KB / 3 x 16 KB beside the 16-row slabs
+    return p;
+}
+
+static GemmPlan plan_gemm(const GatherGeom& g, int elem_bytes, bool have_zero_page, bool full_epilogue = false) {
     // Build-time constants that were tuning knobs in r01 / r02 (swept on the step, profiles/r02_step_knob_sweep*_same_box.log, and
     // per layer, profiles/r02_microbench_narrow_k.log): GEMMs with K <= 128 elements use the 128x64 tile (3 workgroups per CU for
     // the HBM-bound short-K 1x1 layers; at K = 256 the 128-wide tile re-reads the activations half as often: 150 -> 124 us on
@@ -2404,8 +2683,11 @@ static GemmPlan plan_gemm(const GatherGeom& g, int elem_bytes, bool have_zero_pa
     const bool bf16 = elem_bytes == 2;
     const bool wide = g.Cout > 64 && !(narrow_k > 0 && g.T * g.Cin <= narrow_k);
     const bool glds = use_glds && have_zero_page;
-    GemmPlan p{glds ? GEMM_GLDS : GEMM_REG, 128, wide ? 128 : 64, 2, 2, g.CV % 8 == 0 ? 8 : 4, 2, g.CV % 4 == 0};
+    GemmPlan p{glds ? GEMM_GLDS : GEMM_REG, 128, wide ? 128 : 64, 2, 2, g.CV % 8 == 0 ? 8 : 4, 2, g.CV % 4 == 0, 0, 0, 0, 0};
     if (!(bf16 && glds && g.CV % 8 == 0)) return p;
+    // 1x1 layers with K <= 256 and <= 256 output channels: the persistent streaming kernel (ET_CONV_S1=0: the tiled kernels below)
+    static const int use_s1 = env_int("ET_CONV_S1", 2);                   // 0: off, 1: plain layers only, 2: also the FULL-epilogue dgrads
+    if (use_s1 && (use_s1 >= 2 || !full_epilogue) && s1_eligible(g)) return plan_s1(g, full_epilogue);
     // short-K GEMMs (K <= 256, i.e. <= 4 chunks of 64) run 32-wide chunks in a 3-deep ring -- 48 KB of LDS, three
     // workgroups per CU, two chunks in flight each (measured 3-10 % on the 1x1 layers); everything else the 64-wide
     // double buffer (deeper rings or taller 4-wave tiles cost occupancy and lose: profiles/)
@@ -2425,12 +2707,12 @@ static GemmPlan plan_gemm(const GatherGeom& g, int elem_bytes, bool have_zero_pa
     }
     // 3x3 stride-1 layers on the 128-row tiles: activation rows shared by the three taps of a kernel row (ET_CONV_RS=0: off)
     static const int use_rs = env_int("ET_CONV_RS", 1);
-    if (use_rs && ring == 12882 && rs_eligible(g, 128, RS_A_ROWS(128))) return GemmPlan{GEMM_RS, 128, wide ? 128 : 64, 2, 2, 8, 2, true};
+    if (use_rs && ring == 12882 && rs_eligible(g, 128, RS_A_ROWS(128))) return GemmPlan{GEMM_RS, 128, wide ? 128 : 64, 2, 2, 8, 2, true, 0, 0, 0, 0};
     static const int use_pprs = env_int("ET_CONV_PPRS", 1);
-    if (use_pprs && ring == 25680 && rs_eligible(g, 256, PPRS_ROWS)) return GemmPlan{GEMM_PPRS, 256, 256, 2, 4, 8, 2, true};
+    if (use_pprs && ring == 25680 && rs_eligible(g, 256, PPRS_ROWS)) return GemmPlan{GEMM_PPRS, 256, 256, 2, 4, 8, 2, true, 0, 0, 0, 0};
     switch (ring) {
-        case 25680: p = GemmPlan{GEMM_PP, 256, 256, 2, 4, 8, 2, true}; break;
-        case 25682: p = GemmPlan{GEMM_GLDS, 256, 256, 2, 4, 8, 2, true}; break;
+        case 25680: p = GemmPlan{GEMM_PP, 256, 256, 2, 4, 8, 2, true, 0, 0, 0, 0}; break;
+        case 25682: p = GemmPlan{GEMM_GLDS, 256, 256, 2, 4, 8, 2, true, 0, 0, 0, 0}; break;
         case 12843: p.BKV = 4; p.NS = 3; break;
         default: break;
     }
@@ -2440,11 +2722,21 @@ static GemmPlan plan_gemm(const GatherGeom& g, int elem_bytes, bool have_zero_pa
 // the name rocprofv3 prints for the plan's kernel (template arguments spelled as the demangler does)
 static void plan_name(const GemmPlan& p, int elem_bytes, char* buf, int n) {
     const char* t = elem_bytes == 2 ? "unsigned short" : "float";
-    if (p.kind == GEMM_PP) snprintf(buf, n, "conv_gemm_pp_kernel");
+    if (p.kind == GEMM_S1) snprintf(buf, n, "conv1x1_stream_kernel<%d, %d, %d, %d, %d, %d, %d, %s>", p.kc, p.WN, p.tn, p.WM, p.BM / (32 * p.WM), p.NS, p.wgs, p.full ? "true" : "false");
+    else if (p.kind == GEMM_PP) snprintf(buf, n, "conv_gemm_pp_kernel");
     else if (p.kind == GEMM_PPRS) snprintf(buf, n, "conv_gemm_pprs_kernel");
     else if (p.kind == GEMM_RS) snprintf(buf, n, "conv_gemm_rs_kernel<%d, %d, %d, %d>", p.BM, p.BN, p.WM, p.WN);
     else if (p.kind == GEMM_GLDS) snprintf(buf, n, "conv_gemm_glds_kernel<%s, %d, %d, %d, %d, %d, %d, %s>", t, p.BM, p.BN, p.WM, p.WN, p.BKV, p.NS, p.utap ? "true" : "false");
     else snprintf(buf, n, "conv_gemm_kernel<%s, %d, %d, %d, %d, %d, %s>", t, p.BM, p.BN, p.WM, p.WN, p.BKV, p.utap ? "true" : "false");
+}
+
+// conv1x1_stream_kernel is persistent: as many workgroups as the chip holds at the plan's residency, never more than row tiles
+// (ET_CONV_S1_WGS: tests shrink the grid to exercise the tile loop; read per call).  ONE copy: the launcher and
+// et_conv2d_stats_rows_for both call this.
+static int s1_grid(int ntm, const GemmPlan& p) {
+    int n = env_int("ET_CONV_S1_WGS", p.wgs * device_cus());
+    if (n < 1) n = 1;
+    return n < ntm ? n : ntm;
 }
 
 template <typename T>
@@ -2453,7 +2745,7 @@ static int launch_gemm(const void* X, const void* W, void* Y, const void* zero16
     if (g.M <= 0) return 0;
     const int nfast = 1;
     g.nfast = nfast;
-    const GemmPlan p = plan_gemm(g, (int)sizeof(T), zero16 != nullptr);
+    const GemmPlan p = plan_gemm(g, (int)sizeof(T), zero16 != nullptr, ep.res != nullptr || ep.accumulate || ep.bn_y != nullptr);
     g.ntm = (g.M + p.BM - 1) / p.BM;
     g.ntn = (g.Cout + p.BN - 1) / p.BN;
     const T* x = (const T*)X; const T* w = (const T*)W; T* y = (T*)Y; const T* z = (const T*)zero16;
@@ -2463,6 +2755,36 @@ static int launch_gemm(const void* X, const void* W, void* Y, const void* zero16
 #define ET_REG(BN_, BKV_, UT_) \
     hipLaunchKernelGGL((conv_gemm_kernel<T, 128, BN_, 2, 2, BKV_, UT_>), grid, block, 0, s, x, w, y, g, ep)
     const int key = p.BM * 100000 + p.BN * 100 + p.BKV * 10 + p.NS;
+    if (p.kind == GEMM_S1) {
+        if constexpr (sizeof(T) == 2) {
+            const uint16_t *xs = (const uint16_t*)x, *ws = (const uint16_t*)w, *zs = (const uint16_t*)z;
+            const dim3 sgrid(s1_grid(g.ntm, p));
+#define ET_S1(KC_, WN_, TN_, WM_, TMW_, NS_, WGS_, FULL_) \
+    hipLaunchKernelGGL((conv1x1_stream_kernel<KC_, WN_, TN_, WM_, TMW_, NS_, WGS_, FULL_>), sgrid, block, 0, s, xs, ws, (uint16_t*)y, zs, g, ep)
+            switch ((p.full ? 10000 : 0) + p.kc * 1000 + p.BN) {
+                //            K/64 WN TN WM TMW NS WGS
+                case 4256: ET_S1(4, 4, 2, 1, 1, 8, 2, false); return 0;
+                case 4128: ET_S1(4, 2, 2, 2, 1, 6, 2, false); return 0;
+                case 2256: ET_S1(2, 4, 2, 1, 2, 6, 2, false); return 0;
+                case 2128: ET_S1(2, 2, 2, 2, 2, 3, 2, false); return 0;
+                case 2064: ET_S1(2, 1, 2, 4, 1, 3, 2, false); return 0;
+                case 1256: ET_S1(1, 4, 2, 1, 2, 6, 2, false); return 0;
+                case 1128: ET_S1(1, 2, 2, 2, 2, 3, 2, false); return 0;
+                case 1064: ET_S1(1, 1, 2, 4, 1, 3, 2, false); return 0;
+                case 14256: ET_S1(4, 8, 1, 1, 1, 16, 1, true); return 0;
+                case 14128: ET_S1(4, 4, 1, 2, 1, 10, 1, true); return 0;
+                case 12256: ET_S1(2, 4, 2, 1, 1, 8, 2, true); return 0;
+                case 12128: ET_S1(2, 2, 2, 2, 1, 6, 2, true); return 0;
+                case 12064: ET_S1(2, 1, 2, 4, 1, 3, 2, true); return 0;
+                case 11256: ET_S1(1, 4, 2, 1, 1, 8, 2, true); return 0;
+                case 11128: ET_S1(1, 2, 2, 2, 1, 6, 2, true); return 0;
+                case 11064: ET_S1(1, 1, 2, 4, 1, 3, 2, true); return 0;
+                default: return -2;
+            }
+#undef ET_S1
+        }
+        return -2;
+    }
     if (p.kind == GEMM_PP) {
         if constexpr (sizeof(T) == 2) {
             hipLaunchKernelGGL(conv_gemm_pp_kernel, grid, block, 0, s, (const uint16_t*)x, (const uint16_t*)w, (uint16_t*)y, (const uint16_t*)z, g, ep);
@@ -2519,6 +2841,32 @@ static int launch_gemm(const void* X, const void* W, void* Y, const void* zero16
 }
 
 extern "C" int et_conv2d_stats_rows(int N, int OH, int OW) { return (N * OH * OW + 63) / 64; }
+
+extern "C" int et_conv2d_stats_rows_for(int op, int dtype, int N, int IH, int IW, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                                        int have_zero_page) {
+    // rows of the partial-statistics buffer the kernel selected for this problem writes: op 0 = stats_partial of et_conv2d_fwd,
+    // op 1 = bn_stats_partial of et_conv2d_dgrad_bn (stride 1).  Arguments of the FORWARD conv.  One row per 64 output pixels for
+    // the tiled kernels; the persistent 1x1 kernel writes one row per (workgroup, row group).
+    if (KH * KW > CONV_MAX_TAPS || stride < 1 || N <= 0 || (op != 0 && op != 1)) return -2;
+    const int eb = dtype == ET_F32 ? 4 : 2, vec = dtype == ET_F32 ? 4 : 8;
+    GatherGeom g;
+    int rc;
+    if (op == 0) {
+        if (try_launch_stem(nullptr, nullptr, nullptr, dtype, N, IH, IW, Cin, Cin, Cout, KH, KW, stride, pad, Cout, nullptr, nullptr, 0, nullptr,
+                            nullptr, have_zero_page ? (const void*)&g : nullptr, nullptr, false)) {
+            const int OH = (IH + 2 * pad - KH) / stride + 1, OW = (IW + 2 * pad - KW) / stride + 1;
+            return (N * OH * OW + 63) / 64;
+        }
+        rc = fwd_geom(g, N, IH, IW, Cin, Cin, Cout, KH, KW, stride, pad, Cout, vec);
+    } else {
+        if (stride != 1) return -2;
+        rc = dgrad_geom(g, 0, 0, N, IH, IW, Cin, Cin, Cout, KH, KW, 1, pad, Cout, vec);
+    }
+    if (rc) return rc < 0 ? rc : -2;
+    const GemmPlan p = plan_gemm(g, eb, have_zero_page != 0, op == 1);
+    if (p.kind == GEMM_S1) return s1_grid((g.M + p.BM - 1) / p.BM, p) * p.WM;
+    return (g.M + 63) / 64;
+}
 
 extern "C" int et_conv2d_fwd(const void* x, const void* w, void* y, int dtype, int N, int IH, int IW, int Cin,
                              int ldx, int Cout, int KH, int KW, int stride, int pad, int ldy, const float* scale,
@@ -2850,7 +3198,9 @@ extern "C" int et_colsum(const void* x, int dtype, int P, int C, int ld, float* 
 // ---- introspection (tests, bench.py) -----------------------------------------------------------------------
 extern "C" int et_conv2d_kernel_name(int op, int dtype, int N, int IH, int IW, int Cin, int Cout, int KH, int KW, int stride,
                                      int pad, int have_zero_page, int parity_class, char* buf, int buflen) {
-    // op 0 = forward, 1 = dgrad (stride 2: parity_class 0..3 selects one of its four launches), 2 = wgrad.
+    // op 0 = forward, 1 = dgrad (stride 2: parity_class 0..3 selects one of its four launches), 2 = wgrad, 3 = dgrad whose epilogue
+    // adds a residual / accumulates / carries BN-backward sums (et_conv2d_dgrad with residual or accumulate, et_conv2d_dgrad_bn), 4 =
+    // forward with a residual (the eval-mode Bottleneck shortcut): the persistent 1x1 kernel has separate instantiations for those.
     // Arguments as for et_conv2d_fwd (Cin/Cout of the FORWARD conv).  Writes the name of the kernel instantiation the
     // corresponding entry point launches, spelled as rocprofv3 prints it.  Host only; launches nothing.
     if (!buf || buflen < 8) return -1;
@@ -2863,9 +3213,12 @@ extern "C" int et_conv2d_kernel_name(int op, int dtype, int N, int IH, int IW, i
         return 0;
     }
     GatherGeom g;
+    const bool full = op == 3 || op == 4;
+    if (op == 3) op = 1;
+    if (op == 4) op = 0;
     if (op == 0) {
-        if (try_launch_stem(nullptr, nullptr, nullptr, dtype, N, IH, IW, Cin, Cin, Cout, KH, KW, stride, pad, Cout, nullptr, nullptr, 0,
-                            nullptr, nullptr, have_zero_page ? (const void*)buf : nullptr, nullptr, false)) {
+        if (!full && try_launch_stem(nullptr, nullptr, nullptr, dtype, N, IH, IW, Cin, Cin, Cout, KH, KW, stride, pad, Cout, nullptr, nullptr, 0,
+                                     nullptr, nullptr, have_zero_page ? (const void*)buf : nullptr, nullptr, false)) {
             snprintf(buf, buflen, "conv_stem_kernel");       // rocprofv3: "void conv_stem_kernel<ACT>(StemArgs)"
             return 0;
         }
@@ -2876,13 +3229,13 @@ extern "C" int et_conv2d_kernel_name(int op, int dtype, int N, int IH, int IW, i
         if (py >= stride) return -2;
         if (dgrad_geom(g, py, px, N, IH, IW, Cin, Cin, Cout, KH, KW, stride, pad, Cout, vec)) return -2;
     } else return -2;
-    plan_name(plan_gemm(g, eb, have_zero_page != 0), eb, buf, buflen);
+    plan_name(plan_gemm(g, eb, have_zero_page != 0, full), eb, buf, buflen);
     return 0;
 }
 
 extern "C" int et_env_knobs(char* buf, int buflen) {
     // every ET_* tuning knob that is SET in this process's environment, as "NAME=value;..." (bench.py records it)
-    static const char* names[] = {"ET_CONV_GLDS", "ET_CONV_BIG", "ET_CONV_BIG_MINFILL", "ET_CONV_PP", "ET_CONV_RS", "ET_CONV_PPRS", "ET_CONV_STEM", "ET_CONV_STEM_WGS",
+    static const char* names[] = {"ET_CONV_GLDS", "ET_CONV_BIG", "ET_CONV_BIG_MINFILL", "ET_CONV_PP", "ET_CONV_S1", "ET_CONV_S1_WGS", "ET_CONV_RS", "ET_CONV_PPRS", "ET_CONV_STEM", "ET_CONV_STEM_WGS",
                                   "ET_WGRAD_TR", "ET_WGRAD_BIG", "ET_WGRAD_RS", "ET_WGRAD_GROUP", "ET_WGRAD_STALE", "ET_WGRAD_STREAM", "ET_FUSE_BN_BWD",
                                   "ET_BN_FIN_SMALL", "ET_WT_TILED", "ET_FUSE_BN_BWD_K", "ET_STEP_GRAPH", "ET_ALLREDUCE_CHUNK_MB", "ET_RCCL_CHANNELS", "ET_DP_SINGLE_RANK", "ET_HIP_LIB"};
     if (!buf || buflen < 1) return -1;

@@ -85,16 +85,27 @@ class FamilyTimer:
 
 
 def kernel_name(op, dtype, N, IH, IW, Cin, Cout, k, stride, pad, parity_class=0, zero_page=True):
-    """Name of the kernel instantiation the library launches for this conv problem (op: 'fwd' | 'dgrad' | 'wgrad';
-    arguments of the FORWARD conv), as rocprofv3 prints it.  The selection lives in csrc/conv.hip only
+    """Name of the kernel instantiation the library launches for this conv problem (op: 'fwd' | 'dgrad' | 'wgrad', and
+    'dgrad_full' / 'fwd_res' = the same with a residual / accumulate / BN-backward sums in the epilogue -- the persistent 1x1 kernel
+    has separate instantiations for those; arguments of the FORWARD conv), as rocprofv3 prints it.  The selection lives in csrc/conv.hip only
     (et_conv2d_kernel_name); tests assert on it and bench.py tags its HIP-event timings with it."""
     import ctypes
     buf = ctypes.create_string_buffer(256)
-    code = {"fwd": 0, "dgrad": 1, "wgrad": 2}[op]
+    code = {"fwd": 0, "dgrad": 1, "wgrad": 2, "dgrad_full": 3, "fwd_res": 4}[op]
     dt = ET_F32 if dtype == torch.float32 else ET_BF16
     _lib.check(_lib.load().et_conv2d_kernel_name(code, dt, N, IH, IW, Cin, Cout, k, k, stride, pad, int(bool(zero_page)),
                                                  parity_class, buf, 256), "et_conv2d_kernel_name")
     return buf.value.decode()
+
+
+def stats_rows(op, dtype, N, IH, IW, Cin, Cout, k, stride, pad, zero_page=True):
+    """rows of the partial-statistics buffer the selected kernel writes (op 'fwd': et_conv2d_fwd's stats_partial; 'dgrad_bn':
+    et_conv2d_dgrad_bn's bn_stats_partial; arguments of the FORWARD conv)"""
+    dt = ET_F32 if dtype == torch.float32 else ET_BF16
+    rows = _lib.load().et_conv2d_stats_rows_for({"fwd": 0, "dgrad_bn": 1}[op], dt, N, IH, IW, Cin, Cout, k, k, stride, pad, int(bool(zero_page)))
+    if rows <= 0:
+        raise _lib.EtHipError(f"et_conv2d_stats_rows_for failed with code {rows}")
+    return rows
 
 
 def env_knobs():
@@ -163,10 +174,10 @@ def conv2d_fwd(x, w, stride, pad, *, scale=None, bias=None, act=ACT_NONE, residu
     assert out.shape == (N, OH, OW, Cout)
     stats = None
     if want_stats:
-        rows = lib.et_conv2d_stats_rows(N, OH, OW)
+        rows = stats_rows("fwd", x.dtype, N, IH, IW, Cin, Cout, KH, stride, pad)
         stats = torch.empty((rows, 2, Cout), dtype=torch.float32, device=x.device)
     ldr = _nhwc(residual) if residual is not None else 0
-    ev = TIMER.span(kernel_name("fwd", x.dtype, N, IH, IW, Cin, Cout, KH, stride, pad), 2.0 * N * OH * OW * Cout * Cin * KH * KW,
+    ev = TIMER.span(kernel_name("fwd_res" if residual is not None else "fwd", x.dtype, N, IH, IW, Cin, Cout, KH, stride, pad), 2.0 * N * OH * OW * Cout * Cin * KH * KW,
                     nbytes=(x.numel() + N * OH * OW * Cout + w.numel()) * x.element_size(),
                     shape=("fwd", N, IH, IW, Cin, Cout, KH, stride)) if TIMER else None
     if ev:
@@ -362,9 +373,9 @@ def conv2d_dgrad(dy, wT, in_hw, stride, pad, *, out=None, accumulate=False, resi
         out = torch.empty((N, IH, IW, Cin), dtype=dy.dtype, device=dy.device)
     if bn is not None and stride == 1 and not accumulate and bn.y.shape == out.shape and bn.y.dtype == out.dtype:
         lib = _lib.load()
-        rows = lib.et_conv2d_stats_rows(N, IH, IW)
+        rows = stats_rows("dgrad_bn", dy.dtype, N, IH, IW, Cin, Cout, KH, stride, pad)
         part = torch.empty((rows, 2, Cin), dtype=torch.float32, device=dy.device)
-        ev = TIMER.span(kernel_name("dgrad", dy.dtype, N, IH, IW, Cin, Cout, KH, stride, pad), 2.0 * N * OH * OW * Cout * Cin * KH * KW,
+        ev = TIMER.span(kernel_name("dgrad_full", dy.dtype, N, IH, IW, Cin, Cout, KH, stride, pad), 2.0 * N * OH * OW * Cout * Cin * KH * KW,
                         nbytes=(dy.numel() + 2 * N * IH * IW * Cin + wT.numel()) * dy.element_size(),
                         shape=("dgrad", N, IH, IW, Cin, Cout, KH, stride)) if TIMER else None
         if ev:
@@ -377,7 +388,7 @@ def conv2d_dgrad(dy, wT, in_hw, stride, pad, *, out=None, accumulate=False, resi
             ev[1].record()
         bn.partial, bn.dz_ptr = part, out.data_ptr()
         return out
-    tag = (kernel_name("dgrad", dy.dtype, N, IH, IW, Cin, Cout, KH, stride, pad) if stride == 1 else
+    tag = (kernel_name("dgrad_full" if (accumulate or residual is not None) else "dgrad", dy.dtype, N, IH, IW, Cin, Cout, KH, stride, pad) if stride == 1 else
            "conv_gemm (stride-2 dgrad parity classes)") if TIMER else None
     ev = TIMER.span(tag, 2.0 * N * OH * OW * Cout * Cin * KH * KW,
                     stride * stride, nbytes=(dy.numel() + N * IH * IW * Cin + wT.numel()) * dy.element_size(),

@@ -30,7 +30,7 @@ enum { ET_F32 = 0, ET_BF16 = 1 };
  * for ("gfx950") and the ABI version.  ET_ABI_VERSION changes whenever an entry point is added or a signature / workspace
  * contract changes; a binding must refuse a library whose et_abi_version() differs from the header it was written against
  * (efficientteacher_amd/_lib.py does): a stale libet_hip.so would otherwise read e.g. a new int argument as the stream. */
-#define ET_ABI_VERSION 2
+#define ET_ABI_VERSION 3
 const char* et_build_arch(void);
 int et_abi_version(void);
 
@@ -101,9 +101,11 @@ int et_sgd_nesterov_dev(float* p, const float* grad, float* momentum_buf, void* 
  * strides, KH*KW <= 36, tensors < 2^31 elements.  dgrad/wgrad additionally need Cout % 8 == 0.
  *   fwd epilogue: v = acc (* scale[co]) (+ bias[co]); act (0 none, 1 SiLU, 2 ReLU); (+ residual[pix*ldr + co]);
  *   scale/bias = the eval-mode BatchNorm affine of the EMA teacher (et_bn_eval_affine), or the head bias.
- *   stats_partial, if not NULL: (et_conv2d_stats_rows(N,OH,OW), 2, Cout) fp32 partial per-channel
+ *   stats_partial, if not NULL: (et_conv2d_stats_rows_for(0, ...), 2, Cout) fp32 partial per-channel
  *   sum / sum-of-squares of the raw accumulators (BatchNorm batch statistics, reduced later by
- *   et_bn_finalize) -- every row is fully overwritten.
+ *   et_bn_finalize) -- every row is fully overwritten.  The row count depends on the kernel the library selects for the
+ *   problem (one row per 64 output pixels for the tiled kernels = et_conv2d_stats_rows(N,OH,OW); one row per resident
+ *   workgroup and row group for the persistent 1x1 kernel): ask et_conv2d_stats_rows_for with the arguments of the call.
  *   zero16: device pointer to >= 16 zero bytes (16-byte aligned).  When given, the K-chunks are staged with
  *   LDS-DMA (global_load_lds_dwordx4) and padding / tail lanes fetch from this page; NULL selects the
  *   register-staged kernel.
@@ -112,6 +114,11 @@ int et_sgd_nesterov_dev(float* p, const float* grad, float* momentum_buf, void* 
  *   wgrad: dw (Cout, KH, KW, Cin) fp32 += ... (split-K over pixels, atomicAdd: zero or reuse the
  *          gradient arena as the accumulator).                                                    */
 int et_conv2d_stats_rows(int N, int OH, int OW);
+/* rows of the partial-statistics buffer for one call: op 0 = stats_partial of et_conv2d_fwd, op 1 = bn_stats_partial of
+ * et_conv2d_dgrad_bn; the remaining arguments are those of the FORWARD conv (as for et_conv2d_kernel_name); have_zero_page = the
+ * call passes zero16.  Host only. */
+int et_conv2d_stats_rows_for(int op, int dtype, int N, int IH, int IW, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                             int have_zero_page);
 int et_conv2d_fwd(const void* x, const void* w, void* y, int dtype, int N, int IH, int IW, int Cin,
                   int ldx, int Cout, int KH, int KW, int stride, int pad, int ldy, const float* scale,
                   const float* bias, int act, const void* residual, int ldr, float* stats_partial,
@@ -124,7 +131,7 @@ int et_conv2d_dgrad(const void* dy, const void* wT, void* dx, int dtype, int N, 
  * produces: dx = dgrad (+ residual) is the dz of a Conv block z = act(BN(y)); with that block's raw conv output
  * bn_y (pixel stride ld_bn), its folded affine bn_scale / bn_shift (Cin values: the channels of dx) and activation,
  * the epilogue accumulates per-tile partial sums of du = dz * act'(y*scale+shift) and du*y into
- * bn_stats_partial (et_conv2d_stats_rows(N, IH, IW), 2, Cin) -- computed on the ROUNDED dz it stores, i.e. exactly the
+ * bn_stats_partial (et_conv2d_stats_rows_for(1, ...), 2, Cin) -- computed on the ROUNDED dz it stores, i.e. exactly the
  * values et_bn_act_bwd_from_partials reads back.  Replaces bn_act_bwd's own reduce pass (a 4 B/element re-read of dz
  * and y) by one y read here.  Reference math: torch.nn.BatchNorm2d backward as used by Conv (models/backbone/common.py:480). */
 int et_conv2d_dgrad_bn(const void* dy, const void* wT, void* dx, int dtype, int N, int IH, int IW, int Cin, int ldx, int Cout,

@@ -186,6 +186,7 @@ def test_conv_wgrad_grouped(hip, dtype):
 # a copy -- so a change of the tile policy that silently drops a kernel out of test coverage fails here.
 GLDS = "conv_gemm_glds_kernel<unsigned short, "
 RS128, RS64 = "conv_gemm_rs_kernel<128, 128, 2, 2>", "conv_gemm_rs_kernel<128, 64, 2, 2>"
+S1 = "conv1x1_stream_kernel<"          # prefix: the shape table behind it (csrc/conv.hip plan_s1) is pinned by test_stream_kernel_shape_table
 SELECT = [
     # N, H, W, Cin, Cout, k, s, p, fwd kernel, dgrad kernels (per parity class), wgrad kernel
     ((2, 20, 20, 256, 256, 3, 1, 1), "conv_gemm_pprs_kernel", ["conv_gemm_pprs_kernel"], "conv_wgrad_rs_kernel<128, 128, 2, 4>"),
@@ -196,12 +197,10 @@ SELECT = [
      "conv_wgrad_tr_kernel<128, 128, 2, 2>"),
     ((1, 9, 11, 64, 40, 3, 1, 1), RS64, [GLDS + "128, 64, 2, 2, 4, 2, false>"],                # ragged M, 11-pixel rows
      "conv_wgrad_rs_kernel<64, 64, 2, 2>"),
-    ((2, 12, 12, 64, 128, 1, 1, 0), GLDS + "128, 64, 2, 2, 4, 3, true>", [GLDS + "128, 64, 2, 2, 4, 3, true>"],
-     "conv_wgrad_tr_kernel<128, 64, 2, 2>"),
+    ((2, 12, 12, 64, 128, 1, 1, 0), S1, [S1], "conv_wgrad_tr_kernel<128, 64, 2, 2>"),
     ((2, 12, 12, 128, 128, 3, 1, 1), RS128, [RS128],
      "conv_wgrad_rs_kernel<128, 128, 2, 4>"),
-    ((2, 12, 12, 64, 64, 1, 1, 0), GLDS + "128, 64, 2, 2, 4, 3, true>", [GLDS + "128, 64, 2, 2, 4, 3, true>"],
-     "conv_wgrad_tr_kernel<64, 64, 2, 2>"),
+    ((2, 12, 12, 64, 64, 1, 1, 0), S1, [S1], "conv_wgrad_tr_kernel<64, 64, 2, 2>"),
     ((1, 16, 16, 8, 32, 6, 2, 2), "conv_stem_kernel", None, None),                            # the stem (no dgrad in the net)
     ((1, 5, 5, 64, 264, 3, 1, 1), "conv_gemm_pprs_kernel", [GLDS + "128, 64, 2, 2, 4, 2, false>"],
      "conv_wgrad_tr_kernel<256, 256, 2, 4>"),                                                  # ragged M and Cout on the 256^2 tiles
@@ -215,7 +214,19 @@ SELECT = [
     # 64 -> 128 stride-2 3x3 (the layer after the stem): its four-tap dgrad class is the 64-wide tile with 64-wide chunks
     ((2, 24, 24, 64, 128, 3, 2, 1), GLDS + "128, 128, 2, 2, 8, 2, true>",
      [GLDS + "128, 64, 2, 2, 4, 3, true>"] * 3 + [GLDS + "128, 64, 2, 2, 8, 2, true>"], "conv_wgrad_tr_kernel<128, 128, 2, 2>"),
+    # the persistent streaming kernel of the 1x1 layers with K <= 256 (every instantiation; ragged M, Cout below the column tile,
+    # and -- last two -- a channel count whose dgrad is not eligible, i.e. a tiled dgrad beside a streamed forward)
+    ((2, 13, 11, 64, 64, 1, 1, 0), S1, [S1], "conv_wgrad_tr_kernel<64, 64, 2, 2>"),
+    ((1, 17, 19, 128, 128, 1, 1, 0), S1, [S1], "conv_wgrad_tr_kernel<128, 128, 2, 2>"),
+    ((2, 9, 10, 256, 256, 1, 1, 0), S1, [S1], "conv_wgrad_tr_kernel<128, 128, 2, 2>"),
+    ((1, 12, 12, 256, 128, 1, 1, 0), S1, [S1], "conv_wgrad_tr_kernel<128, 128, 2, 2>"),
+    ((1, 12, 12, 128, 256, 1, 1, 0), S1, [S1], "conv_wgrad_tr_kernel<128, 128, 2, 2>"),
+    ((2, 7, 9, 128, 64, 1, 1, 0), S1, [S1], "conv_wgrad_tr_kernel<64, 128, 2, 2>"),
+    ((1, 9, 9, 256, 200, 1, 1, 0), S1, [GLDS + "128, 128, 2, 2, 4, 2, false>"], "conv_wgrad_tr_kernel<128, 128, 2, 2>"),
+    ((1, 8, 8, 64, 24, 1, 1, 0), S1, [GLDS + "128, 64, 2, 2, 4, 2, false>"], "conv_wgrad_tr_kernel<64, 64, 2, 2>"),
+    ((1, 10, 11, 64, 256, 1, 1, 0), S1, [GLDS + "128, 64, 2, 2, 4, 3, true>"], "conv_wgrad_tr_kernel<128, 64, 2, 2>"),
 ]
+STREAM_CASES = [c for c in SELECT if c[1].startswith(S1)]
 
 
 @pytest.mark.parametrize("case,kf,kd,kw", SELECT, ids=[str(c[0]) for c in SELECT])
@@ -242,11 +253,49 @@ def test_lds_dma_pipelines_under_adversarial_schedules(emu, dma_late, seed):
         del os.environ["ET_CONV_STEM_WGS"]
 
 
+@pytest.mark.parametrize("wgs", [1, 3])
+@pytest.mark.parametrize("dma_late,seed", [(1, 3), (0, 5), (1, 11)])
+def test_stream_kernel_tile_loop_under_adversarial_schedules(emu, dma_late, seed, wgs, monkeypatch):
+    """conv1x1_stream_kernel with a grid of 1 / 3 persistent workgroups: every workgroup walks several row tiles, the chunk ring
+    wraps around across tile boundaries and the statistics accumulate over the tiles -- under the emulator's race-exposing modes (a
+    counted wait that is one chunk too weak, or a chunk staged into a slot that is still being read, fails here)."""
+    monkeypatch.setenv("ET_CONV_S1_WGS", str(wgs))
+    emu.configure(dma_late, seed)
+    for case, kf, kd, kw in STREAM_CASES:
+        _check_instantiation(emu, case, kf, kd, kw)
+    if seed == 3:        # the FULL epilogue (residual + BN-backward sums accumulated over the tiles of a workgroup), one schedule
+        for case in ((2, 9, 11, 256, 256, 1), (1, 13, 13, 128, 128, 1), (2, 9, 9, 64, 64, 1)):
+            test_dgrad_with_fused_bn_backward_sums(emu, case, torch.bfloat16)
+
+
+def test_stream_kernel_statistics_rows_follow_the_grid(hip, monkeypatch):
+    """the persistent kernel writes one partial row per (workgroup, row group): ops.stats_rows reports that count, every row is
+    written (a buffer pre-filled with NaN sums to the reference), and the row count follows ET_CONV_S1_WGS"""
+    from efficientteacher_amd import ops
+    N, H, W, C = 2, 15, 15, 128
+    dt = torch.bfloat16
+    x = _mk(hip, (N, H, W, C), dt, 81)
+    w = (_mk(hip, (C, 1, 1, C), dt, 82) * C ** -0.5).to(dt)
+    ref = _ref_conv(x, w, 1, 0).reshape(-1, C)
+    for wgs, rows in ((1, 2), (2, 4), (1000, 8)):        # 450 pixels = 4 row tiles of 128; two row groups (WM = 2) per workgroup
+        monkeypatch.setenv("ET_CONV_S1_WGS", str(wgs))
+        assert ops.stats_rows("fwd", dt, N, H, W, C, C, 1, 1, 0) == rows
+        y, st = ops.conv2d_fwd(x, w, 1, 0, want_stats=True)
+        assert st.shape == (rows, 2, C)
+        assert torch.allclose(st.sum(0)[0].cpu(), ref.sum(0), rtol=1e-3, atol=0.5)
+        assert torch.allclose(st.sum(0)[1].cpu(), (ref ** 2).sum(0), rtol=2e-2, atol=1e-3)
+
+
+def _same(name, want):
+    """exact name, or -- for the persistent 1x1 kernel -- the kernel family (its template arguments are pinned elsewhere)"""
+    return name.startswith(want) if want == S1 else name == want
+
+
 def _check_instantiation(hip, case, kf, kd, kw):
     from efficientteacher_amd import ops
     N, H, W, Cin, Cout, k, s, p = case
     dt = torch.bfloat16
-    assert ops.kernel_name("fwd", dt, N, H, W, Cin, Cout, k, s, p) == kf
+    assert _same(ops.kernel_name("fwd", dt, N, H, W, Cin, Cout, k, s, p), kf)
     x = _mk(hip, (N, H, W, Cin), dt, 41)
     w = (_mk(hip, (Cout, k, k, Cin), dt, 42) * (1.0 / (k * k * Cin) ** 0.5)).to(dt)
     OH, OW = ops.conv_out_hw(H, W, k, s, p)
@@ -271,7 +320,7 @@ def _check_instantiation(hip, case, kf, kd, kw):
         return
     # dgrad (the operand roles swap: K = taps * Cout)
     names = [ops.kernel_name("dgrad", dt, N, H, W, Cin, Cout, k, s, p, parity_class=c) for c in range(s * s)]
-    assert names == kd, names
+    assert len(names) == len(kd) and all(_same(a, b) for a, b in zip(names, kd)), names
     dy = _mk(hip, (N, OH, OW, Cout), dt, 46)
     w2 = (_mk(hip, (Cout, k, k, Cin), dt, 47) * (1.0 / (k * k * Cout) ** 0.5)).to(dt)
     wT = ops.weight_transpose(w2)
@@ -319,8 +368,9 @@ def test_wgrad_grouped_eight_layers(hip, stride, kernel):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("case", [(2, 12, 12, 64, 40, 3), (2, 20, 20, 256, 256, 3), (3, 10, 10, 32, 128, 1)],
-                         ids=["128x64 tile", "256x256 tile", "1x1"])
+@pytest.mark.parametrize("case", [(2, 12, 12, 64, 40, 3), (2, 20, 20, 256, 256, 3), (3, 10, 10, 32, 128, 1), (2, 9, 11, 256, 256, 1),
+                                  (1, 13, 13, 128, 128, 1), (2, 9, 9, 64, 64, 1)],
+                         ids=["128x64 tile", "256x256 tile", "1x1", "1x1 stream K=256", "1x1 stream K=128", "1x1 stream K=64"])
 def test_dgrad_with_fused_bn_backward_sums(hip, case, dtype):
     """et_conv2d_dgrad_bn + et_bn_act_bwd_from_partials == et_conv2d_dgrad + et_bn_act_bwd (the separate reduce pass),
     with and without the shortcut-gradient residual; and both equal torch autograd of act(BN(y)) on the same tensors."""
@@ -464,17 +514,25 @@ def test_bench_workloads_launch_only_covered_instantiations(hip_lib_path, wl_nam
     compares element-wise with torch (pin the YOLOv8 kernels by name as well).  Host logic only."""
     from efficientteacher_amd import _lib, ops
     _lib._use_library_for_tests(None, False)
+    # what _check_instantiation runs for a SELECT case: the plain forward, the forward with a residual, the plain dgrad, the dgrad
+    # with a residual (test_dgrad_with_fused_bn_backward_sums adds the BN-backward sums on the same instantiation), the wgrad --
+    # resolved through the library, and for the tiled kernels equal to the names SELECT spells out
     covered = set()
-    for _, kf, kd, kw in SELECT:
-        covered.add(kf)
-        covered.update(kd or [])
-        if kw:
-            covered.add(kw)
+    for (N, H, W, Cin, Cout, k, s, p), kf, kd, kw in SELECT:
+        for op in ("fwd", "fwd_res") + (("dgrad", "dgrad_full", "wgrad") if kd is not None else ()):
+            if op == "fwd_res" and k == 6:
+                continue
+            for pc in (range(s * s) if (op in ("dgrad", "dgrad_full") and s == 2) else (0,)):
+                if op == "dgrad_full" and s == 2:
+                    continue
+                covered.add(ops.kernel_name(op, torch.bfloat16, N, H, W, Cin, Cout, k, s, p, parity_class=pc))
     missing = {}
     for B in batches:
         for (h, w, ci, co, k, s, p) in _workload_conv_shapes(wl_name):
             cip, cop = (8 if k == 6 else (ci + 7) // 8 * 8), (co + 7) // 8 * 8
-            for op in (("fwd",) if k == 6 else ("fwd", "dgrad", "wgrad")):
+            for op in (("fwd",) if k == 6 else ("fwd", "fwd_res", "dgrad", "dgrad_full", "wgrad")):
+                if op in ("fwd_res", "dgrad_full") and s != 1:
+                    continue
                 for pc in (range(s * s) if (op == "dgrad" and s == 2) else (0,)):
                     n = ops.kernel_name(op, torch.bfloat16, B, h, w, cip, cop, k, s, p, parity_class=pc)
                     if n not in covered:

@@ -84,6 +84,17 @@ def bench_conv(B=64, dtype=torch.bfloat16, with_ref=True):
         r = dict(cin=cin, cout=cout, k=k, s=s, h=h, count=cnt, gflop=flop / 1e9, fwd_kernel=kname,
                  fwd_ms=t_f * 1e3, dgrad_ms=t_d * 1e3, wgrad_ms=t_w * 1e3,
                  fwd_tf=flop / t_f / 1e12, dgrad_tf=(flop / t_d / 1e12 if t_d else 0), wgrad_tf=flop / t_w / 1e12)
+        if os.environ.get("MB_FULL", "0") == "1" and s == 1 and k != 6:
+            # the Bottleneck.cv1 form of the dgrad: + shortcut-gradient residual + the BatchNorm-backward sums of the producer
+            # (reads dy, the residual and the producer's y; writes dx): 4 tensors of traffic
+            resid, yprod = torch.randn_like(x), torch.randn_like(x)
+            sc, sh = torch.rand(cin, device=dev) + 0.5, torch.randn(cin, device=dev)
+            hand = ops.BnBwdSums(yprod, sc, sh, ops.ACT_SILU)
+            t_df = timeit(lambda: ops.conv2d_dgrad(dy, wT, (h, h), s, p, out=dx, residual=resid, bn=hand))
+            r.update(dgrad_full_ms=t_df * 1e3, dgrad_full_kernel=ops.kernel_name("dgrad_full", dtype, B, h, h, cin, cout, k, s, p))
+            # the teacher's fused forward: folded BN + SiLU (+ residual on the 3x3 of a Bottleneck)
+            t_ft = timeit(lambda: ops.conv2d_fwd(x, w, s, p, scale=sc.new_ones(cout), bias=sc.new_zeros(cout), act=ops.ACT_SILU, out=y))
+            r.update(fwd_teacher_ms=t_ft * 1e3)
         if with_ref:
             xr = x.permute(0, 3, 1, 2)  # channels_last view
             wr = w.permute(0, 3, 1, 2)

@@ -25,7 +25,8 @@ for l in sys.stdin:
     if l.startswith('{'):
         d = json.loads(l); px=B*(d['h']//d['s'])**2
         byt=px*(d['cin']+d['cout'])*2
-        print('%4d->%4d @%3d x%2d  fwd %6.1f us %5.2f TB/s %4.0f TF | dgrad %6.1f us %5.2f TB/s | wgrad %6.1f us %5.2f TB/s' % (d['cin'], d['cout'], d['h'], d['count'], d['fwd_ms']*1e3, byt/d['fwd_ms']/1e9, d['fwd_tf'], d['dgrad_ms']*1e3, byt/d['dgrad_ms']/1e9, d['wgrad_ms']*1e3, byt/d['wgrad_ms']/1e9), d['fwd_kernel'][:60])
+        full = ' | full-dgrad %6.1f us %5.2f TB/s teacher-fwd %6.1f us' % (d['dgrad_full_ms']*1e3, (byt + 2*px*d['cin']*2)/d['dgrad_full_ms']/1e9, d['fwd_teacher_ms']*1e3) if 'dgrad_full_ms' in d else ''
+        print('%4d->%4d @%3d x%2d  fwd %6.1f us %5.2f TB/s %4.0f TF | dgrad %6.1f us %5.2f TB/s | wgrad %6.1f us %5.2f TB/s' % (d['cin'], d['cout'], d['h'], d['count'], d['fwd_ms']*1e3, byt/d['fwd_ms']/1e9, d['fwd_tf'], d['dgrad_ms']*1e3, byt/d['dgrad_ms']/1e9, d['wgrad_ms']*1e3, byt/d['wgrad_ms']/1e9) + full, d['fwd_kernel'][:48])
     elif l.startswith('SUMMARY'): print(l.strip()[:200])
 " | tee -a $OUT/mb_k1.txt; done ;;
 prof) run prof; (cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/bench_under_rocprof.json 2> $GRAFT_REPO_ROOT/$OUT/prof.err); find $OUT/prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv; find $OUT/prof -name "*kernel_trace.csv" | head -1 | xargs -I{} python tools/trace_streams.py {} > $OUT/trace_streams.txt 2>&1; cat $OUT/trace_streams.txt; find $OUT/prof -name "*.db" -delete; find $OUT/prof -name "*kernel_trace.csv" -size +20M -delete; head -8 $OUT/kernel_stats.csv | cut -c1-160 ;;
