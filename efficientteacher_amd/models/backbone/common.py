@@ -155,6 +155,23 @@ class C3(nn.Module):
                 t = b(t, dst=(buf, c_) if i == last else None, bn_in=hand[0] if hand else None, bn_out=nxt)
                 hand = nxt
             return self.cv3(JoinSlicesFn.apply((buf[..., c_:],), t, y2), dst=dst)
+        if (c1s is not None and not self.cv1.bn.training and not self.cv2.bn.training and not torch.is_grad_enabled() and len(self.m) > 0
+                and c3_stem_fusable(c1s, self.cv1.bn._et_slot, c2s, self.cv2.bn._et_slot)
+                and _act_code(self.cv1.act) == _act_code(self.cv2.act)):
+            # eval without autograd (the EMA teacher): cv1 | cv2 as ONE GEMM with the folded BatchNorm affine in its epilogue -- x is
+            # read once, one launch instead of two.  It writes [cv1(x) | cv2(x)] into the buffer cv3 reads; the LAST bottleneck then
+            # writes m(cv1(x)) over the cv1 half (by then its only possible reader is that bottleneck's own shortcut add, which reads the
+            # element it is about to overwrite in the same lane), so the buffer ends up as [m(cv1(x)) | cv2(x)]: no copy.
+            flat = self.cv1._et_flat()
+            o = self.cv1.bn._et_slot.aff_off
+            buf = torch.empty((N, H, W, 2 * c_), dtype=x.dtype, device=x.device)
+            wf = c1s.w_lp.as_strided((2 * c_, 1, 1, c1s.cinp), (c1s.cinp, c1s.cinp, c1s.cinp, 1), c1s.w_lp.storage_offset())
+            ops.conv2d_fwd(x, wf, 1, 0, scale=flat.eval_scale[o:o + 2 * c_], bias=flat.eval_shift[o:o + 2 * c_],
+                           act=_act_code(self.cv1.act), out=buf)
+            t = buf[..., :c_]
+            for i, b in enumerate(self.m):
+                t = b(t, dst=(buf, 0) if i == last else None)
+            return self.cv3(buf, dst=dst)
         buf = torch.empty((N, H, W, 2 * c_), dtype=x.dtype, device=x.device)
         y2 = self.cv2(x, dst=(buf, c_))
         train = self.cv1.bn.training and torch.is_grad_enabled() and _ag.FUSE_BN_BWD and len(self.m) > 0

@@ -9,8 +9,11 @@ per-kernel coverage at the bench shapes (tests/test_conv.py::SELECT) is not a st
       tensor, pseudo-label set <= 1e-6, and EVERY conv / BN / bias gradient against the oracle's (cosine >= 0.9999, relative
       L2 <= 1e-2).
   (b) bf16 performance mode (the dtype the bench line states) on the same inputs against (a)'s fp32-mode HIP step AND the fp32
-      oracle: loss terms <= 5e-2; per-tensor gradient cosine against the fp32 ORACLE for all conv weights, bounds written in the
-      test -- no second noisy path (the CPU autocast calibration of test_step_fullsize.py) is involved.
+      oracle: loss terms <= 5e-2.
+  (c) bf16-mode gradients of all conv weights against the fp32-mode step at 32 + 32, per-tensor cosine >= 0.95 -- at a
+      well-conditioned point (BatchNorm weights 0.3): at the default init the network is chaotic and no reduced-precision path,
+      the reference's own autocast recipe included, keeps its gradients correlated with fp32 (tests/test_step_fullsize.py
+      run_ssod_step_parity, tools/probe/grad_sensitivity.py).  No second noisy path is involved in any bound.
 
 One oracle step at 64 images is ~25-60 s of CPU and ~100 GB of host memory (fp32 activations of 64 images kept for backward);
 when the box has less than ET_TEST_BENCHBATCH_MIN_GB (default 220) of available memory the batch drops to 16 + 16 -- the
@@ -91,28 +94,45 @@ def test_fp32_step_at_the_benchmarked_batch_vs_oracle(dev):
 
 
 def test_bf16_step_at_the_benchmarked_batch_vs_fp32(dev):
-    """the timed dtype.  Bounds (measured values are printed; profiles/r04_benchbatch_parity.txt holds a run):
-    loss terms within 5e-2 of BOTH the fp32-mode HIP step and the fp32 oracle; for every conv weight the cosine of the bf16-mode
-    gradient against the fp32 ORACLE gradient >= 0.90, and >= 0.98 for the median tensor (bf16 storage: 2^-9 relative rounding
-    per stored activation, ~100 layers deep, train-mode BatchNorm over 64 images)."""
+    """the timed dtype, default init (the weights the bench runs with): the six loss terms within 5e-2 of BOTH the fp32-mode HIP
+    step and the fp32 oracle (measured ~1e-3: profiles/r04_benchbatch_parity.txt).  Gradients are compared in the next test -- at
+    this init they are chaotic in ANY reduced precision (run_ssod_step_parity's bn_gamma note; the first run of this test measured
+    a median cosine of 0.11 for the HIP bf16 path, the oracle under CPU autocast sits at 0.13, the oracle with bf16-rounded
+    weights and fp32 arithmetic at 0.32)."""
     r32, g32, (Bl, Bu) = _fp32(dev)
-    g16 = {}
-    r16 = run_ssod_step_parity(dev, torch.bfloat16, Bl=Bl, Bu=Bu, with_oracle=False, all_grads=g16)
+    r16 = run_ssod_step_parity(dev, torch.bfloat16, Bl=Bl, Bu=Bu, with_oracle=False)
     rel_hip = {k: abs(r16["items"][k] - r32["items"][k]) / max(abs(r32["items"][k]), 1e-12) for k in r32["loss_rel"]}
     rel_ref = {k: abs(r16["items"][k] - r32["loss_values"][k][1]) / max(abs(r32["loss_values"][k][1]), 1e-12) for k in r32["loss_rel"]}
-    cos = {}
-    for name, rg in g32["ref"].items():
-        g = g16["hip"].get(name)
-        if g is None or not _is_conv_weight(name, rg) or float(rg.norm()) == 0.0:
-            continue
-        cos[name] = torch.nn.functional.cosine_similarity(g.flatten().double(), rg.flatten().double(), 0).item()
-    vals = sorted(cos.values())
-    worst = min(cos, key=cos.get)
     print(f"PARITY bench-batch bf16 {Bl}+{Bu}: loss vs fp32 HIP", rel_hip, "vs oracle", rel_ref)
-    print("PARITY bench-batch bf16 conv-weight gradient cosine vs the fp32 oracle:", len(vals), "tensors; min", (worst, cos[worst]),
-          "p10", vals[len(vals) // 10], "median", vals[len(vals) // 2])
     for k in rel_hip:
         assert rel_hip[k] <= 5e-2 and rel_ref[k] <= 5e-2, (k, rel_hip[k], rel_ref[k])
+
+
+def test_bf16_gradients_at_the_benchmarked_batch_vs_fp32(dev):
+    """bf16-mode gradients of EVERY conv weight against the fp32-mode HIP step (itself pinned on the oracle above, cosine 0.99999)
+    on the same 32 + 32 inputs, at the well-conditioned point bn_gamma = 0.3: cosine >= 0.95 per tensor, >= 0.975 for the median
+    tensor, relative L2 <= 0.35; loss terms within 5e-2.  (bf16 storage: 2^-9 relative rounding per stored activation, ~100 layers.)"""
+    from tests.test_step_fullsize import BN_GAMMA_CONDITIONED
+    Bl, Bu = _batch()
+    g32, g16 = {}, {}
+    r32 = run_ssod_step_parity(dev, torch.float32, Bl=Bl, Bu=Bu, with_oracle=False, all_grads=g32, bn_gamma=BN_GAMMA_CONDITIONED)
+    torch.cuda.empty_cache()
+    r16 = run_ssod_step_parity(dev, torch.bfloat16, Bl=Bl, Bu=Bu, with_oracle=False, all_grads=g16, bn_gamma=BN_GAMMA_CONDITIONED)
+    rel = {k: abs(r16["items"][k] - v) / max(abs(v), 1e-12) for k, v in r32["items"].items() if k in ("box", "obj", "cls", "ss_box", "ss_obj", "ss_cls")}
+    cos, l2 = {}, {}
+    for name, rg in g32["hip"].items():
+        g = g16["hip"].get(name)
+        if g is None or rg.dim() != 4 or float(rg.norm()) == 0.0:
+            continue
+        cos[name] = torch.nn.functional.cosine_similarity(g.flatten().double(), rg.flatten().double(), 0).item()
+        l2[name] = ((g - rg).norm() / rg.norm()).item()
+    vals = sorted(cos.values())
+    worst = min(cos, key=cos.get)
+    print(f"PARITY bench-batch bf16 gradients {Bl}+{Bu} (bn_gamma {BN_GAMMA_CONDITIONED}) vs the fp32-mode step:", len(vals), "conv tensors; cosine min",
+          (worst, cos[worst]), "p10", vals[len(vals) // 10], "median", vals[len(vals) // 2], "; worst relative L2", max(l2.values()), "; loss", rel)
+    for k, v in rel.items():
+        assert v <= 5e-2, (k, v)
     assert len(vals) >= 100
-    assert vals[0] >= 0.90, (worst, cos[worst])
-    assert vals[len(vals) // 2] >= 0.98, vals[len(vals) // 2]
+    assert vals[0] >= 0.95, (worst, cos[worst])
+    assert vals[len(vals) // 2] >= 0.975, vals[len(vals) // 2]
+    assert max(l2.values()) <= 0.35, max(l2, key=l2.get)

@@ -52,11 +52,21 @@ def _canon(a):
     return a[np.lexsort((np.round(a[:, 3], 5), np.round(a[:, 2], 5), a[:, 1], a[:, 0]))]
 
 
-def run_ssod_step_parity(dev, dtype, width=1.0, depth=1.0, S=640, Bl=1, Bu=1, with_oracle=True, amp_calibration=True, all_grads=None):
+BN_GAMMA_CONDITIONED = 0.3
+
+
+def run_ssod_step_parity(dev, dtype, width=1.0, depth=1.0, S=640, Bl=1, Bu=1, with_oracle=True, amp_calibration=True, all_grads=None,
+                         bn_gamma=None):
     """shared by the dtype tests (and importable by tools): returns the measured deviations.
     with_oracle=False: only the HIP step (items, decoded teacher output, gradients) -- tests/test_step_benchbatch.py compares two HIP
     modes with it.  all_grads: a dict that receives {"hip": {name: grad}, "ref": {name: grad}} of EVERY parameter (the HIP ones
-    recovered from the first SGD update)."""
+    recovered from the first SGD update).
+    bn_gamma: every BatchNorm weight is set to this value before the step (None = the default init, 1.0).  At the default init the
+    ~100-layer train-mode-BatchNorm network is CHAOTIC: rounding nothing but the conv weights to bf16, all arithmetic fp32, already
+    decorrelates the weight gradients (cosine 0.2-0.3 against the unperturbed fp32 oracle; CPU bf16 autocast 0.05-0.13:
+    tools/probe/grad_sensitivity.py, profiles/r04_grad_sensitivity.txt), so a gradient comparison across precisions says nothing
+    about the arithmetic there.  With gamma = 0.3 the same probes give 0.992 / 0.98: the gradient bounds of the bf16 tests are
+    taken at that point."""
     from efficientteacher_amd.configs import get_cfg
     from efficientteacher_amd.trainer import SSODTrainer
     from efficientteacher_amd.utils.torch_utils import ModelEMA
@@ -68,6 +78,11 @@ def run_ssod_step_parity(dev, dtype, width=1.0, depth=1.0, S=640, Bl=1, Bu=1, wi
     cfg.freeze()
     torch.manual_seed(0)
     tr = SSODTrainer(cfg, dev, nb=1000)
+    if bn_gamma is not None:
+        with torch.no_grad():
+            for m in tr.model.modules():
+                if isinstance(m, torch.nn.BatchNorm2d):
+                    m.weight.fill_(float(bn_gamma))
     tr.model.set_compute_dtype(dtype)
     tr.build_optimizer(cfg)
     tr.ema = ModelEMA(tr.model)
@@ -174,17 +189,39 @@ def test_yolov5l_640_ssod_step_bf16_vs_oracle(dev, Bl, Bu):
     """the dtype the bench runs.  bf16 has an 8-bit mantissa (2^-9 relative rounding per stored activation): after ~100
     conv layers the logits carry ~1e-2 relative noise, the loss terms (means over 10^4..10^6 cells) far less.
     2+2 images (nothing checked the bf16 step above 1+1): the oracle leg takes ~10 s of CPU."""
-    r = run_ssod_step_parity(dev, torch.bfloat16, Bl=Bl, Bu=Bu)
-    print("PARITY bf16", r)
+    r = run_ssod_step_parity(dev, torch.bfloat16, Bl=Bl, Bu=Bu, amp_calibration=False)
+    print("PARITY bf16", {k: v for k, v in r.items() if k != "items"})
     assert r["teacher_box_abs"] <= 8.0                       # pixels, boxes up to 640 px wide
     assert r["nms_keep_equal"]                               # NMS itself is fp32 on whatever the teacher produced
     for k, v in r["loss_rel"].items():
         assert v <= 5e-2, (k, v, r["loss_values"][k])
-    # Gradients: with two images and train-mode BatchNorm at random init, the rounding of bf16 activations is amplified
-    # chaotically on the way back (the reference's own AMP recipe moves them by tens of percent: `amp_l2`).  The HIP
-    # bf16 path must not be further from the fp32 oracle than twice that recipe's own deviation.
-    for k, v in r["grad_l2"].items():
-        assert v <= 2.0 * r["amp_l2"][k] + 0.05, (k, v, r["amp_l2"][k])
+    # gradients: test_yolov5l_640_ssod_step_bf16_gradients_vs_oracle below (at the default init they are chaotic, see bn_gamma)
+
+
+def test_yolov5l_640_ssod_step_bf16_gradients_vs_oracle(dev):
+    """bf16-mode weight gradients against the fp32 ORACLE, directly (the bound used to lean on a second noisy
+    path, the oracle under CPU autocast).  2 + 2 images at the well-conditioned point bn_gamma = 0.3 (run_ssod_step_parity explains
+    why not at the default init): EVERY conv weight's gradient has cosine >= 0.95 and relative L2 <= 0.35 against the oracle's
+    (the oracle's own weights-rounded-to-bf16 probe sits at 0.992, CPU bf16 autocast at 0.98: tools/probe/grad_sensitivity.py),
+    the loss terms stay within 5e-2."""
+    grads = {}
+    r = run_ssod_step_parity(dev, torch.bfloat16, Bl=2, Bu=2, amp_calibration=False, all_grads=grads, bn_gamma=BN_GAMMA_CONDITIONED)
+    for k, v in r["loss_rel"].items():
+        assert v <= 5e-2, (k, v, r["loss_values"][k])
+    cos, l2 = {}, {}
+    for name, rg in grads["ref"].items():
+        g = grads["hip"].get(name)
+        if g is None or rg.dim() != 4 or float(rg.norm()) == 0.0:
+            continue
+        cos[name] = torch.nn.functional.cosine_similarity(g.flatten().double(), rg.flatten().double(), 0).item()
+        l2[name] = ((g - rg).norm() / rg.norm()).item()
+    worst = min(cos, key=cos.get)
+    vals = sorted(cos.values())
+    print("PARITY bf16 gradients vs fp32 oracle (bn_gamma 0.3, 2+2):", len(vals), "conv tensors; cosine min", (worst, cos[worst]), "median",
+          vals[len(vals) // 2], "; worst relative L2", max(l2.values()), "; loss_rel", r["loss_rel"])
+    assert len(vals) >= 100
+    assert vals[0] >= 0.95, (worst, cos[worst])
+    assert max(l2.values()) <= 0.35, max(l2, key=l2.get)
 
 
 def test_yolov5s_640_supervised_bf16_vs_oracle(dev):
