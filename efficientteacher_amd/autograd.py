@@ -19,14 +19,34 @@ FUSE_BN_BWD = _os.environ.get("ET_FUSE_BN_BWD", "1") != "0"
 # reduce pass's time between the BatchNorm family and the dgrads, the step does not change.  Default 1: the HBM-bound 1x1 dgrads carry
 # the sums (one y read instead of a dz + y pass), the MFMA-bound 3x3 dgrads keep a pure GEMM epilogue (their launches were 160 us
 # with the sums against 125 us without; the separate reduce pass of the same tensor is ~19 us).
-FUSE_BN_BWD_K = int(_os.environ.get("ET_FUSE_BN_BWD_K", "1"))
+# Bit 4 (r04): the k > 1 layers whose dgrad runs on the 128-row row-shift tiles (conv_gemm_rs_kernel: < 256 channels).  Their epilogue
+# now issues the producer's y reads of a whole slab round up front (conv.hip conv_epilogue_act, EPF) instead of one exposed load per
+# store iteration -- what made the sums cost 35 us per launch in r03; the register-bound 256x256 tiles cannot afford that prefetch and
+# keep the separate reduce pass.
+FUSE_BN_BWD_K = int(_os.environ.get("ET_FUSE_BN_BWD_K", "5"))
+_RS_DGRAD = {}
 
 
-def _fuse_into(cs, bn):
+def _dgrad_on_rs_tile(cs, x):
+    """does the stride-1 dgrad of conv slot `cs` (input x) run on a conv_gemm_rs_kernel tile?  (asked of the library's own selection)"""
+    key = (tuple(x.shape), x.dtype, cs.cinp, cs.coutp, cs.k, cs.stride, cs.pad)
+    r = _RS_DGRAD.get(key)
+    if r is None:
+        N, H, W, _ = x.shape
+        r = _RS_DGRAD[key] = cs.stride == 1 and ops.kernel_name("dgrad_full", x.dtype, N, H, W, cs.cinp, cs.coutp, cs.k, cs.stride,
+                                                               cs.pad).startswith("conv_gemm_rs_kernel")
+    return r
+
+
+def _fuse_into(cs, bn, x=None):
     """bn (a BnBwdSums or None) if the dgrad of conv slot `cs` may carry it, else None (-> the separate reduce pass)"""
-    if bn is None or not (FUSE_BN_BWD_K & (1 if cs.k == 1 else 2)):
+    if bn is None:
         return None
-    return bn
+    if FUSE_BN_BWD_K & (1 if cs.k == 1 else 2):
+        return bn
+    if cs.k > 1 and (FUSE_BN_BWD_K & 4) and x is not None and _dgrad_on_rs_tile(cs, x):
+        return bn
+    return None
 # two-consumer tensors: the later consumer's backward adds into the earlier one's gradient in its own kernel (GradFork below);
 # ET_GRAD_FORK=0 leaves the sum to autograd (a torch bf16 add per tensor: A/B knob)
 GRAD_FORK = _os.environ.get("ET_GRAD_FORK", "1") != "0"
@@ -177,7 +197,7 @@ class ConvBnActFn(Function):
                 dx = ops.conv2d_dgrad(dy, wT, (x.shape[1], x.shape[2]), cs.stride, cs.pad, out=into, accumulate=True)
                 ctx.acc.merged = True
             else:
-                dx = ops.conv2d_dgrad(dy, wT, (x.shape[1], x.shape[2]), cs.stride, cs.pad, bn=_fuse_into(cs, ctx.bn_in))
+                dx = ops.conv2d_dgrad(dy, wT, (x.shape[1], x.shape[2]), cs.stride, cs.pad, bn=_fuse_into(cs, ctx.bn_in, x))
         return dx, (dz if ctx.has_res else None), None, None, None, None, None, None, None, None, None
 
 
@@ -223,7 +243,7 @@ class BottleneckFn(Function):
             _wgrad(h, dy2, cs2)
         # h = act(BN1(y1)) has exactly one consumer (cv2, inside this node): the reduce pass of BN1's backward rides
         # the epilogue of cv2's dgrad
-        inner = _fuse_into(cs2, ops.BnBwdSums(y1, s1, b1, act1)) if FUSE_BN_BWD else None
+        inner = _fuse_into(cs2, ops.BnBwdSums(y1, s1, b1, act1), h) if FUSE_BN_BWD else None
         dh = ops.conv2d_dgrad(dy2, cs2.transposed(), (h.shape[1], h.shape[2]), cs2.stride, cs2.pad, bn=inner)
         dy1 = ops.bn_act_bwd(dh, y1, bs1.gamma, s1, b1, m1, i1, act1, bs1.ggamma, bs1.gbeta,
                              partial=inner.take(dh) if inner is not None else None)
@@ -232,7 +252,7 @@ class BottleneckFn(Function):
         dx = None
         if ctx.x_needs_grad:
             dx = ops.conv2d_dgrad(dy1, cs1.transposed(), (x.shape[1], x.shape[2]), cs1.stride, cs1.pad,
-                                  residual=dz, bn=_fuse_into(cs1, ctx.bn_in))
+                                  residual=dz, bn=_fuse_into(cs1, ctx.bn_in, x))
         return (dx,) + (None,) * 13
 
 

@@ -277,7 +277,7 @@ __device__ __forceinline__ void conv_epilogue_write_stats(EpiSums<BN / WN / 32>&
     }
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int ACT, int SROWS = 32, int MODE = 0, bool DEFER = false>
+template <typename T, int BM, int BN, int WM, int WN, int ACT, int SROWS = 32, int MODE = 0, bool DEFER = false, bool EPF = true>
 __device__ __forceinline__ void conv_epilogue_act(f32x16 (&acc)[BM / WM / 32][BN / WN / 32], u32x4* lds_raw, T* __restrict__ Y,
                                                   const GatherGeom& g, const Epilogue& ep, int bx, int m0, int n0, int tid,
                                                   int lane, int wm, int wn, EpiSums<BN / WN / 32>& st) {
@@ -347,9 +347,41 @@ __device__ __forceinline__ void conv_epilogue_act(f32x16 (&acc)[BM / WM / 32][BN
         else if (ep.bn_act == ACT_RELU) body(std::integral_constant<int, ACT_RELU>{});
         else body(std::integral_constant<int, ACT_NONE>{});
     };
+    // The epilogue's global READS (residual | accumulate, the producer's y for the BN-backward sums) of a slab round are issued at the
+    // TOP of the round, all its iterations at once, and consumed after the slab phase: read inside the store loop, each of them was
+    // a load followed by its own s_waitcnt -- 4-16 exposed memory latencies per wave tile (seen in the ISA of the first persistent
+    // 1x1 kernel; the same code made the 3x3 dgrads 35 us slower when they carried the BN-backward sums, and every eval-mode
+    // Bottleneck.cv2 pays it for its shortcut).  One round ahead would hide them completely but costs 64 VGPRs, and even these 32
+    // make the register-bound kernels spill (the 256x256 tiles: 190-380 spill instructions, the four-workgroup short-K tile: 46):
+    // those pass EPF = false and keep the load in the store loop.
+    constexpr int NIT = SROWS / RPI;
+    constexpr bool PF = EPF && sizeof(T) == 2 && MODE == 0;
+    const bool pf_on = PF && !lean && (ep_res != nullptr || ep_accumulate || bnb);
+    const bool pf_a_is_res = ep_res != nullptr;                  // the A buffer holds the residual, else the old output (accumulate)
+    u32x4 pf_a[NIT], pf_b[NIT];
+    auto pix_of = [&](int p) -> long long {
+        if (ident) return p;
+        const uint32_t t1 = fdiv((uint32_t)p, g.dQW), qx = p - t1 * g.QW;
+        const uint32_t n = fdiv(t1, g.dQH), qy = t1 - n * g.QH;
+        return ((long long)n * g.OH + (qy * g.osy + g.ooy)) * g.OW + (qx * g.osx + g.oox);
+    };
 #pragma unroll
     for (int tmh = 0; tmh < TM * NH; ++tmh) {
         const int tm = tmh / NH, hoff = (tmh % NH) * SROWS;      // accumulator tile, first tile row of this slab round
+        if constexpr (PF) {
+            if (pf_on) {
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int p = m0 + wm * (BM / WM) + tm * 32 + hoff + it * RPI + srow;
+                    if (p < g.M && co + 8 <= g.Cout) {
+                        const long long pix = pix_of(p);
+                        if (pf_a_is_res) pf_a[it] = *(const u32x4*)((const T*)ep_res + pix * ep.ldr + co);
+                        else if (ep_accumulate) pf_a[it] = *(const u32x4*)(Y + pix * g.ldy + co);
+                        if (bnb) pf_b[it] = *(const u32x4*)((const T*)ep.bn_y + pix * ep.ld_bn + co);
+                    }
+                }
+            }
+        }
 #pragma unroll
         for (int rr = 0; rr < 16 / NH; ++rr) {
             const int r = (tmh % NH) * (16 / NH) + rr;
@@ -391,14 +423,7 @@ __device__ __forceinline__ void conv_epilogue_act(f32x16 (&acc)[BM / WM / 32][BN
             const int row = it * RPI + srow;
             const int p = m0 + wm * (BM / WM) + tm * 32 + hoff + row;
             if (p < g.M && co < g.Cout) {
-                long long pix;
-                if (ident) {
-                    pix = p;
-                } else {
-                    const uint32_t t1 = fdiv((uint32_t)p, g.dQW), qx = p - t1 * g.QW;
-                    const uint32_t n = fdiv(t1, g.dQH), qy = t1 - n * g.QH;
-                    pix = ((long long)n * g.OH + (qy * g.osy + g.ooy)) * g.OW + (qx * g.osx + g.oox);
-                }
+                const long long pix = pix_of(p);
                 float v[8];
                 const float4 a = *(const float4*)(stg + row * SLD + scv * 8);
                 const float4 b = *(const float4*)(stg + row * SLD + scv * 8 + 4);
@@ -407,14 +432,18 @@ __device__ __forceinline__ void conv_epilogue_act(f32x16 (&acc)[BM / WM / 32][BN
                 if (co + 8 <= g.Cout) {
                     if constexpr (sizeof(T) == 2) {
                         if (ep_res) {
-                            const u32x4 rr = *(const u32x4*)((const T*)ep_res + pix * ep.ldr + co);
+                            u32x4 rr;
+                            if constexpr (PF) rr = pf_a[it];
+                            else rr = *(const u32x4*)((const T*)ep_res + pix * ep.ldr + co);
                             v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
                             v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
                             v[4] += __uint_as_float(rr.z << 16); v[5] += __uint_as_float(rr.z & 0xffff0000u);
                             v[6] += __uint_as_float(rr.w << 16); v[7] += __uint_as_float(rr.w & 0xffff0000u);
                         }
                         if (ep_accumulate) {
-                            const u32x4 rr = *(const u32x4*)yp;
+                            u32x4 rr;
+                            if (PF && !pf_a_is_res) rr = pf_a[it];       // (with a residual as well, the A buffer is taken: load here)
+                            else rr = *(const u32x4*)yp;
                             v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
                             v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
                             v[4] += __uint_as_float(rr.z << 16); v[5] += __uint_as_float(rr.z & 0xffff0000u);
@@ -425,7 +454,9 @@ __device__ __forceinline__ void conv_epilogue_act(f32x16 (&acc)[BM / WM / 32][BN
                         *(u32x4*)yp = packed;
                         if (bnb) {
                             // statistics of exactly what the apply pass will read back: the bf16-ROUNDED dz
-                            const u32x4 yy = *(const u32x4*)((const T*)ep.bn_y + pix * ep.ld_bn + co);
+                            u32x4 yy;
+                            if constexpr (PF) yy = pf_b[it];
+                            else yy = *(const u32x4*)((const T*)ep.bn_y + pix * ep.ld_bn + co);
                             const unsigned pw[4] = {packed.x, packed.y, packed.z, packed.w}, yw[4] = {yy.x, yy.y, yy.z, yy.w};
                             float dz8[8], y8[8];
 #pragma unroll
@@ -482,23 +513,23 @@ __device__ __forceinline__ void conv_epilogue_act(f32x16 (&acc)[BM / WM / 32][BN
     }
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int SROWS = 32, int MODE = 0, bool DEFER = false>
+template <typename T, int BM, int BN, int WM, int WN, int SROWS = 32, int MODE = 0, bool DEFER = false, bool EPF = true>
 __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN / 32], u32x4* lds_raw, T* __restrict__ Y,
                                               const GatherGeom& g, const Epilogue& ep, int bx, int m0, int n0, int tid,
                                               int lane, int wm, int wn, EpiSums<BN / WN / 32>& st) {
     // one uniform branch per workgroup instead of one per element
-    if (ep.act == ACT_SILU) conv_epilogue_act<T, BM, BN, WM, WN, ACT_SILU, SROWS, MODE, DEFER>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn, st);
-    else if (ep.act == ACT_RELU) conv_epilogue_act<T, BM, BN, WM, WN, ACT_RELU, SROWS, MODE, DEFER>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn, st);
-    else conv_epilogue_act<T, BM, BN, WM, WN, ACT_NONE, SROWS, MODE, DEFER>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn, st);
+    if (ep.act == ACT_SILU) conv_epilogue_act<T, BM, BN, WM, WN, ACT_SILU, SROWS, MODE, DEFER, EPF>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn, st);
+    else if (ep.act == ACT_RELU) conv_epilogue_act<T, BM, BN, WM, WN, ACT_RELU, SROWS, MODE, DEFER, EPF>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn, st);
+    else conv_epilogue_act<T, BM, BN, WM, WN, ACT_NONE, SROWS, MODE, DEFER, EPF>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn, st);
 }
-// the tiled kernels: one tile per workgroup, statistics written by the epilogue itself
-template <typename T, int BM, int BN, int WM, int WN>
+// the tiled kernels: one tile per workgroup, statistics written by the epilogue itself.  EPF: see conv_epilogue_act (register headroom)
+template <typename T, int BM, int BN, int WM, int WN, bool EPF = true>
 __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN / 32], u32x4* lds_raw, T* __restrict__ Y,
                                               const GatherGeom& g, const Epilogue& ep, int bx, int m0, int n0, int tid,
                                               int lane, int wm, int wn) {
     EpiSums<BN / WN / 32> st;
     st.clear();
-    conv_epilogue<T, BM, BN, WM, WN, 32, 0, false>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn, st);
+    conv_epilogue<T, BM, BN, WM, WN, 32, 0, false, EPF>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn, st);
 }
 
 // ---- forward / dgrad gather-GEMM ----------------------------------------------------------------
@@ -646,7 +677,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const T* __restrict__ X,
     }
 
 #undef ET_ADVANCE_CURSOR
-    conv_epilogue<T, BM, BN, WM, WN>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn);
+    conv_epilogue<T, BM, BN, WM, WN, false>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn);
 }
 
 // ---- forward / dgrad gather-GEMM, LDS-DMA staging ------------------------------------------------------
@@ -813,7 +844,8 @@ __global__ __launch_bounds__(64 * WM * WN, (NS == 3 && BKV == 4 && BM == 128) ? 
     }
     __syncthreads();                               // the epilogue reuses the ring as its staging area
 #undef ET_ADVANCE_CURSOR
-    conv_epilogue<T, BM, BN, WM, WN>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn);
+    // (EPF = false: the epilogue's read prefetch costs this kernel a resident workgroup -- 168 -> 194 VGPRs on the 128x128 tile)
+    conv_epilogue<T, BM, BN, WM, WN, false>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn);
 }
 
 // ---- 3x3 stride-1 gather-GEMM with the activation rows shared by the three taps of a kernel row ("row shift") --------------
@@ -1218,7 +1250,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_pp_kernel(const uint16_t* __
     chunk(buf, std::true_type{});
     if (wm == 0) __builtin_amdgcn_s_barrier();     // balances group 1's extra barrier
     __syncthreads();                               // the epilogue reuses the half-tile buffers as its staging area
-    conv_epilogue<uint16_t, BM, BN, WM, WN>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn);
+    conv_epilogue<uint16_t, BM, BN, WM, WN, false>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn);
 #undef ET_PP_DECODE
 #undef ET_PP_ADVANCE
 #undef ET_PP_BAR
@@ -1419,7 +1451,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_pprs_kernel(const uint16_t* 
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();     // balances group 1's extra barrier
     __syncthreads();                               // the epilogue reuses the ring as its staging area
-    conv_epilogue<uint16_t, BM, BN, WM, WN>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn);
+    conv_epilogue<uint16_t, BM, BN, WM, WN, false>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn);
 #undef ET_PP_BAR
 #undef ET_PP_WAIT
 }
