@@ -20,10 +20,11 @@ FUSE_BN_BWD = _os.environ.get("ET_FUSE_BN_BWD", "1") != "0"
 # the sums (one y read instead of a dz + y pass), the MFMA-bound 3x3 dgrads keep a pure GEMM epilogue (their launches were 160 us
 # with the sums against 125 us without; the separate reduce pass of the same tensor is ~19 us).
 # Bit 4 (r04): the k > 1 layers whose dgrad runs on the 128-row row-shift tiles (conv_gemm_rs_kernel: < 256 channels).  Their epilogue
-# now issues the producer's y reads of a whole slab round up front (conv.hip conv_epilogue_act, EPF) instead of one exposed load per
-# store iteration -- what made the sums cost 35 us per launch in r03; the register-bound 256x256 tiles cannot afford that prefetch and
-# keep the separate reduce pass.
-FUSE_BN_BWD_K = int(_os.environ.get("ET_FUSE_BN_BWD_K", "5"))
+# now issues the producer's y reads of a whole slab round up front (conv.hip conv_epilogue_act, EPF) instead of one load + wait per
+# store iteration; the register-bound 256x256 tiles cannot afford that prefetch.  Measured, alternating on one box
+# (profiles/r04_fuse_bn_bwd_rs_tiles_ab.txt): 1 / 5 / 1 / 5 = 52.61 / 52.82 / 52.73 / 52.82 ms -- BatchNorm family -1.0 ms, gather-GEMMs
+# +1.1 ms: still a zero-sum move, so the default stays 1 (the 3x3 dgrads are pure GEMMs).
+FUSE_BN_BWD_K = int(_os.environ.get("ET_FUSE_BN_BWD_K", "1"))
 _RS_DGRAD = {}
 
 
