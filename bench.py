@@ -43,7 +43,25 @@ sys.path.insert(0, ROOT)
 CFG_DIR = os.path.join(ROOT, "efficientteacher_amd", "configs")
 YAML = os.path.join(CFG_DIR, "ssod", "coco-standard", "yolov5l_coco_ssod_10_percent.yaml")
 F_IMG = 111.52e9          # conv FLOPs / image forward, YOLOv5l SSOD model
+F_NETD_IMG = 2.52805e9    # ... of which the six netD convs (256->256 @80^2, 512->512 @40^2, 1024->1024 @20^2 and their 2-channel heads):
+                          # with SSOD.with_da_loss False the step adds d_loss * 0 (ssod_trainer.py:633-636) and the netD BACKWARD is
+                          # never executed (models/detector/yolo_ssod.py:44-55) -- its 2 F_netD per image are not charged as executed work
 PEAK_BF16 = 2.5e15        # dense bf16 MFMA peak, MI355X_MICROARCH.md
+PEAK_HBM = 8.0e12         # HBM3E spec, MI355X_MICROARCH.md; ACHIEVABLE_HBM: the best streaming pass measured on this part (BN apply pass,
+ACHIEVABLE_HBM = 6.3e12   # profiles/r03_*: 6.2-6.3 TB/s)
+# Algorithmic HBM bytes of one YOLOv5l SSOD step, SURVEY.md 8(d): every conv reads its input and writes its output once in bf16
+# (358.6 MB per image and pass; passes = teacher forward, student forward, dgrad, wgrad), weights 95.9 MB per pass (+ the fp32
+# gradient), train-mode BatchNorm + SiLU 4 B/element forward and 10 B/element backward over 78.5 M elements per student image,
+# NMS scan, EMA (two of them) and SGD over 47.9 M parameters.
+ALG_ACT_BYTES_IMG_PASS = 358.6e6
+ALG_BN_ELEMS_IMG = 78.5e6
+
+
+def algorithmic_bytes_per_step(Bl, Bu):
+    conv = ALG_ACT_BYTES_IMG_PASS * (Bu + 3 * (Bl + Bu)) + 4 * 95.9e6 + 47.9e6 * 4
+    bn = ALG_BN_ELEMS_IMG * (Bl + Bu) * (4 + 10)
+    other = Bu * 25200 * 85 * 4 + 3 * (Bl + Bu) * 25200 * 6 * 4 + 48.0e6 * 4 * 3 * 2 + 47.9e6 * 4 * 5
+    return dict(conv_activations_and_weights=conv, batchnorm_silu=bn, nms_loss_ema_sgd=other, total=conv + bn + other)
 
 WORKLOADS = {
     "v5l-ssod": dict(kind="ssod", yaml=YAML, merge=[], per_rank=32,
@@ -151,6 +169,34 @@ def _hip_ssod_losses(cfg, device, dtype, batch, synth):
     return items, tp, sd
 
 
+def reference_timing(Bl, Bu, S, port_images_per_s):
+    """The IMPORTED reference against the port.  Where the reference tree is reachable (ET_REFERENCE, or /root/reference: the build
+    container) it is timed directly, same batch, same cores; everywhere else (the GPU box: the reference cannot travel, SURVEY.md
+    8c) the committed ratio of profiles/r04_reference_vs_port_cpu.json -- both timed in ONE process on the build container's cores
+    (oracle/time_reference_step.py) -- turns this host's port figure into an estimate of the reference's."""
+    out = {}
+    ref_root = os.environ.get("ET_REFERENCE", "/root/reference")
+    try:
+        r = json.load(open(os.path.join(ROOT, "profiles", "r04_reference_vs_port_cpu.json")))
+        out["reference_ratio"] = dict(port_over_reference=r["port_over_reference"], cores=r["cores"], where=r["where"],
+                                      reference_images_per_s=r["images_per_s"], port_images_per_s=r["port_images_per_s"],
+                                      source="profiles/r04_reference_vs_port_cpu.json",
+                                      note="the plain-torch port is FASTER than the imported reference by this factor on the same cores "
+                                           "(the reference's loss / assigner code runs many small tensor ops per target)")
+        out["reference_estimate_images_per_s"] = port_images_per_s / r["port_over_reference"]
+    except (OSError, ValueError, KeyError):
+        pass
+    if os.path.isdir(ref_root) and os.environ.get("ET_BENCH_TIME_REFERENCE", "0") == "1":
+        import subprocess
+        try:
+            p = subprocess.run([sys.executable, "-m", "oracle.time_reference_step", str(Bl)], cwd=ROOT, capture_output=True, text=True, timeout=900)
+            r = json.loads(p.stdout.strip().splitlines()[-1])
+            out["reference_here"] = dict(images_per_s=r["images_per_s"], cores=r["cores"], port_over_reference=r["port_over_reference"])
+        except Exception as e:
+            out["reference_here"] = dict(error=f"{type(e).__name__}: {e}")
+    return out
+
+
 def cpu_baseline_ssod(cfg, device, seconds=25.0, Bl=2, Bu=2):
     """The oracle (oracle/step.py: plain-torch CPU restatement of trainer/ssod_trainer.py:587-680, `kind: "port"`) timed on
     the host cores for a bounded number of Bl + Bu image steps -- and, on the way, the PARITY CHECK of the benchmarked
@@ -228,6 +274,8 @@ def cpu_baseline_ssod(cfg, device, seconds=25.0, Bl=2, Bu=2):
     base = dict(value=(Bl + Bu) / dt, unit="images/s", cores=cores, kind="port",
                 sample=f"{'YOLOv8' if v8 else 'YOLOv5l'} SSOD step, {Bl} labeled + {Bu} unlabeled {S}x{S}, {n} steps, plain-torch fp32 CPU port "
                        f"(oracle/step.py; all {ref['t9'].shape[0]} pseudo labels)")
+    if not v8:
+        base.update(reference_timing(Bl, Bu, S, base["value"]))
     return base, parity
 
 
@@ -555,6 +603,33 @@ def roofline_of(res, dump=None):
     return roof, conv_fl
 
 
+def roofline_hbm(workload, per_rank, step_s):
+    """the HBM side of the step: bytes moved per step (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over EVERY kernel of this very
+    command, separate passes, FETCH doubled per the gfx950 note: profiles/pmc_traffic.json, tools/pmc_to_traffic.py) divided by
+    the step time measured in THIS run, against the HBM3E peak and against the best streaming pass measured on the part; beside
+    it the algorithmic bytes of SURVEY.md 8(d) and the ratio.  The traffic figure is from the committed PMC file (counters cannot
+    be read inside the timed region); it is null when that file does not belong to this workload / batch."""
+    out = dict(bound="hbm", peak=PEAK_HBM / 1e12, achievable=ACHIEVABLE_HBM / 1e12, unit="TB/s", achieved=None, frac=None,
+               frac_of_achievable=None, traffic=None, traffic_unit="bytes per step, all kernels (2*FETCH_SIZE + WRITE_SIZE)", traffic_source=None)
+    if workload == "v5l-ssod":
+        alg = algorithmic_bytes_per_step(per_rank, per_rank)
+        out["algorithmic_bytes_per_step"] = {k: round(v) for k, v in alg.items()}
+        out["algorithmic_achieved"] = alg["total"] / step_s / 1e12
+        out["algorithmic_frac"] = alg["total"] / step_s / PEAK_HBM
+    try:
+        pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        st = pt.get("step")
+        if st and pt.get("workload", "v5l-ssod") == workload and pt.get("per_rank", 32) == per_rank:
+            b = float(st["bytes_per_step"])
+            out.update(traffic=b, traffic_source=pt["source"], traffic_by_family={k: round(v) for k, v in st["by_family"].items()},
+                       achieved=b / step_s / 1e12, frac=b / step_s / PEAK_HBM, frac_of_achievable=b / step_s / ACHIEVABLE_HBM)
+            if "algorithmic_bytes_per_step" in out:
+                out["traffic_over_algorithmic"] = b / out["algorithmic_bytes_per_step"]["total"]
+    except (OSError, ValueError, KeyError):
+        pass
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -628,9 +703,11 @@ def main():
             roof, conv_fl = dict(bound="mfma", kernel=None, achieved=None, peak=PEAK_BF16 / 1e12, unit="TFLOP/s", frac=None,
                                  traffic=None, error=f"{type(e).__name__}: {e}"), None
         if a.workload == "v5l-ssod":
-            step_flop = F_IMG * per_rank + 3 * F_IMG * (2 * per_rank)
+            alg_flop = F_IMG * per_rank + 3 * F_IMG * (2 * per_rank)                     # the number BASELINE quotes
+            da = bool(cfg.SSOD.with_da_loss)
+            step_flop = alg_flop - (0.0 if da else 2 * F_NETD_IMG * (2 * per_rank))      # EXECUTED: no netD backward without the DA loss
         else:
-            step_flop = conv_fl if conv_fl else float("nan")      # measured: sum of 2*M*N*K over every conv launch of the step
+            alg_flop = step_flop = conv_fl if conv_fl else float("nan")      # measured: sum of 2*M*N*K over every conv launch of the step
         if ssod:
             base_cfg = "BASELINE configs[2]" if (world == 1 and per_rank == 32) else \
                        ("BASELINE configs[3]: global 128 labeled + 128 unlabeled over 8 ranks" if (world == 8 and per_rank == 16) else
@@ -648,7 +725,10 @@ def main():
             "replaced by U^16 / U^4 so that NMS and the pseudo-label loss do representative work)" if ssod else "; uniform uint8 images, synthetic COCO-80 targets)"),
             "config": {"workload": workload, "global_batch": world * ips, "img_size": S,
                        "parallelism": f"dp{world}", "optimizer_every_step": True,
-                       "algorithmic_tflop_per_step_per_gpu": step_flop / 1e12,
+                       "algorithmic_tflop_per_step_per_gpu": alg_flop / 1e12,
+                       "executed_tflop_per_step_per_gpu": step_flop / 1e12,
+                       "flop_note": "algorithmic = SURVEY.md 8(d) (teacher F + student 3F, netD included); executed = the same minus the netD "
+                                    "backward, which SSOD.with_da_loss False never runs; step_tflops / frac_of_bf16_mfma_peak use EXECUTED",
                        "step_tflops_per_gpu": step_flop / (dt / a.steps) / 1e12,
                        "frac_of_bf16_mfma_peak": step_flop / (dt / a.steps) / PEAK_BF16, "loss_finite": res["loss_ok"],
                        "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1, "env_knobs": ops.env_knobs(),
@@ -673,6 +753,7 @@ def main():
                                           eager_instrumented_steps=res["n_timed"]),
                        "inputs": "host uint8 (PCIe inclusive)" if a.host_inputs else "resident in HBM"},
             "roofline": roof,
+            "roofline_hbm": roofline_hbm(a.workload, per_rank, dt / a.steps),
             "kernel_ms_by_family": res.get("families"),
         }
         if ssod and world == 8 and per_rank == 16:

@@ -62,6 +62,7 @@ class FlatDataParallel(nn.Module):
         self._works = []
         self._launched = set()
         self._dirty = False              # a backward has moved the per-chunk counters since the last reduce_gradients()
+        self._bcast_stream = None        # side stream of the per-forward buffer broadcast (RCCL only)
         self.timing = False              # bench.py: HIP events around the collective phase of a step
         self.last_timing = None          # (first launch -> all complete, exposed wait after backward) in ms
         self._ev0 = None
@@ -139,8 +140,45 @@ class FlatDataParallel(nn.Module):
             self.reduce_gradients()
         if self.active and self.broadcast_buffers and self.module.training:
             # DDP broadcast_buffers=True: rank 0's BN running stats / anchors at every forward
-            dist.broadcast(self.module.flat_state().buffers, 0, group=self.pg)
+            buf = self.module.flat_state().buffers
+            if buf.is_cuda and dist.get_backend(self.pg) == "nccl":
+                # on a SIDE stream: nothing of the forward reads these buffers before the first BatchNorm finalize updates the
+                # running statistics (train mode normalises with batch statistics), so the broadcast runs beside the input pack
+                # and the stem conv instead of in front of them; ops.bn_finalize joins the side stream before that first update
+                # (ops.PRE_STATS_WAIT).  Inside a step-graph capture the fork / join are captured as graph dependencies.
+                from . import ops as _ops
+                cur = torch.cuda.current_stream(buf.device)
+                if self._bcast_stream is None:
+                    self._bcast_stream = torch.cuda.Stream(device=buf.device)
+                side = self._bcast_stream
+                side.wait_stream(cur)                    # every earlier write of the buffers (last step's statistics, load_state_dict) is done
+                with torch.cuda.stream(side):
+                    dist.broadcast(buf, 0, group=self.pg)
+                ev = torch.cuda.Event()
+                ev.record(side)
+
+                def join(ev=ev, dev=buf.device):
+                    torch.cuda.current_stream(dev).wait_event(ev)
+                _ops.PRE_STATS_WAIT = join
+                try:
+                    return self.module(*a, **k)
+                finally:
+                    if _ops.PRE_STATS_WAIT is join:      # a forward without any BatchNorm finalize: join here
+                        _ops.PRE_STATS_WAIT = None
+                        join()
+            dist.broadcast(buf, 0, group=self.pg)
         return self.module(*a, **k)
+
+    def abort_step(self):
+        """forget a step that will not be finished (a rejected graph capture): collectives already started are waited for,
+        counters and flags return to their start-of-step values; the gradient arena is the caller's to zero"""
+        for w, _, _ in self._works:
+            w.wait()
+        self._works = []
+        self._launched = set()
+        self._remaining = [c[2] for c in self._chunks] if self.active else []
+        self._dirty = False
+        self._ev0 = None
 
     def reduce_gradients(self):
         """Finish the gradient all-reduce (mean over ranks); call after EVERY backward() -- also on the micro-steps of a

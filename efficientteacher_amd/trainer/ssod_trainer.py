@@ -137,7 +137,7 @@ class SSODTrainer(Trainer):
     def train_instance(self, imgs, targets, paths, unlabeled_imgs, unlabeled_imgs_ori, unlabeled_gt, unlabeled_M, ni,
                        pbar=None, callbacks=None):
         """reference signature (ssod_trainer.py:587).  After a few eager steps the whole step is replayed as one HIP graph."""
-        if self.use_graph and self.cuda and self._eager_steps >= self.graph_warmup:
+        if self.use_graph and self._graph_capable() and self._eager_steps >= self.graph_warmup:
             accumulate = 1 if self.fixed_accumulate else max(round(64 / self.batch_size), 1)
             if ni <= self.nw and not self.fixed_accumulate:
                 import numpy as np
@@ -156,7 +156,12 @@ class SSODTrainer(Trainer):
                     logging.getLogger(__name__).warning("step graph dropped (%s: %s): falling back to eager steps", type(e).__name__, e)
                     self.graph_error = f"{type(e).__name__}: {e}"
                     self.use_graph = False
-                    torch.cuda.synchronize(self.device)
+                    if self.cuda:
+                        torch.cuda.synchronize(self.device)
+                    if isinstance(self.model, FlatDataParallel):
+                        # a capture that failed half-way may have counted gradient-ready hooks or started collectives: the eager
+                        # step below starts from clean counters on EVERY rank (all ranks reject the same capture: same code, same signature)
+                        self.model.abort_step()
         self._eager_steps += 1
         time_it = self.use_graph and self.cuda and self._eager_steps == self.graph_warmup    # the graph's yardstick (graph_step.py)
         if time_it:
@@ -169,6 +174,10 @@ class SSODTrainer(Trainer):
             e1.record()
             self._eager_events = (e0, e1)
         return out
+
+    def _graph_capable(self):
+        """the step graph needs a HIP device (tests override this to drive the fall-back path on CPU ranks)"""
+        return self.cuda
 
     def eager_step_ms(self):
         """HIP-event span of the last eager step before the capture (None when it was not timed)"""

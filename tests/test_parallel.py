@@ -296,7 +296,29 @@ def _worker_ssod(rank, world, port, emu_path, out_dir):
     assert isinstance(tr.model, FlatDataParallel) and tr.model.active
     tr.overlap_teacher = False
     e0 = tr.ema.ema.flat_state().params.clone()
+
+    class RejectedCapture:
+        """stands in for trainer/graph_step.StepGraph on these CPU ranks: the capture of the step is REJECTED after it has already
+        run part of a backward (two gradient-ready hooks have counted down) -- what an RCCL build that cannot be captured does"""
+        graph = None
+        calls = 0
+
+        def usable(self, imgs, targets):
+            return True
+
+        def run(self, *a):
+            RejectedCapture.calls += 1
+            slots = sorted(tr.model.flat_state().conv_slots.values(), key=lambda s: s.index)
+            for sl in slots[-2:]:
+                tr.model._on_conv_grad_ready(sl)
+            raise RuntimeError("capture rejected (test)")
+    # step 0 eagerly; step 1 asks for the step graph, whose capture is rejected on BOTH ranks: the step must fall back to an eager
+    # step with clean all-reduce counters and give the gradients / parameters of a run that never tried (the test's reference)
+    tr.use_graph, tr.graph_warmup, tr._graph = True, 1, RejectedCapture()
+    tr._graph_capable = lambda: True
     _run_ssod_steps(tr, [rank])
+    assert RejectedCapture.calls == 1 and tr.use_graph is False and "capture rejected" in tr.graph_error
+    assert not tr.model._dirty and not tr.model._launched and not tr.model._works
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), params=tr.model.flat_state().params.numpy(), ema0=e0.numpy(),
              ema=tr.ema.ema.flat_state().params.numpy(), semi=tr.semi_ema.ema.flat_state().params.numpy())
     dist.destroy_process_group()
@@ -307,7 +329,8 @@ def test_two_rank_ssod_train_instance_gloo(emu_lib_path):
     batch, ComputeLoss + ComputeStudentMatchLoss, backward, all-reduce, SGD, both EMAs) on two gloo ranks with different local
     batches: student and teacher parameters stay identical across the ranks, and equal a single process that accumulates the
     two ranks' gradients of every step before its optimizer step (loss x WORLD_SIZE and the mean over ranks = the sum,
-    ssod_trainer.py:638-649 + trainer.py:313)."""
+    ssod_trainer.py:638-649 + trainer.py:313).  The second step asks for the captured step graph and has the capture REJECTED on
+    both ranks after part of a backward has run: it falls back to an eager step with identical results."""
     world = 2
     port = 29500 + ((os.getpid() + 13) % 2000)
     with tempfile.TemporaryDirectory() as d:
