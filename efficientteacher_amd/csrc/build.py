@@ -52,7 +52,9 @@ def build(verbose=False, force=False):
             raise RuntimeError(f"hipcc failed on {src}")
         if verbose and out:
             print(out.decode())
-    if rebuilt or not os.path.exists(LIB):
+    # relink also when an object is newer than the library (an object compiled by hand, e.g. with -save-temps for an ISA check,
+    # used to leave a STALE library behind: two GPU runs of r04 measured the previous build)
+    if rebuilt or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
         cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:
             print(" ".join(cmd))
