@@ -20,11 +20,12 @@ FUSE_BN_BWD = _os.environ.get("ET_FUSE_BN_BWD", "1") != "0"
 # the sums (one y read instead of a dz + y pass), the MFMA-bound 3x3 dgrads keep a pure GEMM epilogue (their launches were 160 us
 # with the sums against 125 us without; the separate reduce pass of the same tensor is ~19 us).
 # Bit 4 (r04): the k > 1 layers whose dgrad runs on the 128-row row-shift tiles (conv_gemm_rs_kernel: < 256 channels).  Their epilogue
-# now issues the producer's y reads of a whole slab round up front (conv.hip conv_epilogue_act, EPF) instead of one load + wait per
-# store iteration; the register-bound 256x256 tiles cannot afford that prefetch.  Measured, alternating on one box
-# (profiles/r04_fuse_bn_bwd_rs_tiles_ab.txt): 1 / 5 / 1 / 5 = 52.61 / 52.82 / 52.73 / 52.82 ms -- BatchNorm family -1.0 ms, gather-GEMMs
-# +1.1 ms: still a zero-sum move, so the default stays 1 (the 3x3 dgrads are pure GEMMs).
-FUSE_BN_BWD_K = int(_os.environ.get("ET_FUSE_BN_BWD_K", "1"))
+# issues the producer's y reads of a whole slab round up front (conv.hip conv_epilogue_act, EPF) instead of one load + wait per store
+# iteration; the register-bound 256x256 tiles cannot afford that prefetch and keep the separate reduce pass.  Measured, alternating,
+# two boxes (profiles/r04_stream_full_and_fuse_ab_current_build.txt, r04_knob_combinations_ab.txt): 1 -> 5 = 52.27 / 52.46 -> 52.15 /
+# 52.29 ms and 51.37 / 51.43 -> 51.24 / 51.31 ms: BatchNorm family -0.7 ms, gather-GEMMs +0.6 ms, -0.1 ms net in every pair.  Default 5.
+# (An earlier A/B of this round that showed +0.15 ms had run a STALE library without the prefetch: profiles/r04_fuse_bn_bwd_rs_tiles_ab.txt.)
+FUSE_BN_BWD_K = int(_os.environ.get("ET_FUSE_BN_BWD_K", "5"))
 _RS_DGRAD = {}
 
 

@@ -2718,13 +2718,14 @@ static GemmPlan plan_gemm(const GatherGeom& g, int elem_bytes, bool have_zero_pa
     GemmPlan p{glds ? GEMM_GLDS : GEMM_REG, 128, wide ? 128 : 64, 2, 2, g.CV % 8 == 0 ? 8 : 4, 2, g.CV % 4 == 0, 0, 0, 0, 0};
     if (!(bf16 && glds && g.CV % 8 == 0)) return p;
     // 1x1 layers with K <= 256 and <= 256 output channels: the persistent streaming kernel (ET_CONV_S1=0: the tiled kernels below)
-    // ET_CONV_S1: 0 off, 1 (default) the plain layers, 2 also the dgrads with a residual / accumulate / BN-backward sums in the
-    // epilogue.  Measured (profiles/r04_mb_1x1_stream_kernel_ab.txt, r04_stream_kernel_step_ab.txt): plain layers 4.4-5.3 TB/s
-    // against 3.7-5.1 of the tiled kernels (128->128 @80x80: 54 -> 46 us, 256->256 @80x80: 111 -> 86-97 us), step 53.4 -> 52.7 ms.
-    // The FULL epilogue LOSES in this kernel (128->128 @80x80 with residual + sums: 105 -> 111 us): its residual / y loads return
-    // in order BEHIND every LDS-DMA piece the ring has in flight, so each of them waits out the whole ring; the tiled kernels
-    // hide that latency across four short-lived workgroups per CU.
-    static const int use_s1 = env_int("ET_CONV_S1", 1);
+    // ET_CONV_S1: 0 off, 1 the plain layers only, 2 (default) also the dgrads with a residual / accumulate / BN-backward sums in
+    // the epilogue.  Measured (profiles/r04_mb_1x1_stream_kernel_ab.txt, r04_stream_full_and_fuse_ab_current_build.txt): plain layers
+    // 4.4-5.3 TB/s against 3.7-5.1 of the tiled kernels (128->128 @80x80: 54 -> 46 us, 256->256 @80x80: 111 -> 86-97 us); step, same
+    // box, alternating: 0 / 1 / 2 = 53.18 / 52.27-52.46 / 52.10-52.13 ms.  The FULL epilogue only pays since its reads are issued a
+    // slab round at a time (conv_epilogue_act, EPF): with one load + wait per store iteration it LOST to the tiled kernels
+    // (128->128 @80x80 with residual + sums: 105 -> 111 us) -- those loads return in order BEHIND every LDS-DMA piece the ring has in
+    // flight, and the tiled kernels hide that latency across four short-lived workgroups per CU.
+    static const int use_s1 = env_int("ET_CONV_S1", 2);
     if (use_s1 && (use_s1 >= 2 || !full_epilogue) && s1_eligible(g)) return plan_s1(g, full_epilogue);
     // short-K GEMMs (K <= 256, i.e. <= 4 chunks of 64) run 32-wide chunks in a 3-deep ring -- 48 KB of LDS, three
     // workgroups per CU, two chunks in flight each (measured 3-10 % on the 1x1 layers); everything else the 64-wide
