@@ -141,11 +141,13 @@ class FlatDataParallel(nn.Module):
         if self.active and self.broadcast_buffers and self.module.training:
             # DDP broadcast_buffers=True: rank 0's BN running stats / anchors at every forward
             buf = self.module.flat_state().buffers
-            if buf.is_cuda and dist.get_backend(self.pg) == "nccl":
+            if buf.is_cuda and dist.get_backend(self.pg) == "nccl" and not torch.cuda.is_current_stream_capturing():
                 # on a SIDE stream: nothing of the forward reads these buffers before the first BatchNorm finalize updates the
                 # running statistics (train mode normalises with batch statistics), so the broadcast runs beside the input pack
                 # and the stem conv instead of in front of them; ops.bn_finalize joins the side stream before that first update
-                # (ops.PRE_STATS_WAIT).  Inside a step-graph capture the fork / join are captured as graph dependencies.
+                # (ops.PRE_STATS_WAIT).  NOT while a step graph is being captured: a collective on a forked stream of the capture
+                # made torch's NCCL watchdog thread query an event "last recorded in a capturing stream" (hipErrorCapturedEvent,
+                # process abort) in one of three runs on the GPU box -- in the graph the dependency edges order it anyway.
                 from . import ops as _ops
                 cur = torch.cuda.current_stream(buf.device)
                 if self._bcast_stream is None:
