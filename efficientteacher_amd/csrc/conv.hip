@@ -2087,6 +2087,12 @@ template <int SLOTS> __device__ __forceinline__ int tr_swz(int p) {
     if constexpr (SLOTS >= 16) return 4 * (p & 3);
     else return 4 * ((p >> 1) & 1);
 }
+// the X tile of the stride-2 row-sharing weight gradient: a fragment's 16 K-slots are 16 ALTERNATE rows (2 * slot + tap), so the
+// swizzle is taken from the row PAIR -- rows 0, 2, 4, 6 (and 1, 3, 5, 7) get four different values, and it repeats every 8 rows
+template <int SLOTS> __device__ __forceinline__ int tr_swz2(int p) {
+    if constexpr (SLOTS >= 16) return 4 * ((p >> 1) & 3);
+    else return 4 * ((p >> 2) & 1);
+}
 
 // Up to WGRAD_MAX_GROUP layers of IDENTICAL geometry in one launch (et_conv2d_wgrad_grouped): the K-split that
 // fills the chip is then shared by the whole group, so every dW address receives group-size times fewer fp32
@@ -2283,9 +2289,16 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_tr_kernel(WgradGroup 
 // x - 1 / x + 1 of a row's first / last pixel is the X pad slot -- no masks (conv_gemm_rs_kernel's layout).  Per 64-slot chunk:
 // 64 + 72 rows staged for three taps instead of 3 * (64 + 64); fragment bases per (tap, lane) are precomputed, the k-step and the
 // row half are immediates (the swizzle only depends on the row modulo 4, which 16*ks + 4*r does not change).
-template <int BM, int BNC, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN) ET_WAVES_PER_EU(4) void conv_wgrad_rs_kernel(WgradGroup grp, const uint16_t* __restrict__ ZERO, WgradGeom g) {
-    constexpr int NT = 64 * WM * WN, BKP = 64, BROWS = 72;      // threads; padded slots per chunk; X rows per chunk (66 used)
+// STRIDE 2 (r04; 3x3 stride-2 pad-1 layers, even input size): the K axis is the padded raster of dY (= the OUTPUT lattice), and the taps
+// of a kernel row read input columns 2x - 1, 2x, 2x + 1.  The X tile therefore holds TWO rows per K-slot: row 2j = input column
+// 2x(j) - 1, row 2j + 1 = input column 2x(j) of slot j's pixel; tap k of slot j reads row 2j + k -- and row 2j + 2 (tap 2) IS row
+// 2(j + 1) + 0: column 2x + 1 of a pixel is column 2(x + 1) - 1 of its right neighbour.  At a row end the neighbour is the pad slot
+// (dY = 0 there, so what it multiplies does not matter) and the slot after it starts the next image row, whose tap 0 reads column -1:
+// zero page.  One dY tile + one X tile of 129 rows per 64-slot chunk serve three taps (the per-tap kernel staged 3 x 64 X rows and ran
+// these six layers at 340-700 TFLOP/s against the stride-1 kernel's ~1000).
+template <int BM, int BNC, int WM, int WN, int STRIDE = 1>
+__global__ __launch_bounds__(64 * WM * WN) ET_WAVES_PER_EU(STRIDE == 1 ? 4 : 2) void conv_wgrad_rs_kernel(WgradGroup grp, const uint16_t* __restrict__ ZERO, WgradGeom g) {
+    constexpr int NT = 64 * WM * WN, BKP = 64, BROWS = STRIDE == 1 ? 72 : 136;      // threads; padded slots per chunk; X rows per chunk (66 / 129 used)
     constexpr int TM = BM / WM / 32, TN = BNC / WN / 32;
     constexpr int SA = BM / 8, SB = BNC / 8;                     // 16-byte slots per row of the A / B tile
     constexpr int RPA = NT / SA, RPB = NT / SB;                  // rows staged per pass of the workgroup
@@ -2316,24 +2329,27 @@ __global__ __launch_bounds__(64 * WM * WN) ET_WAVES_PER_EU(4) void conv_wgrad_rs
     const int k_begin = tz * g.Pper;                 // padded slots [k_begin, k_end)
     const int k_end = min(g.PP, k_begin + g.Pper);
 
-    static_assert(BKP % RPA == 0 && BKP % RPB == 0 && RPA % 4 == 0 && RPB % 4 == 0, "pieces are whole row groups; the swizzle repeats every 4 rows");
+    static_assert(BKP % RPA == 0 && BKP % RPB == 0 && RPA % 4 == 0 && RPB % (4 * STRIDE) == 0, "pieces are whole row groups; the swizzle repeats every 4 (8) rows");
     // this lane's rows: A piece j = LDS row a_pl0 + j*RPA, B piece j = row b_pl0 + j*RPB; the 8-channel group is the same for all of them
     const int a_pl0 = tid / SA, b_pl0 = tid / SB;
     const int a_co = m0 + ((tid % SA) ^ tr_swz<SA>(a_pl0)) * 8;
-    const int b_ci = c0 + ((tid % SB) ^ tr_swz<SB>(b_pl0)) * 8;
+    const int b_ci = c0 + ((tid % SB) ^ (STRIDE == 1 ? tr_swz<SB>(b_pl0) : tr_swz2<SB>(b_pl0))) * 8;
     const bool a_okc = a_co < g.Cout, b_okc = b_ci < g.Cin;
 
     // Padded coordinates (image row counted through the batch, column) of piece 0's row, kept across chunks: the pieces of a chunk
     // are RPA / RPB slots apart and a chunk is a whole number of pieces, so stepping piece to piece IS the advance to the next chunk
     // -- no division in the loop (two per staged row and chunk were ~100 of the ~170 staging instructions of a chunk, four waves per
     // SIMD deep: as much VALU time as the MFMAs take).  Host guarantees 64 / (QW + 1) + 2 <= QH: one subtraction wraps the image row.
-    const int qa = RPA / W1, ra = RPA - qa * W1, qb = RPB / W1, rb = RPB - qb * W1;   // uniform
+    constexpr int SPB = RPB / STRIDE;              // K-slots a B piece advances (stride 2: two X rows per slot)
+    const int qa = RPA / W1, ra = RPA - qa * W1, qb = SPB / W1, rb = SPB - qb * W1;   // uniform
+    const int b_par = STRIDE == 1 ? 0 : (b_pl0 & 1);   // stride 2: this lane's X rows are all even (column 2x - 1) or all odd (column 2x)
     int a_yg, a_xp, b_yg, b_xp, b_qy;              // b_yg = -1 for the slot before the first (X row r <-> slot k0 - 1 + r)
     {
         const uint32_t sl = k_begin + a_pl0;
         a_yg = fdiv(sl, g.dW1);
         a_xp = sl - a_yg * W1;
-        const uint32_t s1 = k_begin - 1 + b_pl0 + W1;                   // one padded row further down: never negative
+        // stride 1: X row r <-> slot k0 - 1 + r; stride 2: X row r <-> slot k0 + r / 2
+        const uint32_t s1 = (STRIDE == 1 ? k_begin - 1 + b_pl0 : k_begin + (b_pl0 >> 1)) + W1;       // one padded row further down: never negative
         const uint32_t yg1 = fdiv(s1, g.dW1);
         b_xp = s1 - yg1 * W1;
         b_yg = (int)yg1 - 1;
@@ -2366,11 +2382,22 @@ __global__ __launch_bounds__(64 * WM * WN) ET_WAVES_PER_EU(4) void conv_wgrad_rs
         int yg = b_yg, xp = b_xp, qy = b_qy;
 #pragma unroll
         for (int j = 0; j < RB; ++j) {
-            if (j * RPB == BKP) { b_yg = yg; b_xp = xp; b_qy = qy; }                                 // piece 0 of the next chunk
+            if (j * RPB == BKP * STRIDE) { b_yg = yg; b_xp = xp; b_qy = qy; }                       // piece 0 of the next chunk
             if (RB * RPB > BROWS && j == RB - 1 && wave * 64 >= (BROWS - j * RPB) * SB) continue;   // wave-uniform: the partial pass
-            const bool ok = b_okc && yg >= 0 && k0 - 1 + b_pl0 + j * RPB < g.PP && b_pl0 + j * RPB < BROWS && xp < g.QW &&
-                            (unsigned)(qy + dyr) < (unsigned)g.IH;
-            const uint16_t* src = ok ? X + ((size_t)(unsigned)((yg * g.QW + xp + dyr * g.IW) * ldx + b_ci)) : ZERO;
+            bool ok;
+            const uint16_t* src;
+            if constexpr (STRIDE == 1) {
+                ok = b_okc && yg >= 0 && k0 - 1 + b_pl0 + j * RPB < g.PP && b_pl0 + j * RPB < BROWS && xp < g.QW &&
+                     (unsigned)(qy + dyr) < (unsigned)g.IH;
+                src = ok ? X + ((size_t)(unsigned)((yg * g.QW + xp + dyr * g.IW) * ldx + b_ci)) : ZERO;
+            } else {
+                // slot (yg, xp) of the OUTPUT raster (xp == QW: the pad slot, whose even row is the previous pixel's column 2x + 1):
+                // input row 2 * yg + dyr (IH = 2 * QH: image rows stay aligned through the batch), input column 2 * xp - 1 + parity
+                const int col = 2 * xp - 1 + b_par, iy = 2 * qy + dyr;
+                ok = b_okc && yg >= 0 && k0 + ((b_pl0 + j * RPB) >> 1) < g.PP + 1 && b_pl0 + j * RPB < BROWS && xp <= g.QW &&
+                     (unsigned)col < (unsigned)g.IW && (unsigned)iy < (unsigned)g.IH && yg < g.N * g.QH;
+                src = ok ? X + ((size_t)(unsigned)(((2 * yg + dyr) * g.IW + col) * ldx + b_ci)) : ZERO;
+            }
             et_glds16(src, wb + j * NT);
             int dq = qb;
             xp += rb;
@@ -2394,9 +2421,10 @@ __global__ __launch_bounds__(64 * WM * WN) ET_WAVES_PER_EU(4) void conv_wgrad_rs
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
             const int ch = wn * (BNC / WN) + tn * 32 + fc;
-            bbase[k][tn] = ((fp + k) * SB + ((ch >> 3) ^ tr_swz<SB>(fp + k))) * 16 + (ch & 4) * 2;
+            const int row = STRIDE * fp + k;                       // K-slot fp of the k-step, tap k
+            bbase[k][tn] = (row * SB + ((ch >> 3) ^ (STRIDE == 1 ? tr_swz<SB>(row) : tr_swz2<SB>(row)))) * 16 + (ch & 4) * 2;
         }
-    auto frag = [&](const char* tile, int base, int row_bytes, int ks) -> s16x8 {
+    auto frag = [&](const char* tile, int base, int row_bytes, int ks) -> s16x8 {      // row_bytes: bytes per K-SLOT (stride 2: two rows)
         s16x8 o;
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
@@ -2417,7 +2445,7 @@ __global__ __launch_bounds__(64 * WM * WN) ET_WAVES_PER_EU(4) void conv_wgrad_rs
 #pragma unroll
             for (int k = 0; k < 3; ++k)
 #pragma unroll
-                for (int tn = 0; tn < TN; ++tn) bf[k][tn] = frag(tb, bbase[k][tn], SB * 16, ks);
+                for (int tn = 0; tn < TN; ++tn) bf[k][tn] = frag(tb, bbase[k][tn], STRIDE * SB * 16, ks);
 #pragma unroll
             for (int k = 0; k < 3; ++k)
 #pragma unroll
@@ -3015,11 +3043,11 @@ static void wgrad_geom(WgradGeom& g, int N, int IH, int IW, int Cin, int ldx, in
         }
 }
 
-struct WgradPlan { bool tr; int bm, bn; bool rs; };
+struct WgradPlan { bool tr; int bm, bn; bool rs; int rs_stride; };
 static WgradPlan plan_wgrad(const WgradGeom& g, int elem_bytes, bool have_zero_page) {
     const bool wideN = g.NC > 64;
     const bool tallM = g.Cout > 64;            // Cout <= 64 layers: a 64-row tile wastes no MFMA rows
-    WgradPlan p{false, tallM ? 128 : 64, wideN ? 128 : 64, false};
+    WgradPlan p{false, tallM ? 128 : 64, wideN ? 128 : 64, false, 1};
     // bf16 + zero page: LDS-DMA staging with transposing LDS reads (ET_WGRAD_TR=0 forces the register path)
     static const int use_tr = env_int("ET_WGRAD_TR", 1);
     p.tr = elem_bytes == 2 && use_tr && have_zero_page;
@@ -3042,11 +3070,20 @@ static WgradPlan plan_wgrad(const WgradGeom& g, int elem_bytes, bool have_zero_p
         if (g.Cout >= 128 && g.Cin >= 128) { p.rs = true; p.bm = 128; p.bn = 128; }
         else if (g.Cout <= 64 && g.Cin <= 64) { p.rs = true; p.bm = 64; p.bn = 64; }
     }
+    // 3x3 stride-2 pad-1 layers with an even input size (the five down-sampling convs of the backbone / neck): the stride-2 form of the
+    // same kernel (two X rows per K-slot).  ET_WGRAD_RS bit 4 (default on since r04).
+    static const int use_rs2 = env_int("ET_WGRAD_RS2", 1);
+    if (use_rs2 && p.tr && g.T == 9 && g.isy == 2 && g.isx == 2 && g.dy[0] == -1 && g.dx[0] == -1 && g.dy[8] == 1 && g.dx[8] == 1 &&
+        g.IH == 2 * g.QH && g.IW == 2 * g.QW && g.QW >= 2 && 64 / (g.QW + 1) + 2 <= g.QH && g.Cout >= 128 && g.Cin >= 64 &&
+        (long long)g.N * g.IH * g.IW * (g.ldx > g.ldy ? g.ldx : g.ldy) < (1ll << 31)) {
+        p.rs = true; p.rs_stride = 2; p.bm = 128; p.bn = g.Cin >= 128 ? 128 : 64;
+    }
     return p;
 }
 static void wgrad_plan_name(const WgradPlan& p, int elem_bytes, char* buf, int n) {
     if (p.rs) {
-        snprintf(buf, n, "conv_wgrad_rs_kernel<%d, %d, %d, %d>", p.bm, p.bn, 2, p.bm == 128 ? 4 : 2);
+        if (p.rs_stride == 2) snprintf(buf, n, "conv_wgrad_rs_kernel<%d, %d, %d, %d, 2>", p.bm, p.bn, 2, p.bn == 128 ? 4 : 2);
+        else snprintf(buf, n, "conv_wgrad_rs_kernel<%d, %d, %d, %d>", p.bm, p.bn, 2, p.bm == 128 ? 4 : 2);
     } else if (p.tr) {
         const int wm = p.bm == 256 ? (p.bn == 256 ? 2 : 4) : (p.bm == 128 ? 2 : (p.bn == 256 ? 1 : 2));
         const int wn = p.bm == 256 ? (p.bn == 256 ? 4 : (p.bn == 128 ? 2 : 1)) : (p.bn == 256 ? 4 : 2);
@@ -3070,7 +3107,8 @@ static void launch_wgrad(const WgradGroup& grp, const void* zero16, WgradGeom& g
             g.ntn = 3 * nci; g.ntm = (g.Cout + bm - 1) / bm;
             const int tiles = grp.n * g.ntn * g.ntm;
             const int n_cu = device_cus();
-            const int slots = bm == 128 ? 2 : 4;               // 68 KB / 34 KB of LDS; 8 / 4 waves, <= 128 VGPRs
+            // stride 1: 68 KB / 34 KB of LDS, 8 / 4 waves, <= 128 VGPRs; stride 2: 102 KB (8 waves) / 67 KB (4 waves)
+            const int slots = wp.rs_stride == 2 ? (bn == 128 ? 1 : 2) : (bm == 128 ? 2 : 4);
             const int cap = slots * n_cu;
             const int max_sk = max(1, g.PP / (64 * 25));
             auto eff = [&](int k) { const int b = tiles * k; return (double)b / ((double)((b + cap - 1) / cap) * cap); };
@@ -3085,7 +3123,10 @@ static void launch_wgrad(const WgradGroup& grp, const void* zero16, WgradGeom& g
             g.xcd = 1; g.Pper = per; g.nsk = sk;
             const dim3 grid(grp.n * g.ntn * g.ntm * sk);
             const uint16_t* z = (const uint16_t*)zero16;
-            if (bm == 128) hipLaunchKernelGGL((conv_wgrad_rs_kernel<128, 128, 2, 4>), grid, dim3(512), 0, s, grp, z, g);
+            if (wp.rs_stride == 2) {
+                if (bn == 128) hipLaunchKernelGGL((conv_wgrad_rs_kernel<128, 128, 2, 4, 2>), grid, dim3(512), 0, s, grp, z, g);
+                else hipLaunchKernelGGL((conv_wgrad_rs_kernel<128, 64, 2, 2, 2>), grid, dim3(256), 0, s, grp, z, g);
+            } else if (bm == 128) hipLaunchKernelGGL((conv_wgrad_rs_kernel<128, 128, 2, 4>), grid, dim3(512), 0, s, grp, z, g);
             else hipLaunchKernelGGL((conv_wgrad_rs_kernel<64, 64, 2, 2>), grid, dim3(256), 0, s, grp, z, g);
             return;
         }
@@ -3275,7 +3316,7 @@ extern "C" int et_conv2d_kernel_name(int op, int dtype, int N, int IH, int IW, i
 extern "C" int et_env_knobs(char* buf, int buflen) {
     // every ET_* tuning knob that is SET in this process's environment, as "NAME=value;..." (bench.py records it)
     static const char* names[] = {"ET_CONV_GLDS", "ET_CONV_BIG", "ET_CONV_BIG_MINFILL", "ET_CONV_PP", "ET_CONV_S1", "ET_CONV_S1_WGS", "ET_CONV_RS", "ET_CONV_PPRS", "ET_CONV_STEM", "ET_CONV_STEM_WGS",
-                                  "ET_WGRAD_TR", "ET_WGRAD_BIG", "ET_WGRAD_RS", "ET_WGRAD_GROUP", "ET_WGRAD_STALE", "ET_WGRAD_STREAM", "ET_FUSE_BN_BWD",
+                                  "ET_WGRAD_TR", "ET_WGRAD_BIG", "ET_WGRAD_RS", "ET_WGRAD_RS2", "ET_WGRAD_GROUP", "ET_WGRAD_STALE", "ET_WGRAD_STREAM", "ET_FUSE_BN_BWD",
                                   "ET_BN_FIN_SMALL", "ET_WT_TILED", "ET_FUSE_BN_BWD_K", "ET_STEP_GRAPH", "ET_ALLREDUCE_CHUNK_MB", "ET_RCCL_CHANNELS", "ET_DP_SINGLE_RANK", "ET_HIP_LIB"};
     if (!buf || buflen < 1) return -1;
     int off = 0;

@@ -430,16 +430,7 @@ def colsum(x2d_like, out):
 
 
 # ---- BatchNorm + activation -----------------------------------------------------------------------
-# set by parallel.FlatDataParallel.forward: a callable run ONCE, right before the first kernel of a forward that touches the
-# BatchNorm running statistics (it makes the launching stream wait for the side-stream broadcast of rank 0's buffers)
-PRE_STATS_WAIT = None
-
-
 def bn_finalize(stats, count, gamma, beta, eps, momentum, running_mean=None, running_var=None):
-    global PRE_STATS_WAIT
-    if PRE_STATS_WAIT is not None and running_mean is not None:
-        w, PRE_STATS_WAIT = PRE_STATS_WAIT, None
-        w()
     rows, _, C = stats.shape
     dev = stats.device
     aff = torch.empty((4, C), dtype=torch.float32, device=dev)

@@ -62,7 +62,6 @@ class FlatDataParallel(nn.Module):
         self._works = []
         self._launched = set()
         self._dirty = False              # a backward has moved the per-chunk counters since the last reduce_gradients()
-        self._bcast_stream = None        # side stream of the per-forward buffer broadcast (RCCL only)
         self.timing = False              # bench.py: HIP events around the collective phase of a step
         self.last_timing = None          # (first launch -> all complete, exposed wait after backward) in ms
         self._ev0 = None
@@ -139,36 +138,13 @@ class FlatDataParallel(nn.Module):
             # and the late layers' gradients would never be averaged (ranks diverge silently).
             self.reduce_gradients()
         if self.active and self.broadcast_buffers and self.module.training:
-            # DDP broadcast_buffers=True: rank 0's BN running stats / anchors at every forward
-            buf = self.module.flat_state().buffers
-            if buf.is_cuda and dist.get_backend(self.pg) == "nccl" and not torch.cuda.is_current_stream_capturing():
-                # on a SIDE stream: nothing of the forward reads these buffers before the first BatchNorm finalize updates the
-                # running statistics (train mode normalises with batch statistics), so the broadcast runs beside the input pack
-                # and the stem conv instead of in front of them; ops.bn_finalize joins the side stream before that first update
-                # (ops.PRE_STATS_WAIT).  NOT while a step graph is being captured: a collective on a forked stream of the capture
-                # made torch's NCCL watchdog thread query an event "last recorded in a capturing stream" (hipErrorCapturedEvent,
-                # process abort) in one of three runs on the GPU box -- in the graph the dependency edges order it anyway.
-                from . import ops as _ops
-                cur = torch.cuda.current_stream(buf.device)
-                if self._bcast_stream is None:
-                    self._bcast_stream = torch.cuda.Stream(device=buf.device)
-                side = self._bcast_stream
-                side.wait_stream(cur)                    # every earlier write of the buffers (last step's statistics, load_state_dict) is done
-                with torch.cuda.stream(side):
-                    dist.broadcast(buf, 0, group=self.pg)
-                ev = torch.cuda.Event()
-                ev.record(side)
-
-                def join(ev=ev, dev=buf.device):
-                    torch.cuda.current_stream(dev).wait_event(ev)
-                _ops.PRE_STATS_WAIT = join
-                try:
-                    return self.module(*a, **k)
-                finally:
-                    if _ops.PRE_STATS_WAIT is join:      # a forward without any BatchNorm finalize: join here
-                        _ops.PRE_STATS_WAIT = None
-                        join()
-            dist.broadcast(buf, 0, group=self.pg)
+            # DDP broadcast_buffers=True: rank 0's BN running stats / anchors at every forward, on the compute stream, in front of the
+            # forward.  r04 moved it to a side stream (joined before the first running-statistics update) and took that back: the
+            # forward's first launches already write the arena (the bulk num_batches_tracked bump of flat_state.prepare_forward), so the
+            # broadcast raced with them on the non-root ranks; and with the collective on a forked stream the single-rank RCCL test
+            # aborted in torch's NCCL watchdog (hipErrorCapturedEvent) once in three processes.  The broadcast is ~0.4 MB: tens of
+            # microseconds per step on xGMI.
+            dist.broadcast(self.module.flat_state().buffers, 0, group=self.pg)
         return self.module(*a, **k)
 
     def abort_step(self):

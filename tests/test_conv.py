@@ -192,6 +192,14 @@ SELECT = [
     ((2, 20, 20, 256, 256, 3, 1, 1), "conv_gemm_pprs_kernel", ["conv_gemm_pprs_kernel"], "conv_wgrad_rs_kernel<128, 128, 2, 4>"),
     ((2, 20, 20, 128, 256, 3, 2, 1), "conv_gemm_pp_kernel",
      [GLDS + "128, 128, 2, 2, 4, 3, true>", GLDS + "128, 128, 2, 2, 8, 2, true>", GLDS + "128, 128, 2, 2, 8, 2, true>",
+      GLDS + "128, 128, 2, 2, 8, 2, true>"], "conv_wgrad_rs_kernel<128, 128, 2, 4, 2>"),         # stride-2 row-sharing weight gradient
+    ((1, 22, 18, 128, 256, 3, 2, 1), "conv_gemm_pp_kernel",                                      # ... ragged K-split, 9-pixel output rows
+     [GLDS + "128, 128, 2, 2, 4, 3, true>", GLDS + "128, 128, 2, 2, 8, 2, true>", GLDS + "128, 128, 2, 2, 8, 2, true>",
+      GLDS + "128, 128, 2, 2, 8, 2, true>"], "conv_wgrad_rs_kernel<128, 128, 2, 4, 2>"),
+    ((1, 24, 20, 256, 264, 3, 2, 1), "conv_gemm_pp_kernel",                                      # ... ragged cout tile; odd-size fallback below
+     [GLDS + "128, 128, 2, 2, 4, 2, false>"] * 4, "conv_wgrad_rs_kernel<128, 128, 2, 4, 2>"),
+    ((1, 15, 15, 128, 256, 3, 2, 1), "conv_gemm_pp_kernel",                                      # odd input size: the per-tap kernel
+     [GLDS + "128, 128, 2, 2, 4, 3, true>", GLDS + "128, 128, 2, 2, 8, 2, true>", GLDS + "128, 128, 2, 2, 8, 2, true>",
       GLDS + "128, 128, 2, 2, 8, 2, true>"], "conv_wgrad_tr_kernel<256, 256, 2, 4>"),
     ((2, 20, 20, 512, 512, 1, 1, 0), GLDS + "128, 128, 2, 2, 8, 2, true>", [GLDS + "128, 128, 2, 2, 8, 2, true>"],
      "conv_wgrad_tr_kernel<128, 128, 2, 2>"),
@@ -213,7 +221,7 @@ SELECT = [
      "conv_wgrad_tr_kernel<64, 128, 2, 2>"),
     # 64 -> 128 stride-2 3x3 (the layer after the stem): its four-tap dgrad class is the 64-wide tile with 64-wide chunks
     ((2, 24, 24, 64, 128, 3, 2, 1), GLDS + "128, 128, 2, 2, 8, 2, true>",
-     [GLDS + "128, 64, 2, 2, 4, 3, true>"] * 3 + [GLDS + "128, 64, 2, 2, 8, 2, true>"], "conv_wgrad_tr_kernel<128, 128, 2, 2>"),
+     [GLDS + "128, 64, 2, 2, 4, 3, true>"] * 3 + [GLDS + "128, 64, 2, 2, 8, 2, true>"], "conv_wgrad_rs_kernel<128, 64, 2, 2, 2>"),
     # the persistent streaming kernel of the 1x1 layers with K <= 256 (every instantiation; ragged M, Cout below the column tile,
     # and -- last two -- a channel count whose dgrad is not eligible, i.e. a tiled dgrad beside a streamed forward)
     ((2, 13, 11, 64, 64, 1, 1, 0), S1, [S1], "conv_wgrad_tr_kernel<64, 64, 2, 2>"),
@@ -243,7 +251,7 @@ def test_lds_dma_pipelines_under_adversarial_schedules(emu, dma_late, seed):
     one at a time in random order between barriers.  A wait that is one half-tile too weak, or a half-tile staged
     into a buffer that is still being read, fails here (checked by mutation when the kernel was written)."""
     emu.configure(dma_late, seed)
-    for case, kf, kd, kw in (SELECT[0], SELECT[1], SELECT[4], SELECT[8], SELECT[3], SELECT[5]):     # [3], [5]: the row-shift 3x3 tiles
+    for case, kf, kd, kw in (SELECT[0], SELECT[1], SELECT[4], SELECT[8], SELECT[3], SELECT[5]):     # [3], [5]: the row-shift 3x3 tiles; [1]: stride-2 wgrad
         _check_instantiation(emu, case, kf, kd, kw)
     import os
     os.environ["ET_CONV_STEM_WGS"] = "2"          # 6 tiles on 2 persistent workgroups: the single patch buffer is re-staged
@@ -342,6 +350,32 @@ def _check_instantiation(hip, case, kf, kd, kw):
     F.conv2d(x.float().cpu().permute(0, 3, 1, 2), wr, stride=s, padding=p).backward(dy.float().cpu().permute(0, 3, 1, 2))
     wref = wr.grad.permute(0, 2, 3, 1)
     assert (dw.cpu() - wref).abs().max().item() <= 1e-4 * max(1.0, wref.abs().max().item())
+
+
+def test_wgrad_stride2_row_sharing_grouped(hip):
+    """conv_wgrad_rs_kernel<..., 2>: three same-shaped stride-2 3x3 layers in one grouped launch, one of them reading a channel slice of a
+    wider buffer; 12-pixel output rows (a 64-slot K chunk spans five padded rows), dY with a pixel stride"""
+    from efficientteacher_amd import ops
+    N, H, W, Cin, Cout, k = 2, 24, 24, 128, 128, 3
+    dt = torch.bfloat16
+    assert ops.kernel_name("wgrad", dt, N, H, W, Cin, Cout, k, 2, 1) == "conv_wgrad_rs_kernel<128, 128, 2, 4, 2>"
+    items, refs = [], []
+    for i in range(3):
+        if i == 1:
+            wide = _mk(hip, (N, H, W, Cin + 16), dt, 120 + i)
+            x = wide[..., 8:8 + Cin]
+        else:
+            x = _mk(hip, (N, H, W, Cin), dt, 120 + i)
+        dyw = _mk(hip, (N, H // 2, W // 2, Cout + 8), dt, 130 + i)
+        dy = dyw[..., :Cout] if i == 2 else dyw[..., :Cout].contiguous()
+        dw = torch.zeros((Cout, k, k, Cin), dtype=torch.float32, device=hip.device)
+        items.append((x, dy, dw))
+        wr = torch.zeros((Cout, Cin, k, k), requires_grad=True)
+        F.conv2d(x.float().cpu().permute(0, 3, 1, 2), wr, stride=2, padding=1).backward(dy.float().cpu().permute(0, 3, 1, 2))
+        refs.append(wr.grad.permute(0, 2, 3, 1))
+    ops.conv2d_wgrad_grouped(items, k, 2, 1)
+    for (_, _, dw), ref in zip(items, refs):
+        assert (dw.cpu() - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item())
 
 
 @pytest.mark.parametrize("stride,kernel", [(1, "conv_wgrad_rs_kernel<128, 128, 2, 4>"), (2, "conv_wgrad_tr_kernel<256, 256, 2, 4>")])

@@ -31,6 +31,13 @@ for l in sys.stdin:
 " | tee -a $OUT/mb_k1.txt; done ;;
 dp_sweep1) run dp_sweep1; timeout 1500 python tools/dp_sweep.py --gpus 1 --chunks 48 --channels 0,8 --steps 12 --warmup 4 --out $OUT/dp_sweep_1rank.json > $OUT/dp_sweep1.log 2>&1; tail -6 $OUT/dp_sweep1.log | cut -c1-400 ;;
 t_par) run t_par; timeout 1200 python -m pytest tests/test_parallel.py -x -q -m gpu -s > $OUT/pytest_par.log 2>&1; tail -4 $OUT/pytest_par.log ;;
+mb_k3w) run mb_k3w; for K in ${MB_K3_ENV:-"X=0"}; do echo "--- $K" | tee -a $OUT/mb_k3w.txt; env $K MB_REF=0 MB_K=3 timeout 600 python tools/microbench.py conv 2>&1 | python -c "
+import sys, json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d = json.loads(l)
+        print('%4d->%4d s%d @%3d x%2d  fwd %6.1f us %4.0f TF | dgrad %6.1f us %4.0f TF | wgrad %6.1f us %4.0f TF' % (d['cin'], d['cout'], d['s'], d['h'], d['count'], d['fwd_ms']*1e3, d['fwd_tf'], d['dgrad_ms']*1e3, d['dgrad_tf'], d['wgrad_ms']*1e3, d['wgrad_tf']))
+" | tee -a $OUT/mb_k3w.txt; done ;;
 prof) run prof; (cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/bench_under_rocprof.json 2> $GRAFT_REPO_ROOT/$OUT/prof.err); find $OUT/prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv; find $OUT/prof -name "*kernel_trace.csv" | head -1 | xargs -I{} python tools/trace_streams.py {} > $OUT/trace_streams.txt 2>&1; cat $OUT/trace_streams.txt; find $OUT/prof -name "*.db" -delete; find $OUT/prof -name "*kernel_trace.csv" -size +20M -delete; head -8 $OUT/kernel_stats.csv | cut -c1-160 ;;
 pmc) run pmc; for C in FETCH_SIZE WRITE_SIZE; do (cd /tmp && timeout 900 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmc_$C -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/bench_pmc_$C.json 2> $GRAFT_REPO_ROOT/$OUT/pmc_$C.err); done; python tools/pmc_summarize.py $OUT > $OUT/pmc_bench_summary.csv; find $OUT -name "*.db" -delete; find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*kernel_trace.csv" -delete; timeout 600 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --dump-launches $OUT/launches_for_pmc.json > /dev/null 2>&1; python tools/pmc_to_traffic.py $OUT/pmc_bench_summary.csv $OUT/pmc_traffic.json $OUT/launches_for_pmc.json ;;
 *) echo "unknown section $s" ;;
