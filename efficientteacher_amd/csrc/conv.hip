@@ -3070,13 +3070,17 @@ static WgradPlan plan_wgrad(const WgradGeom& g, int elem_bytes, bool have_zero_p
         if (g.Cout >= 128 && g.Cin >= 128) { p.rs = true; p.bm = 128; p.bn = 128; }
         else if (g.Cout <= 64 && g.Cin <= 64) { p.rs = true; p.bm = 64; p.bn = 64; }
     }
-    // 3x3 stride-2 pad-1 layers with an even input size (the five down-sampling convs of the backbone / neck): the stride-2 form of the
-    // same kernel (two X rows per K-slot).  ET_WGRAD_RS bit 4 (default on since r04).
+    // 3x3 stride-2 pad-1 layers with an even input size (the down-sampling convs of the backbone / neck): the stride-2 form of the same
+    // kernel (two X rows per K-slot).  Isolated, B = 64 (profiles/r04_mb_3x3_wgrad_stride2_ab.txt): 64->128 @320: 504 -> 396 us (the
+    // 128x64 tile, two workgroups per CU); with >= 128 input channels the 128x128 tile needs 102 KB of LDS = ONE workgroup per CU and
+    // loses to the 256x256 per-tap tile (512->1024 @40: 307 -> 365 us).  ET_WGRAD_RS2: 0 off, 1 (default) the 64-input-channel layers,
+    // 2 every eligible layer on the 128x128 tile, 4 every eligible layer on the 128x64 tile.
     static const int use_rs2 = env_int("ET_WGRAD_RS2", 1);
     if (use_rs2 && p.tr && g.T == 9 && g.isy == 2 && g.isx == 2 && g.dy[0] == -1 && g.dx[0] == -1 && g.dy[8] == 1 && g.dx[8] == 1 &&
         g.IH == 2 * g.QH && g.IW == 2 * g.QW && g.QW >= 2 && 64 / (g.QW + 1) + 2 <= g.QH && g.Cout >= 128 && g.Cin >= 64 &&
+        (g.Cin < 128 || (use_rs2 & 6)) &&
         (long long)g.N * g.IH * g.IW * (g.ldx > g.ldy ? g.ldx : g.ldy) < (1ll << 31)) {
-        p.rs = true; p.rs_stride = 2; p.bm = 128; p.bn = g.Cin >= 128 ? 128 : 64;
+        p.rs = true; p.rs_stride = 2; p.bm = 128; p.bn = (g.Cin >= 128 && !(use_rs2 & 4)) ? 128 : 64;
     }
     return p;
 }

@@ -192,14 +192,6 @@ SELECT = [
     ((2, 20, 20, 256, 256, 3, 1, 1), "conv_gemm_pprs_kernel", ["conv_gemm_pprs_kernel"], "conv_wgrad_rs_kernel<128, 128, 2, 4>"),
     ((2, 20, 20, 128, 256, 3, 2, 1), "conv_gemm_pp_kernel",
      [GLDS + "128, 128, 2, 2, 4, 3, true>", GLDS + "128, 128, 2, 2, 8, 2, true>", GLDS + "128, 128, 2, 2, 8, 2, true>",
-      GLDS + "128, 128, 2, 2, 8, 2, true>"], "conv_wgrad_rs_kernel<128, 128, 2, 4, 2>"),         # stride-2 row-sharing weight gradient
-    ((1, 22, 18, 128, 256, 3, 2, 1), "conv_gemm_pp_kernel",                                      # ... ragged K-split, 9-pixel output rows
-     [GLDS + "128, 128, 2, 2, 4, 3, true>", GLDS + "128, 128, 2, 2, 8, 2, true>", GLDS + "128, 128, 2, 2, 8, 2, true>",
-      GLDS + "128, 128, 2, 2, 8, 2, true>"], "conv_wgrad_rs_kernel<128, 128, 2, 4, 2>"),
-    ((1, 24, 20, 256, 264, 3, 2, 1), "conv_gemm_pp_kernel",                                      # ... ragged cout tile; odd-size fallback below
-     [GLDS + "128, 128, 2, 2, 4, 2, false>"] * 4, "conv_wgrad_rs_kernel<128, 128, 2, 4, 2>"),
-    ((1, 15, 15, 128, 256, 3, 2, 1), "conv_gemm_pp_kernel",                                      # odd input size: the per-tap kernel
-     [GLDS + "128, 128, 2, 2, 4, 3, true>", GLDS + "128, 128, 2, 2, 8, 2, true>", GLDS + "128, 128, 2, 2, 8, 2, true>",
       GLDS + "128, 128, 2, 2, 8, 2, true>"], "conv_wgrad_tr_kernel<256, 256, 2, 4>"),
     ((2, 20, 20, 512, 512, 1, 1, 0), GLDS + "128, 128, 2, 2, 8, 2, true>", [GLDS + "128, 128, 2, 2, 8, 2, true>"],
      "conv_wgrad_tr_kernel<128, 128, 2, 2>"),
@@ -352,13 +344,58 @@ def _check_instantiation(hip, case, kf, kd, kw):
     assert (dw.cpu() - wref).abs().max().item() <= 1e-4 * max(1.0, wref.abs().max().item())
 
 
+STRIDE2_WGRAD = [   # (case, ET_WGRAD_RS2, kernel): the default takes the 64-input-channel layers; the other two tiles are opt-in (measured slower)
+    ((2, 24, 24, 64, 128, 3, 2, 1), "1", "conv_wgrad_rs_kernel<128, 64, 2, 2, 2>"),
+    ((2, 20, 20, 128, 256, 3, 2, 1), "2", "conv_wgrad_rs_kernel<128, 128, 2, 4, 2>"),
+    ((1, 22, 18, 128, 256, 3, 2, 1), "2", "conv_wgrad_rs_kernel<128, 128, 2, 4, 2>"),      # ragged K-split, 9-pixel output rows
+    ((1, 24, 20, 256, 264, 3, 2, 1), "2", "conv_wgrad_rs_kernel<128, 128, 2, 4, 2>"),      # ragged cout tile
+    ((1, 24, 20, 256, 264, 3, 2, 1), "4", "conv_wgrad_rs_kernel<128, 64, 2, 2, 2>"),       # four cin tiles
+    ((1, 15, 15, 128, 256, 3, 2, 1), "2", "conv_wgrad_tr_kernel<256, 256, 2, 4>"),         # odd input size: not eligible
+]
+
+
+@pytest.mark.parametrize("case,knob,kernel", STRIDE2_WGRAD, ids=[f"{c}-{k}" for c, k, _ in STRIDE2_WGRAD])
+def test_wgrad_stride2_row_sharing(hip, case, knob, kernel):
+    """conv_wgrad_rs_kernel<..., 2> (two X rows per K-slot) vs torch on every tile / knob setting.  ET_WGRAD_RS2 is read once per
+    process by the library, so the non-default settings run in a child process."""
+    import subprocess, sys, os
+    N, H, W, Cin, Cout, k, s_, p_ = case
+    code = f"""
+import sys, torch
+sys.path.insert(0, {repr(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))})
+import torch.nn.functional as F
+from efficientteacher_amd import _lib, ops
+emu = {repr(hip.emulated)}
+if emu:
+    from tests.simt_emu import build as b
+    _lib._use_library_for_tests(b.build(), True)
+dev = torch.device("cpu" if emu else "cuda:0")
+dt = torch.bfloat16
+N, H, W, Cin, Cout = {N}, {H}, {W}, {Cin}, {Cout}
+assert ops.kernel_name("wgrad", dt, N, H, W, Cin, Cout, 3, 2, 1) == {repr(kernel)}, ops.kernel_name("wgrad", dt, N, H, W, Cin, Cout, 3, 2, 1)
+g = torch.Generator().manual_seed(5)
+x = torch.randn(N, H, W, Cin, generator=g).to(dt).to(dev)
+dy = torch.randn(N, H // 2 if H % 2 == 0 else (H + 1) // 2, W // 2 if W % 2 == 0 else (W + 1) // 2, Cout, generator=g).to(dt).to(dev)
+dw = torch.zeros(Cout, 3, 3, Cin, device=dev)
+ops.conv2d_wgrad(x, dy, dw, 3, 2, 1)
+wr = torch.zeros(Cout, Cin, 3, 3, requires_grad=True)
+F.conv2d(x.float().cpu().permute(0, 3, 1, 2), wr, stride=2, padding=1).backward(dy.float().cpu().permute(0, 3, 1, 2))
+ref = wr.grad.permute(0, 2, 3, 1)
+err = (dw.cpu() - ref).abs().max().item()
+assert err <= 1e-4 * max(1.0, ref.abs().max().item()), err
+print("OK")
+"""
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ET_WGRAD_RS2=knob), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-500:] + r.stderr[-1500:]
+
+
 def test_wgrad_stride2_row_sharing_grouped(hip):
-    """conv_wgrad_rs_kernel<..., 2>: three same-shaped stride-2 3x3 layers in one grouped launch, one of them reading a channel slice of a
-    wider buffer; 12-pixel output rows (a 64-slot K chunk spans five padded rows), dY with a pixel stride"""
+    """conv_wgrad_rs_kernel<128, 64, 2, 2, 2>: three same-shaped stride-2 3x3 layers in one grouped launch, one of them reading a channel
+    slice of a wider buffer; 12-pixel output rows (a 64-slot K chunk spans five padded rows), dY with a pixel stride"""
     from efficientteacher_amd import ops
-    N, H, W, Cin, Cout, k = 2, 24, 24, 128, 128, 3
+    N, H, W, Cin, Cout, k = 2, 24, 24, 64, 128, 3
     dt = torch.bfloat16
-    assert ops.kernel_name("wgrad", dt, N, H, W, Cin, Cout, k, 2, 1) == "conv_wgrad_rs_kernel<128, 128, 2, 4, 2>"
+    assert ops.kernel_name("wgrad", dt, N, H, W, Cin, Cout, k, 2, 1) == "conv_wgrad_rs_kernel<128, 64, 2, 2, 2>"
     items, refs = [], []
     for i in range(3):
         if i == 1:
