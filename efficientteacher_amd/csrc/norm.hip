@@ -13,9 +13,22 @@
 
 enum { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2 };
 
+typedef unsigned u4raw __attribute__((ext_vector_type(4)));
+// Keeps a group of 16-byte loads where they were written: the use of all four registers in one (empty) asm statement
+// makes the compiler issue the four loads back to back and wait once.  Without it the loads of the SECOND tensor are
+// sunk to their first use, i.e. below the activation math of the first, and each is waited for on its own: three
+// serialized HBM round trips per loop iteration (r04: bn_act_bwd_reduce at 4.15 TB/s of cold reads).
+__device__ __forceinline__ void pin_loaded(u4raw& a, u4raw& b, u4raw& c, u4raw& d) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
+__device__ __forceinline__ void pin_loaded(u4raw& a, u4raw& b) { asm volatile("" : "+v"(a), "+v"(b)); }
+
 template <typename T> struct Vec16;
 template <> struct Vec16<float> {
     static constexpr int N = 4;
+    __device__ static __forceinline__ u4raw load_raw(const float* p) { return *(const u4raw*)p; }
+    __device__ static __forceinline__ u4raw load_stream_raw(const float* p) { return *(const u4raw*)p; }
+    __device__ static __forceinline__ void unpack(const u4raw t, float (&v)[4]) {
+        v[0] = __uint_as_float(t.x); v[1] = __uint_as_float(t.y); v[2] = __uint_as_float(t.z); v[3] = __uint_as_float(t.w);
+    }
     __device__ static __forceinline__ void load(const float* p, float (&v)[4]) {
         const float4 t = *(const float4*)p; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
     }
@@ -26,6 +39,13 @@ template <> struct Vec16<float> {
 };
 template <> struct Vec16<uint16_t> {
     static constexpr int N = 8;
+    __device__ static __forceinline__ u4raw load_raw(const uint16_t* p) { return *(const u4raw*)p; }
+    __device__ static __forceinline__ u4raw load_stream_raw(const uint16_t* p) { return __builtin_nontemporal_load((const u4raw*)p); }
+    __device__ static __forceinline__ void unpack(const u4raw t, float (&v)[8]) {
+        const unsigned w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+    }
     __device__ static __forceinline__ void load(const uint16_t* p, float (&v)[8]) {
         const uint4 t = *(const uint4*)p;
         const unsigned w[4] = {t.x, t.y, t.z, t.w};
@@ -222,28 +242,42 @@ template <int ACT> __device__ __forceinline__ float act_grad(float u) {
         else hipLaunchKernelGGL((KERNEL<T, ACT_NONE>), __VA_ARGS__);                                          \
     } while (0)
 
+// The pixels one thread visits: p0 = gt / CV, p0 + pstep, ... below P (pstep = threads of the grid / CV; the grid is sized so
+// that CV divides it).  32-bit arithmetic: a 64-bit division is ~150 instructions per thread, a quarter of the work of a thread
+// that handles eight vectors.  (r04: walking the tensor from its END -- to start on the bytes the previous pass over it touched
+// last -- changes nothing, profiles/r04_bn_reduce_pin_and_reverse_walk_ab.txt: the memory-side cache does not keep streamed data.)
+struct PixelWalk { long long p, step; int n; };
+__device__ __forceinline__ PixelWalk pixel_walk(int P, int CV) {
+    const unsigned gt = blockIdx.x * 256u + threadIdx.x;
+    const unsigned p0 = gt / (unsigned)CV, ps = (gridDim.x * 256u) / (unsigned)CV;
+    PixelWalk w;
+    w.n = p0 < (unsigned)P ? (int)(((unsigned)P - 1u - p0) / ps) + 1 : 0;
+    w.p = (long long)p0;
+    w.step = (long long)ps;
+    return w;
+}
+
 template <typename T, int ACT>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y, int ldy, T* __restrict__ z, int ldz,
                                                          const T* __restrict__ res, int ldr, int P, int CV,
                                                          const float* __restrict__ scale, const float* __restrict__ shift) {
     constexpr int N = Vec16<T>::N;
-    // 32-bit index arithmetic (the grid is at most 2048 x 256 threads): a 64-bit division here is ~150 instructions per thread,
-    // a quarter of the work of a thread that handles eight vectors
-    const unsigned gt = blockIdx.x * 256u + threadIdx.x;
-    const int cv = (int)(gt % (unsigned)CV);
-    long long p = gt / (unsigned)CV;
-    const long long pstep = (gridDim.x * 256u) / (unsigned)CV;   // grid is sized so that CV | gridDim.x*256
+    const int cv = (int)((blockIdx.x * 256u + threadIdx.x) % (unsigned)CV);
+    const PixelWalk w = pixel_walk(P, CV);
+    long long p = w.p;
     float sc[N], sh[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) { sc[i] = scale[cv * N + i]; sh[i] = shift[cv * N + i]; }
-    for (; p < P; p += pstep) {
+    for (int it = 0; it < w.n; ++it, p += w.step) {
         float v[N];
-        Vec16<T>::load_stream(y + p * ldy + cv * N, v);
+        u4raw ry = Vec16<T>::load_stream_raw(y + p * ldy + cv * N), rr = ry;
+        if (res) { rr = Vec16<T>::load_raw(res + p * ldr + cv * N); pin_loaded(ry, rr); }   // both loads in flight before the math
+        Vec16<T>::unpack(ry, v);
 #pragma unroll
         for (int i = 0; i < N; ++i) v[i] = act_fwd<ACT>(v[i] * sc[i] + sh[i]);
         if (res) {
             float r[N];
-            Vec16<T>::load(res + p * ldr + cv * N, r);
+            Vec16<T>::unpack(rr, r);
 #pragma unroll
             for (int i = 0; i < N; ++i) v[i] += r[i];
         }
@@ -263,12 +297,11 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const T* __restr
     const int C = CV * N;
     for (int i = threadIdx.x; i < C; i += 256) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
     __syncthreads();
-    // 32-bit index arithmetic (the grid is at most 2048 x 256 threads): a 64-bit division here is ~150 instructions per thread,
-    // a quarter of the work of a thread that handles eight vectors
-    const unsigned gt = blockIdx.x * 256u + threadIdx.x;
-    const int cv = (int)(gt % (unsigned)CV);
-    long long p = gt / (unsigned)CV;
-    const long long pstep = (gridDim.x * 256u) / (unsigned)CV;
+    const int cv = (int)((blockIdx.x * 256u + threadIdx.x) % (unsigned)CV);
+    const PixelWalk w = pixel_walk(P, CV);
+    long long p = w.p;
+    const long long pstep = w.step;
+    int it = 0;
     // accumulate s1 = sum(du) and s2r = sum(du * y); sum(du * xhat) = invstd * (s2r - mean * s1) is formed once
     // per thread at the end, so mean / invstd stay out of the streaming loop (fewer live registers)
     float sc[N], sh[N], s1[N], s2[N];
@@ -277,12 +310,12 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const T* __restr
         sc[i] = scale[cv * N + i]; sh[i] = shift[cv * N + i];
         s1[i] = 0.f; s2[i] = 0.f;
     }
-    for (; p + pstep < P; p += 2 * pstep) {          // two pixels in flight per thread
+    for (; it + 1 < w.n; it += 2, p += 2 * pstep) {  // two pixels in flight per thread
         float g[N], v[N], g2[N], v2[N];
-        Vec16<T>::load(dz + p * lddz + cv * N, g);
-        Vec16<T>::load(y + p * ldy + cv * N, v);
-        Vec16<T>::load(dz + (p + pstep) * lddz + cv * N, g2);
-        Vec16<T>::load(y + (p + pstep) * ldy + cv * N, v2);
+        u4raw rg = Vec16<T>::load_raw(dz + p * lddz + cv * N), rv = Vec16<T>::load_raw(y + p * ldy + cv * N);
+        u4raw rg2 = Vec16<T>::load_raw(dz + (p + pstep) * lddz + cv * N), rv2 = Vec16<T>::load_raw(y + (p + pstep) * ldy + cv * N);
+        pin_loaded(rg, rv, rg2, rv2);
+        Vec16<T>::unpack(rg, g); Vec16<T>::unpack(rv, v); Vec16<T>::unpack(rg2, g2); Vec16<T>::unpack(rv2, v2);
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             const float du = g[i] * act_grad<ACT>(v[i] * sc[i] + sh[i]);
@@ -291,7 +324,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const T* __restr
             s2[i] += du * v[i] + du2 * v2[i];
         }
     }
-    for (; p < P; p += pstep) {
+    if (it < w.n) {
         float g[N], v[N];
         Vec16<T>::load(dz + p * lddz + cv * N, g);
         Vec16<T>::load(y + p * ldy + cv * N, v);
@@ -338,12 +371,9 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restri
                                                                const float* __restrict__ k0, const float* __restrict__ k1,
                                                                const float* __restrict__ k2) {
     constexpr int N = Vec16<T>::N;
-    // 32-bit index arithmetic (the grid is at most 2048 x 256 threads): a 64-bit division here is ~150 instructions per thread,
-    // a quarter of the work of a thread that handles eight vectors
-    const unsigned gt = blockIdx.x * 256u + threadIdx.x;
-    const int cv = (int)(gt % (unsigned)CV);
-    long long p = gt / (unsigned)CV;
-    const long long pstep = (gridDim.x * 256u) / (unsigned)CV;
+    const int cv = (int)((blockIdx.x * 256u + threadIdx.x) % (unsigned)CV);
+    const PixelWalk w = pixel_walk(P, CV);
+    long long p = w.p;
     // dy = k0*(du - k1 - xhat*k2), xhat = (y-mean)*invstd  ==  A*du + B*y + D with per-channel A, B, D
     float sc[N], sh[N], A[N], B[N], D[N];
 #pragma unroll
@@ -353,7 +383,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restri
         const float a0 = k0[c], w = invstd[c] * k2[c];
         A[i] = a0; B[i] = -a0 * w; D[i] = a0 * (mean[c] * w - k1[c]);
     }
-    for (; p < P; p += pstep) {
+    for (int it = 0; it < w.n; ++it, p += w.step) {
         float g[N], v[N];
         Vec16<T>::load_stream(dz + p * lddz + cv * N, g);
         Vec16<T>::load_stream(y + p * ldy + cv * N, v);

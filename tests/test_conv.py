@@ -354,10 +354,8 @@ STRIDE2_WGRAD = [   # (case, ET_WGRAD_RS2, kernel): the default takes the 64-inp
 ]
 
 
-@pytest.mark.parametrize("case,knob,kernel", STRIDE2_WGRAD, ids=[f"{c}-{k}" for c, k, _ in STRIDE2_WGRAD])
-def test_wgrad_stride2_row_sharing(hip, case, knob, kernel):
-    """conv_wgrad_rs_kernel<..., 2> (two X rows per K-slot) vs torch on every tile / knob setting.  ET_WGRAD_RS2 is read once per
-    process by the library, so the non-default settings run in a child process."""
+def _wgrad_in_child(hip, case, env, kernel):
+    """one weight gradient vs torch in a CHILD process: the tile knobs (ET_WGRAD_RS2) are read once per process"""
     import subprocess, sys, os
     N, H, W, Cin, Cout, k, s_, p_ = case
     code = f"""
@@ -371,22 +369,29 @@ if emu:
     _lib._use_library_for_tests(b.build(), True)
 dev = torch.device("cpu" if emu else "cuda:0")
 dt = torch.bfloat16
-N, H, W, Cin, Cout = {N}, {H}, {W}, {Cin}, {Cout}
-assert ops.kernel_name("wgrad", dt, N, H, W, Cin, Cout, 3, 2, 1) == {repr(kernel)}, ops.kernel_name("wgrad", dt, N, H, W, Cin, Cout, 3, 2, 1)
+N, H, W, Cin, Cout, k, s, p = {N}, {H}, {W}, {Cin}, {Cout}, {k}, {s_}, {p_}
+assert ops.kernel_name("wgrad", dt, N, H, W, Cin, Cout, k, s, p) == {repr(kernel)}, ops.kernel_name("wgrad", dt, N, H, W, Cin, Cout, k, s, p)
 g = torch.Generator().manual_seed(5)
 x = torch.randn(N, H, W, Cin, generator=g).to(dt).to(dev)
-dy = torch.randn(N, H // 2 if H % 2 == 0 else (H + 1) // 2, W // 2 if W % 2 == 0 else (W + 1) // 2, Cout, generator=g).to(dt).to(dev)
-dw = torch.zeros(Cout, 3, 3, Cin, device=dev)
-ops.conv2d_wgrad(x, dy, dw, 3, 2, 1)
-wr = torch.zeros(Cout, Cin, 3, 3, requires_grad=True)
-F.conv2d(x.float().cpu().permute(0, 3, 1, 2), wr, stride=2, padding=1).backward(dy.float().cpu().permute(0, 3, 1, 2))
+OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+dy = torch.randn(N, OH, OW, Cout, generator=g).to(dt).to(dev)
+dw = torch.zeros(Cout, k, k, Cin, device=dev)
+ops.conv2d_wgrad(x, dy, dw, k, s, p)
+wr = torch.zeros(Cout, Cin, k, k, requires_grad=True)
+F.conv2d(x.float().cpu().permute(0, 3, 1, 2), wr, stride=s, padding=p).backward(dy.float().cpu().permute(0, 3, 1, 2))
 ref = wr.grad.permute(0, 2, 3, 1)
 err = (dw.cpu() - ref).abs().max().item()
 assert err <= 1e-4 * max(1.0, ref.abs().max().item()), err
 print("OK")
 """
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ET_WGRAD_RS2=knob), capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-500:] + r.stderr[-1500:]
+
+
+@pytest.mark.parametrize("case,knob,kernel", STRIDE2_WGRAD, ids=[f"{c}-{k}" for c, k, _ in STRIDE2_WGRAD])
+def test_wgrad_stride2_row_sharing(hip, case, knob, kernel):
+    """conv_wgrad_rs_kernel<..., 2> (two X rows per K-slot) vs torch on every tile / knob setting"""
+    _wgrad_in_child(hip, case, {"ET_WGRAD_RS2": knob}, kernel)
 
 
 def test_wgrad_stride2_row_sharing_grouped(hip):

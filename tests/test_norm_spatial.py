@@ -29,8 +29,9 @@ def finalize_form(request):
         os.environ["ET_BN_FIN_SMALL"] = old
 
 
+# the last shape gives every thread 6 or 7 vectors (512 blocks for 819200 / 1638400 vectors): the paired loop AND its odd tail
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("shape", [(2, 7, 9, 32), (1, 5, 5, 48), (3, 4, 4, 8), (2, 40, 40, 24), (4, 72, 72, 8)])
+@pytest.mark.parametrize("shape", [(2, 7, 9, 32), (1, 5, 5, 48), (3, 4, 4, 8), (2, 40, 40, 24), (4, 72, 72, 8), (2, 160, 160, 128)])
 def test_bn_silu_fwd_bwd(hip, finalize_form, shape, dtype):
     from efficientteacher_amd import ops
     N, H, W, C = shape
