@@ -557,6 +557,22 @@ def measure(a, wl_name, per_rank, device, rank, world, dev_index, full=True):
         except Exception:
             ops.TIMER = None
     res["solo"] = solo
+    # ... and the teacher's forward + decode ALONE on the GPU (in the step it shares the CUs with the student's forward, so the
+    # teacher_stream figures above are durations under contention, not cost)
+    if ssod and isinstance(fam, dict) and "error" not in fam:
+        try:
+            with torch.no_grad():
+                for _ in range(2):
+                    tr.ema.ema(u_ori, augment=False)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(5):
+                    tr.ema.ema(u_ori, augment=False)
+                e1.record()
+            torch.cuda.synchronize()
+            fam["teacher_forward_alone_ms"] = round(e0.elapsed_time(e1) / 5, 3)
+        except Exception as e:
+            fam["teacher_forward_alone_ms"] = f"{type(e).__name__}: {e}"
     del tr
     torch.cuda.empty_cache()
     return res

@@ -214,6 +214,13 @@ SELECT = [
     # 64 -> 128 stride-2 3x3 (the layer after the stem): its four-tap dgrad class is the 64-wide tile with 64-wide chunks
     ((2, 24, 24, 64, 128, 3, 2, 1), GLDS + "128, 128, 2, 2, 8, 2, true>",
      [GLDS + "128, 64, 2, 2, 4, 3, true>"] * 3 + [GLDS + "128, 64, 2, 2, 8, 2, true>"], "conv_wgrad_rs_kernel<128, 64, 2, 2, 2>"),
+    # ... an ODD input size: the four parity classes differ in pixel count (1, 2, 2, 4 taps: K = 128, 256, 256, 512)
+    ((1, 15, 15, 64, 128, 3, 2, 1), GLDS + "128, 128, 2, 2, 8, 2, true>",
+     [GLDS + "128, 64, 2, 2, 4, 3, true>"] * 3 + [GLDS + "128, 64, 2, 2, 8, 2, true>"], "conv_wgrad_tr_kernel<128, 128, 2, 2>"),
+    # the single-launch form of the short-K ring on the 128-wide tile: dgrad of a 512 -> 256 1x1 layer (K = 256, 512 dX channels)
+    ((1, 12, 12, 512, 256, 1, 1, 0), GLDS + "128, 128, 2, 2, 8, 2, true>", [GLDS + "128, 128, 2, 2, 4, 3, true>"], "conv_wgrad_tr_kernel<128, 128, 2, 2>"),
+    # ... and >= 256 dX channels: the classes run on the 256x256 ping-pong tile, one launch each
+    ((1, 16, 16, 256, 512, 3, 2, 1), "conv_gemm_pp_kernel", ["conv_gemm_pp_kernel"] * 4, "conv_wgrad_tr_kernel<256, 256, 2, 4>"),
     # the persistent streaming kernel of the 1x1 layers with K <= 256 (every instantiation; ragged M, Cout below the column tile,
     # and -- last two -- a channel count whose dgrad is not eligible, i.e. a tiled dgrad beside a streamed forward)
     ((2, 13, 11, 64, 64, 1, 1, 0), S1, [S1], "conv_wgrad_tr_kernel<64, 64, 2, 2>"),
