@@ -169,17 +169,25 @@ __global__ __launch_bounds__(1024) void rows_reduce_finalize_small_kernel(const 
     double s = 0.0, q = 0.0;
     if (c < C) {
         int r = rg;
-        for (; r + 192 < rows; r += 256) {
-            const float s0 = part[((size_t)r * 2 + 0) * C + c], q0 = part[((size_t)r * 2 + 1) * C + c];
-            const float s1 = part[((size_t)(r + 64) * 2 + 0) * C + c], q1 = part[((size_t)(r + 64) * 2 + 1) * C + c];
-            const float s2 = part[((size_t)(r + 128) * 2 + 0) * C + c], q2 = part[((size_t)(r + 128) * 2 + 1) * C + c];
-            const float s3 = part[((size_t)(r + 192) * 2 + 0) * C + c], q3 = part[((size_t)(r + 192) * 2 + 1) * C + c];
-            s += ((double)s0 + (double)s1) + ((double)s2 + (double)s3);
-            q += ((double)q0 + (double)q1) + ((double)q2 + (double)q3);
-        }
-        for (; r < rows; r += 64) {
-            s += (double)part[((size_t)r * 2 + 0) * C + c];
-            q += (double)part[((size_t)r * 2 + 1) * C + c];
+        // sixteen rows (32 loads) in flight per thread, rows beyond the end predicated off: 1024 rows per trip of the block, so the
+        // 200 / 800-row layers are ONE L2 round trip instead of one per four rows (this kernel is nothing but dependent latencies:
+        // launch, loads, LDS, the fp64 finalize)
+        for (; r < rows; r += 16 * 64) {
+            float sv[16], qv[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int rr = min(r + 64 * k, rows - 1);           // UNCONDITIONAL loads (a select around a load compiles to a branch
+                sv[k] = part[((size_t)rr * 2 + 0) * C + c];         // with its own wait: 32 serialized round trips, measured +2 ms per step)
+                qv[k] = part[((size_t)rr * 2 + 1) * C + c];
+            }
+            double ts[4] = {0.0, 0.0, 0.0, 0.0}, tq[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const bool ok = r + 64 * k < rows;
+                ts[k & 3] += ok ? (double)sv[k] : 0.0; tq[k & 3] += ok ? (double)qv[k] : 0.0;
+            }
+            s += (ts[0] + ts[1]) + (ts[2] + ts[3]);
+            q += (tq[0] + tq[1]) + (tq[2] + tq[3]);
         }
     }
     red[0][rg][cl] = s; red[1][rg][cl] = q;

@@ -42,19 +42,55 @@ def nms_ssod_padded(prediction, conf_thres=0.25, iou_thres=0.45, agnostic=False,
     return dets, counts, keep, ncand
 
 
+def _with_apriori_labels(prediction, labels):
+    """utils/general.py:924-931 (and :1027-1034): per-image (n, 5) [cls, x, y, w, h] boxes join the candidates with obj = 1 and a
+    one-hot class row, BEHIND the image's own anchors (the order the reference's torch.cat gives, which the stable sort of the NMS
+    sees).  Images with fewer labels are padded with all-zero rows: obj = 0 never passes `obj > conf_thres`."""
+    B, A, no = prediction.shape
+    nc = no - 5
+    n_max = max((len(l) for l in labels), default=0)
+    if n_max == 0:
+        return prediction
+    extra = torch.zeros((B, n_max, no), dtype=prediction.dtype, device=prediction.device)
+    for i, l in enumerate(labels):
+        if len(l):
+            l = torch.as_tensor(l, dtype=prediction.dtype, device=prediction.device)
+            extra[i, :len(l), :4] = l[:, 1:5]
+            extra[i, :len(l), 4] = 1.0
+            extra[i, torch.arange(len(l), device=prediction.device), l[:, 0].long() + 5] = 1.0
+    return torch.cat((prediction, extra), 1)
+
+
 def non_max_suppression_ssod(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False,
                              num_points=0, multi_label=False, labels=(), max_det=300):
     """Runs Non-Maximum Suppression (NMS) on inference results (reference utils/general.py:887).
 
     Returns:
          list of detections, on (n,8) tensor per image [xyxy, conf, cls, obj_conf, cls_conf]
+         ((n,6) [xyxy, conf, cls] with multi_label, as the reference's :948-950 builds it)
+
+    The SSOD configs call this with the defaults (one kernel family, et_nms_ssod).  The optional arguments are served by the same
+    kernels: `labels` appends rows to the prediction; `classes` (single label) clears the objectness of the boxes whose best
+    class is not listed, which removes exactly the rows :958-959 drops; `multi_label` is the val path's kernel (et_nms) -- its extra
+    candidate test `max cls > conf_thres` (:1002) never removes a row that :948 would emit while obj <= 1 (sigmoid outputs).
     """
-    if classes is not None or num_points or labels:
-        raise NotImplementedError("classes / num_points / labels are outside the SSOD hot path")
+    if num_points:
+        raise NotImplementedError("key points (num_points > 0) are outside the SSOD hot path")
+    if prediction.dtype != torch.float32:
+        prediction = prediction.float()
     nc = prediction.shape[2] - 5
+    if labels and any(len(l) for l in labels):
+        prediction = _with_apriori_labels(prediction, labels)
     if multi_label and nc > 1:
-        raise NotImplementedError("the reference's non_max_suppression_ssod never runs multi_label on the SSOD path "
-                                  "(configs: multi_label False); use non_max_suppression for the val.py path")
+        dets, counts, _, _ = nms_padded(prediction, conf_thres, iou_thres, classes, agnostic, True, max_det)
+        counts = counts.tolist()
+        return [dets[i, :n] for i, n in enumerate(counts)]
+    if classes is not None:
+        # best class of a box as :952 finds it (first maximum of cls * obj); a box of another class leaves the candidate set
+        best = (prediction[..., 5:5 + nc] * prediction[..., 4:5]).argmax(-1)
+        allowed = torch.isin(best, torch.as_tensor(list(classes), device=prediction.device, dtype=best.dtype))
+        prediction = prediction.clone()
+        prediction[..., 4] = torch.where(allowed, prediction[..., 4], torch.zeros_like(prediction[..., 4]))
     dets, counts, _, _ = nms_ssod_padded(prediction, conf_thres, iou_thres, agnostic, max_det)
     counts = counts.tolist()  # the one host sync of the list-returning API
     return [dets[i, :n] for i, n in enumerate(counts)]
@@ -101,8 +137,8 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
     Returns:
          list of detections, on (n,6) tensor per image [xyxy, conf, cls]
     """
-    if labels:
-        raise NotImplementedError("apriori `labels` (autolabelling, utils/general.py:1027-1034) is outside the path")
+    if labels and any(len(l) for l in labels):          # autolabelling, utils/general.py:1027-1034
+        prediction = _with_apriori_labels(prediction.float(), labels)
     dets, counts, _, _ = nms_padded(prediction, conf_thres, iou_thres, classes, agnostic, multi_label, max_det)
     counts = counts.tolist()  # the one host sync of the list-returning API
     return [dets[i, :n] for i, n in enumerate(counts)]

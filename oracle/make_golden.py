@@ -96,6 +96,44 @@ def case_nms():
     save("nms", **out)
 
 
+def case_nms_ssod_options():
+    """non_max_suppression_ssod's optional arguments (utils/general.py:887: classes, multi_label, labels, agnostic) -- off every
+    shipped SSOD config, pinned so that the drop-in signature is complete"""
+    from utils.general import non_max_suppression_ssod
+    rng = np.random.default_rng(23)
+    pred = synth_pred(rng, 3, 500, 6, obj_pow=1, cls_pow=1, dup=True)
+    centers = rng.uniform(100, 540, (3, 10, 2)).astype(np.float32)
+    idx = rng.integers(0, 10, pred.shape[:2])
+    pred[..., 0:2] = np.take_along_axis(centers, idx[..., None].repeat(2, 2), 1) + rng.normal(0, 6, pred.shape[:2] + (2,)).astype(np.float32)
+    pred[..., 2:4] = 80 + rng.normal(0, 8, pred.shape[:2] + (2,)).astype(np.float32)
+    labels = [np.array([[2, 300, 300, 90, 90], [5, 120, 140, 60, 70]], np.float32), np.zeros((0, 5), np.float32),
+              np.array([[0, 500, 480, 100, 80]], np.float32)]
+    variants = {
+        "classes": dict(classes=[1, 4]),
+        "classes_agnostic": dict(classes=[0, 2, 5], agnostic=True),
+        "multi_label": dict(multi_label=True),
+        "multi_label_classes": dict(multi_label=True, classes=[3]),
+        "labels": dict(labels=[torch.from_numpy(l) for l in labels]),
+        "labels_multi": dict(labels=[torch.from_numpy(l) for l in labels], multi_label=True, agnostic=True),
+    }
+    out = dict(pred=pred, thr=np.array([0.1, 0.6], np.float64), apriori_rows=np.concatenate(labels, 0),
+               apriori_counts=np.array([len(l) for l in labels], np.int64))
+    for k, kw in variants.items():
+        ref = non_max_suppression_ssod(torch.from_numpy(pred.copy()), 0.1, 0.6, **kw)
+        okw = dict(kw)
+        if "labels" in okw:
+            okw["labels"] = labels
+        mine, keeps = o_nms.non_max_suppression_ssod(pred, 0.1, 0.6, **okw)
+        w = 6 if kw.get("multi_label") else 8
+        for r, m in zip(ref, mine):
+            r = r.numpy().reshape(-1, w) if r.shape[0] else np.zeros((0, w), np.float32)
+            assert np.array_equal(r, m), f"nms_ssod options pin failed ({k})"
+        assert sum(m.shape[0] for m in mine) > 0, k
+        out[f"{k}_counts"] = np.array([m.shape[0] for m in mine], np.int64)
+        out[f"{k}_dets"] = np.concatenate(mine, 0)
+    save("nms_ssod_options", **out)
+
+
 def synth_targets(rng, B, n_per=(1, 9), with_edge=True):
     rows = []
     for b in range(B):
@@ -792,12 +830,16 @@ def main():
         print("== LabelMatch")
         case_labelmatch()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "nms_options":
+        print("== non_max_suppression_ssod options")
+        case_nms_ssod_options()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "ota":
         print("== SimOTA loss")
         case_ota()
         return
     torch.set_num_threads(4)
-    print("nms ..."); case_nms()
+    print("nms ..."); case_nms(); case_nms_ssod_options()
     print("assigner / losses ..."); cfg, model = case_assigner_and_losses()
     print("pseudo label ..."); case_pseudo_label(cfg)
     print("model ..."); case_model(cfg, model)

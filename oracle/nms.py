@@ -79,31 +79,48 @@ def nms_torch(boxes, scores, iou_threshold):
 
 
 def non_max_suppression_ssod(prediction, conf_thres=0.25, iou_thres=0.45, agnostic=False,
-                             max_det=300):
-    """utils/general.py:887-992, multi_label=False, classes=None, labels=().
+                             max_det=300, classes=None, multi_label=False, labels=()):
+    """utils/general.py:887-992 (num_points = 0).
 
     prediction (B, A, 5+nc) fp32 -> list of B arrays (n_i, 8)
-    [x1,y1,x2,y2, conf, cls, obj_conf, cls_conf]; also returns the pre-NMS
-    candidate rows and the keep indices so tests can check indices bit-exactly.
+    [x1,y1,x2,y2, conf, cls, obj_conf, cls_conf] -- (n_i, 6) [x1,y1,x2,y2, conf, cls] with multi_label (:948-950);
+    also returns the keep indices (into the pre-NMS candidate rows) so tests can check indices bit-exactly.
+    classes: keep only these class ids (:958-959); labels: per-image (n, 5) [cls, x, y, w, h] apriori boxes appended to
+    the candidates with obj = cls = 1 (:924-931).
     """
     prediction = np.asarray(prediction, dtype=F32)
     nc = prediction.shape[2] - 5
     ct = F32(conf_thres)
+    multi_label = multi_label and nc > 1                  # :912
+    width = 6 if multi_label else 8
     out, keeps = [], []
-    for x in prediction:
+    for xi, x in enumerate(prediction):
         x = x[x[:, 4] > ct].copy()                       # :921 obj filter
+        if labels and len(labels[xi]):                    # :924-931
+            l = np.asarray(labels[xi], dtype=F32)
+            v = np.zeros((len(l), nc + 5), F32)
+            v[:, :4] = l[:, 1:5]
+            v[:, 4] = 1.0
+            v[np.arange(len(l)), l[:, 0].astype(np.int64) + 5] = 1.0
+            x = np.concatenate((x, v), 0)
         if not x.shape[0]:
-            out.append(np.zeros((0, 8), F32)); keeps.append(np.zeros((0,), np.int64)); continue
+            out.append(np.zeros((0, width), F32)); keeps.append(np.zeros((0,), np.int64)); continue
         cls_score = x[:, 5:5 + nc].max(1, keepdims=True)  # :937
         x[:, 5:5 + nc] *= x[:, 4:5]                       # :938
         box = xywh2xyxy(x[:, :4])                         # :943
-        j = x[:, 5:5 + nc].argmax(1)[:, None]             # :952 (first max index)
-        conf = np.take_along_axis(x[:, 5:5 + nc], j, 1)
-        obj = x[:, 4:5]
-        x = np.concatenate((box, conf, j.astype(F32), obj, cls_score), 1)[conf.reshape(-1) > ct]
+        if multi_label:                                   # :948-950
+            i, j = np.nonzero(x[:, 5:5 + nc] > ct)
+            x = np.concatenate((box[i], x[i, j + 5, None], j[:, None].astype(F32)), 1)
+        else:
+            j = x[:, 5:5 + nc].argmax(1)[:, None]             # :952 (first max index)
+            conf = np.take_along_axis(x[:, 5:5 + nc], j, 1)
+            obj = x[:, 4:5]
+            x = np.concatenate((box, conf, j.astype(F32), obj, cls_score), 1)[conf.reshape(-1) > ct]
+        if classes is not None:                           # :958-959
+            x = x[np.isin(x[:, 5], np.asarray(classes, F32))]
         n = x.shape[0]
         if not n:
-            out.append(np.zeros((0, 8), F32)); keeps.append(np.zeros((0,), np.int64)); continue
+            out.append(np.zeros((0, width), F32)); keeps.append(np.zeros((0,), np.int64)); continue
         if n > MAX_NMS:                                   # :969
             x = x[np.argsort(-x[:, 4], kind="stable")[:MAX_NMS]]
         c = x[:, 5:6] * F32(0 if agnostic else MAX_WH)    # :972

@@ -61,6 +61,53 @@ def test_nms_max_det_and_list_api(hip):
         assert o.shape == (50, 8) and np.array_equal(o.cpu().numpy(), r)
 
 
+NMS_SSOD_OPTIONS = {
+    "classes": dict(classes=[1, 4]),
+    "classes_agnostic": dict(classes=[0, 2, 5], agnostic=True),
+    "multi_label": dict(multi_label=True),
+    "multi_label_classes": dict(multi_label=True, classes=[3]),
+    "labels": dict(labels=True),
+    "labels_multi": dict(labels=True, multi_label=True, agnostic=True),
+}
+
+
+@pytest.mark.parametrize("variant", sorted(NMS_SSOD_OPTIONS))
+def test_nms_ssod_optional_arguments_golden(hip, variant):
+    """classes / multi_label / labels / agnostic of non_max_suppression_ssod (utils/general.py:887-992) vs the reference's own output
+    (tests/golden/nms_ssod_options.npz, oracle/make_golden.py::case_nms_ssod_options): bit-exact rows, in order"""
+    from efficientteacher_amd.utils.general import non_max_suppression_ssod
+    g = golden("nms_ssod_options")
+    kw = dict(NMS_SSOD_OPTIONS[variant])
+    if kw.pop("labels", False):
+        rows, cnt = g["apriori_rows"], g["apriori_counts"]
+        offs = np.concatenate(([0], np.cumsum(cnt)))
+        kw["labels"] = [hip.t(rows[offs[i]:offs[i + 1]]) for i in range(len(cnt))]
+    out = non_max_suppression_ssod(hip.t(g["pred"]), float(g["thr"][0]), float(g["thr"][1]), **kw)
+    w = 6 if kw.get("multi_label") else 8
+    assert [o.shape[0] for o in out] == list(g[f"{variant}_counts"])
+    got = np.concatenate([o.cpu().numpy().reshape(-1, w) for o in out], 0)
+    assert np.array_equal(got, g[f"{variant}_dets"].reshape(-1, w))
+
+
+def test_nms_val_path_apriori_labels(hip):
+    """non_max_suppression(labels=...) (utils/general.py:1027-1034) vs the oracle restatement with the label rows appended"""
+    from efficientteacher_amd.utils.general import non_max_suppression
+    g = golden("nms_ssod_options")
+    rows, cnt = g["apriori_rows"], g["apriori_counts"]
+    offs = np.concatenate(([0], np.cumsum(cnt)))
+    labels = [rows[offs[i]:offs[i + 1]] for i in range(len(cnt))]
+    pred = g["pred"]
+    nc = pred.shape[2] - 5
+    ext = np.zeros((pred.shape[0], max(cnt), pred.shape[2]), np.float32)
+    for i, l in enumerate(labels):
+        ext[i, :len(l), :4] = l[:, 1:5]; ext[i, :len(l), 4] = 1.0
+        ext[i, np.arange(len(l)), l[:, 0].astype(np.int64) + 5] = 1.0
+    ref = o_nms.non_max_suppression(np.concatenate((pred, ext), 1), 0.1, 0.6, multi_label=True)
+    out = non_max_suppression(hip.t(pred), 0.1, 0.6, multi_label=True, labels=[hip.t(l) for l in labels])
+    for o, r in zip(out, ref):
+        assert np.array_equal(o.cpu().numpy().reshape(-1, 6), r.reshape(-1, 6))
+
+
 # ---- general non_max_suppression: the val.py path (SURVEY.md 8 f-1) and boundary entry (8b) -----------------
 def _run_general(hip, pred, ct, it, **kw):
     from efficientteacher_amd.utils.general import nms_padded

@@ -22,6 +22,21 @@ def test_nms_oracle_vs_golden():
         assert np.array_equal(np.concatenate(v, 0), g[f"{case}_val_dets"])
 
 
+def test_nms_ssod_options_oracle_vs_golden():
+    """the optional arguments of non_max_suppression_ssod (classes, multi_label, labels, agnostic) against the reference's output"""
+    g = golden("nms_ssod_options")
+    rows, cnt = g["apriori_rows"], g["apriori_counts"]
+    offs = np.concatenate(([0], np.cumsum(cnt)))
+    labels = [rows[offs[i]:offs[i + 1]] for i in range(len(cnt))]
+    variants = {"classes": dict(classes=[1, 4]), "classes_agnostic": dict(classes=[0, 2, 5], agnostic=True),
+                "multi_label": dict(multi_label=True), "multi_label_classes": dict(multi_label=True, classes=[3]),
+                "labels": dict(labels=labels), "labels_multi": dict(labels=labels, multi_label=True, agnostic=True)}
+    for k, kw in variants.items():
+        dets, _ = o_nms.non_max_suppression_ssod(g["pred"], g["thr"][0], g["thr"][1], **kw)
+        assert [d.shape[0] for d in dets] == list(g[f"{k}_counts"]), k
+        assert np.array_equal(np.concatenate(dets, 0), g[f"{k}_dets"]), k
+
+
 def test_assigner_oracle_vs_golden():
     g = golden("assigner")
     shapes = [tuple(s) for s in g["shapes"]]
