@@ -194,6 +194,54 @@ __device__ __forceinline__ float ciou_fwd_bwd(const float pb[4], const float tb[
     return ciou;
 }
 
+// Class term of the positive slots of one wave: the wave walks its slots that have one (do_cls) and spreads the nc class logits of
+// each over the lanes (coalesced loads and atomics; one lane per slot looping over 80 classes touched 64 different cache lines per
+// iteration).  FOUR slots per trip: their logit loads are issued together (unconditionally; a missing slot re-reads the first
+// one's row) before any of the focal / BCE arithmetic -- one slot per trip was a chain of up to 64 dependent L2 round trips per
+// wave, most of loss_pos_kernel's 87 us on the bench batch (r04).  The element type is a template parameter: a run-time dtype
+// switch inside the loop puts every load behind its own branch and wait.  Per-lane summation order: slots ascending, as before.
+template <typename T> __device__ __forceinline__ float ld_logit_t(const void* p, long long off);
+template <> __device__ __forceinline__ float ld_logit_t<float>(const void* p, long long off) { return ((const float*)p)[off]; }
+template <> __device__ __forceinline__ float ld_logit_t<uint16_t>(const void* p, long long off) { return et_bf2f(((const uint16_t*)p)[off]); }
+
+template <typename T>
+__device__ __forceinline__ float loss_class_walk(const LossArgs& A, const LossLevel& L, bool do_cls, long long cls_off, int cls_c,
+                                                 float cls_wgt) {
+    const int lane = threadIdx.x & 63;
+    float cls_sum = 0.f;
+    unsigned long long m = __ballot(do_cls);
+    while (m) {
+        long long off_s[4];
+        int c_s[4];
+        float wgt_s[4];
+        int n = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int src = 0;
+            if (m) { src = __ffsll((long long)m) - 1; m &= m - 1; n = k + 1; }
+            const unsigned lo = __shfl((unsigned)(cls_off & 0xffffffffll), src);
+            const unsigned hi = __shfl((unsigned)((unsigned long long)cls_off >> 32), src);
+            off_s[k] = k < n ? (long long)(((unsigned long long)hi << 32) | lo) : off_s[0];
+            c_s[k] = __shfl(cls_c, src);
+            wgt_s[k] = __shfl(cls_wgt, src);
+        }
+        for (int c = lane; c < A.nc; c += 64) {
+            float x[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) x[k] = ld_logit_t<T>(L.p, off_s[k] + 5 + c);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (k < n) {                                     // wave-uniform
+                    float gr_;
+                    cls_sum += focal_bce_logits(x[k], c == c_s[k] ? A.cp : A.cn, A.cls_pw, A.fl_gamma, gr_);
+                    atomicAdd(L.dp + off_s[k] + 5 + c, wgt_s[k] * gr_);
+                }
+            }
+        }
+    }
+    return cls_sum;
+}
+
 __global__ __launch_bounds__(256) void loss_pos_kernel(LossArgs A, LossLevel L, int level) {
     const int nslot = 5 * A.na * A.NT;
     const int s = blockIdx.x * 256 + threadIdx.x;
@@ -214,7 +262,16 @@ __global__ __launch_bounds__(256) void loss_pos_kernel(LossArgs A, LossLevel L, 
             if (want_box) {
                 float lg[4], sg[4], pb[4], g[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { lg[i] = ld_logit(L.p, A.dtype, off + i); sg[i] = 1.0f / (1.0f + expf(-lg[i])); }
+                for (int i = 0; i < 4; ++i) lg[i] = 0.f;
+                if (A.dtype == ET_F32) {                  // the dtype switch OUTSIDE the loads: four loads in flight, one wait
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) lg[i] = ld_logit_t<float>(L.p, off + i);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) lg[i] = ld_logit_t<uint16_t>(L.p, off + i);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sg[i] = 1.0f / (1.0f + expf(-lg[i]));
                 pb[0] = sg[0] * 2.f - 0.5f; pb[1] = sg[1] * 2.f - 0.5f;
                 const float tw = sg[2] * 2, th = sg[3] * 2;
                 pb[2] = tw * tw * L.anchors[r.a][0]; pb[3] = th * th * L.anchors[r.a][1];
@@ -244,27 +301,8 @@ __global__ __launch_bounds__(256) void loss_pos_kernel(LossArgs A, LossLevel L, 
         }
     }
     // class term: the wave walks its slots that have one and spreads the nc class logits of each over the lanes
-    // (coalesced loads and atomics; one lane per slot looping over 80 classes touched 64 different cache lines
-    // per iteration)
-    {
-        const int lane = threadIdx.x & 63;
-        unsigned long long m = __ballot(do_cls);
-        while (m) {
-            const int src = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            const unsigned lo = __shfl((unsigned)(cls_off & 0xffffffffll), src);
-            const unsigned hi = __shfl((unsigned)((unsigned long long)cls_off >> 32), src);
-            const long long off_s = (long long)(((unsigned long long)hi << 32) | lo);
-            const int c_s = __shfl(cls_c, src);
-            const float wgt_s = __shfl(cls_wgt, src);
-            for (int c = lane; c < A.nc; c += 64) {
-                const float x = ld_logit(L.p, A.dtype, off_s + 5 + c);
-                float gr_;
-                cls_sum += focal_bce_logits(x, c == c_s ? A.cp : A.cn, A.cls_pw, A.fl_gamma, gr_);
-                atomicAdd(L.dp + off_s + 5 + c, wgt_s * gr_);
-            }
-        }
-    }
+    if (A.dtype == ET_F32) cls_sum += loss_class_walk<float>(A, L, do_cls, cls_off, cls_c, cls_wgt);
+    else cls_sum += loss_class_walk<uint16_t>(A, L, do_cls, cls_off, cls_c, cls_wgt);
     box_sum = et_wave_sum(box_sum);
     cls_sum = et_wave_sum(cls_sum);
     if ((threadIdx.x & 63) == 0) {
