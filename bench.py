@@ -559,7 +559,7 @@ def measure(a, wl_name, per_rank, device, rank, world, dev_index, full=True):
     res["solo"] = solo
     # ... and the teacher's forward + decode ALONE on the GPU (in the step it shares the CUs with the student's forward, so the
     # teacher_stream figures above are durations under contention, not cost)
-    if ssod and isinstance(fam, dict) and "error" not in fam:
+    if ssod and isinstance(fam, dict) and "error" not in fam and not a.no_teacher_alone:
         try:
             with torch.no_grad():
                 for _ in range(2):
@@ -655,6 +655,8 @@ def main():
     ap.add_argument("--per-rank", type=int, default=0, help="images per rank (SSOD: labeled = unlabeled = this); default: the "
                     "BASELINE config of the workload (v5l-ssod: 32, and 16 at --gpus 8 = configs[3], global 128+128)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-teacher-alone", action="store_true", help="skip the teacher-forward-alone timing after the timed region (profiling "
+                    "runs: its seven extra forwards would count into the per-step kernel totals)")
     ap.add_argument("--no-weak-point", action="store_true", help="--gpus 8: skip the second (32+32 per rank) measurement")
     ap.add_argument("--no-overlap", action="store_true", help="run the teacher on the main stream (A/B)")
     ap.add_argument("--graph", action="store_true", help="replay the step as one captured HIP graph (trainer/graph_step.py) instead of "

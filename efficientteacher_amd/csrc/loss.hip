@@ -196,7 +196,7 @@ __device__ __forceinline__ float ciou_fwd_bwd(const float pb[4], const float tb[
 
 // Class term of the positive slots of one wave: the wave walks its slots that have one (do_cls) and spreads the nc class logits of
 // each over the lanes (coalesced loads and atomics; one lane per slot looping over 80 classes touched 64 different cache lines per
-// iteration).  FOUR slots per trip: their logit loads are issued together (unconditionally; a missing slot re-reads the first
+// iteration).  EIGHT slots per trip: their logit loads are issued together (unconditionally; a missing slot re-reads the first
 // one's row) before any of the focal / BCE arithmetic -- one slot per trip was a chain of up to 64 dependent L2 round trips per
 // wave, most of loss_pos_kernel's 87 us on the bench batch (r04).  The element type is a template parameter: a run-time dtype
 // switch inside the loop puts every load behind its own branch and wait.  Per-lane summation order: slots ascending, as before.
@@ -207,16 +207,17 @@ template <> __device__ __forceinline__ float ld_logit_t<uint16_t>(const void* p,
 template <typename T>
 __device__ __forceinline__ float loss_class_walk(const LossArgs& A, const LossLevel& L, bool do_cls, long long cls_off, int cls_c,
                                                  float cls_wgt) {
+    constexpr int NB = 8;                                    // slots per trip
     const int lane = threadIdx.x & 63;
     float cls_sum = 0.f;
     unsigned long long m = __ballot(do_cls);
     while (m) {
-        long long off_s[4];
-        int c_s[4];
-        float wgt_s[4];
+        long long off_s[NB];
+        int c_s[NB];
+        float wgt_s[NB];
         int n = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < NB; ++k) {
             int src = 0;
             if (m) { src = __ffsll((long long)m) - 1; m &= m - 1; n = k + 1; }
             const unsigned lo = __shfl((unsigned)(cls_off & 0xffffffffll), src);
@@ -226,11 +227,11 @@ __device__ __forceinline__ float loss_class_walk(const LossArgs& A, const LossLe
             wgt_s[k] = __shfl(cls_wgt, src);
         }
         for (int c = lane; c < A.nc; c += 64) {
-            float x[4];
+            float x[NB];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) x[k] = ld_logit_t<T>(L.p, off_s[k] + 5 + c);
+            for (int k = 0; k < NB; ++k) x[k] = ld_logit_t<T>(L.p, off_s[k] + 5 + c);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < NB; ++k) {
                 if (k < n) {                                     // wave-uniform
                     float gr_;
                     cls_sum += focal_bce_logits(x[k], c == c_s[k] ? A.cp : A.cn, A.cls_pw, A.fl_gamma, gr_);

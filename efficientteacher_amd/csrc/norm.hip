@@ -286,8 +286,12 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
         if (res) {
             float r[N];
             Vec16<T>::unpack(rr, r);
+            // an ADD with its own rounding, as the reference's `x + self.cv2(self.cv1(x))` (common.py:544) -- with the residual in
+            // registers before the activation the compiler contracts u * sigmoid(u) + r into one fma, which moved fp32 activations by
+            // an ulp and, through ~100 train-mode BatchNorm layers at random init, some fp32-mode gradients by 1 % (r04,
+            // tests/test_step_benchbatch.py: worst relative L2 vs the oracle 3.6e-3 -> 1.16e-2)
 #pragma unroll
-            for (int i = 0; i < N; ++i) v[i] += r[i];
+            for (int i = 0; i < N; ++i) v[i] = __fadd_rn(v[i], r[i]);
         }
         Vec16<T>::store(z + p * ldz + cv * N, v);
     }

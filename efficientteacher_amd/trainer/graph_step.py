@@ -140,12 +140,21 @@ class StepGraph:
             e.capturing = True
         t._capturing = True
         opt.capturing = True
+        # No cyclic garbage collection while the stream captures: a collection that happens to run inside the capture finalizes
+        # whatever unreachable objects exist at that moment -- a dropped CUDAGraph with its memory pool, pinned staging buffers --
+        # and their hipFree / hipHostFree are illegal during a global-mode capture: the process ABORTS (seen once in the GPU tier,
+        # in a re-capture, with the interpreter "Garbage-collecting" inside conv2d_fwd).  torch.cuda.graph() collects once on entry.
+        import gc
+        gc_was_on = gc.isenabled()
+        gc.disable()
         try:
             # data parallel: torch's NCCL watchdog thread may touch the device while this thread captures
             with torch.cuda.graph(g, capture_error_mode="thread_local" if t.RANK != -1 else "global"):
                 self.items = t._train_instance_eager(self.s_imgs, None, None, self.s_ustr, self.s_uori, None, self.s_M, 0,
                                                      sup_table=self.s_table)
         finally:
+            if gc_was_on:
+                gc.enable()
             t._capturing = False
             opt.capturing = False
             for e in emas:

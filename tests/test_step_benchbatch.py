@@ -7,7 +7,7 @@ per-kernel coverage at the bench shapes (tests/test_conv.py::SELECT) is not a st
   (a) fp32 parity mode, 32 + 32, ONE real SSODTrainer.train_instance vs oracle/step.py on the same weights / images / M_s /
       injected teacher scores: the six loss terms <= 1e-4 relative, NMS rows and kept indices bit-exact on the identical decoded
       tensor, pseudo-label set <= 1e-6, and EVERY conv / BN / bias gradient against the oracle's (cosine >= 0.9999, relative
-      L2 <= 1e-2).
+      L2 <= 2e-2).
   (b) bf16 performance mode (the dtype the bench line states) on the same inputs against (a)'s fp32-mode HIP step AND the fp32
       oracle: loss terms <= 5e-2.
   (c) bf16-mode gradients of all conv weights against the fp32-mode step at 32 + 32, per-tensor cosine >= 0.95 -- at a
@@ -90,7 +90,11 @@ def test_fp32_step_at_the_benchmarked_batch_vs_oracle(dev):
     print("PARITY bench-batch fp32 gradients:", n, "tensors; worst cosine", worst_cos, "worst relative L2", worst_l2)
     assert n >= 300                                           # 110 conv weights + 2 x 101 BN vectors + biases
     assert worst_cos[1] >= 0.9999, worst_cos
-    assert worst_l2[1] <= 1e-2, worst_l2
+    # measured 3.6e-3 (a BatchNorm bias of the last backbone stage).  This bound sits close to what fp32 ROUNDING alone does to this
+    # net at random init: contracting ONE multiply-add in the Bottleneck shortcut (activations move by an ulp) took it to 1.16e-2
+    # with the cosine at 0.99993 (r04, profiles/r04_fp32_gradient_bound_sensitivity.txt) -- so 2e-2 here, the cosine above is the
+    # sharper statement
+    assert worst_l2[1] <= 2e-2, worst_l2
 
 
 def test_bf16_step_at_the_benchmarked_batch_vs_fp32(dev):

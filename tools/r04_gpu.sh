@@ -16,7 +16,7 @@ t_all) run t_all; timeout 2400 python -m pytest tests -x -q -m gpu -rs > $OUT/py
 smoke) run smoke; timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -3 $OUT/smoke.log ;;
 bench) run bench; timeout 900 python bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err; cut -c1-400 $OUT/bench.json; tail -3 $OUT/bench.err ;;
 bench_quick) run bench_quick; timeout 900 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2> $OUT/bench_quick.err | tee $OUT/bench_quick.json | line quick ;;
-launches) run launches; timeout 900 python bench.py --steps 12 --warmup 4 --no-cpu-baseline --dump-launches $OUT/launches_one_step.json > $OUT/bench_launches.json 2> $OUT/launches.err; python tools/launch_table.py $OUT/launches_one_step.json > $OUT/launch_table.txt 2>&1; tail -16 $OUT/launch_table.txt ;;
+launches) run launches; timeout 900 python bench.py --steps 12 --warmup 4 --no-cpu-baseline --no-teacher-alone --dump-launches $OUT/launches_one_step.json > $OUT/bench_launches.json 2> $OUT/launches.err; python tools/launch_table.py $OUT/launches_one_step.json > $OUT/launch_table.txt 2>&1; tail -16 $OUT/launch_table.txt ;;
 ab_env) run ab_env; for K in ${AB_ENV:-"X=0"}; do env $K timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | line "$K" | tee -a $OUT/ab_env.txt; done ;;
 mb_k1) run mb_k1; for K in ${MB_K1_ENV:-"X=0"}; do echo "--- $K" | tee -a $OUT/mb_k1.txt; env $K MB_REF=0 MB_K=1 MB_ROTATE=3 MB_B=${MB_B:-64} timeout 600 python tools/microbench.py conv 2>&1 | python -c "
 import sys, json, os
@@ -38,8 +38,8 @@ for l in sys.stdin:
         d = json.loads(l)
         print('%4d->%4d s%d @%3d x%2d  fwd %6.1f us %4.0f TF | dgrad %6.1f us %4.0f TF | wgrad %6.1f us %4.0f TF' % (d['cin'], d['cout'], d['s'], d['h'], d['count'], d['fwd_ms']*1e3, d['fwd_tf'], d['dgrad_ms']*1e3, d['dgrad_tf'], d['wgrad_ms']*1e3, d['wgrad_tf']))
 " | tee -a $OUT/mb_k3w.txt; done ;;
-prof) run prof; (cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/bench_under_rocprof.json 2> $GRAFT_REPO_ROOT/$OUT/prof.err); find $OUT/prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv; find $OUT/prof -name "*kernel_trace.csv" | head -1 | xargs -I{} python tools/trace_streams.py {} > $OUT/trace_streams.txt 2>&1; cat $OUT/trace_streams.txt; find $OUT/prof -name "*.db" -delete; find $OUT/prof -name "*kernel_trace.csv" -size +20M -delete; head -8 $OUT/kernel_stats.csv | cut -c1-160 ;;
-pmc) run pmc; for C in FETCH_SIZE WRITE_SIZE; do (cd /tmp && timeout 900 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmc_$C -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/bench_pmc_$C.json 2> $GRAFT_REPO_ROOT/$OUT/pmc_$C.err); done; python tools/pmc_summarize.py $OUT > $OUT/pmc_bench_summary.csv; find $OUT -name "*.db" -delete; find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*kernel_trace.csv" -delete; timeout 600 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --dump-launches $OUT/launches_for_pmc.json > /dev/null 2>&1; python tools/pmc_to_traffic.py $OUT/pmc_bench_summary.csv $OUT/pmc_traffic.json $OUT/launches_for_pmc.json ;;
+prof) run prof; (cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-teacher-alone > $GRAFT_REPO_ROOT/$OUT/bench_under_rocprof.json 2> $GRAFT_REPO_ROOT/$OUT/prof.err); find $OUT/prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv; find $OUT/prof -name "*kernel_trace.csv" | head -1 | xargs -I{} python tools/trace_streams.py {} > $OUT/trace_streams.txt 2>&1; cat $OUT/trace_streams.txt; find $OUT/prof -name "*.db" -delete; find $OUT/prof -name "*kernel_trace.csv" -size +20M -delete; head -8 $OUT/kernel_stats.csv | cut -c1-160 ;;
+pmc) run pmc; for C in FETCH_SIZE WRITE_SIZE; do (cd /tmp && timeout 900 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmc_$C -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-teacher-alone > $GRAFT_REPO_ROOT/$OUT/bench_pmc_$C.json 2> $GRAFT_REPO_ROOT/$OUT/pmc_$C.err); done; python tools/pmc_summarize.py $OUT > $OUT/pmc_bench_summary.csv; find $OUT -name "*.db" -delete; find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*kernel_trace.csv" -delete; timeout 600 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-teacher-alone --dump-launches $OUT/launches_for_pmc.json > /dev/null 2>&1; python tools/pmc_to_traffic.py $OUT/pmc_bench_summary.csv $OUT/pmc_traffic.json $OUT/launches_for_pmc.json ;;
 *) echo "unknown section $s" ;;
 esac
 done
