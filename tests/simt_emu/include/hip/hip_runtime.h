@@ -252,6 +252,8 @@ static inline int __float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; 
 static inline unsigned __float_as_uint(float f) { unsigned i; memcpy(&i, &f, 4); return i; }
 static inline float __int_as_float(int i) { float f; memcpy(&f, &i, 4); return f; }
 static inline float __uint_as_float(unsigned i) { float f; memcpy(&f, &i, 4); return f; }
+// an addition with its own rounding (never contracted into a multiply-add)
+static inline float __fadd_rn(float a, float b) { volatile float s = a + b; return s; }
 static inline double __longlong_as_double(long long i) { double f; memcpy(&f, &i, 8); return f; }
 static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 using std::max;
