@@ -316,8 +316,11 @@ def conv2d_wgrad_grouped(items, ksize, stride, pad):
         assert dw.dtype == torch.float32 and dw.is_contiguous() and dw.shape == (Cout, ksize, ksize, Cin)
         arr[i].x, arr[i].dy, arr[i].dw = _lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw)
         arr[i].ldx, arr[i].ldy = _nhwc(x), _nhwc(dy)
+    # algorithmic bytes of a weight gradient: x and dy read once, dw (fp32) read-modify-written once -- per item of the group
     ev = TIMER.span(kernel_name("wgrad", x0.dtype, N, IH, IW, Cin, Cout, ksize, stride, pad),
-                    2.0 * len(items) * N * OH * OW * Cout * Cin * ksize * ksize) if TIMER else None
+                    2.0 * len(items) * N * OH * OW * Cout * Cin * ksize * ksize, 1,
+                    nbytes=len(items) * ((N * IH * IW * Cin + N * OH * OW * Cout) * x0.element_size() + 8 * Cout * Cin * ksize * ksize),
+                    shape=("wgrad", N, IH, IW, Cin, Cout, ksize, stride)) if TIMER else None
     if ev:
         ev[0].record()
     _lib.check(_lib.load().et_conv2d_wgrad_grouped(arr, len(items), et_dtype(x0), N, IH, IW, Cin, Cout, ksize, ksize,

@@ -31,14 +31,15 @@ def main(path, n_cu=256):
         f = fam[key]
         f[0] += r["launches"]; f[1] += r["ms"]; f[2] += r["flops"]; f[3] += r["bytes"]
     print(f"{sum(v[1] for v in agg.values()):.2f} ms of conv launches in the step (both streams, overlap counted twice)\n")
-    for (kern, sh), v in sorted(agg.items(), key=lambda x: -x[1][1])[:40]:
+    for (kern, sh), v in sorted(agg.items(), key=lambda x: -x[1][1])[:48]:
         extra = ""
         if sh and ("pp_kernel" in kern or "256, 256" in kern):
             op, N, IH, IW, Cin, Cout, k, st = sh
             M = N * IH * IW if (op == "dgrad" or st == 1) else N * (IH // st) * (IW // st)
             tiles = math.ceil(M / 256) * math.ceil((Cout if op == "fwd" else Cin) / 256)
             extra = f"  tiles {tiles} = {tiles / n_cu:.2f} rounds, last-round fill {tiles / n_cu / math.ceil(tiles / n_cu):.2f}"
-        print(f"{v[1]:7.3f} ms  x{v[0]:3d}  {v[2] / v[1] / 1e9:6.0f} TFLOP/s  {kern[:46]:46s} {sh}{extra}")
+        tb = f"  {v[3] / v[1] / 1e9:5.2f} TB/s alg." if v[3] else ""
+        print(f"{v[1]:7.3f} ms  x{v[0]:3d}  {v[2] / v[1] / 1e9:6.0f} TFLOP/s{tb}  {kern[:46]:46s} {sh}{extra}")
     print()
     for key, v in sorted(fam.items(), key=lambda x: -x[1][1]):
         print(f"{v[1]:7.2f} ms  x{v[0]:4d}  {v[2] / v[1] / 1e9:6.0f} TFLOP/s  {v[3] / v[1] / 1e9:6.2f} TB/s algorithmic  {key}")
