@@ -42,6 +42,11 @@ __device__ __forceinline__ void et_pin_loaded(u32x4& v) {
 // workgroups per CU the short-K 128x64 tile (32-wide chunks, 3-deep ring, 36 KB of LDS) is compiled for: 3 = 129 VGPRs, 4 = 128 + two spilled
 // dwords.  Four resident workgroups keep more bytes in flight on these HBM-bound 1x1 layers: step 53.70 -> 53.38 ms, same box, two
 // alternations (profiles/r03_shortk_four_workgroups_ab.txt)
+#ifndef ET_S1_NT
+#define ET_S1_NT 1               // non-temporal LDS-DMA for the stream kernel's activation rows: every row is read once, by one CU
+                                 // (isolated, B = 64: 128->64 @160 119.7 -> 113.0 us, 128->128 @160 160 -> 153, 256->256 @80 86 -> 83; 0 = default
+                                 // policy; on the activation units of the ping-pong row-shift tile the same hint LOST 1-2 %: 116.5 -> 118.6 us)
+#endif
 #ifndef ET_GLDS_SHORTK_WGS
 #define ET_GLDS_SHORTK_WGS 4
 #endif
@@ -1541,7 +1546,11 @@ __global__ __launch_bounds__(64 * WM * WN, WGS) void conv1x1_stream_kernel(const
             for (int j = 0; j < PER; ++j) {
                 const int p = m0i + a_row[j];
                 const T* src = p < g.M ? X + ((size_t)p * g.ldx + is_kc * 64 + a_lv[j]) : ZERO;
+#if ET_S1_NT
+                et_glds16_nt(src, wbase + j * DT);
+#else
                 et_glds16(src, wbase + j * DT);
+#endif
             }
         }
         ++issued;

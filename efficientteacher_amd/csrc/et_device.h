@@ -93,5 +93,10 @@ __device__ __forceinline__ void et_glds16(const void* g, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
+// the same with the non-temporal cache policy (aux = 2): for a stream that ONE CU reads once (MI355X_MICROARCH.md "nt-weights")
+__device__ __forceinline__ void et_glds16_nt(const void* g, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 2);
+}
 // s_waitcnt vmcnt(0): all of this wave's LDS-DMA writes have landed (expcnt / lgkmcnt left at max)
 __device__ __forceinline__ void et_wait_vmem() { __builtin_amdgcn_s_waitcnt(0x0F70); }
