@@ -169,32 +169,30 @@ def _hip_ssod_losses(cfg, device, dtype, batch, synth):
     return items, tp, sd
 
 
-def reference_timing(Bl, Bu, S, port_images_per_s):
-    """The IMPORTED reference against the port.  Where the reference tree is reachable (ET_REFERENCE, or /root/reference: the build
-    container) it is timed directly, same batch, same cores; everywhere else (the GPU box: the reference cannot travel, SURVEY.md
-    8c) the committed ratio of profiles/r04_reference_vs_port_cpu.json -- both timed in ONE process on the build container's cores
-    (oracle/time_reference_step.py) -- turns this host's port figure into an estimate of the reference's."""
-    out = {}
-    ref_root = os.environ.get("ET_REFERENCE", "/root/reference")
+def reference_timing(Bl, Bu, S, seconds=20.0):
+    """The IMPORTED reference (SSODTrainer.train_instance + update_optimizer, /root/reference's own code) timed on THIS host's
+    cores in THIS run: oracle/time_reference_step.py in a subprocess (its import shims patch torch and sys.modules), against
+    ET_REFERENCE if set, else the shipped byte-compiled image oracle/_ref/ (oracle/make_ref.py: git-ignored, built by
+    __graft_entry__.build() in the build container, travels with the push), else the live /root/reference.  None when no
+    reference is reachable (a checkout without the image): the caller then reports the port, `kind: "port"`."""
+    import subprocess
+    ref_root = os.environ.get("ET_REFERENCE")
+    if not ref_root:
+        for cand in (os.path.join(ROOT, "oracle", "_ref"), "/root/reference"):
+            if os.path.isdir(os.path.join(cand, "models")):
+                ref_root = cand
+                break
+    if not ref_root or Bl != Bu:
+        return None
+    cores = min(os.cpu_count() or 1, 32)
     try:
-        r = json.load(open(os.path.join(ROOT, "profiles", "r04_reference_vs_port_cpu.json")))
-        out["reference_ratio"] = dict(port_over_reference=r["port_over_reference"], cores=r["cores"], where=r["where"],
-                                      reference_images_per_s=r["images_per_s"], port_images_per_s=r["port_images_per_s"],
-                                      source="profiles/r04_reference_vs_port_cpu.json",
-                                      note="the plain-torch port is FASTER than the imported reference by this factor on the same cores "
-                                           "(the reference's loss / assigner code runs many small tensor ops per target)")
-        out["reference_estimate_images_per_s"] = port_images_per_s / r["port_over_reference"]
-    except (OSError, ValueError, KeyError):
-        pass
-    if os.path.isdir(ref_root) and os.environ.get("ET_BENCH_TIME_REFERENCE", "0") == "1":
-        import subprocess
-        try:
-            p = subprocess.run([sys.executable, "-m", "oracle.time_reference_step", str(Bl)], cwd=ROOT, capture_output=True, text=True, timeout=900)
-            r = json.loads(p.stdout.strip().splitlines()[-1])
-            out["reference_here"] = dict(images_per_s=r["images_per_s"], cores=r["cores"], port_over_reference=r["port_over_reference"])
-        except Exception as e:
-            out["reference_here"] = dict(error=f"{type(e).__name__}: {e}")
-    return out
+        p = subprocess.run([sys.executable, "-m", "oracle.time_reference_step", str(Bl), "--cores", str(cores), "--seconds", str(seconds)],
+                           cwd=ROOT, env=dict(os.environ, ET_REFERENCE=ref_root), capture_output=True, text=True, timeout=900)
+        r = json.loads(p.stdout.strip().splitlines()[-1])
+        return dict(value=r["images_per_s"], cores=r["cores"], steps=r["steps"], s_per_step=r["s_per_step"],
+                    where=os.path.relpath(ref_root, ROOT) if ref_root.startswith(ROOT) else ref_root)
+    except Exception as e:
+        return dict(error=f"{type(e).__name__}: {e}"[:400])
 
 
 def cpu_baseline_ssod(cfg, device, seconds=25.0, Bl=2, Bu=2):
@@ -275,7 +273,17 @@ def cpu_baseline_ssod(cfg, device, seconds=25.0, Bl=2, Bu=2):
                 sample=f"{'YOLOv8' if v8 else 'YOLOv5l'} SSOD step, {Bl} labeled + {Bu} unlabeled {S}x{S}, {n} steps, plain-torch fp32 CPU port "
                        f"(oracle/step.py; all {ref['t9'].shape[0]} pseudo labels)")
     if not v8:
-        base.update(reference_timing(Bl, Bu, S, base["value"]))
+        ref_t = reference_timing(Bl, Bu, S)
+        if ref_t and "value" in ref_t:
+            # north_star: "the reference's CPU path timed on the host cores of the same box in the same run"
+            port = base
+            base = dict(value=ref_t["value"], unit="images/s", cores=ref_t["cores"], kind="reference",
+                        sample=f"the IMPORTED reference's SSODTrainer.train_instance + update_optimizer (trainer/ssod_trainer.py:587-680, 458-488), "
+                               f"YOLOv5l, {Bl} labeled + {Bu} unlabeled {S}x{S}, {ref_t['steps']} steps, fp32 CPU, from {ref_t['where']} "
+                               "(oracle/make_ref.py; torchvision.ops.nms stubbed by oracle/nms.py)",
+                        port=port, port_over_reference=port["value"] / ref_t["value"])
+        elif ref_t:
+            base["reference_error"] = ref_t["error"]
     return base, parity
 
 

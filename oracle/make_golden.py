@@ -66,6 +66,19 @@ def case_nms():
         "c": (synth_pred(rng, 2, 300, 5, obj_pow=8), 0.25, 0.45),
         "empty": (synth_pred(rng, 2, 64, 4) * np.float32(0.05), 0.1, 0.65),
     }
+    # exact tie at the threshold: IoU == fp32(0.6) -- xyxy [100,100,110,110] (area 100) against [100,100,106,110] (inside it, area 60):
+    # inter / union = 60 / 100, and the correctly rounded fp32 quotient IS fp32(0.6).  The pinned compare (torchvision's CUDA kernel,
+    # fp32 threshold: oracle/nms.py header) KEEPS the second box, the CPU kernel's double compare would drop it; rows 2-3 / 4-5 are
+    # the controls one ulp-ish either side (6.01 / 5.99 wide), 6-7 an unrelated pair
+    tie = np.zeros((1, 8, 5 + 2), np.float32)
+    tie[0, :, 0:4] = [[105, 105, 10, 10], [103, 105, 6, 10], [305, 105, 10, 10], [303.005, 105, 6.01, 10],
+                      [505, 105, 10, 10], [502.995, 105, 5.99, 10], [105, 305, 10, 10], [400, 400, 30, 30]]
+    tie[0, :, 4] = [0.9, 0.8, 0.9, 0.8, 0.9, 0.8, 0.7, 0.6]
+    tie[0, :, 5] = 0.95
+    cases["tie06"] = (tie, 0.1, 0.6)
+    bx = o_nms.xywh2xyxy(tie[0, :2, :4])
+    assert o_nms.nms(bx, tie[0, :2, 4], 0.6).tolist() == [0, 1] and o_nms.nms(bx, tie[0, :2, 4], 0.6, "cpu_double").tolist() == [0], \
+        "tie06 must separate the fp32 (CUDA) threshold compare from the double (CPU) one"
     # cluster boxes so that suppression actually happens
     for k in ("a", "b"):
         p = cases[k][0]
@@ -829,6 +842,10 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "labelmatch":
         print("== LabelMatch")
         case_labelmatch()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "nms":
+        print("== nms")
+        case_nms()
         return
     if len(sys.argv) > 1 and sys.argv[1] == "nms_options":
         print("== non_max_suppression_ssod options")

@@ -9,6 +9,17 @@ Restates, in numpy fp32:
     has inter/(area_i+area_j-inter) > thr (strict), area=(x2-x1)*(y2-y1),
     inter=max(0,xx2-xx1)*max(0,yy2-yy1), all fp32; returns int64 indices into
     the input in descending-score order.
+    WHICH THRESHOLD COMPARE IS PINNED: the fp32 one, ``ovr > float(thr)`` -- the
+    rule of torchvision's *CUDA* kernel (torchvision/csrc/ops/cuda/nms_kernel.cu:
+    ``devIoU(a, b, const float threshold)``), the kernel the reference trains on
+    (utils/general.py:976 runs on the model's device).  The CPU kernel keeps
+    ``iou_threshold`` a double and compares ``double(ovr) > thr``.  The two differ
+    ONLY when ovr == fp32(thr) exactly and fp32(thr) > thr: 0.6 (val.py's
+    setting) is such a value (fp32(0.6) = 0.60000002...: the CPU rule suppresses
+    an exact tie, the CUDA rule keeps it), 0.65 (SSOD.nms_iou_thres) and 0.45 are
+    not.  ``nms(..., thr_compare="cpu_double")`` restates the other rule; the
+    golden case ``tie06`` (tests/golden/nms.npz) holds an exact tie at 0.6 and the
+    keep set under the pinned (CUDA) rule.
   * ``non_max_suppression_ssod``  utils/general.py:887-992
   * ``non_max_suppression``       utils/general.py:994-1100  (val.py path, row f-1)
   * ``xywh2xyxy`` / ``xyxy2xywh`` utils/general.py:630-637 / 549-556
@@ -38,8 +49,10 @@ def xyxy2xywh(x):
     return y
 
 
-def nms(boxes, scores, iou_thres):
-    """Greedy NMS, fp32, returns int64 keep indices (descending score)."""
+def nms(boxes, scores, iou_thres, thr_compare="cuda_fp32"):
+    """Greedy NMS, fp32, returns int64 keep indices (descending score).  thr_compare: "cuda_fp32" (pinned: threshold rounded to
+    fp32, torchvision's CUDA kernel) or "cpu_double" (torchvision's CPU kernel: fp32 overlap promoted to double) -- see the header."""
+    assert thr_compare in ("cuda_fp32", "cpu_double")
     boxes = np.ascontiguousarray(boxes, dtype=F32)
     scores = np.ascontiguousarray(scores, dtype=F32)
     n = boxes.shape[0]
@@ -48,7 +61,7 @@ def nms(boxes, scores, iou_thres):
     order = np.argsort(-scores, kind="stable")
     x1, y1, x2, y2 = (boxes[order, k] for k in range(4))
     areas = (x2 - x1) * (y2 - y1)
-    thr = F32(iou_thres)
+    thr = F32(iou_thres) if thr_compare == "cuda_fp32" else np.float64(iou_thres)
     suppressed = np.zeros(n, bool)
     keep = []
     with np.errstate(invalid="ignore", divide="ignore"):
@@ -66,7 +79,7 @@ def nms(boxes, scores, iou_thres):
             h = np.maximum(F32(0), yy2 - yy1)
             inter = w * h
             ovr = inter / (areas[i] + areas[i + 1:] - inter)
-            suppressed[i + 1:] |= ovr > thr
+            suppressed[i + 1:] |= (ovr > thr) if thr_compare == "cuda_fp32" else (ovr.astype(np.float64) > thr)
     return np.asarray(keep, np.int64)
 
 

@@ -13,7 +13,7 @@ def _run(hip, pred, ct, it, max_det=300):
     return dets.cpu().numpy(), counts.cpu().numpy(), keep.cpu().numpy(), ncand.cpu().numpy()
 
 
-@pytest.mark.parametrize("case", ["a", "b", "c", "empty"])
+@pytest.mark.parametrize("case", ["a", "b", "c", "empty", "tie06"])
 def test_nms_golden(hip, case):
     g = golden("nms")
     pred, (ct, it) = g[f"{case}_pred"], g[f"{case}_thr"]
@@ -115,7 +115,7 @@ def _run_general(hip, pred, ct, it, **kw):
     return dets.cpu().numpy(), counts.cpu().numpy(), keep.cpu().numpy(), ncand.cpu().numpy()
 
 
-@pytest.mark.parametrize("case", ["a", "b", "c", "empty"])
+@pytest.mark.parametrize("case", ["a", "b", "c", "empty", "tie06"])
 def test_nms_val_golden(hip, case):
     """multi_label NMS vs the reference's own non_max_suppression(multi_label=True) output."""
     g = golden("nms")

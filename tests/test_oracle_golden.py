@@ -13,13 +13,28 @@ from tests.conftest import golden
 
 def test_nms_oracle_vs_golden():
     g = golden("nms")
-    for case in ("a", "b", "c", "empty"):
+    for case in ("a", "b", "c", "empty", "tie06"):
         ct, it = g[f"{case}_thr"]
         dets, keeps = o_nms.non_max_suppression_ssod(g[f"{case}_pred"], ct, it)
         assert np.array_equal(np.concatenate(dets, 0), g[f"{case}_dets"])
         assert np.array_equal(np.concatenate(keeps, 0), g[f"{case}_keep"])
         v = o_nms.non_max_suppression(g[f"{case}_pred"], ct, it, multi_label=True)
         assert np.array_equal(np.concatenate(v, 0), g[f"{case}_val_dets"])
+
+
+def test_nms_threshold_compare_rule_is_the_cuda_kernels():
+    """tie06: IoU == fp32(0.6) exactly.  Pinned = torchvision's CUDA kernel (fp32 threshold: the tie survives); the CPU kernel's double
+    compare would suppress it (oracle/nms.py header) -- the golden holds the pinned rule and the two rules must differ on this case"""
+    g = golden("nms")
+    bx = o_nms.xywh2xyxy(g["tie06_pred"][0, :, :4])
+    sc = g["tie06_pred"][0, :, 4]
+    cuda = o_nms.nms(bx, sc, 0.6)
+    cpu = o_nms.nms(bx, sc, 0.6, thr_compare="cpu_double")
+    assert np.array_equal(cuda, g["tie06_keep"])
+    assert 1 in cuda.tolist() and 1 not in cpu.tolist() and len(cpu) == len(cuda) - 1
+    # 0.65 (SSOD.nms_iou_thres): fp32(0.65) < 0.65, the rules cannot differ
+    for thr in (0.65, 0.45):
+        assert np.array_equal(o_nms.nms(bx, sc, thr), o_nms.nms(bx, sc, thr, thr_compare="cpu_double"))
 
 
 def test_nms_ssod_options_oracle_vs_golden():
