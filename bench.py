@@ -608,6 +608,22 @@ def roofline_of(res, dump=None):
             traffic, traffic_src = pt["kernels"][dom]["bytes_per_launch"], pt["source"]
     except (OSError, ValueError, KeyError):
         pass
+    # MFMA utilisation of the same kernel as the HARDWARE counts it (north_star: "rocprof ... MFMA utilisation"): matrix-pipe busy
+    # cycles over (4 SIMDs x 256 CUs x kernel cycles) from a committed `rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES ...` pass over this
+    # very command (tools/pmc_mfma.py -> profiles/pmc_mfma.json).  `frac` above it is FLOPs / time / 2.5 PFLOP/s at the 2.4 GHz the
+    # peak is quoted at; the counter fraction is against the clock the kernel actually ran at, so it reads higher by max / effective.
+    mfma = None
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_mfma.json")))
+        km = pm["kernels"].get(dom)
+        if km and km.get("mfma_busy_frac") is not None:
+            mfma = dict(mfma_busy_frac=km["mfma_busy_frac"], cu_busy_frac=km.get("cu_busy_frac"), wait_inst_frac=km.get("wait_inst_frac"),
+                        avg_us_in_that_run=km.get("avg_us"), effective_clock_ghz=pm.get("effective_clock_ghz"), clock_source=km.get("clock_source"),
+                        mfma_cycles_counted_over_expected=km.get("mfma_cycles_counted_over_expected"), source=pm.get("source"),
+                        top_kernels={k: round(pm["kernels"][k]["mfma_busy_frac"], 4) for k in pm.get("top_by_time", [])[:8]
+                                     if pm["kernels"][k].get("mfma_busy_frac") is not None})
+    except (OSError, ValueError, KeyError):
+        pass
     roof = dict(bound="mfma", kernel=dom, achieved=per_launch_flops / per_launch_s / 1e12, peak=PEAK_BF16 / 1e12,
                 unit="TFLOP/s", frac=per_launch_flops / per_launch_s / PEAK_BF16, traffic=traffic,
                 traffic_unit="bytes per launch (2*FETCH_SIZE + WRITE_SIZE)", traffic_source=traffic_src,
@@ -616,6 +632,8 @@ def roofline_of(res, dump=None):
                 avg_launch_us=per_launch_s * 1e6, algorithmic_gflop_per_launch=per_launch_flops / 1e9,
                 all_conv_kernels=dict(ms_per_step=conv_ms, tflops=conv_fl / (conv_ms * 1e-3) / 1e12,
                                       algorithmic_tflop_per_step=conv_fl / 1e12))
+    roof["mfma_busy_frac"] = mfma["mfma_busy_frac"] if mfma else None
+    roof["mfma_counters"] = mfma
     solo = res.get("solo")
     if solo and dom in solo:
         sd = solo[dom]

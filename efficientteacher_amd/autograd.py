@@ -11,10 +11,9 @@ from . import ops
 ACT_CODE = {"silu": ops.ACT_SILU, "relu": ops.ACT_RELU, "none": ops.ACT_NONE}
 
 # the reduce pass of BatchNorm backward inside the epilogue of the dgrad that produces its input gradient
-# (et_conv2d_dgrad_bn); ET_FUSE_BN_BWD=0 restores the separate reduce pass everywhere (A/B knob)
-import os as _os
-FUSE_BN_BWD = _os.environ.get("ET_FUSE_BN_BWD", "1") != "0"
-# ... and which dgrads carry those sums: bit 1 = the 1x1 layers, bit 2 = the k > 1 layers.  Measured on the YOLOv5l SSOD step, same box,
+# (et_conv2d_dgrad_bn).  Constants since r05 (were the env knobs ET_FUSE_BN_BWD / ET_FUSE_BN_BWD_K; every arm has an A/B file):
+FUSE_BN_BWD = True
+# which dgrads carry those sums: bit 1 = the 1x1 layers, bit 2 = the k > 1 layers.  Measured on the YOLOv5l SSOD step, same box,
 # alternating (profiles/r03_fuse_bn_bwd_by_kernel_size_ab.txt): 3 / 1 / 2 / 0 = 54.70 / 54.78 / 55.00 / 54.74 ms -- the fusion moves the
 # reduce pass's time between the BatchNorm family and the dgrads, the step does not change.  Default 1: the HBM-bound 1x1 dgrads carry
 # the sums (one y read instead of a dz + y pass), the MFMA-bound 3x3 dgrads keep a pure GEMM epilogue (their launches were 160 us
@@ -23,9 +22,9 @@ FUSE_BN_BWD = _os.environ.get("ET_FUSE_BN_BWD", "1") != "0"
 # issues the producer's y reads of a whole slab round up front (conv.hip conv_epilogue_act, EPF) instead of one load + wait per store
 # iteration; the register-bound 256x256 tiles cannot afford that prefetch and keep the separate reduce pass.  Measured, alternating,
 # two boxes (profiles/r04_stream_full_and_fuse_ab_current_build.txt, r04_knob_combinations_ab.txt): 1 -> 5 = 52.27 / 52.46 -> 52.15 /
-# 52.29 ms and 51.37 / 51.43 -> 51.24 / 51.31 ms: BatchNorm family -0.7 ms, gather-GEMMs +0.6 ms, -0.1 ms net in every pair.  Default 5.
+# 52.29 ms and 51.37 / 51.43 -> 51.24 / 51.31 ms: BatchNorm family -0.7 ms, gather-GEMMs +0.6 ms, -0.1 ms net in every pair.  Hence 5.
 # (An earlier A/B of this round that showed +0.15 ms had run a STALE library without the prefetch: profiles/r04_fuse_bn_bwd_rs_tiles_ab.txt.)
-FUSE_BN_BWD_K = int(_os.environ.get("ET_FUSE_BN_BWD_K", "5"))
+FUSE_BN_BWD_K = 5
 _RS_DGRAD = {}
 
 
@@ -49,9 +48,9 @@ def _fuse_into(cs, bn, x=None):
     if cs.k > 1 and (FUSE_BN_BWD_K & 4) and x is not None and _dgrad_on_rs_tile(cs, x):
         return bn
     return None
-# two-consumer tensors: the later consumer's backward adds into the earlier one's gradient in its own kernel (GradFork below);
-# ET_GRAD_FORK=0 leaves the sum to autograd (a torch bf16 add per tensor: A/B knob)
-GRAD_FORK = _os.environ.get("ET_GRAD_FORK", "1") != "0"
+# two-consumer tensors: the later consumer's backward adds into the earlier one's gradient in its own kernel (GradFork below)
+# instead of a torch bf16 add per tensor by autograd (step-neutral, six ATen launches fewer: NOTEBOOK.md round 3)
+GRAD_FORK = True
 
 # set by parallel.FlatDataParallel: callable(ConvSlot) invoked right after a layer's wgrad has been
 # launched, so that the gradient all-reduce of finished arena chunks overlaps the rest of backward

@@ -1021,9 +1021,7 @@ __global__ __launch_bounds__(64 * WM * WN, BN <= 64 ? 3 : 2) void conv_gemm_rs_k
             __builtin_amdgcn_s_barrier();                // ... for every wave; all reads of the slots rewritten below are done
             constexpr int kn = k < 2 ? k + 1 : 0;
             if (k < 2 || more_units) stage_b(slotB + (bs ^ 1) * B_VEC, (k < 2 ? j : nj) * 3 + (sgn > 0 ? kn : 2 - kn), k < 2 ? cv_u : ncv);
-#if !defined(RS_ABL) || !(RS_ABL & 4)
             if (k == 0 && more_units) stage_a(slotA + ((u + 1) & 1) * A_VEC, nj, ncv);
-#endif
             mma_step(sa, slotB + bs * B_VEC, ktag);
             bs ^= 1;
         };
@@ -1144,9 +1142,6 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_pp_kernel(const uint16_t* __
     auto stage_piece = [&](int k, int buf, int jj) {
         u32x4* const wbase = lds_raw + (2 * k + buf) * HALF_VEC + wave * 64;
         if (k < 2) {
-#if defined(RS_ABL) && (RS_ABL & 8)
-            if (udx != 0) return;                      // timing probe: the activation half-tiles of one tap per kernel row only
-#endif
             const int i = k;
             const int doff = (udy * g.IW + udx) * g.ldx + (cv_u + lv) * VEC;
             const bool ok = (bool)((a_okm >> (i * 2 + jj)) & 1u) & ((unsigned)(a_iy[i][jj] + udy) < (unsigned)g.IH) &
@@ -1860,8 +1855,7 @@ static int device_cus() {
 static int try_launch_stem(const void* x, const void* w, void* y, int dtype, int N, int IH, int IW, int Cin, int ldx, int Cout,
                            int KH, int KW, int stride, int pad, int ldy, const float* scale, const float* bias, int act,
                            const void* residual, float* stats, const void* zero16, hipStream_t s, bool launch) {
-    static const int use_stem = env_int("ET_CONV_STEM", 1);
-    if (!use_stem || dtype != ET_BF16 || KH != 6 || KW != 6 || stride != 2 || pad != 2 || Cin != 8 || Cout > 64 || Cout % 8 ||
+    if (dtype != ET_BF16 || KH != 6 || KW != 6 || stride != 2 || pad != 2 || Cin != 8 || Cout > 64 || Cout % 8 ||
         residual || !zero16)
         return 0;
     if (!launch) return 1;
@@ -2742,53 +2736,44 @@ static GemmPlan plan_gemm(const GatherGeom& g, int elem_bytes, bool have_zero_pa
     // Build-time constants that were tuning knobs in r01 / r02 (swept on the step, profiles/r02_step_knob_sweep*_same_box.log, and
     // per layer, profiles/r02_microbench_narrow_k.log): GEMMs with K <= 128 elements use the 128x64 tile (3 workgroups per CU for
     // the HBM-bound short-K 1x1 layers; at K = 256 the 128-wide tile re-reads the activations half as often: 150 -> 124 us on
-    // 256->256 @80x80, B=64); the LDS ring shape follows K (below).  What stays switchable are whole code paths, for A/B runs and
-    // for the tests that exercise them: ET_CONV_GLDS=0 VGPR staging, ET_CONV_BIG=0 no 256x256 tiles, ET_CONV_PP=0 the lockstep
-    // 256x256 kernel instead of the ping-pong one, ET_CONV_BIG_MINFILL (below), ET_CONV_STEM=0 the generic kernel for the stem.
+    // 256->256 @80x80, B=64); the LDS ring shape follows K (below).  The whole-code-path switches of r02-r04 (ET_CONV_GLDS / _BIG /
+    // _PP / _BIG_MINFILL / _S1 / _RS / _PPRS / _STEM) are gone with their losing arms: each has a same-box A/B file under profiles/
+    // (NOTEBOOK.md rounds 2-4); the register-staged kernel remains for fp32 parity mode and for callers without a zero page.
     constexpr int narrow_k = 128;
-    static const int use_glds = env_int("ET_CONV_GLDS", 1);
-    static const int big = env_int("ET_CONV_BIG", 1);
-    static const int use_pp = env_int("ET_CONV_PP", 1);
     const bool bf16 = elem_bytes == 2;
     const bool wide = g.Cout > 64 && !(narrow_k > 0 && g.T * g.Cin <= narrow_k);
-    const bool glds = use_glds && have_zero_page;
+    const bool glds = have_zero_page;
     GemmPlan p{glds ? GEMM_GLDS : GEMM_REG, 128, wide ? 128 : 64, 2, 2, g.CV % 8 == 0 ? 8 : 4, 2, g.CV % 4 == 0, 0, 0, 0, 0};
     if (!(bf16 && glds && g.CV % 8 == 0)) return p;
-    // 1x1 layers with K <= 256 and <= 256 output channels: the persistent streaming kernel (ET_CONV_S1=0: the tiled kernels below)
-    // ET_CONV_S1: 0 off, 1 the plain layers only, 2 (default) also the dgrads with a residual / accumulate / BN-backward sums in
-    // the epilogue.  Measured (profiles/r04_mb_1x1_stream_kernel_ab.txt, r04_stream_full_and_fuse_ab_current_build.txt): plain layers
+    // 1x1 layers with K <= 256 and <= 256 output channels: the persistent streaming kernel, also for the dgrads with a residual /
+    // accumulate / BN-backward sums in the epilogue.  Measured (profiles/r04_mb_1x1_stream_kernel_ab.txt, r04_stream_full_and_fuse_ab_current_build.txt): plain layers
     // 4.4-5.3 TB/s against 3.7-5.1 of the tiled kernels (128->128 @80x80: 54 -> 46 us, 256->256 @80x80: 111 -> 86-97 us); step, same
-    // box, alternating: 0 / 1 / 2 = 53.18 / 52.27-52.46 / 52.10-52.13 ms.  The FULL epilogue only pays since its reads are issued a
+    // box, alternating, tiled kernels / stream kernel for the plain layers only / for all = 53.18 / 52.27-52.46 / 52.10-52.13 ms.  The FULL epilogue only pays since its reads are issued a
     // slab round at a time (conv_epilogue_act, EPF): with one load + wait per store iteration it LOST to the tiled kernels
     // (128->128 @80x80 with residual + sums: 105 -> 111 us) -- those loads return in order BEHIND every LDS-DMA piece the ring has in
     // flight, and the tiled kernels hide that latency across four short-lived workgroups per CU.
-    static const int use_s1 = env_int("ET_CONV_S1", 2);
-    if (use_s1 && (use_s1 >= 2 || !full_epilogue) && s1_eligible(g)) return plan_s1(g, full_epilogue);
+    if (s1_eligible(g)) return plan_s1(g, full_epilogue);
     // short-K GEMMs (K <= 256, i.e. <= 4 chunks of 64) run 32-wide chunks in a 3-deep ring -- 48 KB of LDS, three
     // workgroups per CU, two chunks in flight each (measured 3-10 % on the 1x1 layers); everything else the 64-wide
     // double buffer (deeper rings or taller 4-wave tiles cost occupancy and lose: profiles/)
     int ring = g.T * g.Cin <= 256 ? 12843 : 12882;
     // 8-wave 256x256 tile (one workgroup per CU, half the L2->LDS bytes per flop): 3x3 layers with >= 256 output
     // channels, and deep 1x1 layers when the grid fills whole residency rounds reasonably
-    if (big && g.Cout >= 256) {
+    if (g.Cout >= 256) {
         const int n_cu = device_cus();
         const long long blocks = (long long)((g.M + 255) / 256) * ((g.Cout + 255) / 256);
         const double rounds = (double)blocks / n_cu;
         const bool fills = (double)((blocks + n_cu - 1) / n_cu) / rounds <= 1.35;
-        // a grid that leaves most CUs without a 256x256 tile (the teacher's 32-image 20x20 layers: 100 tiles) is better
-        // served by four times as many 128x128 tiles at two workgroups per CU (ET_CONV_BIG_MINFILL, percent of the CUs)
-        static const int minfill = env_int("ET_CONV_BIG_MINFILL", 0);
-        const bool enough = blocks * 100 >= (long long)minfill * n_cu;
-        if (enough && (g.TT > 1 || (g.T * g.Cin >= 512 && fills))) ring = use_pp ? 25680 : 25682;
+        // (a grid that leaves most CUs without a 256x256 tile -- the teacher's 32-image 20x20 layers: 100 tiles -- still runs it: 128x128
+        // tiles for such grids won isolated and lost on the step three times, profiles/r02_microbench_big_tile_minfill.log,
+        // r03_big_tile_minfill_ab.txt, NOTEBOOK.md round 4: the 256x256 tile costs less CU-time and the other stream fills the rest)
+        if (g.TT > 1 || (g.T * g.Cin >= 512 && fills)) ring = 25680;
     }
-    // 3x3 stride-1 layers on the 128-row tiles: activation rows shared by the three taps of a kernel row (ET_CONV_RS=0: off)
-    static const int use_rs = env_int("ET_CONV_RS", 1);
-    if (use_rs && ring == 12882 && rs_eligible(g, 128, RS_A_ROWS(128))) return GemmPlan{GEMM_RS, 128, wide ? 128 : 64, 2, 2, 8, 2, true, 0, 0, 0, 0};
-    static const int use_pprs = env_int("ET_CONV_PPRS", 1);
-    if (use_pprs && ring == 25680 && rs_eligible(g, 256, PPRS_ROWS)) return GemmPlan{GEMM_PPRS, 256, 256, 2, 4, 8, 2, true, 0, 0, 0, 0};
+    // 3x3 stride-1 layers on the 128-row tiles: activation rows shared by the three taps of a kernel row
+    if (ring == 12882 && rs_eligible(g, 128, RS_A_ROWS(128))) return GemmPlan{GEMM_RS, 128, wide ? 128 : 64, 2, 2, 8, 2, true, 0, 0, 0, 0};
+    if (ring == 25680 && rs_eligible(g, 256, PPRS_ROWS)) return GemmPlan{GEMM_PPRS, 256, 256, 2, 4, 8, 2, true, 0, 0, 0, 0};
     switch (ring) {
         case 25680: p = GemmPlan{GEMM_PP, 256, 256, 2, 4, 8, 2, true, 0, 0, 0, 0}; break;
-        case 25682: p = GemmPlan{GEMM_GLDS, 256, 256, 2, 4, 8, 2, true, 0, 0, 0, 0}; break;
         case 12843: p.BKV = 4; p.NS = 3; break;
         default: break;
     }
@@ -2886,7 +2871,6 @@ static int launch_gemm(const void* X, const void* W, void* Y, const void* zero16
     }
     if (p.kind == GEMM_GLDS) {
         if constexpr (sizeof(T) == 2) {
-            if (p.WN == 4) { ET_GLDS(256, 256, 2, 4, 8, 2, true); return 0; }      // lockstep 256x256 (ET_CONV_PP=0)
             switch (key) {
                 case 12812843: ET_GLDS(128, 128, 2, 2, 4, 3, true); return 0;     // short-K: 32-wide chunks, 3-deep ring
                 case 12806443: ET_GLDS(128, 64, 2, 2, 4, 3, true); return 0;
@@ -2921,15 +2905,19 @@ extern "C" int et_conv2d_stats_rows(int N, int OH, int OW) { return (N * OH * OW
 extern "C" int et_conv2d_stats_rows_for(int op, int dtype, int N, int IH, int IW, int Cin, int Cout, int KH, int KW, int stride, int pad,
                                         int have_zero_page) {
     // rows of the partial-statistics buffer the kernel selected for this problem writes: op 0 = stats_partial of et_conv2d_fwd,
-    // op 1 = bn_stats_partial of et_conv2d_dgrad_bn (stride 1).  Arguments of the FORWARD conv.  One row per 64 output pixels for
-    // the tiled kernels; the persistent 1x1 kernel writes one row per (workgroup, row group).
-    if (KH * KW > CONV_MAX_TAPS || stride < 1 || N <= 0 || (op != 0 && op != 1)) return -2;
+    // op 1 = bn_stats_partial of et_conv2d_dgrad_bn (stride 1), op 2 = stats_partial of an et_conv2d_fwd call that ALSO passes a
+    // residual (launch_gemm then selects the full-epilogue plan, whose persistent 1x1 form has another tile height and grid: asking
+    // with op 0 for such a call used to return the plain plan's row count -- ADVICE r04).  Arguments of the FORWARD conv.  One row
+    // per 64 output pixels for the tiled kernels; the persistent 1x1 kernel writes one row per (workgroup, row group).
+    if (KH * KW > CONV_MAX_TAPS || stride < 1 || N <= 0 || op < 0 || op > 2) return -2;
+    const bool fwd_full = op == 2;
+    if (fwd_full) op = 0;
     const int eb = dtype == ET_F32 ? 4 : 2, vec = dtype == ET_F32 ? 4 : 8;
     GatherGeom g;
     int rc;
     if (op == 0) {
-        if (try_launch_stem(nullptr, nullptr, nullptr, dtype, N, IH, IW, Cin, Cin, Cout, KH, KW, stride, pad, Cout, nullptr, nullptr, 0, nullptr,
-                            nullptr, have_zero_page ? (const void*)&g : nullptr, nullptr, false)) {
+        if (!fwd_full && try_launch_stem(nullptr, nullptr, nullptr, dtype, N, IH, IW, Cin, Cin, Cout, KH, KW, stride, pad, Cout, nullptr, nullptr, 0, nullptr,
+                                         nullptr, have_zero_page ? (const void*)&g : nullptr, nullptr, false)) {
             const int OH = (IH + 2 * pad - KH) / stride + 1, OW = (IW + 2 * pad - KW) / stride + 1;
             return (N * OH * OW + 63) / 64;
         }
@@ -2939,7 +2927,7 @@ extern "C" int et_conv2d_stats_rows_for(int op, int dtype, int N, int IH, int IW
         rc = dgrad_geom(g, 0, 0, N, IH, IW, Cin, Cin, Cout, KH, KW, 1, pad, Cout, vec);
     }
     if (rc) return rc < 0 ? rc : -2;
-    const GemmPlan p = plan_gemm(g, eb, have_zero_page != 0, op == 1);
+    const GemmPlan p = plan_gemm(g, eb, have_zero_page != 0, op == 1 || fwd_full);
     if (p.kind == GEMM_S1) return s1_grid((g.M + p.BM - 1) / p.BM, p) * p.WM;
     return (g.M + 63) / 64;
 }
@@ -3057,24 +3045,18 @@ static WgradPlan plan_wgrad(const WgradGeom& g, int elem_bytes, bool have_zero_p
     const bool wideN = g.NC > 64;
     const bool tallM = g.Cout > 64;            // Cout <= 64 layers: a 64-row tile wastes no MFMA rows
     WgradPlan p{false, tallM ? 128 : 64, wideN ? 128 : 64, false, 1};
-    // bf16 + zero page: LDS-DMA staging with transposing LDS reads (ET_WGRAD_TR=0 forces the register path)
-    static const int use_tr = env_int("ET_WGRAD_TR", 1);
-    p.tr = elem_bytes == 2 && use_tr && have_zero_page;
-    // 256-wide tiles (8 waves, one workgroup per CU): half the L2->LDS bytes per flop of the 128^2 tile.
-    // ET_WGRAD_BIG: 0 = never, 1 = where the layer has the rows/columns (tuning knob)
-    static const int big = env_int("ET_WGRAD_BIG", 1);
-    if (p.tr && big) {
+    // bf16 + zero page: LDS-DMA staging with transposing LDS reads
+    p.tr = elem_bytes == 2 && have_zero_page;
+    // 256-wide tiles (8 waves, one workgroup per CU): half the L2->LDS bytes per flop of the 128^2 tile
+    if (p.tr) {
         // measured (B=64 YOLOv5l shapes): the 256^2 tile wins on the 3x3 layers with >= 256 output channels
         // (691-765 TFLOP/s vs ~600), 128x256 on the 128-channel stride-1 3x3 layers; 1x1 layers keep 128^2
         if (g.T > 1 && g.Cout >= 256 && g.NC >= 256) { p.bm = 256; p.bn = 256; }
-        else if (g.T > 1 && g.isy == 1 && g.NC >= 256 && g.Cout == 128 && (big & 1)) p.bn = 256;
-        if (big & 2) { if (g.NC >= 256) p.bn = 256; if (g.Cout >= 256) p.bm = 256; }   // experiment: always
+        else if (g.T > 1 && g.isy == 1 && g.NC >= 256 && g.Cout == 128) p.bn = 256;
     }
-    // 3x3 stride-1 pad-1 layers: the three taps of a kernel row share both staged operands (conv_wgrad_rs_kernel).
-    // ET_WGRAD_RS bits: 1 = layers below 256 output channels, 2 = the others (0: the per-tap kernel everywhere)
-    static const int use_rs = env_int("ET_WGRAD_RS", 3);
+    // 3x3 stride-1 pad-1 layers: the three taps of a kernel row share both staged operands (conv_wgrad_rs_kernel)
     if (p.tr && g.T == 9 && g.isy == 1 && g.isx == 1 && g.dy[0] == -1 && g.dx[0] == -1 && g.dy[8] == 1 && g.dx[8] == 1 &&
-        g.QH == g.IH && g.QW == g.IW && g.QW >= 2 && 64 / (g.QW + 1) + 2 <= g.QH && (use_rs & (g.Cout >= 256 ? 2 : 1)) &&
+        g.QH == g.IH && g.QW == g.IW && g.QW >= 2 && 64 / (g.QW + 1) + 2 <= g.QH &&
         (long long)g.N * g.IH * g.IW * (g.ldx > g.ldy ? g.ldx : g.ldy) < (1ll << 31)) {          // 32-bit element offsets in the kernel
         if (g.Cout >= 128 && g.Cin >= 128) { p.rs = true; p.bm = 128; p.bn = 128; }
         else if (g.Cout <= 64 && g.Cin <= 64) { p.rs = true; p.bm = 64; p.bn = 64; }
@@ -3082,20 +3064,17 @@ static WgradPlan plan_wgrad(const WgradGeom& g, int elem_bytes, bool have_zero_p
     // 3x3 stride-2 pad-1 layers with an even input size (the down-sampling convs of the backbone / neck): the stride-2 form of the same
     // kernel (two X rows per K-slot).  Isolated, B = 64 (profiles/r04_mb_3x3_wgrad_stride2_ab.txt): 64->128 @320: 504 -> 396 us (the
     // 128x64 tile, two workgroups per CU); with >= 128 input channels the 128x128 tile needs 102 KB of LDS = ONE workgroup per CU and
-    // loses to the 256x256 per-tap tile (512->1024 @40: 307 -> 365 us).  ET_WGRAD_RS2: 0 off, 1 (default) the 64-input-channel layers,
-    // 2 every eligible layer on the 128x128 tile, 4 every eligible layer on the 128x64 tile.
-    static const int use_rs2 = env_int("ET_WGRAD_RS2", 1);
-    if (use_rs2 && p.tr && g.T == 9 && g.isy == 2 && g.isx == 2 && g.dy[0] == -1 && g.dx[0] == -1 && g.dy[8] == 1 && g.dx[8] == 1 &&
-        g.IH == 2 * g.QH && g.IW == 2 * g.QW && g.QW >= 2 && 64 / (g.QW + 1) + 2 <= g.QH && g.Cout >= 128 && g.Cin >= 64 &&
-        (g.Cin < 128 || (use_rs2 & 6)) &&
+    // loses to the 256x256 per-tap tile (512->1024 @40: 307 -> 365 us): only the 64-input-channel layers take this form.
+    if (p.tr && g.T == 9 && g.isy == 2 && g.isx == 2 && g.dy[0] == -1 && g.dx[0] == -1 && g.dy[8] == 1 && g.dx[8] == 1 &&
+        g.IH == 2 * g.QH && g.IW == 2 * g.QW && g.QW >= 2 && 64 / (g.QW + 1) + 2 <= g.QH && g.Cout >= 128 && g.Cin >= 64 && g.Cin < 128 &&
         (long long)g.N * g.IH * g.IW * (g.ldx > g.ldy ? g.ldx : g.ldy) < (1ll << 31)) {
-        p.rs = true; p.rs_stride = 2; p.bm = 128; p.bn = (g.Cin >= 128 && !(use_rs2 & 4)) ? 128 : 64;
+        p.rs = true; p.rs_stride = 2; p.bm = 128; p.bn = 64;
     }
     return p;
 }
 static void wgrad_plan_name(const WgradPlan& p, int elem_bytes, char* buf, int n) {
     if (p.rs) {
-        if (p.rs_stride == 2) snprintf(buf, n, "conv_wgrad_rs_kernel<%d, %d, %d, %d, 2>", p.bm, p.bn, 2, p.bn == 128 ? 4 : 2);
+        if (p.rs_stride == 2) snprintf(buf, n, "conv_wgrad_rs_kernel<%d, %d, %d, %d, 2>", p.bm, p.bn, 2, 2);
         else snprintf(buf, n, "conv_wgrad_rs_kernel<%d, %d, %d, %d>", p.bm, p.bn, 2, p.bm == 128 ? 4 : 2);
     } else if (p.tr) {
         const int wm = p.bm == 256 ? (p.bn == 256 ? 2 : 4) : (p.bm == 128 ? 2 : (p.bn == 256 ? 1 : 2));
@@ -3120,8 +3099,8 @@ static void launch_wgrad(const WgradGroup& grp, const void* zero16, WgradGeom& g
             g.ntn = 3 * nci; g.ntm = (g.Cout + bm - 1) / bm;
             const int tiles = grp.n * g.ntn * g.ntm;
             const int n_cu = device_cus();
-            // stride 1: 68 KB / 34 KB of LDS, 8 / 4 waves, <= 128 VGPRs; stride 2: 102 KB (8 waves) / 67 KB (4 waves)
-            const int slots = wp.rs_stride == 2 ? (bn == 128 ? 1 : 2) : (bm == 128 ? 2 : 4);
+            // stride 1: 68 KB / 34 KB of LDS, 8 / 4 waves, <= 128 VGPRs; stride 2: 67 KB (4 waves)
+            const int slots = wp.rs_stride == 2 ? 2 : (bm == 128 ? 2 : 4);
             const int cap = slots * n_cu;
             const int max_sk = max(1, g.PP / (64 * 25));
             auto eff = [&](int k) { const int b = tiles * k; return (double)b / ((double)((b + cap - 1) / cap) * cap); };
@@ -3136,10 +3115,8 @@ static void launch_wgrad(const WgradGroup& grp, const void* zero16, WgradGeom& g
             g.xcd = 1; g.Pper = per; g.nsk = sk;
             const dim3 grid(grp.n * g.ntn * g.ntm * sk);
             const uint16_t* z = (const uint16_t*)zero16;
-            if (wp.rs_stride == 2) {
-                if (bn == 128) hipLaunchKernelGGL((conv_wgrad_rs_kernel<128, 128, 2, 4, 2>), grid, dim3(512), 0, s, grp, z, g);
-                else hipLaunchKernelGGL((conv_wgrad_rs_kernel<128, 64, 2, 2, 2>), grid, dim3(256), 0, s, grp, z, g);
-            } else if (bm == 128) hipLaunchKernelGGL((conv_wgrad_rs_kernel<128, 128, 2, 4>), grid, dim3(512), 0, s, grp, z, g);
+            if (wp.rs_stride == 2) hipLaunchKernelGGL((conv_wgrad_rs_kernel<128, 64, 2, 2, 2>), grid, dim3(256), 0, s, grp, z, g);
+            else if (bm == 128) hipLaunchKernelGGL((conv_wgrad_rs_kernel<128, 128, 2, 4>), grid, dim3(512), 0, s, grp, z, g);
             else hipLaunchKernelGGL((conv_wgrad_rs_kernel<64, 64, 2, 2>), grid, dim3(256), 0, s, grp, z, g);
             return;
         }
@@ -3182,7 +3159,7 @@ static void launch_wgrad(const WgradGroup& grp, const void* zero16, WgradGeom& g
             return;
         }
     }
-    // register-staged kernel (fp32 parity mode, ET_WGRAD_TR=0): one launch per item
+    // register-staged kernel (fp32 parity mode, callers without a zero page): one launch per item
     const dim3 grid(g.ntn * g.ntm * sk);
     for (int i = 0; i < grp.n; ++i) {
         const T* xx = (const T*)grp.it[i].x; const T* yy = (const T*)grp.it[i].dy;
@@ -3255,9 +3232,8 @@ extern "C" int et_weight_transpose_all(const void* w_arena, void* wT_arena, int 
                            (float*)wT_arena, table, n_layers, total_elems);
     else if (dtype == ET_BF16) {
         // layer offsets are multiples of 16 elements and bf16 channel counts multiples of 8 (flat_state.py): 16-byte rows (a layer
-        // whose channels are not is copied element by element inside the same launch); ET_WT_TILED=0 keeps the element-wise kernel
-        static const int tiled = env_int("ET_WT_TILED", 1);
-        if (tiled && (((uintptr_t)w_arena | (uintptr_t)wT_arena) & 15) == 0)
+        // whose channels are not is copied element by element inside the same launch)
+        if ((((uintptr_t)w_arena | (uintptr_t)wT_arena) & 15) == 0)
             hipLaunchKernelGGL(weight_transpose_all_tiled_kernel, dim3(96, n_layers), block, 0, (hipStream_t)stream,
                                (const uint16_t*)w_arena, (uint16_t*)wT_arena, table, n_layers);
         else
@@ -3327,10 +3303,11 @@ extern "C" int et_conv2d_kernel_name(int op, int dtype, int N, int IH, int IW, i
 }
 
 extern "C" int et_env_knobs(char* buf, int buflen) {
-    // every ET_* tuning knob that is SET in this process's environment, as "NAME=value;..." (bench.py records it)
-    static const char* names[] = {"ET_CONV_GLDS", "ET_CONV_BIG", "ET_CONV_BIG_MINFILL", "ET_CONV_PP", "ET_CONV_S1", "ET_CONV_S1_WGS", "ET_CONV_RS", "ET_CONV_PPRS", "ET_CONV_STEM", "ET_CONV_STEM_WGS",
-                                  "ET_WGRAD_TR", "ET_WGRAD_BIG", "ET_WGRAD_RS", "ET_WGRAD_RS2", "ET_WGRAD_GROUP", "ET_WGRAD_STALE", "ET_WGRAD_STREAM", "ET_FUSE_BN_BWD",
-                                  "ET_BN_FIN_SMALL", "ET_WT_TILED", "ET_FUSE_BN_BWD_K", "ET_STEP_GRAPH", "ET_ALLREDUCE_CHUNK_MB", "ET_RCCL_CHANNELS", "ET_DP_SINGLE_RANK", "ET_HIP_LIB"};
+    // every ET_* runtime knob that is SET in this process's environment, as "NAME=value;..." (bench.py records it).  The complete list:
+    // three test hooks (persistent-grid sizes, the BatchNorm finalize form), the opt-in arms that change WHAT runs beside what (step
+    // graph, weight-gradient stream, teacher CU mask), the data-parallel transport settings, and the experiment-library path.
+    static const char* names[] = {"ET_CONV_S1_WGS", "ET_CONV_STEM_WGS", "ET_BN_FIN_SMALL", "ET_STEP_GRAPH", "ET_WGRAD_STREAM", "ET_TEACHER_CUS",
+                                  "ET_ALLREDUCE_CHUNK_MB", "ET_RCCL_CHANNELS", "ET_DP_SINGLE_RANK", "ET_HIP_LIB"};
     if (!buf || buflen < 1) return -1;
     int off = 0;
     buf[0] = 0;

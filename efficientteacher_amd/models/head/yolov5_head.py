@@ -9,34 +9,40 @@ from ...autograd import ConvBiasFn, head_view
 
 
 class Detect(nn.Module):
-    stride = None  # strides computed during build
+    """Attribute names (`nc`, `no`, `nl`, `na`, `m`, `anchors`, `stride`, `grid`, `anchor_grid`, `export`, `cur_imgsize`,
+    `num_keypoints`) are the reference's: checkpoints pickle them and `state_dict` keys (`head.m.<i>.weight`, `head.anchors`)
+    depend on them (tests/test_model.py pins the key list)."""
+    stride = None
 
-    def __init__(self, cfg):  # detection layer
-        super(Detect, self).__init__()
-        self.nc = cfg.Dataset.nc  # number of classes
-        self.num_keypoints = cfg.Dataset.np
-        if self.num_keypoints:
+    def __init__(self, cfg):
+        super().__init__()
+        ds, mdl = cfg.Dataset, cfg.Model
+        if ds.np:
             raise NotImplementedError("keypoint heads are outside the hot path")
-        self.cur_imgsize = [cfg.Dataset.img_size, cfg.Dataset.img_size]
-        anchors = cfg.Model.anchors
-        ch = [int(out_c * cfg.Model.width_multiple) for out_c in cfg.Model.Neck.out_channels]
-        self.no = self.nc + self.num_keypoints + 5  # number of outputs per anchor
-        self.nl = len(anchors)  # number of detection layers
-        self.na = len(anchors[0]) // 2  # number of anchors
-        self.grid = [torch.zeros(1)] * self.nl
-        self.register_buffer('anchors', torch.tensor(anchors).float().view(self.nl, -1, 2))  # shape(nl,na,2)
-        self.anchor_grid = [torch.zeros(1)] * self.nl
-        self.m = nn.ModuleList(nn.Conv2d(x, self.no * self.na, 1) for x in ch)  # output conv
-        self.stride = cfg.Model.Head.strides
+        self.nc, self.num_keypoints = ds.nc, ds.np
+        self.cur_imgsize = [ds.img_size] * 2
+        anchor_table = torch.tensor(mdl.anchors, dtype=torch.float32)              # one row of (w, h) pairs per level
+        self.nl, self.na = anchor_table.shape[0], anchor_table.shape[1] // 2
+        self.no = 5 + self.nc + self.num_keypoints                                   # box 4 + objectness + classes
+        self.register_buffer('anchors', anchor_table.view(self.nl, self.na, 2))
+        self.grid = [torch.zeros(1) for _ in range(self.nl)]
+        self.anchor_grid = [torch.zeros(1) for _ in range(self.nl)]
+        widths = [int(c * mdl.width_multiple) for c in mdl.Neck.out_channels]
+        self.m = nn.ModuleList([nn.Conv2d(c, self.na * self.no, kernel_size=1) for c in widths])
+        self.stride = mdl.Head.strides
         self.export = False
 
-    def initialize_biases(self, cf=None):  # initialize biases into Detect(), cf is class frequency
-        # https://arxiv.org/abs/1708.02002 section 3.3
-        for mi, s in zip(self.m, self.stride):
-            b = mi.bias.view(self.na, -1)  # conv.bias(255) to (3,85)
-            b.data[:, 4] += math.log(8 / (640 / s) ** 2)  # obj (8 objects per 640 image)
-            b.data[:, 5:] += math.log(0.6 / (self.nc - 0.99)) if cf is None else torch.log(cf / cf.sum())  # cls
-            mi.bias = torch.nn.Parameter(b.view(-1), requires_grad=True)
+    def initialize_biases(self, cf=None):
+        """Prior-probability bias init of the output convs (RetinaNet's focal-loss paper, sec. 3.3; reference
+        models/head/yolov5_head.py:37-46): objectness starts at "8 objects per 640-pixel image" for the level's cell count,
+        class logits at 0.6 / (nc - 0.99), or at the class frequencies `cf` when given."""
+        cls_prior = math.log(0.6 / (self.nc - 0.99)) if cf is None else torch.log(cf / cf.sum())
+        for conv, s in zip(self.m, self.stride):
+            cells = (640 / s) ** 2
+            bias = conv.bias.detach().view(self.na, self.no).clone()
+            bias[:, 4] += math.log(8 / cells)
+            bias[:, 5:] += cls_prior
+            conv.bias = torch.nn.Parameter(bias.reshape(-1), requires_grad=True)
 
     def _raw(self, xi, i):
         """head conv -> logits viewed as (B, na, ny, nx, no) over the NHWC GEMM output (no copy)."""

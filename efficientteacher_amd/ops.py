@@ -99,10 +99,10 @@ def kernel_name(op, dtype, N, IH, IW, Cin, Cout, k, stride, pad, parity_class=0,
 
 
 def stats_rows(op, dtype, N, IH, IW, Cin, Cout, k, stride, pad, zero_page=True):
-    """rows of the partial-statistics buffer the selected kernel writes (op 'fwd': et_conv2d_fwd's stats_partial; 'dgrad_bn':
-    et_conv2d_dgrad_bn's bn_stats_partial; arguments of the FORWARD conv)"""
+    """rows of the partial-statistics buffer the selected kernel writes (op 'fwd': et_conv2d_fwd's stats_partial; 'fwd_res': the same
+    for a call that also passes a residual; 'dgrad_bn': et_conv2d_dgrad_bn's bn_stats_partial; arguments of the FORWARD conv)"""
     dt = ET_F32 if dtype == torch.float32 else ET_BF16
-    rows = _lib.load().et_conv2d_stats_rows_for({"fwd": 0, "dgrad_bn": 1}[op], dt, N, IH, IW, Cin, Cout, k, k, stride, pad, int(bool(zero_page)))
+    rows = _lib.load().et_conv2d_stats_rows_for({"fwd": 0, "dgrad_bn": 1, "fwd_res": 2}[op], dt, N, IH, IW, Cin, Cout, k, k, stride, pad, int(bool(zero_page)))
     if rows <= 0:
         raise _lib.EtHipError(f"et_conv2d_stats_rows_for failed with code {rows}")
     return rows
@@ -174,7 +174,7 @@ def conv2d_fwd(x, w, stride, pad, *, scale=None, bias=None, act=ACT_NONE, residu
     assert out.shape == (N, OH, OW, Cout)
     stats = None
     if want_stats:
-        rows = stats_rows("fwd", x.dtype, N, IH, IW, Cin, Cout, KH, stride, pad)
+        rows = stats_rows("fwd_res" if residual is not None else "fwd", x.dtype, N, IH, IW, Cin, Cout, KH, stride, pad)
         stats = torch.empty((rows, 2, Cout), dtype=torch.float32, device=x.device)
     ldr = _nhwc(residual) if residual is not None else 0
     ev = TIMER.span(kernel_name("fwd_res" if residual is not None else "fwd", x.dtype, N, IH, IW, Cin, Cout, KH, stride, pad), 2.0 * N * OH * OW * Cout * Cin * KH * KW,
@@ -198,7 +198,8 @@ class WgradQueue:
     and launched together: the K-split that fills the chip is shared by the group, so every dW address gets
     group-size times fewer fp32 atomics.  A group is launched when it reaches ``group`` items and at the end of
     the backward pass (autograd engine callback); ``on_done`` callbacks (gradient-ready hooks of the data-parallel
-    wrapper) run right after the launch that covers their layer.  ET_WGRAD_GROUP=1 launches every layer at once.
+    wrapper) run right after the launch that covers their layer.  Groups of 8 (8 / 4 / 2 / 1 measured 54.73 / 54.84 / 55.44 /
+    56.75 ms on the step, profiles/r03_wgrad_ident_and_group_ab.txt; ``group = 1`` launches every layer at once).
 
     Nothing in backward consumes a weight gradient, so on a GPU the grouped launches CAN go to a second HIP stream
     (ET_WGRAD_STREAM=1): the MFMA-bound wgrad workgroups then run beside the critical path (dgrad -> BatchNorm backward -> dgrad ...)
@@ -214,8 +215,8 @@ class WgradQueue:
 
     def __init__(self):
         import os
-        self.group = max(1, min(16, int(os.environ.get("ET_WGRAD_GROUP", "8"))))
-        self.stale = int(os.environ.get("ET_WGRAD_STALE", "20"))   # a group nobody added to for this many submissions is launched (its stage of
+        self.group = 8
+        self.stale = 20              # a group nobody added to for this many submissions is launched (its stage of
         self.pending = {}            # the network is over): keeps the gradient all-reduce overlapped with backward
         self.last = {}
         self.tick = 0

@@ -23,7 +23,7 @@ def apply_rccl_knobs(env=None):
     the communicator is created).  ``ET_RCCL_CHANNELS=n`` pins the number of RCCL channels (= workgroups = CUs the
     all-reduce kernel occupies): the gradient all-reduce runs beside backward's 256x256-tile kernels, which want every CU,
     so the CU share of the collective is a trade between its own bandwidth (7 xGMI links x ~153 GB/s per GPU, a ring is
-    per-link bound) and the compute it displaces.  ``ET_RCCL_PROTO`` / ``ET_RCCL_ALGO`` pass through to NCCL_PROTO / NCCL_ALGO.
+    per-link bound) and the compute it displaces.  (Protocol / algorithm: set RCCL's own NCCL_PROTO / NCCL_ALGO.)
     Values already present in the environment win.  Returns what was set (bench.py records it)."""
     env = os.environ if env is None else env
     out = {}
@@ -33,16 +33,21 @@ def apply_rccl_knobs(env=None):
             if k not in env:
                 env[k] = str(int(n))
             out[k] = env[k]
-    for src, dst in (("ET_RCCL_PROTO", "NCCL_PROTO"), ("ET_RCCL_ALGO", "NCCL_ALGO")):
-        if env.get(src):
-            env.setdefault(dst, env[src])
-            out[dst] = env[dst]
+    for k in ("NCCL_PROTO", "NCCL_ALGO"):           # recorded when the user set them
+        if env.get(k):
+            out[k] = env[k]
     return out
 
 
 class FlatDataParallel(nn.Module):
-    def __init__(self, module, process_group=None, chunk_mb=None, broadcast_buffers=True, overlap=True, single_rank_collectives=None):
+    def __init__(self, module, process_group=None, chunk_mb=None, broadcast_buffers=True, overlap=True, single_rank_collectives=None,
+                 grad_dtype=None):
         """chunk_mb: size of the all-reduce pieces of the conv-weight gradient segment (default 48, ``ET_ALLREDUCE_CHUNK_MB``).
+        grad_dtype: None / torch.float32 = the fp32 gradient arena is reduced as it is (191.8 MB per step for YOLOv5l);
+        torch.bfloat16 = every piece is cast into a persistent bf16 staging arena, reduced there (half the bytes on the xGMI
+        links: a ring all-reduce is per-link bound) and cast back into the fp32 arena once its collective has completed.  The
+        mean then carries bf16 rounding (2^-9 relative per element, bounded in tests/test_parallel.py); master weights, momentum
+        and the optimizer stay fp32.  Opt-in: the reference reduces fp32 gradients (trainer/trainer.py:313, DDP).
         single_rank_collectives (``ET_DP_SINGLE_RANK=1``): issue every collective even in a group of ONE rank -- the way to
         execute the RCCL code path (AVG all-reduce from the gradient-ready hook, broadcast, capture into a step graph) on a
         single-GPU box; with more ranks it changes nothing."""
@@ -53,6 +58,10 @@ class FlatDataParallel(nn.Module):
         if chunk_mb is None:
             chunk_mb = float(os.environ.get("ET_ALLREDUCE_CHUNK_MB", "48"))
         self.chunk = int(chunk_mb * (1 << 20) // 4)
+        if grad_dtype not in (None, torch.float32, torch.bfloat16):
+            raise ValueError(f"grad_dtype {grad_dtype}: float32 (default) or bfloat16")
+        self.grad_dtype = torch.float32 if grad_dtype is None else grad_dtype
+        self._stage = None               # bf16 staging arena, same element offsets as the gradient arena (grad_dtype = bfloat16)
         self.broadcast_buffers = broadcast_buffers
         self.overlap = overlap
         if single_rank_collectives is None:
@@ -113,8 +122,17 @@ class FlatDataParallel(nn.Module):
             self._ev0 = torch.cuda.Event(enable_timing=True)
             self._ev0.record()
         avg = dist.get_backend(self.pg) == "nccl"        # RCCL averages inside the collective
-        w = dist.all_reduce(view, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=self.pg, async_op=True)
-        self._works.append((w, None if avg else view, int(view.numel()) * 4))
+        wire, back = view, None
+        if self.grad_dtype != torch.float32:
+            g = self.module.flat_state().grads
+            if self._stage is None or self._stage.numel() != g.numel() or self._stage.device != g.device:
+                self._stage = torch.empty(g.numel(), dtype=self.grad_dtype, device=g.device)
+            o = (view.data_ptr() - g.data_ptr()) // 4
+            wire = self._stage[o:o + view.numel()]
+            wire.copy_(view)                             # on the launching stream, in front of the collective (async_op orders it behind)
+            back = view
+        w = dist.all_reduce(wire, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        self._works.append((w, None if avg else wire, int(wire.numel()) * wire.element_size(), wire, back))
 
     def _on_conv_grad_ready(self, slot):
         """Called from the conv backward right after its wgrad launch: when every layer of a chunk has
@@ -130,13 +148,22 @@ class FlatDataParallel(nn.Module):
             self._all_reduce(self.module.flat_state().grads[o:o + n])
 
     def forward(self, *a, **k):
-        if self._works or self._launched or self._dirty:
+        if self._works or self._launched:
             # a backward whose collectives nobody finished (an exception between backward and reduce_gradients, or a caller
             # that skipped it): never let an all-reduce in flight overlap the next backward's writes into the same arena.
-            # _dirty covers a backward that aborted after some wgrad hooks had counted down but before any chunk was complete:
-            # with stale counters the next backward would launch a chunk's all-reduce before all of its layers had accumulated,
-            # and the late layers' gradients would never be averaged (ranks diverge silently).
+            # A chunk was launched, i.e. every layer of it had produced its gradient: the matching collectives exist on every rank
+            # that ran the same backward, so finishing the set here pairs up.
             self.reduce_gradients()
+        elif self._dirty:
+            # a backward that aborted after some wgrad hooks had counted down but BEFORE any chunk was complete: nothing is in
+            # flight, and issuing collectives from here would not pair up if the abort was local to this rank (the peers issue
+            # none: a hang, or mismatched buffers).  Only the stale counters are reset -- with them the next backward would launch
+            # a chunk's all-reduce before all of its layers had accumulated.  The half-accumulated gradient arena is the caller's
+            # to zero (optimizer.zero_grad / FlatState.zero_grad), as after any failed step.
+            import warnings
+            warnings.warn("FlatDataParallel: the previous backward did not finish (no collective had been launched); "
+                          "per-chunk counters reset, gradients of that pass are NOT reduced")
+            self.abort_step()
         if self.active and self.broadcast_buffers and self.module.training:
             # DDP broadcast_buffers=True: rank 0's BN running stats / anchors at every forward, on the compute stream, in front of the
             # forward.  r04 moved it to a side stream (joined before the first running-statistics update) and took that back: the
@@ -150,7 +177,7 @@ class FlatDataParallel(nn.Module):
     def abort_step(self):
         """forget a step that will not be finished (a rejected graph capture): collectives already started are waited for,
         counters and flags return to their start-of-step values; the gradient arena is the caller's to zero"""
-        for w, _, _ in self._works:
+        for w, *_ in self._works:
             w.wait()
         self._works = []
         self._launched = set()
@@ -179,10 +206,12 @@ class FlatDataParallel(nn.Module):
             e.record()                                     # backward is over on this stream: what follows is exposed
             evs.append(e)
         sizes = []
-        for w, view, nbytes in self._works:
+        for w, view, nbytes, wire, back in self._works:
             w.wait()
             if view is not None:                           # gloo (CPU tests) has no AVG
                 view.mul_(1.0 / self.world)
+            if back is not None:                           # bf16 wire format: the mean returns to the fp32 arena
+                back.copy_(wire)
             if timed:
                 e = torch.cuda.Event(enable_timing=True)
                 e.record()                                 # the compute stream has passed this collective's completion

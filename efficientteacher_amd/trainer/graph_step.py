@@ -70,8 +70,7 @@ class StepGraph:
         self.replays = 0
         self.recaptures = 0
         self.sig = None
-        import os
-        self.slow_factor = float(os.environ.get("ET_GRAPH_SLOW_FACTOR", self.SLOW_FACTOR))
+        self.slow_factor = float(self.SLOW_FACTOR)
         self._probe = []                # (start, end) events of the timed replays of the current capture
         self._since_capture = 0
         self.slow_captures = 0

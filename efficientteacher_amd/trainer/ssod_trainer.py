@@ -18,6 +18,26 @@ from ..utils.torch_utils import CosineEMA, SemiSupModelEMA
 from .trainer import Trainer
 
 
+def _cu_masked_stream(device, n_cu, stride=1):
+    """A HIP stream whose kernels may only occupy `n_cu` compute units (hipExtStreamCreateWithCUMask), as a torch ExternalStream:
+    ET_TEACHER_CUS=n gives the teacher stream such a mask, so that its workgroups stop displacing the student's on the other CUs
+    ("make the overlap real or drop it").  The low n bits of the mask are set: the driver deals mask bits
+    round-robin to the XCDs and, inside one, to its shader engines, so the n CUs are spread evenly over the eight L2s.
+    Opt-in experiment arm; the A/B against the unmasked stream and against no overlap is in profiles/r05_teacher_cu_mask_ab.txt."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    words = (max(1, n_cu * stride) + 31) // 32
+    mask = (ctypes.c_uint32 * words)()
+    for i in range(n_cu):                          # "n/s" = n bits, every s-th (another spreading of the same CU count)
+        mask[(i * stride) // 32] |= 1 << ((i * stride) % 32)
+    h = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), ctypes.c_uint32(words), mask)
+    if rc != 0 or not h.value:
+        raise RuntimeError(f"hipExtStreamCreateWithCUMask({n_cu} CUs) failed with code {rc}")
+    return torch.cuda.ExternalStream(h.value, device=device)
+
+
 class SSODTrainer(Trainer):
     MODEL_MODULE = "efficientteacher_amd.models.detector.yolo_ssod"
 
@@ -58,9 +78,7 @@ class SSODTrainer(Trainer):
         self.extra_teacher_models = []
         self.teacher_pred_hook = None      # optional callable(teacher_pred) -> teacher_pred (bench: synthetic scores)
         self.overlap_teacher = True        # teacher forward + pseudo labels on a second stream
-        import os as _os
-        ta = _os.environ.get("ET_TEACHER_AFTER", "p2")                 # "start" | "p1" | "p2" | "p3" | "p4" (see _train_instance_eager)
-        self.teacher_after = "" if ta in ("", "start", "0") else ta
+        self.teacher_after = "p2"          # "" (start of the step) | "p1" | "p2" | "p3" | "p4": see _train_instance_eager
         self._side = None
         # the step as one captured HIP graph (trainer/graph_step.py), opt-in: ET_STEP_GRAPH=1 or use_graph=True.  Measured on
         # MI355X (profiles/r02_graph_step_timing.txt): issuing the ~750 launches of an eager step takes the host 18-24 ms, a
@@ -78,7 +96,10 @@ class SSODTrainer(Trainer):
 
     def _side_stream(self):
         if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
+            import os
+            spec = (os.environ.get("ET_TEACHER_CUS", "") or "0").split("/")
+            n_cu, stride = int(spec[0]), int(spec[1]) if len(spec) > 1 else 1
+            self._side = _cu_masked_stream(self.device, n_cu, stride) if n_cu > 0 else torch.cuda.Stream(device=self.device)
         return self._side
 
     def build_model(self, cfg, device):
@@ -215,8 +236,8 @@ class SSODTrainer(Trainer):
                 t9, valid = self.pseudo_label_creator.create_pseudo_label_padded(teacher_pred, unlabeled_M, width, height)
                 return t9, valid, valid.any().float()        # has_targets == not invalid_target_shape, as a device flag
 
-        # The teacher stream starts when the student's forward has passed its stride-4 stage (ET_TEACHER_AFTER=p2, the default;
-        # p1 / p3 / p4 / "start" are the other measured settings), not at the start of the step: both networks begin with their
+        # The teacher stream starts when the student's forward has passed its stride-4 stage (teacher_after = "p2"; p1 / p3 / p4 /
+        # start-of-step are the other measured settings, profiles/r03_teacher_start_ab.txt, r04_knob_combinations_ab.txt), not at the start: both networks begin with their
         # large, HBM-bound maps, and running those side by side only makes both slower.  Same-box A/B, three alternations
         # (profiles/r03_teacher_start_ab.txt): 58.64 / 58.74 / 58.74 ms against 59.06 / 58.78 / 59.00 ms, and the dominant
         # gather-GEMM's in-step roofline fraction 0.240 / 0.242 / 0.240 against 0.232 / 0.229 / 0.232.

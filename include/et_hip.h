@@ -114,7 +114,8 @@ int et_sgd_nesterov_dev(float* p, const float* grad, float* momentum_buf, void* 
  *   wgrad: dw (Cout, KH, KW, Cin) fp32 += ... (split-K over pixels, atomicAdd: zero or reuse the
  *          gradient arena as the accumulator).                                                    */
 int et_conv2d_stats_rows(int N, int OH, int OW);
-/* rows of the partial-statistics buffer for one call: op 0 = stats_partial of et_conv2d_fwd, op 1 = bn_stats_partial of
+/* rows of the partial-statistics buffer for one call: op 0 = stats_partial of et_conv2d_fwd (no residual), op 2 = stats_partial of
+ * an et_conv2d_fwd call that also passes `residual` (another kernel form, another row count), op 1 = bn_stats_partial of
  * et_conv2d_dgrad_bn; the remaining arguments are those of the FORWARD conv (as for et_conv2d_kernel_name); have_zero_page = the
  * call passes zero16.  Host only. */
 int et_conv2d_stats_rows_for(int op, int dtype, int N, int IH, int IW, int Cin, int Cout, int KH, int KW, int stride, int pad,
