@@ -186,8 +186,13 @@ def reference_timing(Bl, Bu, S, seconds=20.0):
         return None
     cores = min(os.cpu_count() or 1, 32)
     try:
+        # the GPU is hidden from this child: the reference hard-codes `.cuda()` in its losses (models/loss/loss.py:392,418) and the
+        # import shims (oracle/ref_loader.py) turn that into the identity only where torch sees no device -- this leg is the CPU path
+        env = dict(os.environ, ET_REFERENCE=ref_root, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
         p = subprocess.run([sys.executable, "-m", "oracle.time_reference_step", str(Bl), "--cores", str(cores), "--seconds", str(seconds)],
-                           cwd=ROOT, env=dict(os.environ, ET_REFERENCE=ref_root), capture_output=True, text=True, timeout=900)
+                           cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+        if p.returncode != 0 or not p.stdout.strip():
+            return dict(error=f"oracle.time_reference_step rc {p.returncode}: {p.stderr.strip()[-600:]}")
         r = json.loads(p.stdout.strip().splitlines()[-1])
         return dict(value=r["images_per_s"], cores=r["cores"], steps=r["steps"], s_per_step=r["s_per_step"],
                     where=os.path.relpath(ref_root, ROOT) if ref_root.startswith(ROOT) else ref_root)
@@ -617,7 +622,8 @@ def roofline_of(res, dump=None):
         pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_mfma.json")))
         km = pm["kernels"].get(dom)
         if km and km.get("mfma_busy_frac") is not None:
-            mfma = dict(mfma_busy_frac=km["mfma_busy_frac"], cu_busy_frac=km.get("cu_busy_frac"), wait_inst_frac=km.get("wait_inst_frac"),
+            mfma = dict(mfma_busy_frac=km["mfma_busy_frac"], cu_busy_frac=km.get("cu_busy_frac"), mfma_busy_of_cu_busy=km.get("mfma_busy_of_cu_busy"),
+                        wait_inst_frac=km.get("wait_inst_frac"),
                         avg_us_in_that_run=km.get("avg_us"), effective_clock_ghz=pm.get("effective_clock_ghz"), clock_source=km.get("clock_source"),
                         mfma_cycles_counted_over_expected=km.get("mfma_cycles_counted_over_expected"), source=pm.get("source"),
                         top_kernels={k: round(pm["kernels"][k]["mfma_busy_frac"], 4) for k in pm.get("top_by_time", [])[:8]

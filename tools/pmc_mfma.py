@@ -106,6 +106,10 @@ def main():
             if 0.2 < f_ <= 0.3:                                 # quad-cycle units
                 f_, o["cu_busy_unit"] = f_ * 4, "quad-cycles (x4)"
             o["cu_busy_frac"] = f_
+            if o.get("mfma_busy_frac") is not None and f_ > 0:
+                # matrix-pipe busy share of the time a CU is busy with this kernel: independent of the clock estimate and of the grid's
+                # tail / ramp (what the main loop itself achieves; the in-loop s_memtime stamps of NOTEBOOK.md read 62-64 % for pprs)
+                o["mfma_busy_of_cu_busy"] = o["mfma_busy_frac"] / f_
         if o.get("SQ_WAVE_CYCLES"):
             for c, n in (("SQ_WAIT_INST_ANY", "wait_inst_frac"), ("SQ_ACTIVE_INST_ANY", "active_frac"), ("SQ_WAIT_ANY", "wait_any_frac")):
                 if o.get(c) is not None:
