@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ET_HIP_LIB") or os.path.join(_HERE, "libet_hip.so")   # ET_HIP_LIB: experiment builds
 
-ET_F32, ET_BF16 = 0, 1
+ET_F32, ET_BF16, ET_F16 = 0, 1, 2
 
 P = c_void_p
 # name -> (restype, argtypes); kept in the order of include/et_hip.h
@@ -29,11 +29,13 @@ SIGNATURES = {
     "et_detect_decode": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int64,
                                  P, c_float, P, c_int64, c_int64, P]),
     "et_ema_update": (c_int, [P, P, c_int64, c_float, c_float, P]),
-    "et_adamw": (c_int, [P, P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int, c_float, P]),
-    "et_sgd_nesterov": (c_int, [P, P, P, P, c_int64, c_float, c_float, c_float, c_int, c_float, P]),
-    "et_cast_f32_to_bf16": (c_int, [P, P, c_int64, P]),
+    "et_adamw": (c_int, [P, P, P, P, P, c_int, c_int64, c_float, c_float, c_float, c_float, c_float, c_int, c_float, P, P]),
+    "et_sgd_nesterov": (c_int, [P, P, P, P, c_int, c_int64, c_float, c_float, c_float, c_int, c_float, P, P]),
+    "et_cast_f32_to_lp": (c_int, [P, P, c_int, c_int64, P]),
+    "et_scaler_check": (c_int, [P, c_int64, P, P]),
+    "et_scaler_update": (c_int, [P, c_float, c_float, c_int, P]),
     "et_ema_update_dev": (c_int, [P, P, c_int64, P, P]),
-    "et_sgd_nesterov_dev": (c_int, [P, P, P, P, c_int64, P, c_int, P]),
+    "et_sgd_nesterov_dev": (c_int, [P, P, P, P, c_int, c_int64, P, c_int, P, P]),
     "et_conv2d_stats_rows": (c_int, [c_int, c_int, c_int]),
     "et_conv2d_stats_rows_for": (c_int, [c_int] * 12),
     "et_conv2d_fwd": (c_int, [P, P, P, c_int] + [c_int] * 11 + [P, P, c_int, P, c_int, P, P, P]),

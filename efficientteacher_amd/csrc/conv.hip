@@ -28,6 +28,7 @@
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;   // 16-byte register vector (SSA, no struct)
 __device__ __forceinline__ u32x4 mk4(unsigned a, unsigned b, unsigned c, unsigned d) { u32x4 v = {a, b, c, d}; return v; }
 // "this register is defined HERE": whatever load produced it has completed in front of this point, and later uses depend on
@@ -36,6 +37,16 @@ __device__ __forceinline__ void et_pin_loaded(u32x4& v) {
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("" : "+v"(v));
 #endif
+}
+
+// one v_mfma_f32_32x32x16 of the 16-bit storage format T (uint16_t = bf16, et_f16 = IEEE half): a, b = 8 K-contiguous values per lane
+// (V = any 16-byte register vector: u32x4, or the s16x8 the transposing LDS reads return)
+template <typename T, typename V> __device__ __forceinline__ f32x16 et_mfma32(const V a, const V b, const f32x16 c) {
+    static_assert(sizeof(V) == 16, "8 x 16-bit operands");
+    if constexpr (std::is_same<T, et_f16>::value)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
 #define CONV_MAX_TAPS 36
@@ -185,8 +196,7 @@ __device__ __forceinline__ void mma_chunk(const u32x4* __restrict__ sm, f32x16 (
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) {
                 if constexpr (sizeof(T) == 2) {
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                        __builtin_bit_cast(bf16x8, af[cur][tm]), __builtin_bit_cast(bf16x8, bf[cur][tn]), acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = et_mfma32<T>(af[cur][tm], bf[cur][tn], acc[tm][tn]);
                 } else {
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(af[cur][tm].x), __uint_as_float(bf[cur][tn].x), acc[tm][tn], 0, 0, 0);
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(af[cur][tm].y), __uint_as_float(bf[cur][tn].y), acc[tm][tn], 0, 0, 0);
@@ -416,7 +426,7 @@ __device__ __forceinline__ void conv_epilogue_act(f32x16 (&acc)[BM / WM / 32][BN
                     const long long p = m0 + wm * (BM / WM) + tm * 32 + hoff + row;
                     const float4 a = *(const float4*)(stg + row * SLD + scv * 8);
                     const float4 b = *(const float4*)(stg + row * SLD + scv * 8 + 4);
-                    *(u32x4*)(Y + p * g.ldy + co) = mk4(et_pack_bf2(a.x, a.y), et_pack_bf2(a.z, a.w), et_pack_bf2(b.x, b.y), et_pack_bf2(b.z, b.w));
+                    *(u32x4*)(Y + p * g.ldy + co) = mk4(et_lp<T>::pack(a.x, a.y), et_lp<T>::pack(a.z, a.w), et_lp<T>::pack(b.x, b.y), et_lp<T>::pack(b.z, b.w));
                 }
                 __builtin_amdgcn_s_waitcnt(0xC07F);
                 __builtin_amdgcn_wave_barrier();
@@ -440,22 +450,22 @@ __device__ __forceinline__ void conv_epilogue_act(f32x16 (&acc)[BM / WM / 32][BN
                             u32x4 rr;
                             if constexpr (PF) rr = pf_a[it];
                             else rr = *(const u32x4*)((const T*)ep_res + pix * ep.ldr + co);
-                            v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
-                            v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
-                            v[4] += __uint_as_float(rr.z << 16); v[5] += __uint_as_float(rr.z & 0xffff0000u);
-                            v[6] += __uint_as_float(rr.w << 16); v[7] += __uint_as_float(rr.w & 0xffff0000u);
+                            v[0] += et_lp<T>::lo(rr.x); v[1] += et_lp<T>::hi(rr.x);
+                            v[2] += et_lp<T>::lo(rr.y); v[3] += et_lp<T>::hi(rr.y);
+                            v[4] += et_lp<T>::lo(rr.z); v[5] += et_lp<T>::hi(rr.z);
+                            v[6] += et_lp<T>::lo(rr.w); v[7] += et_lp<T>::hi(rr.w);
                         }
                         if (ep_accumulate) {
                             u32x4 rr;
                             if (PF && !pf_a_is_res) rr = pf_a[it];       // (with a residual as well, the A buffer is taken: load here)
                             else rr = *(const u32x4*)yp;
-                            v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
-                            v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
-                            v[4] += __uint_as_float(rr.z << 16); v[5] += __uint_as_float(rr.z & 0xffff0000u);
-                            v[6] += __uint_as_float(rr.w << 16); v[7] += __uint_as_float(rr.w & 0xffff0000u);
+                            v[0] += et_lp<T>::lo(rr.x); v[1] += et_lp<T>::hi(rr.x);
+                            v[2] += et_lp<T>::lo(rr.y); v[3] += et_lp<T>::hi(rr.y);
+                            v[4] += et_lp<T>::lo(rr.z); v[5] += et_lp<T>::hi(rr.z);
+                            v[6] += et_lp<T>::lo(rr.w); v[7] += et_lp<T>::hi(rr.w);
                         }
-                        const u32x4 packed = mk4(et_pack_bf2(v[0], v[1]), et_pack_bf2(v[2], v[3]), et_pack_bf2(v[4], v[5]),
-                                                 et_pack_bf2(v[6], v[7]));
+                        const u32x4 packed = mk4(et_lp<T>::pack(v[0], v[1]), et_lp<T>::pack(v[2], v[3]), et_lp<T>::pack(v[4], v[5]),
+                                                 et_lp<T>::pack(v[6], v[7]));
                         *(u32x4*)yp = packed;
                         if (bnb) {
                             // statistics of exactly what the apply pass will read back: the bf16-ROUNDED dz
@@ -466,8 +476,8 @@ __device__ __forceinline__ void conv_epilogue_act(f32x16 (&acc)[BM / WM / 32][BN
                             float dz8[8], y8[8];
 #pragma unroll
                             for (int e = 0; e < 8; ++e) {
-                                dz8[e] = __uint_as_float((e & 1) ? (pw[e >> 1] & 0xffff0000u) : (pw[e >> 1] << 16));
-                                y8[e] = __uint_as_float((e & 1) ? (yw[e >> 1] & 0xffff0000u) : (yw[e >> 1] << 16));
+                                dz8[e] = (e & 1) ? et_lp<T>::hi(pw[e >> 1]) : et_lp<T>::lo(pw[e >> 1]);
+                                y8[e] = (e & 1) ? et_lp<T>::hi(yw[e >> 1]) : et_lp<T>::lo(yw[e >> 1]);
                             }
                             bn_bwd_sums(dz8, y8);
                         }
@@ -864,11 +874,10 @@ __global__ __launch_bounds__(64 * WM * WN, (NS == 3 && BKV == 4 && BM == 128) ? 
 // Only the weight tile is staged per step: (BM + 16) + 3 * BN instead of 3 * (BM + BN) rows per unit of L2->LDS traffic.
 // Ring: two A-unit slots + two B-step slots; B(s+1) is issued at the start of step s, A(u+1) at the first step of unit u, BEHIND
 // that step's B so that the counted vmcnt wait of the next step releases B while A is still in flight.
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN, BN <= 64 ? 3 : 2) void conv_gemm_rs_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W,
-                                                                       uint16_t* __restrict__ Y, const uint16_t* __restrict__ ZERO,
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, BN <= 64 ? 3 : 2) void conv_gemm_rs_kernel(const T* __restrict__ X, const T* __restrict__ W,
+                                                                       T* __restrict__ Y, const T* __restrict__ ZERO,
                                                                        GatherGeom g, Epilogue ep) {
-    using T = uint16_t;
     constexpr int VEC = 8, BKV = 8;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int NW = WM * WN, NT = 64 * NW;
@@ -993,8 +1002,7 @@ __global__ __launch_bounds__(64 * WM * WN, BN <= 64 ? 3 : 2) void conv_gemm_rs_k
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn)
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                        __builtin_bit_cast(bf16x8, af[cur][tm]), __builtin_bit_cast(bf16x8, bf[cur][tn]), acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = et_mfma32<T>(af[cur][tm], bf[cur][tn], acc[tm][tn]);
         }
     };
 
@@ -1062,8 +1070,9 @@ template <int N> __device__ __forceinline__ void et_wait_vmem_le_pp() {
     __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 0xF) | ((N >> 4) << 14));
 }
 
-__global__ __launch_bounds__(512, 2) void conv_gemm_pp_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W,
-                                                              uint16_t* __restrict__ Y, const uint16_t* __restrict__ ZERO,
+template <typename T>
+__global__ __launch_bounds__(512, 2) void conv_gemm_pp_kernel(const T* __restrict__ X, const T* __restrict__ W,
+                                                              T* __restrict__ Y, const T* __restrict__ ZERO,
                                                               GatherGeom g, Epilogue ep) {
     constexpr int BM = 256, BN = 256, WM = 2, WN = 4, BKV = 8, VEC = 8;
     constexpr int HALF_VEC = 128 * BKV;            // one half-tile in 16-byte vectors (16 KB)
@@ -1185,8 +1194,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_pp_kernel(const uint16_t* __
         for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                acc[2 * i + t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[t][kk]),
-                                                                           __builtin_bit_cast(bf16x8, bf[kk]), acc[2 * i + t][j], 0, 0, 0);
+                acc[2 * i + t][j] = et_mfma32<T>(af[t][kk], bf[kk], acc[2 * i + t][j]);
                 const int n = kk * 2 + t;
                 if (sk >= 0 && (n == 1 || n == 4)) {
                     __builtin_amdgcn_sched_barrier(0);
@@ -1250,7 +1258,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_pp_kernel(const uint16_t* __
     chunk(buf, std::true_type{});
     if (wm == 0) __builtin_amdgcn_s_barrier();     // balances group 1's extra barrier
     __syncthreads();                               // the epilogue reuses the half-tile buffers as its staging area
-    conv_epilogue<uint16_t, BM, BN, WM, WN, false>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn);
+    conv_epilogue<T, BM, BN, WM, WN, false>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn);
 #undef ET_PP_DECODE
 #undef ET_PP_ADVANCE
 #undef ET_PP_BAR
@@ -1271,8 +1279,9 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_pp_kernel(const uint16_t* __
 // RAW / WAR as in conv_gemm_pp_kernel (its header): the weight schedule is unchanged, the activation unit is written two
 // units before... no: ONE unit before it is read (buffer (u+1)&1 during unit u; its last reader was unit u-1).
 #define PPRS_ROWS 320
-__global__ __launch_bounds__(512, 2) void conv_gemm_pprs_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W,
-                                                                uint16_t* __restrict__ Y, const uint16_t* __restrict__ ZERO,
+template <typename T>
+__global__ __launch_bounds__(512, 2) void conv_gemm_pprs_kernel(const T* __restrict__ X, const T* __restrict__ W,
+                                                                T* __restrict__ Y, const T* __restrict__ ZERO,
                                                                 GatherGeom g, Epilogue ep) {
     constexpr int BM = 256, BN = 256, WM = 2, WN = 4, BKV = 8, VEC = 8;
     constexpr int HALF_VEC = 128 * BKV;            // one weight half-tile in 16-byte vectors (16 KB)
@@ -1381,8 +1390,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_pprs_kernel(const uint16_t* 
         for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                acc[2 * i + t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[t][kk]),
-                                                                           __builtin_bit_cast(bf16x8, bf[kk]), acc[2 * i + t][j], 0, 0, 0);
+                acc[2 * i + t][j] = et_mfma32<T>(af[t][kk], bf[kk], acc[2 * i + t][j]);
                 const int n = kk * 2 + t;
                 if (n == 1) { __builtin_amdgcn_sched_barrier(0); piece0(); __builtin_amdgcn_sched_barrier(0); }
                 if (n == 4) { __builtin_amdgcn_sched_barrier(0); piece1(); __builtin_amdgcn_sched_barrier(0); }
@@ -1451,7 +1459,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_pprs_kernel(const uint16_t* 
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();     // balances group 1's extra barrier
     __syncthreads();                               // the epilogue reuses the ring as its staging area
-    conv_epilogue<uint16_t, BM, BN, WM, WN, false>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn);
+    conv_epilogue<T, BM, BN, WM, WN, false>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn);
 #undef ET_PP_BAR
 #undef ET_PP_WAIT
 }
@@ -1485,11 +1493,10 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_pprs_kernel(const uint16_t* 
 // Statistics: a lane's sums run over ALL tiles of its (persistent) workgroup and are written ONCE, as partial row
 // blockIdx.x * WM + wm of a (gridDim.x * WM, 2, Cout) buffer (et_conv2d_stats_rows_for reports that row count to the caller): the
 // finalize then reads a few hundred rows instead of one per 64 pixels.
-template <int KC, int WN, int TN, int WM, int TMW, int NS, int WGS, bool FULL>
-__global__ __launch_bounds__(64 * WM * WN, WGS) void conv1x1_stream_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W,
-                                                                          uint16_t* __restrict__ Y, const uint16_t* __restrict__ ZERO,
+template <typename T, int KC, int WN, int TN, int WM, int TMW, int NS, int WGS, bool FULL>
+__global__ __launch_bounds__(64 * WM * WN, WGS) void conv1x1_stream_kernel(const T* __restrict__ X, const T* __restrict__ W,
+                                                                          T* __restrict__ Y, const T* __restrict__ ZERO,
                                                                           GatherGeom g, Epilogue ep) {
-    using T = uint16_t;
     constexpr int BN = 32 * TN * WN, BM = 32 * TMW * WM, BKV = 8, VEC = 8;
     constexpr int TM = TMW;                              // a wave owns 32 * TMW rows x 32 * TN output channels
     constexpr int NT = 64 * WM * WN;
@@ -1562,7 +1569,7 @@ __global__ __launch_bounds__(64 * WM * WN, WGS) void conv1x1_stream_kernel(const
     for (int tn = 0; tn < TN; ++tn) {
         const int co = wn * (32 * TN) + tn * 32 + l31;
         const bool cok = co < g.Cout;
-        const uint16_t* wr = W + (size_t)(cok ? co : 0) * g.Cin + gk * VEC;
+        const T* wr = W + (size_t)(cok ? co : 0) * g.Cin + gk * VEC;
 #pragma unroll
         for (int ks = 0; ks < KC * 4; ++ks) {
             bw[tn][ks] = *(const u32x4*)(wr + ks * 16);          // unconditional load (row 0 for a channel beyond Cout), zeroed below
@@ -1633,8 +1640,7 @@ __global__ __launch_bounds__(64 * WM * WN, WGS) void conv1x1_stream_kernel(const
                 for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn)
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[cur][tm]),
-                                                                              __builtin_bit_cast(bf16x8, bw[tn][kc * 4 + kk]), acc[tm][tn], 0, 0, 0);
+                        acc[tm][tn] = et_mfma32<T>(af[cur][tm], bw[tn][kc * 4 + kk], acc[tm][tn]);
             }
             rd = rd + 1 == NS ? 0 : rd + 1;
         }
@@ -1678,8 +1684,8 @@ struct StemArgs {
     float* stats; int stat_rows;        // [stat_rows][2][Cout] or null
 };
 
-template <int ACT>
-__global__ __launch_bounds__(256, 2) void conv_stem_kernel(StemArgs a) {
+template <typename T, int ACT>
+__global__ __launch_bounds__(256, 2) void conv_stem_kernel(StemArgs a) {            // T: the 16-bit format behind StemArgs' raw pointers
     __shared__ __attribute__((aligned(16))) u32x4 wl[STEM_WSLOTS];
     __shared__ __attribute__((aligned(16))) u32x4 pl[STEM_PSLOTS];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1764,8 +1770,7 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(StemArgs a) {
             for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
                 for (int pb = 0; pb < 2; ++pb)
-                    acc[cb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[cb]),
-                                                                          __builtin_bit_cast(bf16x8, pf[pb]), acc[cb][pb], 0, 0, 0);
+                    acc[cb][pb] = et_mfma32<T>(wf[cb], pf[pb], acc[cb][pb]);
         }
         // every wave is done with the patch: the next tile's patch streams in behind this tile's epilogue
         __syncthreads();
@@ -1808,7 +1813,7 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(StemArgs a) {
                         v[e] = u;
                     }
                     if (pok && ch < a.Cout)
-                        *(u32x4*)(yp + ch) = mk4(et_pack_bf2(v[0], v[1]), et_pack_bf2(v[2], v[3]), et_pack_bf2(v[4], v[5]), et_pack_bf2(v[6], v[7]));
+                        *(u32x4*)(yp + ch) = mk4(et_lp<T>::pack(v[0], v[1]), et_lp<T>::pack(v[2], v[3]), et_lp<T>::pack(v[4], v[5]), et_lp<T>::pack(v[6], v[7]));
                 }
             }
         }
@@ -1855,7 +1860,7 @@ static int device_cus() {
 static int try_launch_stem(const void* x, const void* w, void* y, int dtype, int N, int IH, int IW, int Cin, int ldx, int Cout,
                            int KH, int KW, int stride, int pad, int ldy, const float* scale, const float* bias, int act,
                            const void* residual, float* stats, const void* zero16, hipStream_t s, bool launch) {
-    if (dtype != ET_BF16 || KH != 6 || KW != 6 || stride != 2 || pad != 2 || Cin != 8 || Cout > 64 || Cout % 8 ||
+    if ((dtype != ET_BF16 && dtype != ET_F16) || KH != 6 || KW != 6 || stride != 2 || pad != 2 || Cin != 8 || Cout > 64 || Cout % 8 ||
         residual || !zero16)
         return 0;
     if (!launch) return 1;
@@ -1871,9 +1876,14 @@ static int try_launch_stem(const void* x, const void* w, void* y, int dtype, int
     if (grid < 1) grid = 1;
     if (grid > a.ntiles) grid = a.ntiles;
     if (stats && grid > a.stat_rows) grid = a.stat_rows;
-    if (act == ACT_SILU) hipLaunchKernelGGL((conv_stem_kernel<ACT_SILU>), dim3(grid), dim3(256), 0, s, a);
-    else if (act == ACT_RELU) hipLaunchKernelGGL((conv_stem_kernel<ACT_RELU>), dim3(grid), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((conv_stem_kernel<ACT_NONE>), dim3(grid), dim3(256), 0, s, a);
+#define ET_STEM(T_) \
+    do { \
+        if (act == ACT_SILU) hipLaunchKernelGGL((conv_stem_kernel<T_, ACT_SILU>), dim3(grid), dim3(256), 0, s, a); \
+        else if (act == ACT_RELU) hipLaunchKernelGGL((conv_stem_kernel<T_, ACT_RELU>), dim3(grid), dim3(256), 0, s, a); \
+        else hipLaunchKernelGGL((conv_stem_kernel<T_, ACT_NONE>), dim3(grid), dim3(256), 0, s, a); \
+    } while (0)
+    if (dtype == ET_F16) ET_STEM(et_f16); else ET_STEM(uint16_t);
+#undef ET_STEM
     return 1;
 }
 
@@ -1911,6 +1921,7 @@ template <> struct Transposer<uint16_t> {   // 8x8 block of 16-bit elements
         }
     }
 };
+template <> struct Transposer<et_f16> : Transposer<uint16_t> {};      // moves 16-bit words: format-agnostic
 template <> struct Transposer<float> {      // 4x4 block of 32-bit elements
     __device__ static __forceinline__ void run(const u32x4 (&in)[4], u32x4 (&out)[4]) {
         out[0] = mk4(in[0].x, in[1].x, in[2].x, in[3].x);
@@ -2105,9 +2116,9 @@ template <int SLOTS> __device__ __forceinline__ int tr_swz2(int p) {
 struct WgradItem { const uint16_t* x; const uint16_t* dy; float* dw; int ldx, ldy; };
 struct WgradGroup { WgradItem it[WGRAD_MAX_GROUP]; int n; };
 
-template <int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_tr_kernel(WgradGroup grp, const uint16_t* __restrict__ ZERO,
-                                                                     WgradGeom g) {
+                                                                     WgradGeom g) {          // T: the 16-bit format behind the raw pointers
     constexpr int NT = 64 * WM * WN, BKP = 64;       // threads per workgroup; pixels (GEMM-K) per chunk
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int SA = BM / 8, SB = BN / 8;            // 16-byte slots per pixel row of the A / B tile
@@ -2234,8 +2245,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_tr_kernel(WgradGroup 
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn)
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[tm]),
-                                                                         __builtin_bit_cast(bf16x8, bf[tn]), acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = et_mfma32<T>(af[tm], bf[tn], acc[tm][tn]);
         }
     };
 
@@ -2299,7 +2309,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_tr_kernel(WgradGroup 
 // (dY = 0 there, so what it multiplies does not matter) and the slot after it starts the next image row, whose tap 0 reads column -1:
 // zero page.  One dY tile + one X tile of 129 rows per 64-slot chunk serve three taps (the per-tap kernel staged 3 x 64 X rows and ran
 // these six layers at 340-700 TFLOP/s against the stride-1 kernel's ~1000).
-template <int BM, int BNC, int WM, int WN, int STRIDE = 1>
+template <typename T, int BM, int BNC, int WM, int WN, int STRIDE = 1>
 __global__ __launch_bounds__(64 * WM * WN) ET_WAVES_PER_EU(STRIDE == 1 ? 4 : 2) void conv_wgrad_rs_kernel(WgradGroup grp, const uint16_t* __restrict__ ZERO, WgradGeom g) {
     constexpr int NT = 64 * WM * WN, BKP = 64, BROWS = STRIDE == 1 ? 72 : 136;      // threads; padded slots per chunk; X rows per chunk (66 / 129 used)
     constexpr int TM = BM / WM / 32, TN = BNC / WN / 32;
@@ -2455,8 +2465,7 @@ __global__ __launch_bounds__(64 * WM * WN) ET_WAVES_PER_EU(STRIDE == 1 ? 4 : 2) 
                 for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn)
-                        acc[k][tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[tm]),
-                                                                                __builtin_bit_cast(bf16x8, bf[k][tn]), acc[k][tm][tn], 0, 0, 0);
+                        acc[k][tm][tn] = et_mfma32<T>(af[tm], bf[k][tn], acc[k][tm][tn]);
         }
     };
 
@@ -2588,7 +2597,8 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
 // ---- host side -------------------------------------------------------------------------------------
 // bf16 column sums with 16-byte loads: a thread owns one 8-channel vector and every (256 / CV)-th row of its block's rows (the
 // element-per-thread kernel above moves 128 bytes per wave instruction: 88 us for the 210 MB of the stride-8 Detect gradient)
-__global__ __launch_bounds__(256) void colsum_vec8_kernel(const uint16_t* __restrict__ x, int P, int CV, int ld, int rows_per_block,
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_vec8_kernel(const T* __restrict__ x, int P, int CV, int ld, int rows_per_block,
                                                           float* __restrict__ out) {
     __shared__ float red[256][9];
     const int rgs = 256 / CV;                                // row groups per block (CV divides 256: host)
@@ -2604,15 +2614,15 @@ __global__ __launch_bounds__(256) void colsum_vec8_kernel(const uint16_t* __rest
             const unsigned wa[4] = {a.x, a.y, a.z, a.w}, wb[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                s[2 * j] += __uint_as_float(wa[j] << 16) + __uint_as_float(wb[j] << 16);
-                s[2 * j + 1] += __uint_as_float(wa[j] & 0xffff0000u) + __uint_as_float(wb[j] & 0xffff0000u);
+                s[2 * j] += et_lp<T>::lo(wa[j]) + et_lp<T>::lo(wb[j]);
+                s[2 * j + 1] += et_lp<T>::hi(wa[j]) + et_lp<T>::hi(wb[j]);
             }
         }
         for (; p < p1; p += rgs) {
             const u32x4 a = *(const u32x4*)(x + (long long)p * ld + cv * 8);
             const unsigned wa[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { s[2 * j] += __uint_as_float(wa[j] << 16); s[2 * j + 1] += __uint_as_float(wa[j] & 0xffff0000u); }
+            for (int j = 0; j < 4; ++j) { s[2 * j] += et_lp<T>::lo(wa[j]); s[2 * j + 1] += et_lp<T>::hi(wa[j]); }
         }
     }
 #pragma unroll
@@ -2781,12 +2791,13 @@ static GemmPlan plan_gemm(const GatherGeom& g, int elem_bytes, bool have_zero_pa
 }
 
 // the name rocprofv3 prints for the plan's kernel (template arguments spelled as the demangler does)
-static void plan_name(const GemmPlan& p, int elem_bytes, char* buf, int n) {
-    const char* t = elem_bytes == 2 ? "unsigned short" : "float";
-    if (p.kind == GEMM_S1) snprintf(buf, n, "conv1x1_stream_kernel<%d, %d, %d, %d, %d, %d, %d, %s>", p.kc, p.WN, p.tn, p.WM, p.BM / (32 * p.WM), p.NS, p.wgs, p.full ? "true" : "false");
-    else if (p.kind == GEMM_PP) snprintf(buf, n, "conv_gemm_pp_kernel");
-    else if (p.kind == GEMM_PPRS) snprintf(buf, n, "conv_gemm_pprs_kernel");
-    else if (p.kind == GEMM_RS) snprintf(buf, n, "conv_gemm_rs_kernel<%d, %d, %d, %d>", p.BM, p.BN, p.WM, p.WN);
+static const char* dtype_tname(int dtype) { return dtype == ET_F32 ? "float" : (dtype == ET_F16 ? "et_f16" : "unsigned short"); }
+static void plan_name(const GemmPlan& p, int dtype, char* buf, int n) {
+    const char* t = dtype_tname(dtype);
+    if (p.kind == GEMM_S1) snprintf(buf, n, "conv1x1_stream_kernel<%s, %d, %d, %d, %d, %d, %d, %d, %s>", t, p.kc, p.WN, p.tn, p.WM, p.BM / (32 * p.WM), p.NS, p.wgs, p.full ? "true" : "false");
+    else if (p.kind == GEMM_PP) snprintf(buf, n, "conv_gemm_pp_kernel<%s>", t);
+    else if (p.kind == GEMM_PPRS) snprintf(buf, n, "conv_gemm_pprs_kernel<%s>", t);
+    else if (p.kind == GEMM_RS) snprintf(buf, n, "conv_gemm_rs_kernel<%s, %d, %d, %d, %d>", t, p.BM, p.BN, p.WM, p.WN);
     else if (p.kind == GEMM_GLDS) snprintf(buf, n, "conv_gemm_glds_kernel<%s, %d, %d, %d, %d, %d, %d, %s>", t, p.BM, p.BN, p.WM, p.WN, p.BKV, p.NS, p.utap ? "true" : "false");
     else snprintf(buf, n, "conv_gemm_kernel<%s, %d, %d, %d, %d, %d, %s>", t, p.BM, p.BN, p.WM, p.WN, p.BKV, p.utap ? "true" : "false");
 }
@@ -2818,10 +2829,9 @@ static int launch_gemm(const void* X, const void* W, void* Y, const void* zero16
     const int key = p.BM * 100000 + p.BN * 100 + p.BKV * 10 + p.NS;
     if (p.kind == GEMM_S1) {
         if constexpr (sizeof(T) == 2) {
-            const uint16_t *xs = (const uint16_t*)x, *ws = (const uint16_t*)w, *zs = (const uint16_t*)z;
             const dim3 sgrid(s1_grid(g.ntm, p));
 #define ET_S1(KC_, WN_, TN_, WM_, TMW_, NS_, WGS_, FULL_) \
-    hipLaunchKernelGGL((conv1x1_stream_kernel<KC_, WN_, TN_, WM_, TMW_, NS_, WGS_, FULL_>), sgrid, block, 0, s, xs, ws, (uint16_t*)y, zs, g, ep)
+    hipLaunchKernelGGL((conv1x1_stream_kernel<T, KC_, WN_, TN_, WM_, TMW_, NS_, WGS_, FULL_>), sgrid, block, 0, s, x, w, y, z, g, ep)
             switch ((p.full ? 10000 : 0) + p.kc * 1000 + p.BN) {
                 //            K/64 WN TN WM TMW NS WGS
                 case 4256: ET_S1(4, 4, 2, 1, 1, 8, 2, false); return 0;
@@ -2848,23 +2858,22 @@ static int launch_gemm(const void* X, const void* W, void* Y, const void* zero16
     }
     if (p.kind == GEMM_PP) {
         if constexpr (sizeof(T) == 2) {
-            hipLaunchKernelGGL(conv_gemm_pp_kernel, grid, block, 0, s, (const uint16_t*)x, (const uint16_t*)w, (uint16_t*)y, (const uint16_t*)z, g, ep);
+            hipLaunchKernelGGL((conv_gemm_pp_kernel<T>), grid, block, 0, s, x, w, y, z, g, ep);
             return 0;
         }
         return -2;
     }
     if (p.kind == GEMM_PPRS) {
         if constexpr (sizeof(T) == 2) {
-            hipLaunchKernelGGL(conv_gemm_pprs_kernel, grid, block, 0, s, (const uint16_t*)x, (const uint16_t*)w, (uint16_t*)y, (const uint16_t*)z, g, ep);
+            hipLaunchKernelGGL((conv_gemm_pprs_kernel<T>), grid, block, 0, s, x, w, y, z, g, ep);
             return 0;
         }
         return -2;
     }
     if (p.kind == GEMM_RS) {
         if constexpr (sizeof(T) == 2) {
-            const uint16_t *xs = (const uint16_t*)x, *ws = (const uint16_t*)w, *zs = (const uint16_t*)z;
-            if (p.BN == 128) hipLaunchKernelGGL((conv_gemm_rs_kernel<128, 128, 2, 2>), grid, block, 0, s, xs, ws, (uint16_t*)y, zs, g, ep);
-            else hipLaunchKernelGGL((conv_gemm_rs_kernel<128, 64, 2, 2>), grid, block, 0, s, xs, ws, (uint16_t*)y, zs, g, ep);
+            if (p.BN == 128) hipLaunchKernelGGL((conv_gemm_rs_kernel<T, 128, 128, 2, 2>), grid, block, 0, s, x, w, y, z, g, ep);
+            else hipLaunchKernelGGL((conv_gemm_rs_kernel<T, 128, 64, 2, 2>), grid, block, 0, s, x, w, y, z, g, ep);
             return 0;
         }
         return -2;
@@ -2947,9 +2956,23 @@ extern "C" int et_conv2d_fwd(const void* x, const void* w, void* y, int dtype, i
     const int vec = dtype == ET_F32 ? 4 : 8;
     int rc = fwd_geom(g, N, IH, IW, Cin, ldx, Cout, KH, KW, stride, pad, ldy, vec);
     if (rc) return rc;
+    if (residual && !(residual == (const void*)y && ldr == ldy)) {
+        // the residual may BE the output (the in-place shortcut of the eval-mode C3 stem: a lane loads the element it is about to store);
+        // any other overlap of the two ranges would let one lane's store race another lane's load
+        const size_t eb = dtype == ET_F32 ? 4 : 2, npix = (size_t)g.N * g.OH * g.OW;
+        const uintptr_t r0 = (uintptr_t)residual, r1 = r0 + ((npix - 1) * (size_t)ldr + (size_t)Cout) * eb;
+        const uintptr_t y0 = (uintptr_t)y, y1 = y0 + ((npix - 1) * (size_t)ldy + (size_t)Cout) * eb;
+        if (npix > 0 && r0 < y1 && y0 < r1) {
+            // channel slices of ONE wider buffer interleave without touching: same pixel stride, disjoint channel windows
+            const bool same_rows = ldr == ldy && ((r0 > y0 ? r0 - y0 : y0 - r0) % ((size_t)ldy * eb)) >= (size_t)Cout * eb &&
+                                   ((r0 > y0 ? r0 - y0 : y0 - r0) % ((size_t)ldy * eb)) + (size_t)Cout * eb <= (size_t)ldy * eb;
+            if (!same_rows) return -2;
+        }
+    }
     Epilogue ep{scale, bias, act, residual, ldr, stats_partial, 0};
     if (dtype == ET_F32) rc = launch_gemm<float>(x, w, y, zero16, g, ep, (hipStream_t)stream);
     else if (dtype == ET_BF16) rc = launch_gemm<uint16_t>(x, w, y, zero16, g, ep, (hipStream_t)stream);
+    else if (dtype == ET_F16) rc = launch_gemm<et_f16>(x, w, y, zero16, g, ep, (hipStream_t)stream);
     else return -2;
     if (rc) return rc;
     ET_CHECK_LAUNCH();
@@ -3000,6 +3023,7 @@ static int conv2d_dgrad_impl(const void* dy, const void* wT, void* dx, int dtype
             }
             if (dtype == ET_F32) rc = launch_gemm<float>(dy, wT, dx, zero16, g, ep, (hipStream_t)stream);
             else if (dtype == ET_BF16) rc = launch_gemm<uint16_t>(dy, wT, dx, zero16, g, ep, (hipStream_t)stream);
+            else if (dtype == ET_F16) rc = launch_gemm<et_f16>(dy, wT, dx, zero16, g, ep, (hipStream_t)stream);
             else return -2;
             if (rc) return rc;
         }
@@ -3072,16 +3096,17 @@ static WgradPlan plan_wgrad(const WgradGeom& g, int elem_bytes, bool have_zero_p
     }
     return p;
 }
-static void wgrad_plan_name(const WgradPlan& p, int elem_bytes, char* buf, int n) {
+static void wgrad_plan_name(const WgradPlan& p, int dtype, char* buf, int n) {
+    const char* t = dtype_tname(dtype);
     if (p.rs) {
-        if (p.rs_stride == 2) snprintf(buf, n, "conv_wgrad_rs_kernel<%d, %d, %d, %d, 2>", p.bm, p.bn, 2, 2);
-        else snprintf(buf, n, "conv_wgrad_rs_kernel<%d, %d, %d, %d>", p.bm, p.bn, 2, p.bm == 128 ? 4 : 2);
+        if (p.rs_stride == 2) snprintf(buf, n, "conv_wgrad_rs_kernel<%s, %d, %d, %d, %d, 2>", t, p.bm, p.bn, 2, 2);
+        else snprintf(buf, n, "conv_wgrad_rs_kernel<%s, %d, %d, %d, %d>", t, p.bm, p.bn, 2, p.bm == 128 ? 4 : 2);
     } else if (p.tr) {
         const int wm = p.bm == 256 ? (p.bn == 256 ? 2 : 4) : (p.bm == 128 ? 2 : (p.bn == 256 ? 1 : 2));
         const int wn = p.bm == 256 ? (p.bn == 256 ? 4 : (p.bn == 128 ? 2 : 1)) : (p.bn == 256 ? 4 : 2);
-        snprintf(buf, n, "conv_wgrad_tr_kernel<%d, %d, %d, %d>", p.bm, p.bn, wm, wn);
+        snprintf(buf, n, "conv_wgrad_tr_kernel<%s, %d, %d, %d, %d>", t, p.bm, p.bn, wm, wn);
     } else {
-        snprintf(buf, n, "conv_wgrad_kernel<%s, %d, %d>", elem_bytes == 2 ? "unsigned short" : "float", p.bm > 64 ? 128 : 64, p.bn > 64 ? 128 : 64);
+        snprintf(buf, n, "conv_wgrad_kernel<%s, %d, %d>", t, p.bm > 64 ? 128 : 64, p.bn > 64 ? 128 : 64);
     }
 }
 
@@ -3115,9 +3140,9 @@ static void launch_wgrad(const WgradGroup& grp, const void* zero16, WgradGeom& g
             g.xcd = 1; g.Pper = per; g.nsk = sk;
             const dim3 grid(grp.n * g.ntn * g.ntm * sk);
             const uint16_t* z = (const uint16_t*)zero16;
-            if (wp.rs_stride == 2) hipLaunchKernelGGL((conv_wgrad_rs_kernel<128, 64, 2, 2, 2>), grid, dim3(256), 0, s, grp, z, g);
-            else if (bm == 128) hipLaunchKernelGGL((conv_wgrad_rs_kernel<128, 128, 2, 4>), grid, dim3(512), 0, s, grp, z, g);
-            else hipLaunchKernelGGL((conv_wgrad_rs_kernel<64, 64, 2, 2>), grid, dim3(256), 0, s, grp, z, g);
+            if (wp.rs_stride == 2) hipLaunchKernelGGL((conv_wgrad_rs_kernel<T, 128, 64, 2, 2, 2>), grid, dim3(256), 0, s, grp, z, g);
+            else if (bm == 128) hipLaunchKernelGGL((conv_wgrad_rs_kernel<T, 128, 128, 2, 4>), grid, dim3(512), 0, s, grp, z, g);
+            else hipLaunchKernelGGL((conv_wgrad_rs_kernel<T, 64, 64, 2, 2>), grid, dim3(256), 0, s, grp, z, g);
             return;
         }
     }
@@ -3151,7 +3176,7 @@ static void launch_wgrad(const WgradGroup& grp, const void* zero16, WgradGeom& g
         if (tr) {
             const dim3 grid(grp.n * g.ntn * g.ntm * sk);
             const uint16_t* z = (const uint16_t*)zero16;
-#define ET_WG(BM_, BN_, WM_, WN_) hipLaunchKernelGGL((conv_wgrad_tr_kernel<BM_, BN_, WM_, WN_>), grid, dim3(64 * WM_ * WN_), 0, s, grp, z, g)
+#define ET_WG(BM_, BN_, WM_, WN_) hipLaunchKernelGGL((conv_wgrad_tr_kernel<T, BM_, BN_, WM_, WN_>), grid, dim3(64 * WM_ * WN_), 0, s, grp, z, g)
             if (bm == 256) { if (bn == 256) ET_WG(256, 256, 2, 4); else if (bn == 128) ET_WG(256, 128, 4, 2); else ET_WG(256, 64, 4, 1); }
             else if (bm == 128) { if (bn == 256) ET_WG(128, 256, 2, 4); else if (bn == 128) ET_WG(128, 128, 2, 2); else ET_WG(128, 64, 2, 2); }
             else { if (bn == 256) ET_WG(64, 256, 1, 4); else if (bn == 128) ET_WG(64, 128, 2, 2); else ET_WG(64, 64, 2, 2); }
@@ -3196,6 +3221,7 @@ extern "C" int et_conv2d_wgrad_grouped(const et_wgrad_item* items, int n_items, 
     if (g.P <= 0) return 0;
     if (dtype == ET_F32) launch_wgrad<float>(grp, zero16, g, (hipStream_t)stream);
     else if (dtype == ET_BF16) launch_wgrad<uint16_t>(grp, zero16, g, (hipStream_t)stream);
+    else if (dtype == ET_F16) launch_wgrad<et_f16>(grp, zero16, g, (hipStream_t)stream);
     else return -2;
     ET_CHECK_LAUNCH();
     return 0;
@@ -3215,7 +3241,7 @@ extern "C" int et_weight_transpose(const void* w, void* wT, int dtype, int Cout,
     const dim3 grid(et_cdiv(n, 256)), block(256);
     if (dtype == ET_F32)
         hipLaunchKernelGGL((weight_transpose_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)w, (float*)wT, Cout, taps, Cin, n);
-    else if (dtype == ET_BF16)
+    else if (dtype == ET_BF16 || dtype == ET_F16)       // moves 16-bit words: format-agnostic
         hipLaunchKernelGGL((weight_transpose_kernel<uint16_t>), grid, block, 0, (hipStream_t)stream, (const uint16_t*)w, (uint16_t*)wT, Cout, taps, Cin, n);
     else return -2;
     ET_CHECK_LAUNCH();
@@ -3230,8 +3256,8 @@ extern "C" int et_weight_transpose_all(const void* w_arena, void* wT_arena, int 
     if (dtype == ET_F32)
         hipLaunchKernelGGL((weight_transpose_all_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)w_arena,
                            (float*)wT_arena, table, n_layers, total_elems);
-    else if (dtype == ET_BF16) {
-        // layer offsets are multiples of 16 elements and bf16 channel counts multiples of 8 (flat_state.py): 16-byte rows (a layer
+    else if (dtype == ET_BF16 || dtype == ET_F16) {
+        // layer offsets are multiples of 16 elements and 16-bit channel counts multiples of 8 (flat_state.py): 16-byte rows (a layer
         // whose channels are not is copied element by element inside the same launch)
         if ((((uintptr_t)w_arena | (uintptr_t)wT_arena) & 15) == 0)
             hipLaunchKernelGGL(weight_transpose_all_tiled_kernel, dim3(96, n_layers), block, 0, (hipStream_t)stream,
@@ -3250,13 +3276,16 @@ extern "C" int et_colsum(const void* x, int dtype, int P, int C, int ld, float* 
     const int rpb = 256;
     const dim3 grid((C + 255) / 256, (P + rpb - 1) / rpb), block(256);
     if (dtype == ET_F32) hipLaunchKernelGGL((colsum_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)x, P, C, ld, rpb, out);
-    else if (dtype == ET_BF16) {
+    else if (dtype == ET_BF16 || dtype == ET_F16) {
         const int CV = C / 8;
-        if (C % 8 == 0 && ld % 8 == 0 && CV >= 1 && CV <= 256 && 256 % CV == 0 && (((uintptr_t)x) & 15) == 0) {
-            const int rpb2 = 256;                              // rows per block: 8-256 rows per row group, two in flight per thread
-            hipLaunchKernelGGL(colsum_vec8_kernel, dim3((P + rpb2 - 1) / rpb2), block, 0, (hipStream_t)stream, (const uint16_t*)x, P, CV, ld, rpb2, out);
+        const bool vec8 = C % 8 == 0 && ld % 8 == 0 && CV >= 1 && CV <= 256 && 256 % CV == 0 && (((uintptr_t)x) & 15) == 0;
+        const int rpb2 = 256;                                  // rows per block: 8-256 rows per row group, two in flight per thread
+        if (dtype == ET_BF16) {
+            if (vec8) hipLaunchKernelGGL((colsum_vec8_kernel<uint16_t>), dim3((P + rpb2 - 1) / rpb2), block, 0, (hipStream_t)stream, (const uint16_t*)x, P, CV, ld, rpb2, out);
+            else hipLaunchKernelGGL((colsum_kernel<uint16_t>), grid, block, 0, (hipStream_t)stream, (const uint16_t*)x, P, C, ld, rpb, out);
         } else {
-            hipLaunchKernelGGL((colsum_kernel<uint16_t>), grid, block, 0, (hipStream_t)stream, (const uint16_t*)x, P, C, ld, rpb, out);
+            if (vec8) hipLaunchKernelGGL((colsum_vec8_kernel<et_f16>), dim3((P + rpb2 - 1) / rpb2), block, 0, (hipStream_t)stream, (const et_f16*)x, P, CV, ld, rpb2, out);
+            else hipLaunchKernelGGL((colsum_kernel<et_f16>), grid, block, 0, (hipStream_t)stream, (const et_f16*)x, P, C, ld, rpb, out);
         }
     }
     else return -2;
@@ -3278,7 +3307,7 @@ extern "C" int et_conv2d_kernel_name(int op, int dtype, int N, int IH, int IW, i
     if (op == 2) {
         WgradGeom g;
         wgrad_geom(g, N, IH, IW, Cin, Cin, Cout, KH, KW, stride, pad, Cout);
-        wgrad_plan_name(plan_wgrad(g, eb, have_zero_page != 0), eb, buf, buflen);
+        wgrad_plan_name(plan_wgrad(g, eb, have_zero_page != 0), dtype, buf, buflen);
         return 0;
     }
     GatherGeom g;
@@ -3298,15 +3327,15 @@ extern "C" int et_conv2d_kernel_name(int op, int dtype, int N, int IH, int IW, i
         if (py >= stride) return -2;
         if (dgrad_geom(g, py, px, N, IH, IW, Cin, Cin, Cout, KH, KW, stride, pad, Cout, vec)) return -2;
     } else return -2;
-    plan_name(plan_gemm(g, eb, have_zero_page != 0, full), eb, buf, buflen);
+    plan_name(plan_gemm(g, eb, have_zero_page != 0, full), dtype, buf, buflen);
     return 0;
 }
 
 extern "C" int et_env_knobs(char* buf, int buflen) {
     // every ET_* runtime knob that is SET in this process's environment, as "NAME=value;..." (bench.py records it).  The complete list:
     // three test hooks (persistent-grid sizes, the BatchNorm finalize form), the opt-in arms that change WHAT runs beside what (step
-    // graph, weight-gradient stream, teacher CU mask), the data-parallel transport settings, and the experiment-library path.
-    static const char* names[] = {"ET_CONV_S1_WGS", "ET_CONV_STEM_WGS", "ET_BN_FIN_SMALL", "ET_STEP_GRAPH", "ET_WGRAD_STREAM", "ET_TEACHER_CUS",
+    // graph, weight-gradient stream), the data-parallel transport settings, and the experiment-library path.
+    static const char* names[] = {"ET_CONV_S1_WGS", "ET_CONV_STEM_WGS", "ET_BN_FIN_SMALL", "ET_STEP_GRAPH", "ET_WGRAD_STREAM",
                                   "ET_ALLREDUCE_CHUNK_MB", "ET_RCCL_CHANNELS", "ET_DP_SINGLE_RANK", "ET_HIP_LIB"};
     if (!buf || buflen < 1) return -1;
     int off = 0;

@@ -50,6 +50,10 @@ extern "C" int et_detect_decode(const void* raw, int dtype, int B, int na, int n
         hipLaunchKernelGGL((detect_decode_kernel<uint16_t>), grid, block, 0, s, (const uint16_t*)raw, na, ny, nx, no,
                            (long long)sb, (long long)sa, (long long)sy, (long long)sx, anchor_px, stride, z,
                            (long long)A_total, (long long)a_offset);
+    else if (dtype == ET_F16)
+        hipLaunchKernelGGL((detect_decode_kernel<et_f16>), grid, block, 0, s, (const et_f16*)raw, na, ny, nx, no,
+                           (long long)sb, (long long)sa, (long long)sy, (long long)sx, anchor_px, stride, z,
+                           (long long)A_total, (long long)a_offset);
     else
         return -2;
     ET_CHECK_LAUNCH();

@@ -54,7 +54,42 @@ __device__ __forceinline__ int et_opaque_uniform(int v) {
     return v;
 }
 
-// element-type traits: T = float (parity mode) or uint16_t holding bf16 (performance mode)
+// ---- fp16 (IEEE half), storage type et_f16 ---------------------------------------------------------------------------
+// The reference's own reduced precision (torch.cuda.amp autocast + GradScaler, trainer/trainer.py:248,348,399-400): same MFMA rate as
+// bf16 (v_mfma_f32_32x32x16_f16), 11-bit significand, 5-bit exponent -- hence the loss scaling.  A distinct C++ type so that the
+// kernels can be instantiated per format: uint16_t keeps meaning bf16 everywhere.
+struct et_f16 { uint16_t v; };
+typedef _Float16 et_half2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float et_h2f(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+__device__ __forceinline__ uint16_t et_f2h(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }      // round-to-nearest-even
+__device__ __forceinline__ uint32_t et_pack_h2(float lo, float hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    const f32x2_ f = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, et_half2_t));        // v_cvt_pk_f16_f32 (RNE) on gfx950
+#else
+    return (uint32_t)et_f2h(lo) | ((uint32_t)et_f2h(hi) << 16);
+#endif
+}
+
+// 16-bit storage formats, two values per 32-bit word: what the vector kernels need to be format-generic
+//   lo / hi(w)   the two values of a word as fp32          pack(lo, hi)   two fp32 -> one word (RNE)
+template <typename T> struct et_lp;
+template <> struct et_lp<uint16_t> {
+    __device__ static __forceinline__ float lo(uint32_t w) { return __uint_as_float(w << 16); }
+    __device__ static __forceinline__ float hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+    __device__ static __forceinline__ uint32_t pack(float a, float b) { return et_pack_bf2(a, b); }
+};
+template <> struct et_lp<et_f16> {
+    __device__ static __forceinline__ float lo(uint32_t w) { return et_h2f((uint16_t)(w & 0xffffu)); }
+    __device__ static __forceinline__ float hi(uint32_t w) { return et_h2f((uint16_t)(w >> 16)); }
+    __device__ static __forceinline__ uint32_t pack(float a, float b) { return et_pack_h2(a, b); }
+};
+template <typename T> struct et_is_lp { static constexpr bool value = false; };
+template <> struct et_is_lp<uint16_t> { static constexpr bool value = true; };
+template <> struct et_is_lp<et_f16> { static constexpr bool value = true; };
+
+// element-type traits: T = float (parity mode), uint16_t holding bf16 (performance mode) or et_f16 (the reference's fp16 recipe)
 template <typename T> struct et_elem;
 template <> struct et_elem<float> {
     static constexpr int VEC = 4;  // elements per 16-byte vector
@@ -65,6 +100,11 @@ template <> struct et_elem<uint16_t> {
     static constexpr int VEC = 8;
     __device__ static __forceinline__ float ld(uint16_t v) { return et_bf2f(v); }
     __device__ static __forceinline__ uint16_t st(float v) { return et_f2bf(v); }
+};
+template <> struct et_elem<et_f16> {
+    static constexpr int VEC = 8;
+    __device__ static __forceinline__ float ld(et_f16 v) { return et_h2f(v.v); }
+    __device__ static __forceinline__ et_f16 st(float v) { et_f16 r; r.v = et_f2h(v); return r; }
 };
 
 // ---- wave / block reductions ------------------------------------------------------------------

@@ -60,7 +60,7 @@ struct Slot {
 };
 
 __device__ __forceinline__ float ld_logit(const void* p, int dtype, long long off) {
-    return dtype == ET_F32 ? ((const float*)p)[off] : et_bf2f(((const uint16_t*)p)[off]);
+    return dtype == ET_F32 ? ((const float*)p)[off] : (dtype == ET_F16 ? et_h2f(((const uint16_t*)p)[off]) : et_bf2f(((const uint16_t*)p)[off]));
 }
 
 // candidate slot s of pass `pass` on this level -> assignment result
@@ -203,6 +203,7 @@ __device__ __forceinline__ float ciou_fwd_bwd(const float pb[4], const float tb[
 template <typename T> __device__ __forceinline__ float ld_logit_t(const void* p, long long off);
 template <> __device__ __forceinline__ float ld_logit_t<float>(const void* p, long long off) { return ((const float*)p)[off]; }
 template <> __device__ __forceinline__ float ld_logit_t<uint16_t>(const void* p, long long off) { return et_bf2f(((const uint16_t*)p)[off]); }
+template <> __device__ __forceinline__ float ld_logit_t<et_f16>(const void* p, long long off) { return et_h2f(((const uint16_t*)p)[off]); }
 
 template <typename T>
 __device__ __forceinline__ float loss_class_walk(const LossArgs& A, const LossLevel& L, bool do_cls, long long cls_off, int cls_c,
@@ -267,6 +268,9 @@ __global__ __launch_bounds__(256) void loss_pos_kernel(LossArgs A, LossLevel L, 
                 if (A.dtype == ET_F32) {                  // the dtype switch OUTSIDE the loads: four loads in flight, one wait
 #pragma unroll
                     for (int i = 0; i < 4; ++i) lg[i] = ld_logit_t<float>(L.p, off + i);
+                } else if (A.dtype == ET_F16) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) lg[i] = ld_logit_t<et_f16>(L.p, off + i);
                 } else {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) lg[i] = ld_logit_t<uint16_t>(L.p, off + i);
@@ -303,6 +307,7 @@ __global__ __launch_bounds__(256) void loss_pos_kernel(LossArgs A, LossLevel L, 
     }
     // class term: the wave walks its slots that have one and spreads the nc class logits of each over the lanes
     if (A.dtype == ET_F32) cls_sum += loss_class_walk<float>(A, L, do_cls, cls_off, cls_c, cls_wgt);
+    else if (A.dtype == ET_F16) cls_sum += loss_class_walk<et_f16>(A, L, do_cls, cls_off, cls_c, cls_wgt);
     else cls_sum += loss_class_walk<uint16_t>(A, L, do_cls, cls_off, cls_c, cls_wgt);
     box_sum = et_wave_sum(box_sum);
     cls_sum = et_wave_sum(cls_sum);
@@ -658,7 +663,7 @@ extern "C" int et_ota_assign(const et_loss_desc* d, const float* strides, float 
                              et_stream_t stream) {
     if (!d || !d->targets || !strides || !workspace || !match) return -1;
     if (d->nl < 1 || d->nl > LOSS_MAXL || d->na < 1 || d->na > 3 || d->nc < 1 || d->NT < 0 || top_k < 1 || top_k > OTA_K) return -2;
-    if (d->dtype != ET_F32 && d->dtype != ET_BF16) return -2;
+    if (d->dtype != ET_F32 && d->dtype != ET_BF16 && d->dtype != ET_F16) return -2;
     const long long nq = (long long)d->nl * 5 * d->na * d->NT;
     if (nq >= (1ll << 31)) return -2;
     if (d->NT == 0) return 0;
@@ -748,14 +753,15 @@ __global__ __launch_bounds__(256) void scale_cast_kernel(const float* __restrict
 
 // bf16 destination, eight elements per thread (two 16-byte loads, one 16-byte store; the element-per-thread form moves 128 bytes
 // per wave instruction: 2.7 TB/s on the head gradients).  Same arithmetic per element: one multiplication, round to nearest even.
-__global__ __launch_bounds__(256) void scale_cast_bf16_vec8_kernel(const float* __restrict__ s, uint16_t* __restrict__ d, long long n8,
+template <typename T = uint16_t>          // T: the 16-bit destination format
+__global__ __launch_bounds__(256) void scale_cast_bf16_vec8_kernel(const float* __restrict__ s, T* __restrict__ d, long long n8,
                                                                    float scale, const float* __restrict__ dev_scale) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n8) return;
     const float f = dev_scale ? scale * dev_scale[0] : scale;
     const float4 a = *(const float4*)(s + i * 8), b = *(const float4*)(s + i * 8 + 4);
-    *(uint4*)(d + i * 8) = make_uint4(et_pack_bf2(a.x * f, a.y * f), et_pack_bf2(a.z * f, a.w * f), et_pack_bf2(b.x * f, b.y * f),
-                                      et_pack_bf2(b.z * f, b.w * f));
+    *(uint4*)(d + i * 8) = make_uint4(et_lp<T>::pack(a.x * f, a.y * f), et_lp<T>::pack(a.z * f, a.w * f), et_lp<T>::pack(b.x * f, b.y * f),
+                                      et_lp<T>::pack(b.z * f, b.w * f));
 }
 
 // ---- host -------------------------------------------------------------------------------------------------
@@ -775,7 +781,7 @@ extern "C" int et_yolo_loss(const et_loss_desc* d, et_stream_t stream) {
     if (A.balance_dev && A.ssi >= A.nl) return -2;
     if (A.obj_ch < 4 || A.obj_ch >= A.no) return -2;
     A.tgt = d->targets; A.acc = d->acc_ws;
-    if (A.dtype != ET_F32 && A.dtype != ET_BF16) return -2;
+    if (A.dtype != ET_F32 && A.dtype != ET_BF16 && A.dtype != ET_F16) return -2;
     (void)hipMemsetAsync(d->acc_ws, 0, sizeof(float) * 16 * LOSS_MAXL, s);
     float bal[4] = {0, 0, 0, 0};
     long long ncell[4] = {0, 0, 0, 0};
@@ -825,16 +831,20 @@ extern "C" int et_scale_cast(const float* src, void* dst, int dtype, int64_t n, 
     if (n <= 0) return n == 0 ? 0 : -2;
     const dim3 grid(et_cdiv(n, 256));
     if (dtype == ET_F32) hipLaunchKernelGGL((scale_cast_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, src, (float*)dst, (long long)n, scale, dev_scale);
-    else if (dtype == ET_BF16) {
+    else if (dtype == ET_BF16 || dtype == ET_F16) {
         long long done = 0;
         if (((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0 && n >= 8) {
             const long long n8 = n / 8;
-            hipLaunchKernelGGL(scale_cast_bf16_vec8_kernel, dim3(et_cdiv(n8, 256)), dim3(256), 0, (hipStream_t)stream, src, (uint16_t*)dst, n8, scale, dev_scale);
+            if (dtype == ET_BF16) hipLaunchKernelGGL((scale_cast_bf16_vec8_kernel<uint16_t>), dim3(et_cdiv(n8, 256)), dim3(256), 0, (hipStream_t)stream, src, (uint16_t*)dst, n8, scale, dev_scale);
+            else hipLaunchKernelGGL((scale_cast_bf16_vec8_kernel<et_f16>), dim3(et_cdiv(n8, 256)), dim3(256), 0, (hipStream_t)stream, src, (et_f16*)dst, n8, scale, dev_scale);
             done = n8 * 8;
         }
-        if (done < n)
-            hipLaunchKernelGGL((scale_cast_kernel<uint16_t>), dim3(et_cdiv(n - done, 256)), dim3(256), 0, (hipStream_t)stream, src + done,
-                               (uint16_t*)dst + done, (long long)(n - done), scale, dev_scale);
+        if (done < n) {
+            if (dtype == ET_BF16) hipLaunchKernelGGL((scale_cast_kernel<uint16_t>), dim3(et_cdiv(n - done, 256)), dim3(256), 0, (hipStream_t)stream, src + done,
+                                                     (uint16_t*)dst + done, (long long)(n - done), scale, dev_scale);
+            else hipLaunchKernelGGL((scale_cast_kernel<et_f16>), dim3(et_cdiv(n - done, 256)), dim3(256), 0, (hipStream_t)stream, src + done,
+                                    (et_f16*)dst + done, (long long)(n - done), scale, dev_scale);
+        }
     } else return -2;
     ET_CHECK_LAUNCH();
     return 0;
@@ -886,6 +896,7 @@ extern "C" int et_domain_focal(const void* feat, int ldf, int dtype, int64_t P, 
     const dim3 grid(et_cdiv(P, 256));
     if (dtype == ET_F32) hipLaunchKernelGGL((domain_focal_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)feat, ldf, (long long)P, label, gscale, (float*)grad, ldg, loss_sum);
     else if (dtype == ET_BF16) hipLaunchKernelGGL((domain_focal_kernel<uint16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)feat, ldf, (long long)P, label, gscale, (uint16_t*)grad, ldg, loss_sum);
+    else if (dtype == ET_F16) hipLaunchKernelGGL((domain_focal_kernel<et_f16>), grid, dim3(256), 0, (hipStream_t)stream, (const et_f16*)feat, ldf, (long long)P, label, gscale, (et_f16*)grad, ldg, loss_sum);
     else return -2;
     ET_CHECK_LAUNCH();
     return 0;
@@ -897,6 +908,7 @@ extern "C" int et_scale_inplace(void* x, int dtype, int64_t n, float alpha, cons
     const dim3 grid(et_cdiv(n, 256));
     if (dtype == ET_F32) hipLaunchKernelGGL((scale_inplace_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (float*)x, (long long)n, alpha, dev_scale);
     else if (dtype == ET_BF16) hipLaunchKernelGGL((scale_inplace_kernel<uint16_t>), grid, dim3(256), 0, (hipStream_t)stream, (uint16_t*)x, (long long)n, alpha, dev_scale);
+    else if (dtype == ET_F16) hipLaunchKernelGGL((scale_inplace_kernel<et_f16>), grid, dim3(256), 0, (hipStream_t)stream, (et_f16*)x, (long long)n, alpha, dev_scale);
     else return -2;
     ET_CHECK_LAUNCH();
     return 0;

@@ -37,35 +37,37 @@ template <> struct Vec16<float> {
         *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
     }
 };
-template <> struct Vec16<uint16_t> {
+template <typename T> struct Vec16lp {          // the 16-bit storage formats (bf16, IEEE half): et_lp<T> converts
     static constexpr int N = 8;
-    __device__ static __forceinline__ u4raw load_raw(const uint16_t* p) { return *(const u4raw*)p; }
-    __device__ static __forceinline__ u4raw load_stream_raw(const uint16_t* p) { return __builtin_nontemporal_load((const u4raw*)p); }
+    __device__ static __forceinline__ u4raw load_raw(const T* p) { return *(const u4raw*)p; }
+    __device__ static __forceinline__ u4raw load_stream_raw(const T* p) { return __builtin_nontemporal_load((const u4raw*)p); }
     __device__ static __forceinline__ void unpack(const u4raw t, float (&v)[8]) {
         const unsigned w[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+        for (int i = 0; i < 4; ++i) { v[2 * i] = et_lp<T>::lo(w[i]); v[2 * i + 1] = et_lp<T>::hi(w[i]); }
     }
-    __device__ static __forceinline__ void load(const uint16_t* p, float (&v)[8]) {
+    __device__ static __forceinline__ void load(const T* p, float (&v)[8]) {
         const uint4 t = *(const uint4*)p;
         const unsigned w[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+        for (int i = 0; i < 4; ++i) { v[2 * i] = et_lp<T>::lo(w[i]); v[2 * i + 1] = et_lp<T>::hi(w[i]); }
     }
     // last use of the data for a long time (the apply pass of backward, y in the forward pass): a non-temporal
     // load keeps these streams from evicting what the neighbouring conv kernels re-read through L2 / MALL
     // (measured: BN micro-benchmark -2 %, whole step +0.7 %)
-    __device__ static __forceinline__ void load_stream(const uint16_t* p, float (&v)[8]) {
+    __device__ static __forceinline__ void load_stream(const T* p, float (&v)[8]) {
         typedef unsigned u4v __attribute__((ext_vector_type(4)));
         const u4v t = __builtin_nontemporal_load((const u4v*)p);
         const unsigned w[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+        for (int i = 0; i < 4; ++i) { v[2 * i] = et_lp<T>::lo(w[i]); v[2 * i + 1] = et_lp<T>::hi(w[i]); }
     }
-    __device__ static __forceinline__ void store(uint16_t* p, const float (&v)[8]) {
-        *(uint4*)p = make_uint4(et_pack_bf2(v[0], v[1]), et_pack_bf2(v[2], v[3]), et_pack_bf2(v[4], v[5]), et_pack_bf2(v[6], v[7]));
+    __device__ static __forceinline__ void store(T* p, const float (&v)[8]) {
+        *(uint4*)p = make_uint4(et_lp<T>::pack(v[0], v[1]), et_lp<T>::pack(v[2], v[3]), et_lp<T>::pack(v[4], v[5]), et_lp<T>::pack(v[6], v[7]));
     }
 };
+template <> struct Vec16<uint16_t> : Vec16lp<uint16_t> {};
+template <> struct Vec16<et_f16> : Vec16lp<et_f16> {};
 
 // ---- partial-sum reduction + per-channel finalize in ONE launch ---------------------------------------------
 // (rows, 2, C) fp32 partial sums -> fp64 totals -> per-channel results.  grid (C/32, RB): each block reduces a
@@ -484,6 +486,9 @@ extern "C" int et_bn_act_fwd(const void* y, int ldy, void* z, int ldz, const voi
     else if (dtype == ET_BF16)
         ET_ACT_LAUNCH(bn_act_fwd_kernel, uint16_t, act, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)y, ldy,
                       (uint16_t*)z, ldz, (const uint16_t*)residual, ldr, P, CV, scale, shift);
+    else if (dtype == ET_F16)
+        ET_ACT_LAUNCH(bn_act_fwd_kernel, et_f16, act, grid, dim3(256), 0, (hipStream_t)stream, (const et_f16*)y, ldy,
+                      (et_f16*)z, ldz, (const et_f16*)residual, ldr, P, CV, scale, shift);
     else return -2;
     ET_CHECK_LAUNCH();
     return 0;
@@ -514,15 +519,21 @@ extern "C" int et_bn_act_bwd(const void* dz, int lddz, const void* y, int ldy, v
     else if (dtype == ET_BF16)
         ET_ACT_LAUNCH(bn_act_bwd_reduce_kernel, uint16_t, act, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)dz, lddz,
                       (const uint16_t*)y, ldy, P, CV, scale, shift, save_mean, save_invstd, part);
+    else if (dtype == ET_F16)
+        ET_ACT_LAUNCH(bn_act_bwd_reduce_kernel, et_f16, act, grid, dim3(256), 0, (hipStream_t)stream, (const et_f16*)dz, lddz,
+                      (const et_f16*)y, ldy, P, CV, scale, shift, save_mean, save_invstd, part);
     else return -2;
     const BnBwdFin fin{(float)P, gamma, save_invstd, dgamma, dbeta, k0, k1, k2, nullptr};
     launch_rows_reduce_finalize(part, rows, C, tot, fin, (hipStream_t)stream);
     if (dtype == ET_F32)
         ET_ACT_LAUNCH(bn_act_bwd_apply_kernel, float, act, grid, dim3(256), 0, (hipStream_t)stream, (const float*)dz, lddz,
                       (const float*)y, ldy, (float*)dy, lddy, P, CV, scale, shift, save_mean, save_invstd, k0, k1, k2);
-    else
+    else if (dtype == ET_BF16)
         ET_ACT_LAUNCH(bn_act_bwd_apply_kernel, uint16_t, act, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)dz, lddz,
                       (const uint16_t*)y, ldy, (uint16_t*)dy, lddy, P, CV, scale, shift, save_mean, save_invstd, k0, k1, k2);
+    else if (dtype == ET_F16)
+        ET_ACT_LAUNCH(bn_act_bwd_apply_kernel, et_f16, act, grid, dim3(256), 0, (hipStream_t)stream, (const et_f16*)dz, lddz,
+                      (const et_f16*)y, ldy, (et_f16*)dy, lddy, P, CV, scale, shift, save_mean, save_invstd, k0, k1, k2);
     ET_CHECK_LAUNCH();
     return 0;
 }
@@ -551,6 +562,9 @@ extern "C" int et_bn_act_bwd_from_partials(const void* dz, int lddz, const void*
     else if (dtype == ET_BF16)
         ET_ACT_LAUNCH(bn_act_bwd_apply_kernel, uint16_t, act, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)dz, lddz,
                       (const uint16_t*)y, ldy, (uint16_t*)dy, lddy, P, CV, scale, shift, save_mean, save_invstd, k0, k1, k2);
+    else if (dtype == ET_F16)
+        ET_ACT_LAUNCH(bn_act_bwd_apply_kernel, et_f16, act, grid, dim3(256), 0, (hipStream_t)stream, (const et_f16*)dz, lddz,
+                      (const et_f16*)y, ldy, (et_f16*)dy, lddy, P, CV, scale, shift, save_mean, save_invstd, k0, k1, k2);
     else return -2;
     ET_CHECK_LAUNCH();
     return 0;
@@ -569,6 +583,9 @@ extern "C" int et_act_bwd(const void* dz, int lddz, const void* y, int ldy, void
     else if (dtype == ET_BF16)
         ET_ACT_LAUNCH(act_bwd_kernel, uint16_t, act, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)dz, lddz,
                       (const uint16_t*)y, ldy, (uint16_t*)dy, lddy, P, CV);
+    else if (dtype == ET_F16)
+        ET_ACT_LAUNCH(act_bwd_kernel, et_f16, act, grid, dim3(256), 0, (hipStream_t)stream, (const et_f16*)dz, lddz,
+                      (const et_f16*)y, ldy, (et_f16*)dy, lddy, P, CV);
     else return -2;
     ET_CHECK_LAUNCH();
     return 0;

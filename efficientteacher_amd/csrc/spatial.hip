@@ -44,8 +44,8 @@ __global__ __launch_bounds__(256) void pack_input_u8_kernel(const uint8_t* __res
 // bf16 output, FOUR consecutive pixels per thread: one 16-byte (fp32 image) or 4-byte (uint8 image) load per channel and 64
 // contiguous bytes stored, instead of a 4- / 1-byte load per channel and pixel (the fp32 pack ran at 3.7 TB/s, the uint8 one issues
 // 64-byte wave loads).  Same arithmetic: fp32 value rounded to bf16; uint8 value / norm_scale (IEEE division), then rounded.
-template <typename IN>
-__global__ __launch_bounds__(256) void pack_input4_bf16_kernel(const IN* __restrict__ x, uint16_t* __restrict__ y, int C, int HW4,
+template <typename IN, typename T = uint16_t>       // T: the 16-bit output format (uint16_t = bf16, et_f16)
+__global__ __launch_bounds__(256) void pack_input4_bf16_kernel(const IN* __restrict__ x, T* __restrict__ y, int C, int HW4,
                                                                long long total4, float scale) {
     const unsigned qu = blockIdx.x * 256u + threadIdx.x;               // quad index over B*HW/4 (host: < 2^31)
     if (qu >= total4) return;
@@ -67,10 +67,10 @@ __global__ __launch_bounds__(256) void pack_input4_bf16_kernel(const IN* __restr
             }
         }
     }
-    uint16_t* const d = y + ((long long)b * HW4 * 4 + (long long)h4 * 4) * 8;
+    T* const d = y + ((long long)b * HW4 * 4 + (long long)h4 * 4) * 8;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-        *(uint4*)(d + j * 8) = make_uint4(et_pack_bf2(v[0][j], v[1][j]), et_pack_bf2(v[2][j], v[3][j]), 0u, 0u);
+        *(uint4*)(d + j * 8) = make_uint4(et_lp<T>::pack(v[0][j], v[1][j]), et_lp<T>::pack(v[2][j], v[3][j]), 0u, 0u);
 }
 
 template <typename T> struct PV;   // 16-byte vector <-> floats
@@ -79,18 +79,20 @@ template <> struct PV<float> {
     __device__ static __forceinline__ void load(const float* p, float (&v)[4]) { const float4 t = *(const float4*)p; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
     __device__ static __forceinline__ void store(float* p, const float (&v)[4]) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); }
 };
-template <> struct PV<uint16_t> {
+template <typename T> struct PVlp {       // the 16-bit storage formats
     static constexpr int N = 8;
-    __device__ static __forceinline__ void load(const uint16_t* p, float (&v)[8]) {
+    __device__ static __forceinline__ void load(const T* p, float (&v)[8]) {
         const uint4 t = *(const uint4*)p;
         const unsigned w[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+        for (int i = 0; i < 4; ++i) { v[2 * i] = et_lp<T>::lo(w[i]); v[2 * i + 1] = et_lp<T>::hi(w[i]); }
     }
-    __device__ static __forceinline__ void store(uint16_t* p, const float (&v)[8]) {
-        *(uint4*)p = make_uint4(et_pack_bf2(v[0], v[1]), et_pack_bf2(v[2], v[3]), et_pack_bf2(v[4], v[5]), et_pack_bf2(v[6], v[7]));
+    __device__ static __forceinline__ void store(T* p, const float (&v)[8]) {
+        *(uint4*)p = make_uint4(et_lp<T>::pack(v[0], v[1]), et_lp<T>::pack(v[2], v[3]), et_lp<T>::pack(v[4], v[5]), et_lp<T>::pack(v[6], v[7]));
     }
 };
+template <> struct PV<uint16_t> : PVlp<uint16_t> {};
+template <> struct PV<et_f16> : PVlp<et_f16> {};
 
 // y = maxpool5x5(x); idx = window position (ky*5+kx) of the FIRST maximum in scan order
 // (torch max_pool2d tie rule: strict '>' while scanning rows then columns).
@@ -228,6 +230,12 @@ extern "C" int et_pack_input(const float* x_nchw, void* y_nhwc8, int dtype, int 
                                (uint16_t*)y_nhwc8, C, H * W / 4, total / 4, 1.0f);
         else
             hipLaunchKernelGGL((pack_input_kernel<uint16_t>), grid, dim3(256), 0, (hipStream_t)stream, x_nchw, (uint16_t*)y_nhwc8, C, H * W, total);
+    } else if (dtype == ET_F16) {
+        if (C <= 4 && (H * W) % 4 == 0 && ((((uintptr_t)x_nchw) | ((uintptr_t)y_nhwc8)) & 15) == 0)
+            hipLaunchKernelGGL((pack_input4_bf16_kernel<float, et_f16>), dim3(et_cdiv(total / 4, 256)), dim3(256), 0, (hipStream_t)stream, x_nchw,
+                               (et_f16*)y_nhwc8, C, H * W / 4, total / 4, 1.0f);
+        else
+            hipLaunchKernelGGL((pack_input_kernel<et_f16>), grid, dim3(256), 0, (hipStream_t)stream, x_nchw, (et_f16*)y_nhwc8, C, H * W, total);
     } else return -2;
     ET_CHECK_LAUNCH();
     return 0;
@@ -247,6 +255,12 @@ extern "C" int et_pack_input_u8(const uint8_t* x_nchw, void* y_nhwc8, int dtype,
                                (uint16_t*)y_nhwc8, C, H * W / 4, total / 4, norm_scale);
         else
             hipLaunchKernelGGL((pack_input_u8_kernel<uint16_t>), grid, dim3(256), 0, (hipStream_t)stream, x_nchw, (uint16_t*)y_nhwc8, C, H * W, total, norm_scale);
+    } else if (dtype == ET_F16) {
+        if (C <= 4 && (H * W) % 4 == 0 && (((uintptr_t)x_nchw) & 3) == 0 && (((uintptr_t)y_nhwc8) & 15) == 0)
+            hipLaunchKernelGGL((pack_input4_bf16_kernel<uint8_t, et_f16>), dim3(et_cdiv(total / 4, 256)), dim3(256), 0, (hipStream_t)stream, x_nchw,
+                               (et_f16*)y_nhwc8, C, H * W / 4, total / 4, norm_scale);
+        else
+            hipLaunchKernelGGL((pack_input_u8_kernel<et_f16>), grid, dim3(256), 0, (hipStream_t)stream, x_nchw, (et_f16*)y_nhwc8, C, H * W, total, norm_scale);
     } else return -2;
     ET_CHECK_LAUNCH();
     return 0;
@@ -262,6 +276,7 @@ extern "C" int et_maxpool5_fwd(const void* x, int ldx, void* y, int ldy, uint8_t
     if (total >= (1ll << 31)) return -2;               // the kernels index with 32-bit arithmetic
     if (dtype == ET_F32) { const dim3 g(et_cdiv(total, 256)); hipLaunchKernelGGL((maxpool5_fwd_kernel<float>), g, dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, (float*)y, ldy, argmax, H, W, CV, total); }
     else if (dtype == ET_BF16) { const dim3 g(et_cdiv(total, 256)); hipLaunchKernelGGL((maxpool5_fwd_kernel<uint16_t>), g, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, ldx, (uint16_t*)y, ldy, argmax, H, W, CV, total); }
+    else if (dtype == ET_F16) { const dim3 g(et_cdiv(total, 256)); hipLaunchKernelGGL((maxpool5_fwd_kernel<et_f16>), g, dim3(256), 0, (hipStream_t)stream, (const et_f16*)x, ldx, (et_f16*)y, ldy, argmax, H, W, CV, total); }
     else return -2;
     ET_CHECK_LAUNCH();
     return 0;
@@ -277,6 +292,7 @@ extern "C" int et_maxpool5_bwd(const void* dy, int lddy, const uint8_t* argmax, 
     if (total >= (1ll << 31)) return -2;               // the kernels index with 32-bit arithmetic
     if (dtype == ET_F32) { const dim3 g(et_cdiv(total, 256)); hipLaunchKernelGGL((maxpool5_bwd_kernel<float>), g, dim3(256), 0, (hipStream_t)stream, (const float*)dy, lddy, argmax, (const float*)base, ldb, (float*)dx, lddx, H, W, CV, total); }
     else if (dtype == ET_BF16) { const dim3 g(et_cdiv(total, 256)); hipLaunchKernelGGL((maxpool5_bwd_kernel<uint16_t>), g, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)dy, lddy, argmax, (const uint16_t*)base, ldb, (uint16_t*)dx, lddx, H, W, CV, total); }
+    else if (dtype == ET_F16) { const dim3 g(et_cdiv(total, 256)); hipLaunchKernelGGL((maxpool5_bwd_kernel<et_f16>), g, dim3(256), 0, (hipStream_t)stream, (const et_f16*)dy, lddy, argmax, (const et_f16*)base, ldb, (et_f16*)dx, lddx, H, W, CV, total); }
     else return -2;
     ET_CHECK_LAUNCH();
     return 0;
@@ -291,6 +307,7 @@ extern "C" int et_upsample2x_fwd(const void* x, int ldx, void* y, int ldy, int d
     if (total >= (1ll << 31)) return -2;               // the kernels index with 32-bit arithmetic
     if (dtype == ET_F32) { const dim3 g(et_cdiv(total, 256)); hipLaunchKernelGGL((upsample2x_fwd_kernel<float>), g, dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, (float*)y, ldy, H, W, CV, total); }
     else if (dtype == ET_BF16) { const dim3 g(et_cdiv(total, 256)); hipLaunchKernelGGL((upsample2x_fwd_kernel<uint16_t>), g, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, ldx, (uint16_t*)y, ldy, H, W, CV, total); }
+    else if (dtype == ET_F16) { const dim3 g(et_cdiv(total, 256)); hipLaunchKernelGGL((upsample2x_fwd_kernel<et_f16>), g, dim3(256), 0, (hipStream_t)stream, (const et_f16*)x, ldx, (et_f16*)y, ldy, H, W, CV, total); }
     else return -2;
     ET_CHECK_LAUNCH();
     return 0;
@@ -306,6 +323,7 @@ extern "C" int et_upsample2x_bwd(const void* dy, int lddy, void* dx, int lddx, i
     if (total >= (1ll << 31)) return -2;               // the kernels index with 32-bit arithmetic
     if (dtype == ET_F32) { const dim3 g(et_cdiv(total, 256)); hipLaunchKernelGGL((upsample2x_bwd_kernel<float>), g, dim3(256), 0, (hipStream_t)stream, (const float*)dy, lddy, (float*)dx, lddx, H, W, CV, total, accumulate); }
     else if (dtype == ET_BF16) { const dim3 g(et_cdiv(total, 256)); hipLaunchKernelGGL((upsample2x_bwd_kernel<uint16_t>), g, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)dy, lddy, (uint16_t*)dx, lddx, H, W, CV, total, accumulate); }
+    else if (dtype == ET_F16) { const dim3 g(et_cdiv(total, 256)); hipLaunchKernelGGL((upsample2x_bwd_kernel<et_f16>), g, dim3(256), 0, (hipStream_t)stream, (const et_f16*)dy, lddy, (et_f16*)dx, lddx, H, W, CV, total, accumulate); }
     else return -2;
     ET_CHECK_LAUNCH();
     return 0;

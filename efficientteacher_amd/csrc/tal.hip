@@ -69,6 +69,10 @@ extern "C" int et_v8_decode(const void* reg, int ld_reg, const void* cls, int ld
         hipLaunchKernelGGL((v8_decode_kernel<uint16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)reg, ld_reg,
                            (const uint16_t*)cls, ld_cls, B, H, W, reg_max, nc, stride, cell_offset, out, (long long)A_total,
                            (long long)a_offset);
+    else if (dtype == ET_F16)
+        hipLaunchKernelGGL((v8_decode_kernel<et_f16>), grid, dim3(256), 0, (hipStream_t)stream, (const et_f16*)reg, ld_reg,
+                           (const et_f16*)cls, ld_cls, B, H, W, reg_max, nc, stride, cell_offset, out, (long long)A_total,
+                           (long long)a_offset);
     else return -2;
     ET_CHECK_LAUNCH();
     return 0;

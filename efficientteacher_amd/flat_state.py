@@ -184,7 +184,7 @@ class FlatState:
         """Refresh the low-precision weight copy from the fp32 master (after load_state_dict etc.)."""
         if self.shadow is not None:
             o, n = self.w_range
-            ops.cast_f32_to_bf16(self.params[o:o + n], self.shadow)
+            ops.cast_f32_to_lp(self.params[o:o + n], self.shadow)
 
     def refresh_eval_affine(self):
         """scale = g / sqrt(running_var + eps), shift = b - running_mean*scale for every BN channel."""

@@ -83,7 +83,8 @@ class Model(nn.Module):
 
     def half(self):
         """reference callers (val.py:212, trainer.py:475) switch to fp16 for inference / checkpoints; here the fp32 master
-        weights stay and the COMPUTE dtype becomes bf16 (the MFMA path; there are no fp16 kernels)"""
+        weights stay and the COMPUTE dtype becomes bf16 (the default performance mode; fp16 -- same MFMA rate, the reference's own
+        arithmetic -- is ``set_compute_dtype(torch.float16)``)"""
         return self.set_compute_dtype(torch.bfloat16)
 
     def float(self):
@@ -96,8 +97,9 @@ class Model(nn.Module):
         return self._flat
 
     def set_compute_dtype(self, dtype):
-        """torch.float32 = parity mode (exact-f32 MFMA); torch.bfloat16 = performance mode."""
-        if dtype not in (torch.float32, torch.bfloat16):
+        """torch.float32 = parity mode (exact-f32 MFMA); torch.bfloat16 = performance mode; torch.float16 = the reference's AMP
+        arithmetic (v_mfma_f32_32x32x16_f16; training then needs optim.DeviceGradScaler, as the reference needs GradScaler)."""
+        if dtype not in (torch.float32, torch.bfloat16, torch.float16):
             raise TypeError(dtype)
         self._compute_dtype = dtype
         self.rebuild_flat()

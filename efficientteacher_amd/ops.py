@@ -7,7 +7,7 @@ No arithmetic happens here: every function validates shapes, allocates outputs a
 import torch
 
 from . import _lib
-from ._lib import ET_BF16, ET_F32
+from ._lib import ET_BF16, ET_F16, ET_F32
 
 ACT_NONE, ACT_SILU, ACT_RELU = 0, 1, 2
 
@@ -56,7 +56,7 @@ class FamilyTimer:
         "et_tal_loss": "nms_loss_pl", "et_tal_assign": "nms_loss_pl", "et_colsum": "nms_loss_pl", "et_tal_pseudo_split": "nms_loss_pl", "et_tal_targets_pad": "nms_loss_pl",
         "et_tal_assigned_gt": "nms_loss_pl", "et_tal_merge_pseudo": "nms_loss_pl",
         "et_sgd_nesterov": "optimizer_ema", "et_sgd_nesterov_dev": "optimizer_ema", "et_adamw": "optimizer_ema", "et_ema_update": "optimizer_ema",
-        "et_ema_update_dev": "optimizer_ema", "et_cast_f32_to_bf16": "optimizer_ema", "et_weight_transpose": "optimizer_ema",
+        "et_ema_update_dev": "optimizer_ema", "et_cast_f32_to_lp": "optimizer_ema", "et_scaler_check": "optimizer_ema", "et_scaler_update": "optimizer_ema", "et_weight_transpose": "optimizer_ema",
         "et_weight_transpose_all": "optimizer_ema", "et_bn_eval_affine": "optimizer_ema",
     }
 
@@ -92,7 +92,7 @@ def kernel_name(op, dtype, N, IH, IW, Cin, Cout, k, stride, pad, parity_class=0,
     import ctypes
     buf = ctypes.create_string_buffer(256)
     code = {"fwd": 0, "dgrad": 1, "wgrad": 2, "dgrad_full": 3, "fwd_res": 4}[op]
-    dt = ET_F32 if dtype == torch.float32 else ET_BF16
+    dt = _ET_OF[dtype]
     _lib.check(_lib.load().et_conv2d_kernel_name(code, dt, N, IH, IW, Cin, Cout, k, k, stride, pad, int(bool(zero_page)),
                                                  parity_class, buf, 256), "et_conv2d_kernel_name")
     return buf.value.decode()
@@ -101,7 +101,7 @@ def kernel_name(op, dtype, N, IH, IW, Cin, Cout, k, stride, pad, parity_class=0,
 def stats_rows(op, dtype, N, IH, IW, Cin, Cout, k, stride, pad, zero_page=True):
     """rows of the partial-statistics buffer the selected kernel writes (op 'fwd': et_conv2d_fwd's stats_partial; 'fwd_res': the same
     for a call that also passes a residual; 'dgrad_bn': et_conv2d_dgrad_bn's bn_stats_partial; arguments of the FORWARD conv)"""
-    dt = ET_F32 if dtype == torch.float32 else ET_BF16
+    dt = _ET_OF[dtype]
     rows = _lib.load().et_conv2d_stats_rows_for({"fwd": 0, "dgrad_bn": 1, "fwd_res": 2}[op], dt, N, IH, IW, Cin, Cout, k, k, stride, pad, int(bool(zero_page)))
     if rows <= 0:
         raise _lib.EtHipError(f"et_conv2d_stats_rows_for failed with code {rows}")
@@ -141,12 +141,18 @@ def bn_totals_scratch(device):
     return z
 
 
+# compute dtypes: float32 = parity mode (exact-f32 MFMA), bfloat16 = performance mode, float16 = the reference's own reduced precision
+# (torch.cuda.amp autocast + GradScaler, trainer/trainer.py:248,348,399-400: same MFMA rate as bf16, needs the loss scaler below)
+_ET_OF = {torch.float32: ET_F32, torch.bfloat16: ET_BF16, torch.float16: ET_F16}
+LP_DTYPES = (torch.bfloat16, torch.float16)
+
+
 def et_dtype(t):
-    if t.dtype == torch.float32:
-        return ET_F32
-    if t.dtype == torch.bfloat16:
-        return ET_BF16
-    raise TypeError(f"unsupported dtype {t.dtype} (float32 = parity mode, bfloat16 = performance mode)")
+    try:
+        return _ET_OF[t.dtype]
+    except KeyError:
+        raise TypeError(f"unsupported dtype {t.dtype} (float32 = parity mode, bfloat16 = performance mode, float16 = the "
+                        "reference's AMP recipe)") from None
 
 
 def _nhwc(x):
@@ -241,7 +247,7 @@ class WgradQueue:
         self.join()
 
     def submit(self, x, dy, dw, ksize, stride, pad, on_done=None):
-        if self.group <= 1 or x.dtype != torch.bfloat16:
+        if self.group <= 1 or x.dtype not in LP_DTYPES:
             conv2d_wgrad(x, dy, dw, ksize, stride, pad)
             if on_done is not None:
                 on_done()
@@ -758,11 +764,23 @@ def scale_cast(src_flat, dtype, scale=1.0, dev_scale=None, out=None):
 
 
 # ---- flat-arena state updates ------------------------------------------------------------------------
-def cast_f32_to_bf16(src, dst):
-    assert src.dtype == torch.float32 and dst.dtype == torch.bfloat16 and src.numel() == dst.numel()
-    _lib.check(_lib.load().et_cast_f32_to_bf16(_lib.ptr(src), _lib.ptr(dst), src.numel(), _lib.stream(src)),
-               "et_cast_f32_to_bf16")
+def cast_f32_to_lp(src, dst):
+    """fp32 arena -> its 16-bit shadow in the compute format (dst.dtype bfloat16 | float16), round to nearest even"""
+    assert src.dtype == torch.float32 and dst.dtype in LP_DTYPES and src.numel() == dst.numel()
+    _lib.check(_lib.load().et_cast_f32_to_lp(_lib.ptr(src), _lib.ptr(dst), et_dtype(dst), src.numel(), _lib.stream(src)),
+               "et_cast_f32_to_lp")
     return dst
+
+
+def scaler_check(grads, scaler):
+    """found_inf (scaler[2]) = 1 if any element of the scaled fp32 gradient arena is inf / nan"""
+    assert grads.dtype == torch.float32 and scaler.dtype == torch.float32 and scaler.numel() >= 4
+    _lib.check(_lib.load().et_scaler_check(_lib.ptr(grads), grads.numel(), _lib.ptr(scaler), _lib.stream(grads)), "et_scaler_check")
+
+
+def scaler_update(scaler, growth_factor, backoff_factor, growth_interval):
+    _lib.check(_lib.load().et_scaler_update(_lib.ptr(scaler), float(growth_factor), float(backoff_factor), int(growth_interval),
+                                            _lib.stream(scaler)), "et_scaler_update")
 
 
 def bn_eval_affine_into(gamma, beta, running_mean, running_var, eps, scale, shift):
@@ -786,23 +804,28 @@ def ema_update_dev(ema_flat, model_flat, d2):
                                              _lib.stream(ema_flat)), "et_ema_update_dev")
 
 
-def sgd_nesterov_dev(p, g, buf, shadow, hp, first_step):
-    """hp: device tensor [lr, momentum, weight_decay, inv_scale] (graph-replayable form)"""
+def _shadow_dt(shadow):
+    return et_dtype(shadow) if shadow is not None else ET_BF16
+
+
+def sgd_nesterov_dev(p, g, buf, shadow, hp, first_step, scaler=None):
+    """hp: device tensor [lr, momentum, weight_decay, inv_scale] (graph-replayable form); scaler: the device loss-scaler state of
+    fp16 mode (found_inf skips the update, 1/scale multiplies the gradient) or None"""
     assert hp.dtype == torch.float32 and hp.numel() >= 4
-    _lib.check(_lib.load().et_sgd_nesterov_dev(_lib.ptr(p), _lib.ptr(g), _lib.ptr(buf), _lib.ptr(shadow), p.numel(), _lib.ptr(hp),
-                                               int(bool(first_step)), _lib.stream(p)), "et_sgd_nesterov_dev")
+    _lib.check(_lib.load().et_sgd_nesterov_dev(_lib.ptr(p), _lib.ptr(g), _lib.ptr(buf), _lib.ptr(shadow), _shadow_dt(shadow), p.numel(),
+                                               _lib.ptr(hp), int(bool(first_step)), _lib.ptr(scaler), _lib.stream(p)), "et_sgd_nesterov_dev")
 
 
-def adamw(p, g, exp_avg, exp_avg_sq, shadow, lr, beta1, beta2, eps, weight_decay, step, inv_scale=1.0):
-    _lib.check(_lib.load().et_adamw(_lib.ptr(p), _lib.ptr(g), _lib.ptr(exp_avg), _lib.ptr(exp_avg_sq), _lib.ptr(shadow), p.numel(),
-                                    float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step),
-                                    float(inv_scale), _lib.stream(p)), "et_adamw")
+def adamw(p, g, exp_avg, exp_avg_sq, shadow, lr, beta1, beta2, eps, weight_decay, step, inv_scale=1.0, scaler=None):
+    _lib.check(_lib.load().et_adamw(_lib.ptr(p), _lib.ptr(g), _lib.ptr(exp_avg), _lib.ptr(exp_avg_sq), _lib.ptr(shadow), _shadow_dt(shadow),
+                                    p.numel(), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step),
+                                    float(inv_scale), _lib.ptr(scaler), _lib.stream(p)), "et_adamw")
 
 
-def sgd_nesterov(p, g, buf, shadow, lr, momentum, weight_decay, first_step, inv_scale=1.0):
-    _lib.check(_lib.load().et_sgd_nesterov(_lib.ptr(p), _lib.ptr(g), _lib.ptr(buf), _lib.ptr(shadow), p.numel(),
+def sgd_nesterov(p, g, buf, shadow, lr, momentum, weight_decay, first_step, inv_scale=1.0, scaler=None):
+    _lib.check(_lib.load().et_sgd_nesterov(_lib.ptr(p), _lib.ptr(g), _lib.ptr(buf), _lib.ptr(shadow), _shadow_dt(shadow), p.numel(),
                                            float(lr), float(momentum), float(weight_decay), int(bool(first_step)),
-                                           float(inv_scale), _lib.stream(p)), "et_sgd_nesterov")
+                                           float(inv_scale), _lib.ptr(scaler), _lib.stream(p)), "et_sgd_nesterov")
 
 
 def detect_decode(raw5, anchor_px, stride, z, a_offset):
@@ -889,6 +912,12 @@ def tal_targets_pad(targets, B, img_w, img_h):
         # crowded batch (mosaic: thousands of boxes): G = n would make the assigner's B*G*A workspace and its B*G workgroups grow with the
         # BATCH total instead of the per-image maximum the reference pads to (tal_loss.py:131-143).  One host read of the per-image
         # maximum -- the reference's own preprocess synchronises on targets.cpu() at this point anyway.
+        if t.is_cuda and torch.cuda.is_current_stream_capturing():
+            # a host read is illegal inside a graph capture (it would invalidate the capture and the trainer would silently fall back
+            # to eager steps for the rest of the run -- ADVICE r04), and a data-dependent G could not be replayed anyway
+            raise RuntimeError(f"tal_targets_pad: {n} targets for {B} images (> {TAL_PAD_SYNC_FREE_ROWS} per image on average) needs a "
+                               "host read of the per-image maximum, which a step-graph capture cannot contain: run this batch "
+                               "eagerly (ET_STEP_GRAPH=0) or cap the targets per image in the loader")
         G = max(int(torch.bincount(t[:, 0].long().clamp_(0, B - 1), minlength=B).max()), 1)
     out = torch.empty((B, G, 5), dtype=torch.float32, device=t.device)
     mask = torch.empty((B, G, 1), dtype=torch.float32, device=t.device)

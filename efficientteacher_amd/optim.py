@@ -10,6 +10,48 @@ import torch
 from . import ops
 
 
+class DeviceGradScaler:
+    """torch.cuda.amp.GradScaler as the reference drives it (trainer/trainer.py:248 ``GradScaler(enabled=cuda)``, :399
+    ``scaler.scale(loss).backward()``, :400-401 ``scaler.step(optimizer); scaler.update()``; ssod_trainer.py:595,625) for the fp16
+    compute mode -- with its state {scale, 1/scale, found_inf, growth_tracker} in DEVICE memory: ``step`` checks the (scaled, fp32)
+    gradient arena for inf / nan with one pass (et_scaler_check) and the optimizer kernels themselves skip the update or unscale
+    the gradient as they read it, so that a step never synchronises with the host (torch's ``scaler.step`` calls
+    ``found_inf.item()``) and can be captured into the step graph.  Defaults are torch's: init 65536, growth 2.0 every 2000 clean
+    steps, backoff 0.5.  ``enabled=False`` (fp32 parity mode, bf16 performance mode: no loss scaling needed) makes every method
+    the identity."""
+
+    def __init__(self, device, enabled=True, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
+        self.enabled = bool(enabled)
+        self.growth_factor, self.backoff_factor, self.growth_interval = float(growth_factor), float(backoff_factor), int(growth_interval)
+        self.state = torch.tensor([init_scale, 1.0 / init_scale, 0.0, 0.0], dtype=torch.float32, device=device) if self.enabled else None
+
+    def scale(self, loss):
+        return loss * self.state[0] if self.enabled else loss
+
+    def step(self, optimizer):
+        """found_inf over the gradient arena, then the optimizer's (possibly skipped) update"""
+        if not self.enabled:
+            return optimizer.step()
+        ops.WGRAD_QUEUE.join()                   # the deferred weight-gradient launches are in the arena before it is scanned
+        ops.scaler_check(optimizer.flat.grads, self.state)
+        return optimizer.step(scaler=self.state)
+
+    def update(self):
+        if self.enabled:
+            ops.scaler_update(self.state, self.growth_factor, self.backoff_factor, self.growth_interval)
+
+    def get_scale(self):
+        """host read (synchronises): logging / tests only"""
+        return float(self.state[0]) if self.enabled else 1.0
+
+    def state_dict(self):
+        return dict(state=self.state.detach().cpu().clone()) if self.enabled else {}
+
+    def load_state_dict(self, sd):
+        if self.enabled and "state" in sd:
+            self.state.copy_(sd["state"].to(self.state.device))
+
+
 class FlatSGD(torch.optim.Optimizer):
     def __init__(self, model, lr, momentum=0.937, nesterov=True, weight_decay=0.0):
         if not nesterov:
@@ -58,7 +100,9 @@ class FlatSGD(torch.optim.Optimizer):
         self.first = bool(first)
 
     @torch.no_grad()
-    def step(self, closure=None, inv_scale=1.0):
+    def step(self, closure=None, inv_scale=1.0, scaler=None):
+        """scaler: DeviceGradScaler.state (fp16 mode) -- the kernels skip the update when its found_inf flag is set and multiply
+        the gradient by its 1/scale otherwise"""
         f = self.flat
         if f is not self._model.flat_state():
             raise RuntimeError("the model's arenas were rebuilt (model.to() / set_compute_dtype() / _apply) after this optimizer "
@@ -71,10 +115,10 @@ class FlatSGD(torch.optim.Optimizer):
             shadow = f.shadow if (f.shadow is not None and (o, n) == tuple(f.w_range)) else None
             if self.capturing and self.hp_dev is not None:
                 ops.sgd_nesterov_dev(f.params[o:o + n], f.grads[o:o + n], self.momentum_buf[o:o + n], shadow, self.hp_dev[j],
-                                     self.first)
+                                     self.first, scaler)
             else:
                 ops.sgd_nesterov(f.params[o:o + n], f.grads[o:o + n], self.momentum_buf[o:o + n], shadow,
-                                 g['lr'], g['momentum'], g['weight_decay'], self.first, inv_scale)
+                                 g['lr'], g['momentum'], g['weight_decay'], self.first, inv_scale, scaler)
         self.first = False
         f.w_version += 1                 # the compute-precision shadow changed: transposed copies are stale
 
@@ -135,7 +179,7 @@ class FlatAdamW(torch.optim.Optimizer):
         self.steps = int(n)
 
     @torch.no_grad()
-    def step(self, closure=None, inv_scale=1.0):
+    def step(self, closure=None, inv_scale=1.0, scaler=None):
         f = self.flat
         if f is not self._model.flat_state():
             raise RuntimeError("the model's arenas were rebuilt after this optimizer was created")
@@ -146,7 +190,7 @@ class FlatAdamW(torch.optim.Optimizer):
             o, n = g['range']
             shadow = f.shadow if (f.shadow is not None and (o, n) == tuple(f.w_range)) else None
             ops.adamw(f.params[o:o + n], f.grads[o:o + n], self.exp_avg[o:o + n], self.exp_avg_sq[o:o + n], shadow, g['lr'],
-                      g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'], self.steps, inv_scale)
+                      g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'], self.steps, inv_scale, scaler)
         f.w_version += 1
 
     def zero_grad(self, set_to_none=False):

@@ -58,9 +58,11 @@ class FlatDataParallel(nn.Module):
         if chunk_mb is None:
             chunk_mb = float(os.environ.get("ET_ALLREDUCE_CHUNK_MB", "48"))
         self.chunk = int(chunk_mb * (1 << 20) // 4)
-        if grad_dtype not in (None, torch.float32, torch.bfloat16):
+        if grad_dtype is None:                       # transport setting, like the chunk size: ET_ALLREDUCE_DTYPE=bf16 | fp32 (default)
+            grad_dtype = {"bf16": torch.bfloat16, "fp32": torch.float32, "": torch.float32}[os.environ.get("ET_ALLREDUCE_DTYPE", "").lower()]
+        if grad_dtype not in (torch.float32, torch.bfloat16):
             raise ValueError(f"grad_dtype {grad_dtype}: float32 (default) or bfloat16")
-        self.grad_dtype = torch.float32 if grad_dtype is None else grad_dtype
+        self.grad_dtype = grad_dtype
         self._stage = None               # bf16 staging arena, same element offsets as the gradient arena (grad_dtype = bfloat16)
         self.broadcast_buffers = broadcast_buffers
         self.overlap = overlap

@@ -18,34 +18,15 @@ from ..utils.torch_utils import CosineEMA, SemiSupModelEMA
 from .trainer import Trainer
 
 
-def _cu_masked_stream(device, n_cu, stride=1):
-    """A HIP stream whose kernels may only occupy `n_cu` compute units (hipExtStreamCreateWithCUMask), as a torch ExternalStream:
-    ET_TEACHER_CUS=n gives the teacher stream such a mask, so that its workgroups stop displacing the student's on the other CUs
-    ("make the overlap real or drop it").  The low n bits of the mask are set: the driver deals mask bits
-    round-robin to the XCDs and, inside one, to its shader engines, so the n CUs are spread evenly over the eight L2s.
-    Opt-in experiment arm; the A/B against the unmasked stream and against no overlap is in profiles/r05_teacher_cu_mask_ab.txt."""
-    import ctypes
-    hip = ctypes.CDLL("libamdhip64.so")
-    words = (max(1, n_cu * stride) + 31) // 32
-    mask = (ctypes.c_uint32 * words)()
-    for i in range(n_cu):                          # "n/s" = n bits, every s-th (another spreading of the same CU count)
-        mask[(i * stride) // 32] |= 1 << ((i * stride) % 32)
-    h = ctypes.c_void_p()
-    with torch.cuda.device(device):
-        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), ctypes.c_uint32(words), mask)
-    if rc != 0 or not h.value:
-        raise RuntimeError(f"hipExtStreamCreateWithCUMask({n_cu} CUs) failed with code {rc}")
-    return torch.cuda.ExternalStream(h.value, device=device)
-
-
 class SSODTrainer(Trainer):
     MODEL_MODULE = "efficientteacher_amd.models.detector.yolo_ssod"
 
     def __init__(self, cfg, device, callbacks=None, LOCAL_RANK=-1, RANK=-1, WORLD_SIZE=1, nb=1000, target_data_len=None,
-                 label_num_per_image=None, cls_ratio_gt=None):
+                 label_num_per_image=None, cls_ratio_gt=None, amp_dtype=None):
         """target_data_len / label_num_per_image / cls_ratio_gt: what the reference reads off its datasets for LabelMatch
         (ssod_trainer.py:71, :226-227); this core has no data loaders, the caller passes them."""
         self.cfg = cfg
+        self._amp_dtype_arg = amp_dtype            # Trainer.set_env: bf16 (default) | fp16 (the reference's autocast dtype) | fp32
         self.set_env(cfg, device, LOCAL_RANK, RANK, WORLD_SIZE, callbacks, nb)
         self.build_model(cfg, device)
         self.build_optimizer(cfg)
@@ -96,10 +77,9 @@ class SSODTrainer(Trainer):
 
     def _side_stream(self):
         if self._side is None:
-            import os
-            spec = (os.environ.get("ET_TEACHER_CUS", "") or "0").split("/")
-            n_cu, stride = int(spec[0]), int(spec[1]) if len(spec) > 1 else 1
-            self._side = _cu_masked_stream(self.device, n_cu, stride) if n_cu > 0 else torch.cuda.Stream(device=self.device)
+            # (a CU-masked stream, hipExtStreamCreateWithCUMask with 64 / 96 / 128 / 192 of the 256 CUs, was measured in r05: the STEP got
+            # 9-22 ms slower with every mask, main-stream kernels included -- profiles/r05_teacher_cu_mask_ab.txt -- and was removed)
+            self._side = torch.cuda.Stream(device=self.device)
         return self._side
 
     def build_model(self, cfg, device):
@@ -118,11 +98,12 @@ class SSODTrainer(Trainer):
         self.target_loss = TargetLoss()
 
     def update_optimizer(self, loss, ni):
-        loss.backward()
+        self.scaler.scale(loss).backward()     # ssod_trainer.py:469 (identity unless the compute dtype is fp16)
         if self._capturing:                # graph capture: launches only; the host-side schedule runs before each replay
             if isinstance(self.model, FlatDataParallel):
                 self.model.reduce_gradients()      # the remaining chunks + the waits of the async all-reduces, captured too
-            self.optimizer.step()
+            self.scaler.step(self.optimizer)
+            self.scaler.update()
             self.optimizer.zero_grad()
             self.ema.update(self.model)
             if self.semi_ema:
@@ -133,7 +114,8 @@ class SSODTrainer(Trainer):
         self.accumulate = 1 if self.fixed_accumulate else max(round(64 / self.batch_size), 1)
         self._warmup(ni, 1 if self.fixed_accumulate else 64 / self.batch_size)
         if ni - self.last_opt_step >= self.accumulate:
-            self.optimizer.step()
+            self.scaler.step(self.optimizer)       # ssod_trainer.py:482-483
+            self.scaler.update()
             self.optimizer.zero_grad()
             self.ema.update(self.model)
             if self.semi_ema:

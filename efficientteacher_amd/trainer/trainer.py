@@ -3,9 +3,11 @@ build_optimizer :193, build_ddp_model :308, update_optimizer :381, the train_in_
 
 Only the per-iteration hot path is mirrored: data loading, validation, checkpoints and loggers are the
 reference's own host code (out of scope) and plug in around ``train_step``.
-Mixed precision: the reference autocasts to fp16 and scales the loss (trainer.py:248,348); here the
+Mixed precision: the reference autocasts to fp16 and scales the loss (trainer.py:248,348); here the default
 performance mode is bf16 storage with fp32 accumulation and fp32 master weights, which needs no loss
-scaling -- ``self.scaler`` is therefore a fixed scale of 1.
+scaling (``self.scaler`` disabled = identity); ``model.set_compute_dtype(torch.float16)`` before
+``build_optimizer`` selects the reference's own arithmetic, and ``self.scaler`` is then a live
+``optim.DeviceGradScaler`` driven exactly where the reference drives its GradScaler (trainer.py:399-401).
 """
 import logging
 
@@ -14,7 +16,7 @@ import torch
 from torch.optim import lr_scheduler
 
 from ..models.loss import ComputeLoss
-from ..optim import FlatSGD
+from ..optim import DeviceGradScaler, FlatSGD
 from ..parallel import FlatDataParallel
 from ..utils.torch_utils import ModelEMA
 
@@ -24,8 +26,11 @@ LOGGER = logging.getLogger(__name__)
 class Trainer:
     MODEL_MODULE = "efficientteacher_amd.models.detector.yolo"
 
-    def __init__(self, cfg, device, callbacks=None, LOCAL_RANK=-1, RANK=-1, WORLD_SIZE=1, nb=1000):
+    def __init__(self, cfg, device, callbacks=None, LOCAL_RANK=-1, RANK=-1, WORLD_SIZE=1, nb=1000, amp_dtype=None):
+        """amp_dtype: compute dtype on a GPU -- None / torch.bfloat16 (default performance mode), torch.float16 (the reference's
+        autocast dtype: enables the loss scaler), torch.float32 (parity mode)"""
         self.cfg = cfg
+        self._amp_dtype_arg = amp_dtype
         self.set_env(cfg, device, LOCAL_RANK, RANK, WORLD_SIZE, callbacks, nb)
         self.build_model(cfg, device)
         self.build_optimizer(cfg)
@@ -49,7 +54,7 @@ class Trainer:
         self.momentum = cfg.hyp.momentum
         self.nb = nb                                   # batches per epoch (set by whoever owns the loader)
         self.last_opt_step = -1
-        self.amp_dtype = torch.bfloat16 if self.cuda else torch.float32
+        self.amp_dtype = (getattr(self, "_amp_dtype_arg", None) or torch.bfloat16) if self.cuda else torch.float32
         self.model_type = 'yolov5'
         self.sync_bn = False
         if cfg.sync_bn:
@@ -88,6 +93,9 @@ class Trainer:
         self._ckpt = ckpt
 
     def build_optimizer(self, cfg):
+        inner = self.model.module if isinstance(self.model, FlatDataParallel) else self.model
+        # trainer.py:248 GradScaler(enabled=cuda): live in fp16 mode only (bf16 / fp32 need no loss scaling)
+        self.scaler = DeviceGradScaler(self.device, enabled=getattr(inner, "_compute_dtype", None) == torch.float16)
         nbs = 64  # nominal batch size
         self.accumulate = max(round(nbs / self.batch_size), 1)
         weight_decay = cfg.hyp.weight_decay * self.batch_size * self.accumulate / nbs
@@ -157,13 +165,14 @@ class Trainer:
                     x['momentum'] = np.interp(ni, xi, [self.warmup_momentum, self.momentum])
 
     def update_optimizer(self, loss, ni):
-        loss.backward()
+        self.scaler.scale(loss).backward()                     # trainer.py:399
         if isinstance(self.model, FlatDataParallel):
             self.model.reduce_gradients()
         self.accumulate = max(round(64 / self.batch_size), 1)
         self._warmup(ni, 64 / self.batch_size)
         if ni - self.last_opt_step >= self.accumulate:
-            self.optimizer.step()
+            self.scaler.step(self.optimizer)                   # trainer.py:400-401 (skips on inf / nan, on the device)
+            self.scaler.update()
             self.optimizer.zero_grad()
             if self.ema:
                 self.ema.update(self.model)

@@ -11,7 +11,8 @@
  *   - return 0 on success, <0 on error: -1 bad pointer, -2 unsupported shape/argument,
  *     -3 workspace too small, <= -100 HIP launch error (-(100+hipError_t));
  *   - activations are NHWC ("channels last": N, H, W, C with C contiguous) in HBM;
- *     `dtype` is ET_F32 (parity mode) or ET_BF16 (performance mode, fp32 accumulate).
+ *     `dtype` is ET_F32 (parity mode), ET_BF16 (performance mode, fp32 accumulate) or ET_F16 (the reference's own
+ *     reduced precision: torch.cuda.amp autocast + GradScaler, trainer/trainer.py:248,348,399-400; same MFMA rate).
  */
 #ifndef ET_HIP_H
 #define ET_HIP_H
@@ -24,13 +25,13 @@ extern "C" {
 
 typedef void* et_stream_t; /* hipStream_t */
 
-enum { ET_F32 = 0, ET_BF16 = 1 };
+enum { ET_F32 = 0, ET_BF16 = 1, ET_F16 = 2 };   /* ET_F16 (r05): IEEE half storage, fp32 accumulate -- the reference's autocast dtype */
 
 /* Library / device identification (host side). Returns the gfx arch the code objects were built
  * for ("gfx950") and the ABI version.  ET_ABI_VERSION changes whenever an entry point is added or a signature / workspace
  * contract changes; a binding must refuse a library whose et_abi_version() differs from the header it was written against
  * (efficientteacher_amd/_lib.py does): a stale libet_hip.so would otherwise read e.g. a new int argument as the stream. */
-#define ET_ABI_VERSION 3
+#define ET_ABI_VERSION 4
 const char* et_build_arch(void);
 int et_abi_version(void);
 
@@ -74,23 +75,35 @@ int et_detect_decode(const void* raw, int dtype, int B, int na, int ny, int nx, 
  * Flat-arena state updates (one launch instead of the reference's per-tensor python loops).
  * EMA: utils/torch_utils.py:330-338 / :366-375 / :406-416   v = v*d ; v += (1-d)*m   (fp32)
  * SGD: torch.optim.SGD(momentum, nesterov=True) built at trainer/trainer.py:215-223, with the
- *      GradScaler 1/scale (trainer.py:399-400) folded in and an optional bf16 shadow copy of the
- *      updated values (bf16_shadow may be NULL).  Pointers must be 16-byte aligned for EMA.      */
+ *      GradScaler 1/scale (trainer.py:399-400) folded in and an optional 16-bit shadow copy of the
+ *      updated values in the compute format (lp_shadow may be NULL; shadow_dtype ET_BF16 | ET_F16).
+ *      `scaler` (may be NULL): the DEVICE loss-scaler state {scale, 1/scale, found_inf, growth_tracker} of fp16 mode
+ *      (et_scaler_check / et_scaler_update below): found_inf != 0 skips the update (GradScaler.step), else the gradient is
+ *      also multiplied by 1/scale (GradScaler.unscale_).  Pointers must be 16-byte aligned for EMA.      */
 int et_ema_update(float* ema, const float* model, int64_t n, float d, float one_minus_d, et_stream_t stream);
 /* AdamW over a flat arena: torch.optim.AdamW(betas=(hyp.momentum, 0.999)) as built at trainer/trainer.py:212 when cfg.adam
  * (decoupled weight decay, eps 1e-8); `step` = 1-based update count (bias corrections are formed on the host in double).   */
-int et_adamw(float* p, const float* grad, float* exp_avg, float* exp_avg_sq, void* bf16_shadow, int64_t n, float lr,
-             float beta1, float beta2, float eps, float weight_decay, int step, float inv_scale, et_stream_t stream);
-int et_sgd_nesterov(float* p, const float* grad, float* momentum_buf, void* bf16_shadow, int64_t n,
-                    float lr, float momentum, float weight_decay, int first_step, float inv_scale,
+int et_adamw(float* p, const float* grad, float* exp_avg, float* exp_avg_sq, void* lp_shadow, int shadow_dtype, int64_t n, float lr,
+             float beta1, float beta2, float eps, float weight_decay, int step, float inv_scale, const float* scaler,
+             et_stream_t stream);
+int et_sgd_nesterov(float* p, const float* grad, float* momentum_buf, void* lp_shadow, int shadow_dtype, int64_t n,
+                    float lr, float momentum, float weight_decay, int first_step, float inv_scale, const float* scaler,
                     et_stream_t stream);
-int et_cast_f32_to_bf16(const float* src, void* dst, int64_t n, et_stream_t stream);
+/* fp32 -> the 16-bit compute format (dtype ET_BF16 | ET_F16), round to nearest even: the weight shadow of the MFMA kernels */
+int et_cast_f32_to_lp(const float* src, void* dst, int dtype, int64_t n, et_stream_t stream);
+/* Loss scaler of fp16 mode, device resident (torch.cuda.amp.GradScaler as driven at trainer/trainer.py:248,348,399-400;
+ * ssod_trainer.py:595,625).  scaler = 4 floats {scale, 1/scale, found_inf, growth_tracker}.
+ *   et_scaler_check : found_inf = 1 if any of the n (scaled, fp32) gradients is inf / nan  (torch's non-finite check)
+ *   et_scaler_update: GradScaler.update() -- found_inf ? scale *= backoff, tracker = 0 : (++tracker == interval ? scale *= growth);
+ *                     then 1/scale is refreshed and found_inf cleared.                                                      */
+int et_scaler_check(const float* grads, int64_t n, float* scaler, et_stream_t stream);
+int et_scaler_update(float* scaler, float growth_factor, float backoff_factor, int growth_interval, et_stream_t stream);
 /* The same two updates with their per-step scalars in DEVICE memory (d2 = {d, 1-d}; hp = {lr, momentum, weight_decay,
  * inv_scale}): the form a captured HIP graph of the step replays -- warm-up (trainer.py:386-395), the lr schedule and
  * ModelEMA's decay ramp (utils/torch_utils.py:324) change these every step, and kernel arguments are frozen at capture. */
 int et_ema_update_dev(float* ema, const float* model, int64_t n, const float* d_and_one_minus_d, et_stream_t stream);
-int et_sgd_nesterov_dev(float* p, const float* grad, float* momentum_buf, void* bf16_shadow, int64_t n, const float* hp,
-                        int first_step, et_stream_t stream);
+int et_sgd_nesterov_dev(float* p, const float* grad, float* momentum_buf, void* lp_shadow, int shadow_dtype, int64_t n,
+                        const float* hp, int first_step, const float* scaler, et_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Convolution (the conv inside `Conv`, models/backbone/common.py:471-481; Detect.m,
@@ -106,6 +119,9 @@ int et_sgd_nesterov_dev(float* p, const float* grad, float* momentum_buf, void* 
  *   et_bn_finalize) -- every row is fully overwritten.  The row count depends on the kernel the library selects for the
  *   problem (one row per 64 output pixels for the tiled kernels = et_conv2d_stats_rows(N,OH,OW); one row per resident
  *   workgroup and row group for the persistent 1x1 kernel): ask et_conv2d_stats_rows_for with the arguments of the call.
+ *   residual MAY alias y exactly (same pointer, ldr == ldy): the in-place shortcut of the eval-mode C3 stem
+ *   (models/backbone/common.py C3.forward) -- every lane loads the residual element it is about to overwrite; any OTHER overlap of
+ *   the two ranges is rejected (-2).
  *   zero16: device pointer to >= 16 zero bytes (16-byte aligned).  When given, the K-chunks are staged with
  *   LDS-DMA (global_load_lds_dwordx4) and padding / tail lanes fetch from this page; NULL selects the
  *   register-staged kernel.

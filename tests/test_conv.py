@@ -36,7 +36,22 @@ def _tol(dtype):
     return 2e-5 if dtype == torch.float32 else 2e-2
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+DTYPES = [torch.float32, torch.bfloat16, torch.float16]      # parity mode, performance mode, the reference's AMP arithmetic (r05)
+
+
+def kn(*a, **k):
+    """the library's kernel name (et_conv2d_kernel_name: what rocprofv3 prints) with the storage-type template argument removed --
+    `conv_gemm_rs_kernel<unsigned short, 128, ...>` / `<et_f16, 128, ...>` -> `conv_gemm_rs_kernel<128, ...>`,
+    `conv_gemm_pprs_kernel<et_f16>` -> `conv_gemm_pprs_kernel`: the tile selection pinned below does not depend on the 16-bit
+    format, and one table serves both (the type itself is asserted in test_kernel_names_carry_the_storage_type)"""
+    from efficientteacher_amd import ops
+    n = ops.kernel_name(*a, **k)
+    for t in ("unsigned short", "et_f16", "float"):
+        n = n.replace(f"<{t}>", "").replace(f"<{t}, ", "<")
+    return n
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", CASES)
 def test_conv_fwd(hip, case, dtype):
     from efficientteacher_amd import ops
@@ -55,7 +70,7 @@ def test_conv_fwd(hip, case, dtype):
     assert torch.allclose(st[1], (flat ** 2).sum(0), rtol=2e-2 if dtype != torch.float32 else 1e-4, atol=1e-3)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_conv_fwd_epilogue_and_slices(hip, dtype):
     """bias + SiLU + residual, reading a channel slice and writing into a slice of a wider buffer."""
     from efficientteacher_amd import ops
@@ -75,7 +90,7 @@ def test_conv_fwd_epilogue_and_slices(hip, dtype):
     assert (outb[..., :8] == 0).all() and (outb[..., 32:] == 0).all()
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", [c for c in CASES if c[3] % 8 == 0 and c[4] % 8 == 0 and c[5] != 6])
 def test_conv_dgrad(hip, case, dtype):
     from efficientteacher_amd import ops
@@ -98,7 +113,7 @@ def test_conv_dgrad(hip, case, dtype):
     assert torch.allclose(dx2.float().cpu(), 2 * dx.float().cpu(), rtol=2e-2, atol=1e-2 if dtype != torch.float32 else 1e-5)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("shape", [(2, 9, 11, 256), (1, 7, 5, 24), (3, 20, 20, 64)])
 def test_colsum_bias_gradient(hip, shape, dtype):
     """et_colsum: out[c] += sum over pixels (the bias gradient of the Detect convs), on a channel slice of a wider buffer; bf16 with
@@ -113,7 +128,7 @@ def test_colsum_bias_gradient(hip, shape, dtype):
     assert torch.allclose(out.cpu(), ref, rtol=1e-4, atol=1e-3 * (N * H * W) ** 0.5)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_weight_transpose_all_layers(hip, dtype):
     """et_weight_transpose_all: every layer of a flat weight arena [Cout][KH][KW][Cin] -> [Cin][KH][KW][Cout] in one launch
     (bf16: the tiled 8x8-register-block kernel; fp32: one element per thread), ragged 64-tiles, gaps between layers untouched"""
@@ -135,7 +150,7 @@ def test_weight_transpose_all_layers(hip, dtype):
         assert (out[o + n:o + n + 16].float().cpu() == 7.0).all()           # the gap behind the layer is not written
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", [c for c in CASES if c[4] % 8 == 0])
 def test_conv_wgrad(hip, case, dtype):
     from efficientteacher_amd import ops
@@ -155,7 +170,7 @@ def test_conv_wgrad(hip, case, dtype):
     assert torch.allclose(dw.cpu(), 2 * ref, rtol=1e-4, atol=1e-3)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_conv_wgrad_grouped(hip, dtype):
     """et_conv2d_wgrad_grouped: several same-shaped layers in one launch, one of them reading a channel slice of a
     wider buffer (different pixel stride) -- each dW must equal its own single-layer gradient."""
@@ -184,7 +199,7 @@ def test_conv_wgrad_grouped(hip, dtype):
 # (VERDICT r01 "parity gap": the bench-dominant tiles were never compared element-wise with anything.)  Each case
 # names the instantiation csrc/conv.hip must pick for it -- et_conv2d_kernel_name is the selection logic itself, not
 # a copy -- so a change of the tile policy that silently drops a kernel out of test coverage fails here.
-GLDS = "conv_gemm_glds_kernel<unsigned short, "
+GLDS = "conv_gemm_glds_kernel<"
 RS128, RS64 = "conv_gemm_rs_kernel<128, 128, 2, 2>", "conv_gemm_rs_kernel<128, 64, 2, 2>"
 S1 = "conv1x1_stream_kernel<"          # prefix: the shape table behind it (csrc/conv.hip plan_s1) is pinned by test_stream_kernel_shape_table
 SELECT = [
@@ -241,6 +256,27 @@ def test_bench_instantiations_elementwise(hip, case, kf, kd, kw):
     """bf16 fwd (+ stats, scale/bias/SiLU/residual epilogue, output slice), dgrad (+ residual, accumulate) and wgrad of
     the named instantiation, element-wise against F.conv2d (fp32) on the bf16-rounded operands."""
     _check_instantiation(hip, case, kf, kd, kw)
+
+
+@pytest.mark.parametrize("case,kf,kd,kw", SELECT, ids=[str(c[0]) for c in SELECT])
+def test_bench_instantiations_elementwise_fp16(hip, case, kf, kd, kw):
+    """the same instantiations with T = et_f16 (IEEE half, v_mfma_f32_32x32x16_f16: the reference's AMP arithmetic, r05): the tile
+    selection is the bf16 one, the element-wise comparison is against F.conv2d (fp32) on the fp16-rounded operands"""
+    if hip.emulated and case not in [c[0] for c in SELECT[:10]]:
+        pytest.skip("CPU emulator tier: the first ten cases cover every kernel family in fp16; the GPU tier runs all of them")
+    _check_instantiation(hip, case, kf, kd, kw, dt=torch.float16)
+
+
+def test_kernel_names_carry_the_storage_type(hip):
+    """what rocprofv3 prints: the 16-bit kernels are templates on the storage type (unsigned short = bf16, et_f16 = IEEE half)"""
+    from efficientteacher_amd import ops
+    a = (2, 20, 20, 256, 256, 3, 1, 1)
+    assert ops.kernel_name("fwd", torch.bfloat16, *a) == "conv_gemm_pprs_kernel<unsigned short>"
+    assert ops.kernel_name("fwd", torch.float16, *a) == "conv_gemm_pprs_kernel<et_f16>"
+    assert ops.kernel_name("wgrad", torch.float16, *a) == "conv_wgrad_rs_kernel<et_f16, 128, 128, 2, 4>"
+    assert ops.kernel_name("fwd", torch.float16, 2, 12, 12, 128, 128, 3, 1, 1) == "conv_gemm_rs_kernel<et_f16, 128, 128, 2, 2>"
+    assert ops.kernel_name("fwd", torch.bfloat16, 2, 12, 12, 64, 64, 1, 1, 0).startswith("conv1x1_stream_kernel<unsigned short, 1, ")
+    assert ops.kernel_name("fwd", torch.float32, 2, 12, 12, 64, 64, 1, 1, 0).startswith("conv_gemm_glds_kernel<float, ")
 
 
 @pytest.mark.parametrize("dma_late,seed", [(1, 3), (0, 5), (1, 11)])
@@ -310,7 +346,7 @@ def test_forward_statistics_with_a_residual_use_the_full_plans_row_count(hip, mo
         monkeypatch.setenv("ET_CONV_S1_WGS", str(wgs))
         rows_plain = ops.stats_rows("fwd", dt, N, H, W, K, C, 1, 1, 0)
         rows_full = ops.stats_rows("fwd_res", dt, N, H, W, K, C, 1, 1, 0)
-        assert ops.kernel_name("fwd_res", dt, N, H, W, K, C, 1, 1, 0).startswith(S1)
+        assert kn("fwd_res", dt, N, H, W, K, C, 1, 1, 0).startswith(S1)
         y, st = ops.conv2d_fwd(x, w, 1, 0, residual=res, want_stats=True)
         assert st.shape == (rows_full, 2, C) and torch.isfinite(st).all()
         flat = ref.reshape(-1, C)
@@ -326,11 +362,10 @@ def _same(name, want):
     return name.startswith(want) if want == S1 else name == want
 
 
-def _check_instantiation(hip, case, kf, kd, kw):
+def _check_instantiation(hip, case, kf, kd, kw, dt=torch.bfloat16):
     from efficientteacher_amd import ops
     N, H, W, Cin, Cout, k, s, p = case
-    dt = torch.bfloat16
-    assert _same(ops.kernel_name("fwd", dt, N, H, W, Cin, Cout, k, s, p), kf)
+    assert _same(kn("fwd", dt, N, H, W, Cin, Cout, k, s, p), kf)
     x = _mk(hip, (N, H, W, Cin), dt, 41)
     w = (_mk(hip, (Cout, k, k, Cin), dt, 42) * (1.0 / (k * k * Cin) ** 0.5)).to(dt)
     OH, OW = ops.conv_out_hw(H, W, k, s, p)
@@ -354,7 +389,7 @@ def _check_instantiation(hip, case, kf, kd, kw):
     if kd is None:
         return
     # dgrad (the operand roles swap: K = taps * Cout)
-    names = [ops.kernel_name("dgrad", dt, N, H, W, Cin, Cout, k, s, p, parity_class=c) for c in range(s * s)]
+    names = [kn("dgrad", dt, N, H, W, Cin, Cout, k, s, p, parity_class=c) for c in range(s * s)]
     assert len(names) == len(kd) and all(_same(a, b) for a, b in zip(names, kd)), names
     dy = _mk(hip, (N, OH, OW, Cout), dt, 46)
     w2 = (_mk(hip, (Cout, k, k, Cin), dt, 47) * (1.0 / (k * k * Cout) ** 0.5)).to(dt)
@@ -370,7 +405,7 @@ def _check_instantiation(hip, case, kf, kd, kw):
         dx2 = ops.conv2d_dgrad(dy, wT, (H, W), s, p, residual=r2)
         assert (dx2.float().cpu() - (dref + r2.float().cpu())).abs().max().item() <= tol + 2e-2 * r2.float().abs().max().item()
     # wgrad
-    assert ops.kernel_name("wgrad", dt, N, H, W, Cin, Cout, k, s, p) == kw
+    assert kn("wgrad", dt, N, H, W, Cin, Cout, k, s, p) == kw
     dw = torch.zeros((Cout, k, k, Cin), dtype=torch.float32, device=hip.device)
     ops.conv2d_wgrad(x, dy, dw, k, s, p)
     wr = torch.zeros((Cout, Cin, k, k), requires_grad=True)
@@ -405,7 +440,8 @@ if emu:
 dev = torch.device("cpu" if emu else "cuda:0")
 dt = torch.bfloat16
 N, H, W, Cin, Cout, k, s, p = {N}, {H}, {W}, {Cin}, {Cout}, {k}, {s_}, {p_}
-assert ops.kernel_name("wgrad", dt, N, H, W, Cin, Cout, k, s, p) == {repr(kernel)}, ops.kernel_name("wgrad", dt, N, H, W, Cin, Cout, k, s, p)
+name = ops.kernel_name("wgrad", dt, N, H, W, Cin, Cout, k, s, p).replace("<unsigned short, ", "<")
+assert name == {repr(kernel)}, name
 g = torch.Generator().manual_seed(5)
 x = torch.randn(N, H, W, Cin, generator=g).to(dt).to(dev)
 OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
@@ -435,7 +471,7 @@ def test_wgrad_stride2_row_sharing_grouped(hip):
     from efficientteacher_amd import ops
     N, H, W, Cin, Cout, k = 2, 24, 24, 64, 128, 3
     dt = torch.bfloat16
-    assert ops.kernel_name("wgrad", dt, N, H, W, Cin, Cout, k, 2, 1) == "conv_wgrad_rs_kernel<128, 64, 2, 2, 2>"
+    assert kn("wgrad", dt, N, H, W, Cin, Cout, k, 2, 1) == "conv_wgrad_rs_kernel<128, 64, 2, 2, 2>"
     items, refs = [], []
     for i in range(3):
         if i == 1:
@@ -462,7 +498,7 @@ def test_wgrad_grouped_eight_layers(hip, stride, kernel):
     from efficientteacher_amd import ops
     N, H, W, C, k = 1, 10, 10, 256, 3
     dt = torch.bfloat16
-    assert ops.kernel_name("wgrad", dt, N, H, W, C, C, k, stride, 1) == kernel
+    assert kn("wgrad", dt, N, H, W, C, C, k, stride, 1) == kernel
     OH, OW = ops.conv_out_hw(H, W, k, stride, 1)
     items, refs = [], []
     for i in range(8):
@@ -478,7 +514,7 @@ def test_wgrad_grouped_eight_layers(hip, stride, kernel):
         assert (dw.cpu() - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item())
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", [(2, 12, 12, 64, 40, 3), (2, 20, 20, 256, 256, 3), (3, 10, 10, 32, 128, 1), (2, 9, 11, 256, 256, 1),
                                   (1, 13, 13, 128, 128, 1), (2, 9, 9, 64, 64, 1)],
                          ids=["128x64 tile", "256x256 tile", "1x1", "1x1 stream K=256", "1x1 stream K=128", "1x1 stream K=64"])
@@ -541,7 +577,7 @@ def test_stem_kernel(hip, N, H, W, Cout):
 def _stem_case(hip, N, H, W, Cout):
     from efficientteacher_amd import ops
     dt = torch.bfloat16
-    assert ops.kernel_name("fwd", dt, N, H, W, 8, Cout, 6, 2, 2) == "conv_stem_kernel"
+    assert kn("fwd", dt, N, H, W, 8, Cout, 6, 2, 2) == "conv_stem_kernel"
     x = _mk(hip, (N, H, W, 8), dt, 141)
     x[..., 3:] = 0                                   # the packed image: 3 real channels
     w = (_mk(hip, (Cout, 6, 6, 8), dt, 142) * (1.0 / (36 * 3) ** 0.5)).to(dt)
@@ -581,7 +617,7 @@ def test_stem_kernel_full_size():
     x = torch.zeros((N, H, W, 8), dtype=dt, device=dev)
     x[..., :3] = torch.rand((N, H, W, 3), generator=g).to(dev).to(dt)
     w = (torch.randn((Cout, 6, 6, 8), generator=g) * 0.1).to(dev).to(dt)
-    assert ops.kernel_name("fwd", dt, N, H, W, 8, Cout, 6, 2, 2) == "conv_stem_kernel"
+    assert kn("fwd", dt, N, H, W, 8, Cout, 6, 2, 2) == "conv_stem_kernel"
     y, st = ops.conv2d_fwd(x, w, 2, 2, want_stats=True)
     zero = torch.zeros_like(y)
     y2, st2 = ops.conv2d_fwd(x, w, 2, 2, residual=zero, want_stats=True)          # the stem kernel declines residuals
@@ -636,7 +672,7 @@ def test_bench_workloads_launch_only_covered_instantiations(hip_lib_path, wl_nam
             for pc in (range(s * s) if (op in ("dgrad", "dgrad_full") and s == 2) else (0,)):
                 if op == "dgrad_full" and s == 2:
                     continue
-                covered.add(ops.kernel_name(op, torch.bfloat16, N, H, W, Cin, Cout, k, s, p, parity_class=pc))
+                covered.add(kn(op, torch.bfloat16, N, H, W, Cin, Cout, k, s, p, parity_class=pc))
     missing = {}
     for B in batches:
         for (h, w, ci, co, k, s, p) in _workload_conv_shapes(wl_name):
@@ -645,7 +681,7 @@ def test_bench_workloads_launch_only_covered_instantiations(hip_lib_path, wl_nam
                 if op in ("fwd_res", "dgrad_full") and s != 1:
                     continue
                 for pc in (range(s * s) if (op == "dgrad" and s == 2) else (0,)):
-                    n = ops.kernel_name(op, torch.bfloat16, B, h, w, cip, cop, k, s, p, parity_class=pc)
+                    n = kn(op, torch.bfloat16, B, h, w, cip, cop, k, s, p, parity_class=pc)
                     if n not in covered:
                         missing.setdefault(n, (op, B, h, w, ci, co, k, s))
     assert not missing, missing

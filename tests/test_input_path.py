@@ -8,7 +8,7 @@ from tests.conftest import golden
 from tests.test_ssod_step import make_trainer
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("hw", [(20, 24), (5, 3)], ids=["four pixels per thread (bf16)", "one pixel per thread"])
 def test_pack_input_uint8_equals_float_division(hip, hw, dtype):
     """(float)x / 255 in the kernel is bit-identical to the IEEE division `imgs.float() / 255.0` (what torch computes on the CPU --

@@ -30,7 +30,7 @@ def finalize_form(request):
 
 
 # the last shape gives every thread 6 or 7 vectors (512 blocks for 819200 / 1638400 vectors): the paired loop AND its odd tail
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("shape", [(2, 7, 9, 32), (1, 5, 5, 48), (3, 4, 4, 8), (2, 40, 40, 24), (4, 72, 72, 8), (2, 160, 160, 128)])
 def test_bn_silu_fwd_bwd(hip, finalize_form, shape, dtype):
     from efficientteacher_amd import ops
@@ -75,7 +75,7 @@ def test_bn_silu_fwd_bwd(hip, finalize_form, shape, dtype):
     assert (ze.float().cpu().permute(0, 3, 1, 2) - zre).abs().max().item() <= _tol(dtype) * 4
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("shape", [(2, 9, 7, 16), (1, 20, 20, 32), (1, 3, 2, 8)])
 def test_sppf_pool_chain(hip, shape, dtype):
     """x -> y1 -> y2 -> y3 written into slices of one concat buffer; backward through the chain (the pooled maps have plateaus:
@@ -102,7 +102,7 @@ def test_sppf_pool_chain(hip, shape, dtype):
     assert err <= _tol(dtype) * 8, err
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_upsample_and_pack(hip, dtype):
     from efficientteacher_amd import ops
     x = _mk(hip, (2, 3, 5, 16), dtype, 21)

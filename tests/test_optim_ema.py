@@ -95,8 +95,8 @@ def test_adamw_matches_torch(hip):
     assert opt2.steps == 3 and torch.equal(opt2.exp_avg, opt.exp_avg)
 
 
-def test_cast_f32_to_bf16_is_torch_rounding(hip):
-    """et_cast_f32_to_bf16 (the bf16 weight shadow): round-to-nearest-even like torch, for aligned arenas (eight elements per
+def test_cast_f32_to_lp_bf16_is_torch_rounding(hip):
+    """et_cast_f32_to_lp with a bf16 destination (the bf16 weight shadow): round-to-nearest-even like torch, for aligned arenas (eight elements per
     thread + a scalar tail) and for an unaligned slice (scalar kernel)"""
     from efficientteacher_amd import ops
     g = torch.Generator().manual_seed(3)
@@ -105,7 +105,7 @@ def test_cast_f32_to_bf16_is_torch_rounding(hip):
     for sl in (slice(0, 4099), slice(0, 4096), slice(1, 1000), slice(8, 13)):
         s = src[sl]
         d = torch.empty(s.numel(), dtype=torch.bfloat16, device=hip.device)
-        ops.cast_f32_to_bf16(s, d)
+        ops.cast_f32_to_lp(s, d)
         assert torch.equal(d.cpu(), s.cpu().to(torch.bfloat16)), sl
 
 

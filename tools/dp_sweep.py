@@ -4,7 +4,7 @@
 
 Runs BASELINE configs[3] (YOLOv5l SSOD, 16 + 16 images per rank; --per-rank 32 = the weak-scaling point) through bench.py for every
 cell of   {captured step graph, eager}  x  ET_ALLREDUCE_CHUNK_MB {24, 48, 96}  x  ET_RCCL_CHANNELS {library default, 8, 16}
-and writes ONE JSON: per cell the images/s, ms per step, the gradient all-reduce's span and EXPOSED time (what the compute
+x  ET_ALLREDUCE_DTYPE {fp32, bf16: the r05 wire format, half the bytes per link}   and writes ONE JSON: per cell the images/s, ms per step, the gradient all-reduce's span and EXPOSED time (what the compute
 stream waits for after backward, bench.py `grad_allreduce`), and whether the capture of the collectives was accepted.  Each cell is
 its own `torch.distributed.run` launch (RCCL reads its channel count when the communicator is created).
 On a single-GPU box `--gpus 1` runs the same matrix over a ONE-rank RCCL group (bench.py --force-dp): the collectives execute, the
@@ -21,9 +21,9 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_cell(gpus, per_rank, steps, warmup, graph, chunk_mb, channels, port, timeout):
+def run_cell(gpus, per_rank, steps, warmup, graph, chunk_mb, channels, port, timeout, wire="fp32"):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
-               ET_ALLREDUCE_CHUNK_MB=str(chunk_mb))
+               ET_ALLREDUCE_CHUNK_MB=str(chunk_mb), ET_ALLREDUCE_DTYPE=wire)
     env.pop("ET_RCCL_CHANNELS", None)
     if channels:
         env["ET_RCCL_CHANNELS"] = str(channels)
@@ -35,7 +35,7 @@ def run_cell(gpus, per_rank, steps, warmup, graph, chunk_mb, channels, port, tim
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
                "--master-port", str(port), os.path.join(ROOT, "bench.py")] + args
     t0 = time.time()
-    cell = dict(graph=bool(graph), chunk_mb=chunk_mb, rccl_channels=channels or "default")
+    cell = dict(graph=bool(graph), chunk_mb=chunk_mb, rccl_channels=channels or "default", wire=wire)
     try:
         p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
         line = next((ln for ln in reversed(p.stdout.strip().splitlines()) if ln.startswith("{")), None)
@@ -63,19 +63,20 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--chunks", default="24,48,96")
     ap.add_argument("--channels", default="0,8,16", help="0 = the library's default")
+    ap.add_argument("--wire", default="fp32,bf16", help="gradient all-reduce wire formats (ET_ALLREDUCE_DTYPE)")
     ap.add_argument("--timeout", type=int, default=600)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "dp_sweep.json"))
     a = ap.parse_args()
     cells = []
     port = 29500 + (os.getpid() % 1500)
-    for i, (graph, chunk, ch) in enumerate(itertools.product((True, False), [int(c) for c in a.chunks.split(",")],
-                                                             [int(c) for c in a.channels.split(",")])):
-        cell = run_cell(a.gpus, a.per_rank, a.steps, a.warmup, graph, chunk, ch, port + i, a.timeout)
+    for i, (graph, chunk, ch, wire) in enumerate(itertools.product((True, False), [int(c) for c in a.chunks.split(",")],
+                                                                   [int(c) for c in a.channels.split(",")], a.wire.split(","))):
+        cell = run_cell(a.gpus, a.per_rank, a.steps, a.warmup, graph, chunk, ch, port + i, a.timeout, wire)
         cells.append(cell)
         print(json.dumps(cell), flush=True)
     ok = [c for c in cells if "images_per_s" in c]
     best = max(ok, key=lambda c: c["images_per_s"]) if ok else None
-    out = dict(what=f"YOLOv5l SSOD, {a.per_rank}+{a.per_rank} images per rank, {a.gpus} rank(s): step graph x all-reduce chunk x RCCL channels",
+    out = dict(what=f"YOLOv5l SSOD, {a.per_rank}+{a.per_rank} images per rank, {a.gpus} rank(s): step graph x all-reduce chunk x RCCL channels x wire format",
                gpus=a.gpus, per_rank=a.per_rank, steps=a.steps, cells=cells, best=best)
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
     with open(a.out, "w") as f:
