@@ -64,6 +64,7 @@ SIGNATURES = {
     "et_upsample2x_fwd": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "et_upsample2x_bwd": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "et_strong_view_u8": (c_int, [P, P, c_int, c_int, c_int, P, P, P, P, c_int, P]),
+    "et_mosaic4_u8": (c_int, [P, P, c_int, c_int, c_int, P]),
     "et_pseudo_label_transform": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P]),
     "et_score_log_append": (c_int, [P, P, c_int, c_int, P, P, P, c_int64, P]),
     "et_yolo_loss": (c_int, [P, P]),

@@ -118,3 +118,55 @@ extern "C" int et_strong_view_u8(const uint8_t* weak, uint8_t* strong, int B, in
     ET_CHECK_LAUNCH();
     return 0;
 }
+
+// ---- 4-image mosaic (load_mosaic_with_M, utils/datasets_ssod.py:732-782) -----------------------------------------------------
+// The reference pastes four images around a random centre into a 2s x 2s canvas of border value 114 and halves it with
+// cv2.resize(img4, (s, s)).  At this exact 2:1 ratio OpenCV's INTER_LINEAR resize takes its fast INTER_AREA path: an output
+// pixel is (a + b + c + d + 2) >> 2 of its 2 x 2 source pixels.  Here one thread produces one output pixel (three planes)
+// straight from the four source images -- the canvas is never materialised: each of the 2 x 2 canvas positions belongs to the
+// quadrant given by its side of the centre and reads tile i at (cy - y1a + y1b, cx - x1a + x1b) when it lies inside the
+// tile's pasted rectangle, else the border value.  tiles: [B][4][8] int64 = {device pointer of the (3, h, w) uint8 planes, h, w,
+// x1a, y1a, x2a, y2a, x1b << 32 | y1b} (efficientteacher_amd/utils/augment.py mosaic_layout).  PARITY: the placement is pinned on
+// the reference (tests/golden/mosaic.npz); the 2:1 resampling restates OpenCV's published algorithm and is unpinned (no cv2).
+__global__ __launch_bounds__(256) void mosaic4_kernel(const long long* __restrict__ tiles, unsigned char* __restrict__ out, int B, int S,
+                                                      int border) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long plane = (long long)S * S;
+    if (i >= (long long)B * plane) return;
+    const int b = (int)(i / plane);
+    const int rem = (int)(i - (long long)b * plane);
+    const int oy = rem / S, ox = rem - oy * S;
+    const long long* T = tiles + (size_t)b * 32;
+    // the centre: x2a of the top-left tile is xc, its y2a is yc (mosaic_layout)
+    const int xc = (int)T[5], yc = (int)T[6];
+    int acc[3] = {2, 2, 2};                                  // the rounding term of (a + b + c + d + 2) >> 2
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            const int cy = 2 * oy + dy, cx = 2 * ox + dx;
+            const int q = (cy >= yc ? 2 : 0) + (cx >= xc ? 1 : 0);
+            const long long* t = T + q * 8;
+            const int x1a = (int)t[3], y1a = (int)t[4], x2a = (int)t[5], y2a = (int)t[6];
+            if (cx >= x1a && cx < x2a && cy >= y1a && cy < y2a) {
+                const unsigned char* src = (const unsigned char*)(uintptr_t)t[0];
+                const int h = (int)t[1], w = (int)t[2];
+                const int x1b = (int)(t[7] >> 32), y1b = (int)(t[7] & 0xffffffffll);
+                const size_t o = (size_t)(cy - y1a + y1b) * w + (cx - x1a + x1b), pl = (size_t)h * w;
+                acc[0] += src[o]; acc[1] += src[pl + o]; acc[2] += src[2 * pl + o];
+            } else {
+                acc[0] += border; acc[1] += border; acc[2] += border;
+            }
+        }
+    unsigned char* o = out + (size_t)b * 3 * plane + (size_t)oy * S + ox;
+    o[0] = (unsigned char)(acc[0] >> 2); o[plane] = (unsigned char)(acc[1] >> 2); o[2 * plane] = (unsigned char)(acc[2] >> 2);
+}
+
+extern "C" int et_mosaic4_u8(const int64_t* tiles, uint8_t* out, int B, int S, int border_value, et_stream_t stream) {
+    if (!tiles || !out) return -1;
+    if (B <= 0 || S <= 0 || (long long)B * S * S >= (1ll << 40)) return -2;
+    hipLaunchKernelGGL(mosaic4_kernel, dim3(et_cdiv((long long)B * S * S, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const long long*)tiles, out, B, S, border_value);
+    ET_CHECK_LAUNCH();
+    return 0;
+}

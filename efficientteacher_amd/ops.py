@@ -901,6 +901,25 @@ def tal_assign(pd_scores, pd_bboxes, anc_points, gt_labels, gt_bboxes, mask_gt, 
 TAL_PAD_SYNC_FREE_ROWS = 32     # up to this many target rows per image ON AVERAGE the padded table is sized by n without a host sync
 
 
+def mosaic4_u8(tiles, layouts, s, border_value=114):
+    """B mosaics of four uint8 (3, h, w) images each (utils/augment.py MosaicGenerator): tiles[b] = the four device tensors in tile
+    order, layouts[b] = their mosaic_layout rows.  -> (B, 3, s, s) uint8: the 2:1 box average of the (never materialised) 2s x 2s canvas"""
+    B = len(tiles)
+    dev = tiles[0][0].device
+    table = torch.empty((B, 4, 8), dtype=torch.int64)
+    keep = []
+    for b in range(B):
+        for i, (t, row) in enumerate(zip(tiles[b], layouts[b])):
+            assert t.dtype == torch.uint8 and t.dim() == 3 and t.shape[0] == 3 and t.is_contiguous() and t.device == dev
+            x1a, y1a, x2a, y2a, x1b, y1b = (int(v) for v in row[:6])
+            table[b, i] = torch.tensor([t.data_ptr(), t.shape[1], t.shape[2], x1a, y1a, x2a, y2a, (x1b << 32) | (y1b & 0xffffffff)])
+            keep.append(t)
+    tdev = table.to(dev)
+    out = torch.empty((B, 3, s, s), dtype=torch.uint8, device=dev)
+    _lib.check(_lib.load().et_mosaic4_u8(_lib.ptr(tdev), _lib.ptr(out), B, int(s), int(border_value), _lib.stream(out)), "et_mosaic4_u8")
+    return out
+
+
 def tal_targets_pad(targets, B, img_w, img_h):
     """ComputeTalLoss.preprocess on the device: (n,6) [img, cls, x, y, w, h] normalised -> gt_labels (B,G,1), gt_bboxes (B,G,4) xyxy
     pixels, mask_gt (B,G,1).  G = max(n, 1) without a host synchronisation while n <= 32 * B (the reference loops over

@@ -109,3 +109,82 @@ class StrongViewGenerator:
         t = lambda a: torch.from_numpy(a).to(dev, non_blocking=True)
         strong = ops.strong_view_u8(weak_u8.contiguous(), t(minv), t(lut), t(cuts), t(flags))
         return strong, t(M_s)
+
+
+# ---- 4-image mosaic (load_mosaic_with_M, utils/datasets_ssod.py:732-792) ---------------------------------------------------
+def mosaic_layout(s, yc, xc, shapes):
+    """Placement of the four tiles around the centre (xc, yc) of the 2s x 2s canvas (datasets_ssod.py:746-762).
+    shapes: [(h, w)] * 4 in tile order (top left, top right, bottom left, bottom right).
+    -> rows (x1a, y1a, x2a, y2a, x1b, y1b, padw, padh): canvas rectangle, its origin inside the image, label offsets"""
+    rows = []
+    for i, (h, w) in enumerate(shapes):
+        if i == 0:
+            x1a, y1a, x2a, y2a = max(xc - w, 0), max(yc - h, 0), xc, yc
+            x1b, y1b = w - (x2a - x1a), h - (y2a - y1a)
+        elif i == 1:
+            x1a, y1a, x2a, y2a = xc, max(yc - h, 0), min(xc + w, s * 2), yc
+            x1b, y1b = 0, h - (y2a - y1a)
+        elif i == 2:
+            x1a, y1a, x2a, y2a = max(xc - w, 0), yc, xc, min(s * 2, yc + h)
+            x1b, y1b = w - (x2a - x1a), 0
+        else:
+            x1a, y1a, x2a, y2a = xc, yc, min(xc + w, s * 2), min(s * 2, yc + h)
+            x1b, y1b = 0, 0
+        rows.append((x1a, y1a, x2a, y2a, x1b, y1b, x1a - x1b, y1a - y1b))
+    return rows
+
+
+def mosaic_labels(s, layout, shapes, labels):
+    """labels: four (n, 5) arrays [cls, x, y, w, h] normalised to their image -> (N, 5) [cls, x1, y1, x2, y2] in the frame of the
+    s x s mosaic: xywhn2xyxy with w / 2, h / 2, padw / 2, padh / 2 (datasets_ssod.py:768: the canvas is halved by the resize that
+    follows), then the reference's clip to [0, 2s] (:775-776 -- it clips to the CANVAS size although the coordinates are already
+    halved: kept as it is)"""
+    out = []
+    for (x1a, y1a, x2a, y2a, x1b, y1b, padw, padh), (h, w), lb in zip(layout, shapes, labels):
+        lb = np.asarray(lb, dtype=np.float64).reshape(-1, 5).copy()
+        if lb.size:
+            x = lb[:, 1:].copy()
+            lb[:, 1] = (w / 2) * (x[:, 0] - x[:, 2] / 2) + padw / 2
+            lb[:, 2] = (h / 2) * (x[:, 1] - x[:, 3] / 2) + padh / 2
+            lb[:, 3] = (w / 2) * (x[:, 0] + x[:, 2] / 2) + padw / 2
+            lb[:, 4] = (h / 2) * (x[:, 1] + x[:, 3] / 2) + padh / 2
+        out.append(lb)
+    out = np.concatenate(out, 0)
+    np.clip(out[:, 1:], 0, 2 * s, out=out[:, 1:])
+    return out
+
+
+class MosaicGenerator:
+    """The 4-image mosaic of the reference's SSOD loader (load_mosaic_with_M) with the per-pixel work on the device: the host draws
+    the centre and the three partner images exactly as the reference does (same calls on the same `random` stream: two
+    `random.uniform` for (yc, xc), `random.choices(indices, k=3)`, `random.shuffle`) and lays the tiles out; ONE kernel
+    (et_mosaic4_u8, csrc/augment.hip) then writes the s x s mosaic -- the 2s x 2s canvas of border value 114 is never materialised:
+    every output pixel averages its 2 x 2 canvas pixels, which is what cv2.resize(img4, (s, s)) computes at this exact 2:1 ratio
+    (OpenCV switches INTER_LINEAR to its fast INTER_AREA path there: (a + b + c + d + 2) >> 2).  The result is the WEAK view
+    (`img4_ori`); the strong view and M_s come from StrongViewGenerator on it, as random_perspective_with_M follows in the reference.
+    PARITY: placement, label arithmetic and the consumption of the random stream are pinned on the live reference
+    (tests/golden/mosaic.npz); the 2:1 resampling restates OpenCV's published algorithm and is unpinned (no cv2 here)."""
+
+    def __init__(self, img_size, seed=None):
+        self.s = int(img_size)
+        self.border = [-self.s // 2, -self.s // 2]             # datasets_ssod.py:260
+        self.rng = random.Random(seed)
+
+    def sample(self, index, indices):
+        """-> (yc, xc, the four image indices in tile order)"""
+        s = self.s
+        yc, xc = [int(self.rng.uniform(-x, 2 * s + x)) for x in self.border]
+        four = [index] + self.rng.choices(indices, k=3)
+        self.rng.shuffle(four)
+        return yc, xc, four
+
+    def __call__(self, images, labels, index, indices=None):
+        """images: dict / list index -> uint8 device tensor (3, h, w) with max(h, w) <= img_size (what load_image returns, as RGB
+        planes); labels: index -> (n, 5) normalised [cls, x, y, w, h].  -> (mosaic (3, s, s) uint8 on the device, labels (N, 5) xyxy)"""
+        indices = list(range(len(images))) if indices is None else list(indices)
+        yc, xc, four = self.sample(index, indices)
+        tiles = [images[i] for i in four]
+        shapes = [(int(t.shape[1]), int(t.shape[2])) for t in tiles]
+        layout = mosaic_layout(self.s, yc, xc, shapes)
+        out = ops.mosaic4_u8([tiles], [layout], self.s)[0]
+        return out, mosaic_labels(self.s, layout, shapes, [labels[i] for i in four])

@@ -252,6 +252,12 @@ int et_upsample2x_bwd(const void* dy, int lddy, void* dx, int lddx, int dtype, i
  * PARITY UNPINNED (cv2 absent from the build image): restates OpenCV's published 8-bit algorithms, see csrc/augment.hip.   */
 int et_strong_view_u8(const uint8_t* weak, uint8_t* strong, int B, int H, int W, const double* minv, const uint8_t* lut,
                       const int* cutouts, const int* flags, int border_value, et_stream_t stream);
+/* 4-image mosaic of the SSOD loader (load_mosaic_with_M, utils/datasets_ssod.py:732-782) without its 2s x 2s canvas: out (B, 3, S, S)
+ * uint8 = the 2:1 box average ((a + b + c + d + 2) >> 2: what cv2.resize(img4, (S, S)) computes at this exact ratio) of four images
+ * pasted around a centre over border_value.  tiles: DEVICE table [B][4][8] int64 = {device pointer of the tile's (3, h, w) uint8
+ * planes, h, w, x1a, y1a, x2a, y2a, x1b << 32 | y1b}: canvas rectangle and its origin inside the image, tile order top-left,
+ * top-right, bottom-left, bottom-right (x2a / y2a of tile 0 = the centre).  Host recipe: efficientteacher_amd/utils/augment.py. */
+int et_mosaic4_u8(const int64_t* tiles, uint8_t* out, int B, int S, int border_value, et_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Online pseudo labels.  Replaces FairPseudoLabel.create_pseudo_label_online_with_gt

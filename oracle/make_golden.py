@@ -823,6 +823,69 @@ def case_autobalance():
     save("autobalance", **out)
 
 
+def case_mosaic():
+    """load_mosaic_with_M (utils/datasets_ssod.py:732-792) run by the LIVE reference on a small in-memory dataset: what it pastes
+    where (the 2s x 2s canvas it hands to cv2.resize), the labels it hands to random_perspective_with_M, and how much of the
+    `random` stream it consumes.  cv2 is absent: `cv2.resize` is replaced by a recorder that returns the 2:1 box average (the
+    restated INTER_AREA fast path OpenCV takes for this call -- the PIXELS of that step are therefore this package's restatement,
+    unpinned), `random_perspective_with_M` by a recorder (the strong view is a separate stage: StrongViewGenerator)."""
+    import random as pyrandom
+    import types
+    import utils.datasets_ssod as D
+    s = 32
+    rng = np.random.default_rng(5)
+    shapes = [(32, 24), (20, 32), (32, 32), (17, 32), (32, 13), (28, 32)]          # load_image: longest side = img_size
+    imgs = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w in shapes]
+    labels = []
+    for k in range(len(shapes)):
+        n = int(rng.integers(0, 4))
+        lb = np.zeros((n, 5), np.float32)
+        lb[:, 0] = rng.integers(0, 80, n)
+        lb[:, 1:3] = rng.uniform(0.2, 0.8, (n, 2))
+        lb[:, 3:5] = rng.uniform(0.05, 0.5, (n, 2))
+        labels.append(lb)
+    ds = types.SimpleNamespace(img_size=s, mosaic_border=[-s // 2, -s // 2], indices=list(range(len(shapes))), imgs=imgs,
+                               img_hw0=shapes, img_hw=shapes, labels=labels, segments=[[] for _ in shapes],
+                               hyp=dict(degrees=0.0, translate=0.1, scale=0.5, shear=0.0, perspective=0.0))
+    rec = {}
+
+    def resize(img, dsize, **k):
+        rec.setdefault("canvas", []).append(img.copy())
+        assert img.shape[0] == 2 * dsize[1] and img.shape[1] == 2 * dsize[0]
+        a = img.astype(np.int64)
+        return ((a[0::2, 0::2] + a[0::2, 1::2] + a[1::2, 0::2] + a[1::2, 1::2] + 2) >> 2).astype(np.uint8)
+
+    def perspective(img, targets=(), segments=(), **k):
+        rec.setdefault("weak", []).append(img.copy())
+        rec.setdefault("labels4", []).append(np.array(targets, dtype=np.float64).reshape(-1, 5).copy())
+        return img, targets, np.zeros(13)
+    keep = (D.cv2.__dict__.get("resize"), D.random_perspective_with_M)
+    D.cv2.resize = resize
+    D.random_perspective_with_M = perspective
+    out = {}
+    try:
+        pyrandom.seed(1234)
+        for j, index in enumerate((0, 3, 5, 2)):
+            D.load_mosaic_with_M(ds, index)
+        out["next_random"] = np.array([pyrandom.random()])          # the stream position after four mosaics
+    finally:
+        if keep[0] is None:
+            del D.cv2.resize
+        else:
+            D.cv2.resize = keep[0]
+        D.random_perspective_with_M = keep[1]
+    for k, im in enumerate(imgs):
+        out[f"img{k}"] = im
+        out[f"lab{k}"] = labels[k]
+    for j in range(4):
+        out[f"canvas{j}"] = rec["canvas"][j]
+        out[f"weak{j}"] = rec["weak"][j]
+        out[f"labels4_{j}"] = rec["labels4"][j]
+    out["index"] = np.array([0, 3, 5, 2])
+    out["s"] = np.array([s])
+    save("mosaic", **out)
+
+
 def main():
     if not ref_loader.available():
         sys.exit("reference tree not present; golden vectors can only be generated in the build container")
@@ -842,6 +905,10 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "labelmatch":
         print("== LabelMatch")
         case_labelmatch()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "mosaic":
+        print("== mosaic")
+        case_mosaic()
         return
     if len(sys.argv) > 1 and sys.argv[1] == "nms":
         print("== nms")
@@ -866,6 +933,7 @@ def main():
     print("LabelMatch ..."); case_labelmatch()
     print("focal loss ..."); case_focal()
     print("autobalance ..."); case_autobalance()
+    print("mosaic ..."); case_mosaic()
     print("done")
 
 
