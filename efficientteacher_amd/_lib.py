@@ -38,9 +38,9 @@ SIGNATURES = {
     "et_sgd_nesterov_dev": (c_int, [P, P, P, P, c_int, c_int64, P, c_int, P, P]),
     "et_conv2d_stats_rows": (c_int, [c_int, c_int, c_int]),
     "et_conv2d_stats_rows_for": (c_int, [c_int] * 12),
-    "et_conv2d_fwd": (c_int, [P, P, P, c_int] + [c_int] * 11 + [P, P, c_int, P, c_int, P, P, P]),
+    "et_conv2d_fwd": (c_int, [P, P, P, c_int] + [c_int] * 11 + [P, P, c_int, P, c_int, P, c_int, P, P]),
     "et_conv2d_dgrad": (c_int, [P, P, P, c_int] + [c_int] * 11 + [c_int, P, c_int, P, P]),
-    "et_conv2d_dgrad_bn": (c_int, [P, P, P, c_int] + [c_int] * 10 + [P, c_int, P, c_int, P, P, c_int, P, P, P]),
+    "et_conv2d_dgrad_bn": (c_int, [P, P, P, c_int] + [c_int] * 10 + [P, c_int, P, c_int, P, P, c_int, P, c_int, P, P]),
     "et_conv2d_wgrad": (c_int, [P, P, P, c_int] + [c_int] * 11 + [P, P]),
     "et_conv2d_wgrad_grouped": (c_int, [P, c_int, c_int] + [c_int] * 9 + [P, P]),
     "et_weight_transpose_all": (c_int, [P, P, c_int, P, c_int, ctypes.c_longlong, P]),
@@ -52,6 +52,9 @@ SIGNATURES = {
     "et_bn_finalize": (c_int, [P, c_int, c_int, c_double, P, P, c_float, c_float, P, P, P, P, P, P, P, P]),
     "et_bn_eval_affine": (c_int, [c_int, P, P, P, P, c_float, P, P, P]),
     "et_bn_act_fwd": (c_int, [P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, P, P, c_int, P]),
+    "et_bn_act_fwd_sharded": (c_int, [P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, P, c_int, c_double, P, P, c_float, c_float,
+                                      P, P, P, P, P, P, c_int, P]),
+    "et_bn_act_bwd_sharded": (c_int, [P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, P, P, P, P, P, c_int, P, P, P, c_int, c_int, P]),
     "et_bn_act_bwd": (c_int, [P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, P, P, P, P, P, c_int, P, P, P, P,
                               c_size_t, P]),
     "et_bn_act_bwd_from_partials": (c_int, [P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, P, P, P, P, P, c_int, P, P, P,

@@ -48,6 +48,45 @@ def _fuse_into(cs, bn, x=None):
     if cs.k > 1 and (FUSE_BN_BWD_K & 4) and x is not None and _dgrad_on_rs_tile(cs, x):
         return bn
     return None
+# BatchNorm statistics through sharded fp32 accumulators (flat_state.BnSlot): the conv epilogues / the reduce pass ADD their sums, the
+# normalise and apply passes fold the shards themselves -- no finalize launch per layer and pass (~190 launches per YOLOv5l step).
+# 16-bit training modes only (the slots of an fp32 FlatState have no shards: exact, reproducible partial rows + fp64 finalize).
+SHARDED_BN = True
+
+
+def _bn_train_fwd(x, w_lp, cs_stride, cs_pad, bs, act, residual=None, out=None):
+    """y = conv(x, w), z = act(BN_train(y)) (+ residual): (y, z, scale, shift, mean, invstd)"""
+    N, IH, IW, Cin = x.shape
+    sh = None
+    if SHARDED_BN and bs.sh_ld and ops.few_rows("fwd", x.dtype, N, IH, IW, Cin, w_lp.shape[0], w_lp.shape[1], cs_stride, cs_pad):
+        sh = bs.acquire_fwd()
+    if sh is not None:
+        y = ops.conv2d_fwd(x, w_lp, cs_stride, cs_pad, shards=sh)
+        N, OH, OW, _ = y.shape
+        z, scale, shift, mean, invstd = ops.bn_act_fwd_sharded(y, sh, N * OH * OW, bs.gamma, bs.beta, bs.eps, bs.momentum, bs.rmean,
+                                                               bs.rvar, act, residual=residual, out=out)
+        return y, z, scale, shift, mean, invstd
+    y, stats = ops.conv2d_fwd(x, w_lp, cs_stride, cs_pad, want_stats=True)
+    N, OH, OW, _ = y.shape
+    scale, shift, mean, invstd = ops.bn_finalize(stats, N * OH * OW, bs.gamma, bs.beta, bs.eps, bs.momentum, bs.rmean, bs.rvar)
+    z = ops.bn_act_fwd(y, scale, shift, act, residual=residual, out=out)
+    return y, z, scale, shift, mean, invstd
+
+
+def _bn_sums(y, scale, shift, act, bs):
+    """the BnBwdSums a consumer's dgrad fills for the Conv block (y, bs)"""
+    return ops.BnBwdSums(y, scale, shift, act, slot=bs if (SHARDED_BN and bs.sh_ld) else None)
+
+
+def _bn_train_bwd(dz, y, bs, scale, shift, mean, invstd, act, sums=None, out=None):
+    """dy of act(BN_train(y)); sums: the BnBwdSums a dgrad may have filled for exactly this dz"""
+    part = sums.take(dz) if sums is not None else None
+    if SHARDED_BN and bs.sh_ld and (isinstance(part, tuple) or (part is None and ops.few_reduce_rows(y))):
+        sh = part if part is not None else bs.acquire_bwd()
+        return ops.bn_act_bwd(dz, y, bs.gamma, scale, shift, mean, invstd, act, bs.ggamma, bs.gbeta, out=out, partial=part, shards=sh)
+    return ops.bn_act_bwd(dz, y, bs.gamma, scale, shift, mean, invstd, act, bs.ggamma, bs.gbeta, out=out, partial=part)
+
+
 # two-consumer tensors: the later consumer's backward adds into the earlier one's gradient in its own kernel (GradFork below)
 # instead of a torch bf16 add per tensor by autograd (step-neutral, six ATen launches fewer: NOTEBOOK.md round 3)
 GRAD_FORK = True
@@ -161,22 +200,18 @@ class ConvBnActFn(Function):
         ctx.w_needs_grad = wparam.requires_grad
         ctx.bn_in = bn_in if (bn_in is not None and cs.stride == 1 and residual is None) else None
         ctx.acc = acc
-        y, stats = ops.conv2d_fwd(x, cs.w_lp, cs.stride, cs.pad, want_stats=True)
-        N, OH, OW, _ = y.shape
-        scale, shift, mean, invstd = ops.bn_finalize(stats, N * OH * OW, bs.gamma, bs.beta, bs.eps, bs.momentum,
-                                                     bs.rmean, bs.rvar)
         if nbt is not None:
             nbt.add_(1)
         # dst = (buffer, channel offset): write the block output straight into its slice of a concat
         # buffer (JoinSlicesFn turns the filled buffer into the differentiable concat result)
         out = None if dst is None else dst[0][..., dst[1]:dst[1] + cs.coutp]
-        z = ops.bn_act_fwd(y, scale, shift, act, residual=residual, out=out)
+        y, z, scale, shift, mean, invstd = _bn_train_fwd(x, cs.w_lp, cs.stride, cs.pad, bs, act, residual=residual, out=out)
         ctx.cs, ctx.bs, ctx.act = cs, bs, act
         ctx.has_res = residual is not None
         ctx.x_needs_grad = x.requires_grad
         ctx.bn_mine = None
         if bn_out is not None and residual is None:
-            ctx.bn_mine = ops.BnBwdSums(y, scale, shift, act)
+            ctx.bn_mine = _bn_sums(y, scale, shift, act, bs)
             bn_out.append(ctx.bn_mine)
         ctx.save_for_backward(x, y, scale, shift, mean, invstd)
         return z
@@ -186,8 +221,7 @@ class ConvBnActFn(Function):
         x, y, scale, shift, mean, invstd = ctx.saved_tensors
         cs, bs = ctx.cs, ctx.bs
         dz = _dense_or_slice(dz)
-        part = ctx.bn_mine.take(dz) if ctx.bn_mine is not None else None
-        dy = ops.bn_act_bwd(dz, y, bs.gamma, scale, shift, mean, invstd, ctx.act, bs.ggamma, bs.gbeta, partial=part)
+        dy = _bn_train_bwd(dz, y, bs, scale, shift, mean, invstd, ctx.act, sums=ctx.bn_mine)
         if ctx.w_needs_grad:
             _wgrad(x, dy, cs)
         dx = None
@@ -212,23 +246,17 @@ class BottleneckFn(Function):
         # bn_in / bn_out: see ConvBnActFn (x's sole consumer is this node: both the cv1 path and the shortcut are inside it)
         ctx.w_needs_grad = w1.requires_grad or w2.requires_grad
         ctx.bn_in = bn_in
-        y1, st1 = ops.conv2d_fwd(x, cs1.w_lp, cs1.stride, cs1.pad, want_stats=True)
-        N, H1, W1, _ = y1.shape
-        a1 = ops.bn_finalize(st1, N * H1 * W1, bs1.gamma, bs1.beta, bs1.eps, bs1.momentum, bs1.rmean, bs1.rvar)
-        h = ops.bn_act_fwd(y1, a1[0], a1[1], act1)
-        y2, st2 = ops.conv2d_fwd(h, cs2.w_lp, cs2.stride, cs2.pad, want_stats=True)
-        _, H2, W2, _ = y2.shape
-        a2 = ops.bn_finalize(st2, N * H2 * W2, bs2.gamma, bs2.beta, bs2.eps, bs2.momentum, bs2.rmean, bs2.rvar)
+        y1, h, *a1 = _bn_train_fwd(x, cs1.w_lp, cs1.stride, cs1.pad, bs1, act1)
         for nbt in (nbt1, nbt2):
             if nbt is not None:
                 nbt.add_(1)
         out = None if dst is None else dst[0][..., dst[1]:dst[1] + cs2.coutp]
-        z = ops.bn_act_fwd(y2, a2[0], a2[1], act2, residual=x, out=out)
+        y2, z, *a2 = _bn_train_fwd(h, cs2.w_lp, cs2.stride, cs2.pad, bs2, act2, residual=x, out=out)
         ctx.meta = (cs1, bs1, cs2, bs2, act1, act2)
         ctx.x_needs_grad = x.requires_grad
         ctx.bn_mine = None
         if bn_out is not None:
-            ctx.bn_mine = ops.BnBwdSums(y2, a2[0], a2[1], act2)
+            ctx.bn_mine = _bn_sums(y2, a2[0], a2[1], act2, bs2)
             bn_out.append(ctx.bn_mine)
         ctx.save_for_backward(x, y1, h, y2, *a1, *a2)
         return z
@@ -238,16 +266,14 @@ class BottleneckFn(Function):
         x, y1, h, y2, s1, b1, m1, i1, s2, b2, m2, i2 = ctx.saved_tensors
         cs1, bs1, cs2, bs2, act1, act2 = ctx.meta
         dz = _dense_or_slice(dz)
-        part2 = ctx.bn_mine.take(dz) if ctx.bn_mine is not None else None
-        dy2 = ops.bn_act_bwd(dz, y2, bs2.gamma, s2, b2, m2, i2, act2, bs2.ggamma, bs2.gbeta, partial=part2)
+        dy2 = _bn_train_bwd(dz, y2, bs2, s2, b2, m2, i2, act2, sums=ctx.bn_mine)
         if ctx.w_needs_grad:
             _wgrad(h, dy2, cs2)
         # h = act(BN1(y1)) has exactly one consumer (cv2, inside this node): the reduce pass of BN1's backward rides
         # the epilogue of cv2's dgrad
-        inner = _fuse_into(cs2, ops.BnBwdSums(y1, s1, b1, act1), h) if FUSE_BN_BWD else None
+        inner = _fuse_into(cs2, _bn_sums(y1, s1, b1, act1, bs1), h) if FUSE_BN_BWD else None
         dh = ops.conv2d_dgrad(dy2, cs2.transposed(), (h.shape[1], h.shape[2]), cs2.stride, cs2.pad, bn=inner)
-        dy1 = ops.bn_act_bwd(dh, y1, bs1.gamma, s1, b1, m1, i1, act1, bs1.ggamma, bs1.gbeta,
-                             partial=inner.take(dh) if inner is not None else None)
+        dy1 = _bn_train_bwd(dh, y1, bs1, s1, b1, m1, i1, act1, sums=inner)
         if ctx.w_needs_grad:
             _wgrad(x, dy1, cs1)
         dx = None
@@ -289,20 +315,34 @@ class C3StemFn(Function):
         ctx.w_needs_grad = w1.requires_grad or w2.requires_grad
         c = cs1.cout
         wf = cs1.w_lp.as_strided((2 * c, 1, 1, cs1.cinp), (cs1.cinp, cs1.cinp, cs1.cinp, 1), cs1.w_lp.storage_offset())
-        y, st = ops.conv2d_fwd(x, wf, 1, 0, want_stats=True)
-        N, H, W, _ = y.shape
-        aff = ops.bn_finalize(st, N * H * W, _fused_vec(bs1.gamma, bs2.gamma), _fused_vec(bs1.beta, bs2.beta), bs1.eps,
-                              bs1.momentum, _fused_vec(bs1.rmean, bs2.rmean), _fused_vec(bs1.rvar, bs2.rvar))
+        sh1 = sh2 = None
+        if SHARDED_BN and bs1.sh_ld and bs2.sh_ld and ops.few_rows("fwd", x.dtype, x.shape[0], x.shape[1], x.shape[2], cs1.cinp, 2 * c, 1, 1, 0):
+            sh1, sh2 = bs1.acquire_fwd(), bs2.acquire_fwd()
         for nbt in (nbt1, nbt2):
             if nbt is not None:
                 nbt.add_(1)
-        t = ops.bn_act_fwd(y[..., :c], aff[0][:c], aff[1][:c], act, out=buf[..., :c])
-        y2 = ops.bn_act_fwd(y[..., c:], aff[0][c:], aff[1][c:], act, out=buf[..., 2 * c:])
+        if sh1 is not None and sh2 is not None:
+            # one GEMM adds the sums of both halves (adjacent channel ranges of the accumulator, c3_stem_fusable); each half folds its own
+            y = ops.conv2d_fwd(x, wf, 1, 0, shards=sh1)
+            N, H, W, _ = y.shape
+            af = torch.empty((4, 2 * c), dtype=torch.float32, device=y.device)
+            t = ops.bn_act_fwd_sharded(y[..., :c], sh1, N * H * W, bs1.gamma, bs1.beta, bs1.eps, bs1.momentum, bs1.rmean, bs1.rvar,
+                                       act, out=buf[..., :c], aff=af[:, :c])[0]
+            y2 = ops.bn_act_fwd_sharded(y[..., c:], sh2, N * H * W, bs2.gamma, bs2.beta, bs2.eps, bs2.momentum, bs2.rmean, bs2.rvar,
+                                        act, out=buf[..., 2 * c:], aff=af[:, c:])[0]
+            aff = (af[0], af[1], af[2], af[3])
+        else:
+            y, st = ops.conv2d_fwd(x, wf, 1, 0, want_stats=True)
+            N, H, W, _ = y.shape
+            aff = ops.bn_finalize(st, N * H * W, _fused_vec(bs1.gamma, bs2.gamma), _fused_vec(bs1.beta, bs2.beta), bs1.eps,
+                                  bs1.momentum, _fused_vec(bs1.rmean, bs2.rmean), _fused_vec(bs1.rvar, bs2.rvar))
+            t = ops.bn_act_fwd(y[..., :c], aff[0][:c], aff[1][:c], act, out=buf[..., :c])
+            y2 = ops.bn_act_fwd(y[..., c:], aff[0][c:], aff[1][c:], act, out=buf[..., 2 * c:])
         ctx.meta = (cs1, bs1, cs2, bs2, act)
         ctx.x_needs_grad = x.requires_grad
         ctx.bn_mine = None
         if bn_out is not None:
-            ctx.bn_mine = ops.BnBwdSums(y[..., :c], aff[0][:c], aff[1][:c], act)
+            ctx.bn_mine = _bn_sums(y[..., :c], aff[0][:c], aff[1][:c], act, bs1)
             bn_out.append(ctx.bn_mine)
         ctx.save_for_backward(x, y, *aff)
         return t, y2
@@ -320,9 +360,8 @@ class C3StemFn(Function):
                 dy[..., sl].zero_()
                 continue
             g = _dense_or_slice(g)
-            part = ctx.bn_mine.take(g) if (ctx.bn_mine is not None and sl.start == 0) else None
-            ops.bn_act_bwd(g, y[..., sl], bs.gamma, scale[sl], shift[sl], mean[sl], invstd[sl], act,
-                           bs.ggamma, bs.gbeta, out=dy[..., sl], partial=part)
+            _bn_train_bwd(g, y[..., sl], bs, scale[sl], shift[sl], mean[sl], invstd[sl], act,
+                          sums=ctx.bn_mine if sl.start == 0 else None, out=dy[..., sl])
         if ctx.w_needs_grad:
             _wgrad(x, dy, cs1, cs2)
         dx = None

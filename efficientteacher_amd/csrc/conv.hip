@@ -125,6 +125,10 @@ struct Epilogue {
     const float* bn_scale;
     const float* bn_shift;
     int bn_act;
+    // stats_ld != 0: `stats` is a SHARDED accumulator [ET_BN_SHARDS][2][stats_ld] (zero before the launch) instead of partial rows:
+    // every wave ADDS its sums into shard blockIdx.x % ET_BN_SHARDS (= the XCD the workgroup runs on) with hardware fp32 atomics,
+    // and the consumer (et_bn_act_fwd_sharded / et_bn_act_bwd_sharded) folds the 8 shards itself -- no finalize launch per layer
+    int stats_ld;
 };
 
 // Workgroup -> tile.  The launch is 1-D over ntm x ntn tiles.  Workgroups are dealt round-robin to the 8 XCDs
@@ -261,7 +265,13 @@ __device__ __forceinline__ void conv_epilogue_write_stats(EpiSums<BN / WN / 32>&
 #pragma unroll
         for (int e = 0; e < 8; ++e)
             for (int m = CVN; m < 64; m <<= 1) { st.bs1[e] += __shfl_xor(st.bs1[e], m); st.bs2[e] += __shfl_xor(st.bs2[e], m); }
-        if (lane < CVN && co + 8 <= g.Cout) {
+        if (ep.stats_ld) {
+            if (lane < CVN && co + 8 <= g.Cout) {
+                float* d0 = ep.stats + ((size_t)(blockIdx.x % ET_BN_SHARDS) * 2) * ep.stats_ld + co;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { unsafeAtomicAdd(d0 + e, st.bs1[e]); unsafeAtomicAdd(d0 + ep.stats_ld + e, st.bs2[e]); }
+            }
+        } else if (lane < CVN && co + 8 <= g.Cout) {
             for (int r = 0; r <= zero_rows; ++r) {
                 if (row + r >= nrows) break;
                 float* d0 = ep.stats + ((size_t)(row + r) * 2 + 0) * g.Cout + co;
@@ -281,7 +291,12 @@ __device__ __forceinline__ void conv_epilogue_write_stats(EpiSums<BN / WN / 32>&
             const float sv = st.ssum[tn] + __shfl_xor(st.ssum[tn], 32);   // the two lane halves hold the two row halves of a channel
             const float qv = st.ssq[tn] + __shfl_xor(st.ssq[tn], 32);
             const int cc = n0 + wn * WCOLS + tn * 32 + l31;
-            if (hi == 0 && cc < g.Cout) {
+            if (ep.stats_ld) {
+                if (hi == 0 && cc < g.Cout) {
+                    float* d0 = ep.stats + ((size_t)(blockIdx.x % ET_BN_SHARDS) * 2) * ep.stats_ld + cc;
+                    unsafeAtomicAdd(d0, sv); unsafeAtomicAdd(d0 + ep.stats_ld, qv);
+                }
+            } else if (hi == 0 && cc < g.Cout) {
                 for (int r = 0; r <= zero_rows; ++r) {
                     if (row + r >= nrows) break;
                     ep.stats[((size_t)(row + r) * 2 + 0) * g.Cout + cc] = r == 0 ? sv : 0.f;
@@ -289,6 +304,46 @@ __device__ __forceinline__ void conv_epilogue_write_stats(EpiSums<BN / WN / 32>&
                 }
             }
         }
+    }
+}
+
+// Sharded statistics of a PERSISTENT workgroup (Epilogue::stats_ld != 0): the sums of its WM wave rows meet in LDS first, then one
+// atomic per channel and workgroup.  The workgroups of a persistent grid finish together, so their atomics arrive together and
+// queue per address in the memory-side atomic units (~25 ns each, r05): gridDim.x / ET_BN_SHARDS deep instead of WM times that.
+// red: LDS, WM * 2 * BN floats, free to use once every wave has passed the barrier inside.
+template <int BN, int WN, int WM, int MODE>
+__device__ __forceinline__ void conv_stats_add_sharded_wg(EpiSums<BN / WN / 32>& st, const GatherGeom& g, const Epilogue& ep, int tid, int lane,
+                                                          int wm, int wn, float* red) {
+    constexpr int TN = BN / WN / 32, WCOLS = BN / WN, CVN = WCOLS / 8;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const bool bnb = MODE == 1 ? false : ep.bn_y != nullptr;
+    __syncthreads();
+    float* const r0 = red + (wm * 2) * BN + wn * WCOLS;
+    if (bnb) {
+        const int scv = lane % CVN;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            for (int m = CVN; m < 64; m <<= 1) { st.bs1[e] += __shfl_xor(st.bs1[e], m); st.bs2[e] += __shfl_xor(st.bs2[e], m); }
+        if (lane < CVN) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { r0[scv * 8 + e] = st.bs1[e]; r0[BN + scv * 8 + e] = st.bs2[e]; }
+        }
+    } else {
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const float sv = st.ssum[tn] + __shfl_xor(st.ssum[tn], 32);
+            const float qv = st.ssq[tn] + __shfl_xor(st.ssq[tn], 32);
+            if (hi == 0) { r0[tn * 32 + l31] = sv; r0[BN + tn * 32 + l31] = qv; }
+        }
+    }
+    __syncthreads();
+    float* const dst = ep.stats + ((size_t)(blockIdx.x % ET_BN_SHARDS) * 2) * ep.stats_ld;
+    for (int i = tid; i < 2 * BN; i += 64 * WM * WN) {
+        const int t = i / BN, c = i % BN;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) v += red[(w * 2 + t) * BN + c];
+        if (c < g.Cout) unsafeAtomicAdd(dst + (size_t)t * ep.stats_ld + c, v);
     }
 }
 
@@ -1647,7 +1702,10 @@ __global__ __launch_bounds__(64 * WM * WN, WGS) void conv1x1_stream_kernel(const
         conv_epilogue<T, BM, BN, WM, WN, 16, MODE, true>(acc, slabs, Y, g, ep, 0, m0, 0, tid, lane, wm, wn, st);
     }
     // every workgroup of the grid writes its row (also one that had no tile: zeros), so the consumer may sum all gridDim.x * WM rows
-    if (ep.stats) conv_epilogue_write_stats<BN, WN, MODE>(st, g, ep, 0, lane, wn, (int)blockIdx.x * WM + wm, 0, (int)gridDim.x * WM);
+    if (ep.stats) {
+        if (ep.stats_ld) conv_stats_add_sharded_wg<BN, WN, WM, MODE>(st, g, ep, tid, lane, wm, wn, (float*)ring);
+        else conv_epilogue_write_stats<BN, WN, MODE>(st, g, ep, 0, lane, wn, (int)blockIdx.x * WM + wm, 0, (int)gridDim.x * WM);
+    }
 }
 
 // ---- the stem: 6x6 stride-2 pad-2 convolution of the packed image (8 channels, 3 used) ----------------------------
@@ -1682,6 +1740,7 @@ struct StemArgs {
     int trn, tcn, ntiles;               // tile grid per image: rows, cols; total tiles
     const float* scale; const float* bias; int act;
     float* stats; int stat_rows;        // [stat_rows][2][Cout] or null
+    int stats_ld;                       // != 0: sharded accumulator [ET_BN_SHARDS][2][stats_ld] (Epilogue::stats_ld)
 };
 
 template <typename T, int ACT>
@@ -1841,7 +1900,9 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(StemArgs a) {        
             float t = 0.f;
 #pragma unroll
             for (int w = 0; w < 4; ++w) t += red[(w * 2 + which) * 64 + ch];
-            if (ch < a.Cout) {
+            if (ch < a.Cout && a.stats_ld) {
+                unsafeAtomicAdd(a.stats + ((size_t)(blockIdx.x % ET_BN_SHARDS) * 2 + which) * a.stats_ld + ch, t);
+            } else if (ch < a.Cout) {
                 // the consumer sums ALL stat_rows partial rows: this workgroup owns rows blockIdx.x, + gridDim.x, ...
                 for (int row = blockIdx.x; row < a.stat_rows; row += gridDim.x)
                     a.stats[((size_t)row * 2 + which) * a.Cout + ch] = row == (int)blockIdx.x ? t : 0.f;
@@ -1859,7 +1920,7 @@ static int device_cus() {
 // shape gate + launch; returns 1 if the stem kernel took the problem
 static int try_launch_stem(const void* x, const void* w, void* y, int dtype, int N, int IH, int IW, int Cin, int ldx, int Cout,
                            int KH, int KW, int stride, int pad, int ldy, const float* scale, const float* bias, int act,
-                           const void* residual, float* stats, const void* zero16, hipStream_t s, bool launch) {
+                           const void* residual, float* stats, int stats_ld, const void* zero16, hipStream_t s, bool launch) {
     if ((dtype != ET_BF16 && dtype != ET_F16) || KH != 6 || KW != 6 || stride != 2 || pad != 2 || Cin != 8 || Cout > 64 || Cout % 8 ||
         residual || !zero16)
         return 0;
@@ -1870,12 +1931,12 @@ static int try_launch_stem(const void* x, const void* w, void* y, int dtype, int
     a.OH = (IH + 2 * pad - KH) / stride + 1; a.OW = (IW + 2 * pad - KW) / stride + 1;
     a.trn = (a.OH + STEM_TR - 1) / STEM_TR; a.tcn = (a.OW + STEM_TC - 1) / STEM_TC;
     a.ntiles = N * a.trn * a.tcn;
-    a.scale = scale; a.bias = bias; a.act = act; a.stats = stats;
+    a.scale = scale; a.bias = bias; a.act = act; a.stats = stats; a.stats_ld = stats ? stats_ld : 0;
     a.stat_rows = (N * a.OH * a.OW + 63) / 64;        // == et_conv2d_stats_rows
     int grid = env_int("ET_CONV_STEM_WGS", 2 * device_cus());      // read per launch: tests shrink it to exercise the tile loop
     if (grid < 1) grid = 1;
     if (grid > a.ntiles) grid = a.ntiles;
-    if (stats && grid > a.stat_rows) grid = a.stat_rows;
+    if (stats && !stats_ld && grid > a.stat_rows) grid = a.stat_rows;
 #define ET_STEM(T_) \
     do { \
         if (act == ACT_SILU) hipLaunchKernelGGL((conv_stem_kernel<T_, ACT_SILU>), dim3(grid), dim3(256), 0, s, a); \
@@ -2926,7 +2987,7 @@ extern "C" int et_conv2d_stats_rows_for(int op, int dtype, int N, int IH, int IW
     int rc;
     if (op == 0) {
         if (!fwd_full && try_launch_stem(nullptr, nullptr, nullptr, dtype, N, IH, IW, Cin, Cin, Cout, KH, KW, stride, pad, Cout, nullptr, nullptr, 0, nullptr,
-                                         nullptr, have_zero_page ? (const void*)&g : nullptr, nullptr, false)) {
+                                         nullptr, 0, have_zero_page ? (const void*)&g : nullptr, nullptr, false)) {
             const int OH = (IH + 2 * pad - KH) / stride + 1, OW = (IW + 2 * pad - KW) / stride + 1;
             return (N * OH * OW + 63) / 64;
         }
@@ -2944,11 +3005,11 @@ extern "C" int et_conv2d_stats_rows_for(int op, int dtype, int N, int IH, int IW
 extern "C" int et_conv2d_fwd(const void* x, const void* w, void* y, int dtype, int N, int IH, int IW, int Cin,
                              int ldx, int Cout, int KH, int KW, int stride, int pad, int ldy, const float* scale,
                              const float* bias, int act, const void* residual, int ldr, float* stats_partial,
-                             const void* zero16, et_stream_t stream) {
+                             int stats_ld, const void* zero16, et_stream_t stream) {
     if (!x || !w || !y) return -1;
-    if (KH * KW > CONV_MAX_TAPS || stride < 1 || N <= 0 || Cout <= 0) return -2;
+    if (KH * KW > CONV_MAX_TAPS || stride < 1 || N <= 0 || Cout <= 0 || stats_ld < 0 || (stats_ld && stats_ld < Cout)) return -2;
     if (try_launch_stem(x, w, y, dtype, N, IH, IW, Cin, ldx, Cout, KH, KW, stride, pad, ldy, scale, bias, act, residual,
-                        stats_partial, zero16, (hipStream_t)stream, true)) {
+                        stats_partial, stats_ld, zero16, (hipStream_t)stream, true)) {
         ET_CHECK_LAUNCH();
         return 0;
     }
@@ -2970,6 +3031,7 @@ extern "C" int et_conv2d_fwd(const void* x, const void* w, void* y, int dtype, i
         }
     }
     Epilogue ep{scale, bias, act, residual, ldr, stats_partial, 0};
+    ep.stats_ld = stats_partial ? stats_ld : 0;
     if (dtype == ET_F32) rc = launch_gemm<float>(x, w, y, zero16, g, ep, (hipStream_t)stream);
     else if (dtype == ET_BF16) rc = launch_gemm<uint16_t>(x, w, y, zero16, g, ep, (hipStream_t)stream);
     else if (dtype == ET_F16) rc = launch_gemm<et_f16>(x, w, y, zero16, g, ep, (hipStream_t)stream);
@@ -2997,12 +3059,12 @@ __global__ __launch_bounds__(256) void zero_lattice_kernel(T* __restrict__ dx, i
 static int conv2d_dgrad_impl(const void* dy, const void* wT, void* dx, int dtype, int N, int IH, int IW, int Cin,
                              int ldx, int Cout, int KH, int KW, int stride, int pad, int ldy, int accumulate,
                              const void* residual, int ldr, const void* bn_y, int ld_bn, const float* bn_scale,
-                             const float* bn_shift, int bn_act, float* bn_stats, const void* zero16, et_stream_t stream) {
+                             const float* bn_shift, int bn_act, float* bn_stats, int bn_stats_ld, const void* zero16, et_stream_t stream) {
     // dx[n,iy,ix,ci] = sum_{ky,kx,co} dy[n,(iy+pad-ky)/s,(ix+pad-kx)/s,co] * wT[ci,ky,kx,co]
     if (!dy || !wT || !dx) return -1;
     if (KH * KW > CONV_MAX_TAPS || stride < 1 || stride > 2 || N <= 0) return -2;
     if (residual && stride != 1) return -2;        // the fused shortcut-gradient add is a stride-1 (Bottleneck) feature
-    if (bn_y && (stride != 1 || !bn_scale || !bn_shift || !bn_stats || Cin % 8)) return -2;   // one launch, whole channel groups
+    if (bn_y && (stride != 1 || !bn_scale || !bn_shift || !bn_stats || Cin % 8 || bn_stats_ld < 0 || (bn_stats_ld && bn_stats_ld < Cin))) return -2;   // one launch, whole channel groups
     const int vec = dtype == ET_F32 ? 4 : 8;
     for (int py = 0; py < stride; ++py)
         for (int px = 0; px < stride; ++px) {
@@ -3012,7 +3074,7 @@ static int conv2d_dgrad_impl(const void* dy, const void* wT, void* dx, int dtype
             if (rc) return rc;
             const int t = g.T, QH = g.QH, QW = g.QW;
             Epilogue ep{nullptr, nullptr, ACT_NONE, residual, ldr, bn_y ? bn_stats : nullptr, accumulate,
-                        bn_y, ld_bn, bn_scale, bn_shift, bn_act};   // dx = dgrad (+ residual) (+ BN-backward sums)
+                        bn_y, ld_bn, bn_scale, bn_shift, bn_act, bn_y ? bn_stats_ld : 0};   // dx = dgrad (+ residual) (+ BN-backward sums)
             if (t == 0) {            // no tap reaches this class (k < stride): zero gradient unless the caller accumulates
                 const long long total = (long long)N * QH * QW * Cin;
                 if (!accumulate && total > 0) {
@@ -3036,16 +3098,16 @@ extern "C" int et_conv2d_dgrad(const void* dy, const void* wT, void* dx, int dty
                                const void* residual, int ldr,
                                const void* zero16, et_stream_t stream) {
     return conv2d_dgrad_impl(dy, wT, dx, dtype, N, IH, IW, Cin, ldx, Cout, KH, KW, stride, pad, ldy, accumulate, residual, ldr,
-                             nullptr, 0, nullptr, nullptr, 0, nullptr, zero16, stream);
+                             nullptr, 0, nullptr, nullptr, 0, nullptr, 0, zero16, stream);
 }
 
 extern "C" int et_conv2d_dgrad_bn(const void* dy, const void* wT, void* dx, int dtype, int N, int IH, int IW, int Cin,
                                   int ldx, int Cout, int KH, int KW, int pad, int ldy, const void* residual, int ldr,
                                   const void* bn_y, int ld_bn, const float* bn_scale, const float* bn_shift, int bn_act,
-                                  float* bn_stats_partial, const void* zero16, et_stream_t stream) {
+                                  float* bn_stats_partial, int bn_stats_ld, const void* zero16, et_stream_t stream) {
     if (!bn_y) return -1;
     return conv2d_dgrad_impl(dy, wT, dx, dtype, N, IH, IW, Cin, ldx, Cout, KH, KW, 1, pad, ldy, 0, residual, ldr, bn_y, ld_bn,
-                             bn_scale, bn_shift, bn_act, bn_stats_partial, zero16, stream);
+                             bn_scale, bn_shift, bn_act, bn_stats_partial, bn_stats_ld, zero16, stream);
 }
 
 // launch geometry of the weight gradient (ONE copy: the launcher and et_conv2d_kernel_name both call this)
@@ -3316,7 +3378,7 @@ extern "C" int et_conv2d_kernel_name(int op, int dtype, int N, int IH, int IW, i
     if (op == 4) op = 0;
     if (op == 0) {
         if (!full && try_launch_stem(nullptr, nullptr, nullptr, dtype, N, IH, IW, Cin, Cin, Cout, KH, KW, stride, pad, Cout, nullptr, nullptr, 0,
-                                     nullptr, nullptr, have_zero_page ? (const void*)buf : nullptr, nullptr, false)) {
+                                     nullptr, nullptr, 0, have_zero_page ? (const void*)buf : nullptr, nullptr, false)) {
             snprintf(buf, buflen, "conv_stem_kernel");       // rocprofv3: "void conv_stem_kernel<ACT>(StemArgs)"
             return 0;
         }
@@ -3336,7 +3398,7 @@ extern "C" int et_env_knobs(char* buf, int buflen) {
     // three test hooks (persistent-grid sizes, the BatchNorm finalize form), the opt-in arms that change WHAT runs beside what (step
     // graph, weight-gradient stream), the data-parallel transport settings, and the experiment-library path.
     static const char* names[] = {"ET_CONV_S1_WGS", "ET_CONV_STEM_WGS", "ET_BN_FIN_SMALL", "ET_STEP_GRAPH", "ET_WGRAD_STREAM",
-                                  "ET_ALLREDUCE_CHUNK_MB", "ET_RCCL_CHANNELS", "ET_DP_SINGLE_RANK", "ET_HIP_LIB"};
+                                  "ET_ALLREDUCE_CHUNK_MB", "ET_ALLREDUCE_DTYPE", "ET_RCCL_CHANNELS", "ET_DP_SINGLE_RANK", "ET_HIP_LIB"};
     if (!buf || buflen < 1) return -1;
     int off = 0;
     buf[0] = 0;

@@ -45,8 +45,37 @@ class ConvSlot:
         return self.wT_lp
 
 
+BN_SHARDS = 16           # ET_BN_SHARDS of include/et_hip.h
+BN_SHARD_MAX_C = 1024    # et_bn_act_fwd_sharded / et_bn_act_bwd_sharded
+
+
 class BnSlot:
-    __slots__ = ("c", "gamma", "beta", "ggamma", "gbeta", "rmean", "rvar", "eps", "momentum", "aff_off")
+    __slots__ = ("c", "gamma", "beta", "ggamma", "gbeta", "rmean", "rvar", "eps", "momentum", "aff_off",
+                 "sh_fwd", "sh_bwd", "sh_ld", "sh_view", "gen", "fwd_gen", "bwd_gen")
+
+    # Sharded statistics (16-bit training modes; et_hip.h, et_conv2d_fwd stats_ld > 0): every BN layer owns channel range
+    # [aff_off, aff_off + c) of two zero-initialised [BN_SHARDS][2][bn_total] accumulators, one for the forward sums and one for the
+    # backward sums.  FlatState.prepare_forward zeroes both arenas with ONE memset per training forward and bumps the generation; a slot
+    # that is used a second time inside one generation (a module applied twice, two backward passes through one forward) zeroes its own
+    # range first -- correct in every call pattern, one launch per layer cheaper in the usual one.
+    def _acquire(self, which):
+        if self.sh_ld == 0:
+            return None
+        used = self.fwd_gen if which == 0 else self.bwd_gen
+        if used == self.gen[0]:
+            self.sh_view[which].zero_()
+        if which == 0:
+            self.fwd_gen = self.gen[0]
+        else:
+            self.bwd_gen = self.gen[0]
+        return (self.sh_fwd if which == 0 else self.sh_bwd), self.sh_ld
+
+    def acquire_fwd(self, n_channels=None):
+        """(tensor at this layer's channel 0, ld) of the zeroed forward accumulator, or None (fp32 mode / too wide)"""
+        return self._acquire(0)
+
+    def acquire_bwd(self):
+        return self._acquire(1)
 
 
 class FlatState:
@@ -135,10 +164,21 @@ class FlatState:
             m._et_flat_ref = weakref.ref(self)
         self.wT_table = torch.tensor(sorted(rows), dtype=torch.int32, device=dev).reshape(-1, 4)
         bw0 = seg["bn_weight"][0]
+        self._bn_gen = [0]
+        self.bn_shards = (torch.zeros((2, BN_SHARDS, 2, max(bn_total, 1)), dtype=torch.float32, device=dev)
+                          if compute_dtype != torch.float32 else None)
         for b, o in zip(bns, self.bn_off):
             c = b.num_features
             s = BnSlot()
             s.c, s.eps, s.momentum, s.aff_off = c, b.eps, b.momentum, o
+            s.gen, s.fwd_gen, s.bwd_gen = self._bn_gen, -1, -1
+            if self.bn_shards is not None and c <= BN_SHARD_MAX_C:
+                s.sh_ld = bn_total
+                s.sh_fwd = self.bn_shards[0].view(-1)[o:]
+                s.sh_bwd = self.bn_shards[1].view(-1)[o:]
+                s.sh_view = (self.bn_shards[0][:, :, o:o + c], self.bn_shards[1][:, :, o:o + c])
+            else:
+                s.sh_ld, s.sh_fwd, s.sh_bwd, s.sh_view = 0, None, None, None
             s.gamma = self.params[bw0 + o:bw0 + o + c]; s.ggamma = self.grads[bw0 + o:bw0 + o + c]
             s.beta = self.params[o:o + c]; s.gbeta = self.grads[o:o + c]
             repoint(b.weight, s.gamma, s.ggamma)
@@ -210,6 +250,9 @@ class FlatState:
         """Called by Model.forward: bring the bf16 shadow / eval-mode BN affine up to date if needed."""
         if training:
             ops.WGRAD_QUEUE.reset()      # nothing of an earlier (failed) backward lingers; side stream joined
+            if self.bn_shards is not None:
+                self.bn_shards.zero_()
+                self._bn_gen[0] += 1
         if self.weights_dirty:
             self.sync_shadow()
             self.weights_dirty = False

@@ -49,7 +49,7 @@ class FamilyTimer:
     FAMILY = {
         "et_conv2d_fwd": "gather_gemm", "et_conv2d_dgrad": "gather_gemm", "et_conv2d_dgrad_bn": "gather_gemm",
         "et_conv2d_wgrad": "wgrad", "et_conv2d_wgrad_grouped": "wgrad",
-        "et_bn_finalize": "bn", "et_bn_act_fwd": "bn", "et_bn_act_bwd": "bn", "et_bn_act_bwd_from_partials": "bn", "et_act_bwd": "bn",
+        "et_bn_finalize": "bn", "et_bn_act_fwd": "bn", "et_bn_act_fwd_sharded": "bn", "et_bn_act_bwd_sharded": "bn", "et_bn_act_bwd": "bn", "et_bn_act_bwd_from_partials": "bn", "et_act_bwd": "bn",
         "et_nms": "nms_loss_pl", "et_nms_ssod": "nms_loss_pl", "et_detect_decode": "nms_loss_pl", "et_pseudo_label_transform": "nms_loss_pl",
         "et_select_targets": "nms_loss_pl", "et_yolo_loss": "nms_loss_pl", "et_ota_assign": "nms_loss_pl", "et_score_log_append": "nms_loss_pl",
         "et_scale_cast": "nms_loss_pl", "et_domain_focal": "nms_loss_pl", "et_scale_inplace": "nms_loss_pl", "et_v8_decode": "nms_loss_pl",
@@ -106,6 +106,28 @@ def stats_rows(op, dtype, N, IH, IW, Cin, Cout, k, stride, pad, zero_page=True):
     if rows <= 0:
         raise _lib.EtHipError(f"et_conv2d_stats_rows_for failed with code {rows}")
     return rows
+
+
+# Sharded statistics pay when the producer writes FEW partial rows (the persistent 1x1 kernel: one per wave row of its <= 512
+# workgroups; any kernel on the small maps): every row becomes one fp32 atomic per channel, rows / BN_SHARDS of them on one address.
+# Above this many rows the atomics serialise in the memory-side atomic units for longer than the finalize launch they replace
+# (r05: every conv sharded = +5.3 ms of conv time against -1.6 ms of BatchNorm time per step).
+SHARD_MAX_ROWS = 2048
+_FEW_ROWS = {}
+
+
+def few_rows(op, dtype, N, IH, IW, Cin, Cout, k, stride, pad):
+    key = (op, dtype, N, IH, IW, Cin, Cout, k, stride, pad)
+    r = _FEW_ROWS.get(key)
+    if r is None:
+        r = _FEW_ROWS[key] = stats_rows(op, dtype, N, IH, IW, Cin, Cout, k, stride, pad)
+    return r <= SHARD_MAX_ROWS
+
+
+def few_reduce_rows(y):
+    """the same question for the separate reduce pass of the BatchNorm backward (one row per workgroup)"""
+    N, H, W, C = y.shape
+    return _lib.load().et_bn_reduce_rows(N * H * W, C, et_dtype(y)) <= SHARD_MAX_ROWS
 
 
 def env_knobs():
@@ -168,8 +190,9 @@ def conv_out_hw(ih, iw, k, s, p):
     return (ih + 2 * p - k) // s + 1, (iw + 2 * p - k) // s + 1
 
 
-def conv2d_fwd(x, w, stride, pad, *, scale=None, bias=None, act=ACT_NONE, residual=None, out=None, want_stats=False):
-    """y = act(conv(x, w) * scale + bias) + residual ; optional BN partial statistics (rows, 2, Cout)."""
+def conv2d_fwd(x, w, stride, pad, *, scale=None, bias=None, act=ACT_NONE, residual=None, out=None, want_stats=False, shards=None):
+    """y = act(conv(x, w) * scale + bias) + residual ; optional BN partial statistics (rows, 2, Cout) -- or, with shards = (tensor
+    whose first element is this layer's channel 0 of a zeroed [BN_SHARDS][2][ld] accumulator, ld), ADDED into that accumulator."""
     N, IH, IW, Cin = x.shape
     Cout, KH, KW, Cin2 = w.shape
     assert Cin == Cin2 and w.is_contiguous() and w.dtype == x.dtype
@@ -178,7 +201,10 @@ def conv2d_fwd(x, w, stride, pad, *, scale=None, bias=None, act=ACT_NONE, residu
     if out is None:
         out = torch.empty((N, OH, OW, Cout), dtype=x.dtype, device=x.device)
     assert out.shape == (N, OH, OW, Cout)
-    stats = None
+    stats, stats_ld = None, 0
+    if shards is not None:
+        assert not want_stats
+        stats, stats_ld = shards
     if want_stats:
         rows = stats_rows("fwd_res" if residual is not None else "fwd", x.dtype, N, IH, IW, Cin, Cout, KH, stride, pad)
         stats = torch.empty((rows, 2, Cout), dtype=torch.float32, device=x.device)
@@ -190,7 +216,7 @@ def conv2d_fwd(x, w, stride, pad, *, scale=None, bias=None, act=ACT_NONE, residu
         ev[0].record()
     _lib.check(lib.et_conv2d_fwd(_lib.ptr(x), _lib.ptr(w), _lib.ptr(out), et_dtype(x), N, IH, IW, Cin, _nhwc(x),
                                  Cout, KH, KW, stride, pad, _nhwc(out), _lib.ptr(scale), _lib.ptr(bias), act,
-                                 _lib.ptr(residual), ldr, _lib.ptr(stats), _lib.ptr(zero_page(x.device)),
+                                 _lib.ptr(residual), ldr, _lib.ptr(stats), stats_ld, _lib.ptr(zero_page(x.device)),
                                  _lib.stream(x)), "et_conv2d_fwd")
     if ev:
         ev[1].record()
@@ -357,10 +383,12 @@ class BnBwdSums:
     """What the dgrad of a CONSUMER layer needs to run the reduce pass of its PRODUCER's BatchNorm backward in its own
     epilogue (et_conv2d_dgrad_bn): the producer's raw conv output y, folded affine and activation -- and, after that
     dgrad has run, the partial sums it left plus the identity of the tensor they belong to."""
-    __slots__ = ("y", "scale", "shift", "act", "partial", "dz_ptr")
+    __slots__ = ("y", "scale", "shift", "act", "partial", "dz_ptr", "slot")
 
-    def __init__(self, y, scale, shift, act):
-        self.y, self.scale, self.shift, self.act = y, scale, shift, act
+    def __init__(self, y, scale, shift, act, slot=None):
+        # slot: the producer's flat_state.BnSlot when its backward sums go to the sharded accumulator (no partial rows, no finalize
+        # launch): the dgrad that carries the sums acquires the shards, `partial` is then the (tensor, ld) pair it added into
+        self.y, self.scale, self.shift, self.act, self.slot = y, scale, shift, act, slot
         self.partial, self.dz_ptr = None, None
 
     def take(self, dz):
@@ -383,8 +411,13 @@ def conv2d_dgrad(dy, wT, in_hw, stride, pad, *, out=None, accumulate=False, resi
         out = torch.empty((N, IH, IW, Cin), dtype=dy.dtype, device=dy.device)
     if bn is not None and stride == 1 and not accumulate and bn.y.shape == out.shape and bn.y.dtype == out.dtype:
         lib = _lib.load()
-        rows = stats_rows("dgrad_bn", dy.dtype, N, IH, IW, Cin, Cout, KH, stride, pad)
-        part = torch.empty((rows, 2, Cin), dtype=torch.float32, device=dy.device)
+        if bn.slot is not None and few_rows("dgrad_bn", dy.dtype, N, IH, IW, Cin, Cout, KH, stride, pad):
+            keep = bn.slot.acquire_bwd()
+            part, part_ld = keep
+        else:
+            rows = stats_rows("dgrad_bn", dy.dtype, N, IH, IW, Cin, Cout, KH, stride, pad)
+            keep = part = torch.empty((rows, 2, Cin), dtype=torch.float32, device=dy.device)
+            part_ld = 0
         ev = TIMER.span(kernel_name("dgrad_full", dy.dtype, N, IH, IW, Cin, Cout, KH, stride, pad), 2.0 * N * OH * OW * Cout * Cin * KH * KW,
                         nbytes=(dy.numel() + 2 * N * IH * IW * Cin + wT.numel()) * dy.element_size(),
                         shape=("dgrad", N, IH, IW, Cin, Cout, KH, stride)) if TIMER else None
@@ -393,10 +426,10 @@ def conv2d_dgrad(dy, wT, in_hw, stride, pad, *, out=None, accumulate=False, resi
         _lib.check(lib.et_conv2d_dgrad_bn(_lib.ptr(dy), _lib.ptr(wT), _lib.ptr(out), et_dtype(dy), N, IH, IW, Cin, _nhwc(out), Cout,
                                           KH, KW, pad, _nhwc(dy), _lib.ptr(residual), _nhwc(residual) if residual is not None else 0,
                                           _lib.ptr(bn.y), _nhwc(bn.y), _lib.ptr(bn.scale), _lib.ptr(bn.shift), bn.act,
-                                          _lib.ptr(part), _lib.ptr(zero_page(dy.device)), _lib.stream(dy)), "et_conv2d_dgrad_bn")
+                                          _lib.ptr(part), part_ld, _lib.ptr(zero_page(dy.device)), _lib.stream(dy)), "et_conv2d_dgrad_bn")
         if ev:
             ev[1].record()
-        bn.partial, bn.dz_ptr = part, out.data_ptr()
+        bn.partial, bn.dz_ptr = keep, out.data_ptr()
         return out
     tag = (kernel_name("dgrad_full" if (accumulate or residual is not None) else "dgrad", dy.dtype, N, IH, IW, Cin, Cout, KH, stride, pad) if stride == 1 else
            "conv_gemm (stride-2 dgrad parity classes)") if TIMER else None
@@ -475,12 +508,39 @@ def bn_act_fwd(y, scale, shift, act, residual=None, out=None):
     return out
 
 
-def bn_act_bwd(dz, y, gamma, scale, shift, mean, invstd, act, dgamma, dbeta, out=None, partial=None):
-    """partial: (rows, 2, C) sums left by the dgrad that produced dz (BnBwdSums.take) -- the reduce pass is skipped"""
+def bn_act_fwd_sharded(y, shards, count, gamma, beta, eps, momentum, running_mean, running_var, act, residual=None, out=None, aff=None):
+    """bn_finalize + bn_act_fwd in ONE launch on the sharded sums of conv2d_fwd(shards=...): (z, scale, shift, mean, invstd);
+    aff: a (4, C) fp32 view that receives the four per-channel vectors (else allocated)"""
+    N, H, W, C = y.shape
+    if out is None:
+        out = torch.empty((N, H, W, C), dtype=y.dtype, device=y.device)
+    if aff is None:
+        aff = torch.empty((4, C), dtype=torch.float32, device=y.device)
+    ldr = _nhwc(residual) if residual is not None else 0
+    sh, ld = shards
+    _lib.check(_lib.load().et_bn_act_fwd_sharded(_lib.ptr(y), _nhwc(y), _lib.ptr(out), _nhwc(out), _lib.ptr(residual), ldr, et_dtype(y),
+                                                 N * H * W, C, _lib.ptr(sh), ld, float(count), _lib.ptr(gamma), _lib.ptr(beta), eps,
+                                                 momentum, _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(aff[0]),
+                                                 _lib.ptr(aff[1]), _lib.ptr(aff[2]), _lib.ptr(aff[3]), act, _lib.stream(y)),
+               "et_bn_act_fwd_sharded")
+    return out, aff[0], aff[1], aff[2], aff[3]
+
+
+def bn_act_bwd(dz, y, gamma, scale, shift, mean, invstd, act, dgamma, dbeta, out=None, partial=None, shards=None):
+    """partial: (rows, 2, C) sums left by the dgrad that produced dz (BnBwdSums.take) -- the reduce pass is skipped.
+    shards = (tensor, ld): the sharded form, no finalize launch: `partial` (the same pair, from the dgrad) means the sums are there
+    already, else the reduce pass adds them into the (zeroed) shards first."""
     N, H, W, C = y.shape
     lib = _lib.load()
     if out is None:
         out = torch.empty((N, H, W, C), dtype=y.dtype, device=y.device)
+    if shards is not None:
+        sh, ld = shards
+        _lib.check(lib.et_bn_act_bwd_sharded(_lib.ptr(dz), _nhwc(dz), _lib.ptr(y), _nhwc(y), _lib.ptr(out), _nhwc(out), et_dtype(y),
+                                             N * H * W, C, _lib.ptr(gamma), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(mean),
+                                             _lib.ptr(invstd), act, _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(sh), ld,
+                                             0 if partial is not None else 1, _lib.stream(y)), "et_bn_act_bwd_sharded")
+        return out
     if partial is not None:
         ws = torch.empty(3 * C, dtype=torch.float32, device=y.device)
         _lib.check(lib.et_bn_act_bwd_from_partials(_lib.ptr(dz), _nhwc(dz), _lib.ptr(y), _nhwc(y), _lib.ptr(out), _nhwc(out),

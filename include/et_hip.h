@@ -31,7 +31,7 @@ enum { ET_F32 = 0, ET_BF16 = 1, ET_F16 = 2 };   /* ET_F16 (r05): IEEE half stora
  * for ("gfx950") and the ABI version.  ET_ABI_VERSION changes whenever an entry point is added or a signature / workspace
  * contract changes; a binding must refuse a library whose et_abi_version() differs from the header it was written against
  * (efficientteacher_amd/_lib.py does): a stale libet_hip.so would otherwise read e.g. a new int argument as the stream. */
-#define ET_ABI_VERSION 4
+#define ET_ABI_VERSION 5
 const char* et_build_arch(void);
 int et_abi_version(void);
 
@@ -136,9 +136,16 @@ int et_conv2d_stats_rows(int N, int OH, int OW);
  * call passes zero16.  Host only. */
 int et_conv2d_stats_rows_for(int op, int dtype, int N, int IH, int IW, int Cin, int Cout, int KH, int KW, int stride, int pad,
                              int have_zero_page);
+/* stats_partial with stats_ld == 0: partial rows (et_conv2d_stats_rows_for(...), 2, Cout), every row written -- the exact path
+ * (fp64 combine in et_bn_finalize, bit-reproducible).  stats_ld > 0: stats_partial is a SHARDED ACCUMULATOR
+ * [ET_BN_SHARDS][2][stats_ld] fp32 that must be ZERO before the launch; every wave adds its column sums into shard
+ * (workgroup index % ET_BN_SHARDS) with hardware fp32 atomics, channel c at [shard][t][c].  et_bn_act_fwd_sharded folds the shards
+ * itself, so a Conv block is two launches (conv, normalise) instead of three, and one memset per STEP zeroes every layer's shards
+ * when they live in one arena.  Sums are then order-dependent in the last fp32 bits (the 16-bit training modes use this form). */
+#define ET_BN_SHARDS 16
 int et_conv2d_fwd(const void* x, const void* w, void* y, int dtype, int N, int IH, int IW, int Cin,
                   int ldx, int Cout, int KH, int KW, int stride, int pad, int ldy, const float* scale,
-                  const float* bias, int act, const void* residual, int ldr, float* stats_partial,
+                  const float* bias, int act, const void* residual, int ldr, float* stats_partial, int stats_ld,
                   const void* zero16, et_stream_t stream);
 int et_conv2d_dgrad(const void* dy, const void* wT, void* dx, int dtype, int N, int IH, int IW, int Cin,
                     int ldx, int Cout, int KH, int KW, int stride, int pad, int ldy, int accumulate,
@@ -153,8 +160,9 @@ int et_conv2d_dgrad(const void* dy, const void* wT, void* dx, int dtype, int N, 
  * and y) by one y read here.  Reference math: torch.nn.BatchNorm2d backward as used by Conv (models/backbone/common.py:480). */
 int et_conv2d_dgrad_bn(const void* dy, const void* wT, void* dx, int dtype, int N, int IH, int IW, int Cin, int ldx, int Cout,
                        int KH, int KW, int pad, int ldy, const void* residual, int ldr, const void* bn_y, int ld_bn,
-                       const float* bn_scale, const float* bn_shift, int bn_act, float* bn_stats_partial, const void* zero16,
-                       et_stream_t stream);
+                       const float* bn_scale, const float* bn_shift, int bn_act, float* bn_stats_partial,
+                       int bn_stats_ld /* 0: partial rows; > 0: sharded accumulator [ET_BN_SHARDS][2][bn_stats_ld], see et_conv2d_fwd */,
+                       const void* zero16, et_stream_t stream);
 int et_conv2d_wgrad(const void* x, const void* dy, float* dw, int dtype, int N, int IH, int IW, int Cin,
                     int ldx, int Cout, int KH, int KW, int stride, int pad, int ldy, const void* zero16,
                     et_stream_t stream);
@@ -218,6 +226,22 @@ int et_bn_act_bwd_from_partials(const void* dz, int lddz, const void* y, int ldy
                                 const float* gamma, const float* scale, const float* shift, const float* save_mean,
                                 const float* save_invstd, int act, float* dgamma, float* dbeta, double* totals,
                                 const float* partials, int partial_rows, float* workspace, et_stream_t stream);
+/* The Conv block's normalise pass and its backward on SHARDED sums (et_conv2d_fwd stats_ld > 0): no finalize launch.
+ * et_bn_act_fwd_sharded = et_bn_finalize + et_bn_act_fwd in one launch: every workgroup folds the ET_BN_SHARDS shards of its channels
+ * (fp64), derives scale / shift into LDS and streams z = act(y*scale + shift) (+ residual); workgroup 0 also writes scale / shift /
+ * save_mean / save_invstd and updates the running statistics.  shards: [ET_BN_SHARDS][2][shard_ld], this layer's channel 0 at
+ * shards[0].  C <= 1024.
+ * et_bn_act_bwd_sharded: reduce != 0 runs the reduce pass first (sums of du and du*xhat ADDED into the zeroed shards); reduce == 0
+ * means et_conv2d_dgrad_bn (bn_stats_ld > 0) already left sums of du and du*y there.  The apply pass folds the shards per workgroup
+ * and workgroup 0 accumulates dgamma / dbeta.  Same math as et_bn_finalize / et_bn_act_bwd (one device function each). */
+int et_bn_act_fwd_sharded(const void* y, int ldy, void* z, int ldz, const void* residual, int ldr, int dtype, int P, int C,
+                          const float* shards, int shard_ld, double count, const float* gamma, const float* beta, float eps,
+                          float momentum, float* running_mean, float* running_var, float* scale, float* shift, float* save_mean,
+                          float* save_invstd, int act, et_stream_t stream);
+int et_bn_act_bwd_sharded(const void* dz, int lddz, const void* y, int ldy, void* dy, int lddy, int dtype, int P, int C,
+                          const float* gamma, const float* scale, const float* shift, const float* save_mean,
+                          const float* save_invstd, int act, float* dgamma, float* dbeta, float* shards, int shard_ld, int reduce,
+                          et_stream_t stream);
 int et_act_bwd(const void* dz, int lddz, const void* y, int ldy, void* dy, int lddy, int dtype, int P, int C,
                int act, et_stream_t stream);
 

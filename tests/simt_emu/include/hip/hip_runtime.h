@@ -233,6 +233,7 @@ static inline int __clzll(unsigned long long x) { return x ? __builtin_clzll(x) 
 static inline int __clz(unsigned x) { return x ? __builtin_clz(x) : 32; }
 
 template <typename T> static inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
+template <typename T> static inline T unsafeAtomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
 static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { auto o = *p; *p = o + v; return o; }
 template <typename T> static inline T atomicMax(T* p, T v) { T o = *p; *p = std::max(o, v); return o; }
 template <typename T> static inline T atomicMin(T* p, T v) { T o = *p; *p = std::min(o, v); return o; }
