@@ -790,7 +790,9 @@ def main():
                        "frac_of_bf16_mfma_peak": step_flop / (dt / a.steps) / PEAK_BF16, "loss_finite": res["loss_ok"], "loss_scale_after_the_timed_region": res.get("loss_scale"),
                        "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1, "env_knobs": ops.env_knobs(),
                        "rccl_env": rccl_env or None,
-                       "grad_allreduce": (dict(bytes=res["grad_bytes"], span_ms=t_ar[0], exposed_ms=t_ar[1],
+                       "grad_allreduce": (dict(bytes=int(sum(b for b, _ in t_ar[2])), arena_bytes=res["grad_bytes"],
+                                               wire=("bf16" if sum(b for b, _ in t_ar[2]) * 2 <= res["grad_bytes"] + 1024 else "fp32"),
+                                               span_ms=t_ar[0], exposed_ms=t_ar[1],
                                                per_collective=[dict(bytes=b, exposed_ms=round(ms, 4)) for b, ms in t_ar[2]],
                                                note="span: first chunk launch (during backward) -> last collective complete; exposed: "
                                                     "compute stream waiting after backward, in total and per collective in wait order "
