@@ -152,6 +152,8 @@ def test_model_step_with_and_without_sharded_statistics(hip, dtype, monkeypatch)
     (measured on the emulator, where the additions happen in one fixed order: bf16 0.0000 / 0.0004 / 0.0000, fp16 0.024 / all 0.012)"""
     from efficientteacher_amd import autograd
     from tests.test_model import build
+    if hip.emulated and dtype == torch.float16:
+        pytest.skip("six emulated steps per dtype: bf16 covers the bookkeeping on the CPU tier, the GPU tier runs both formats")
     cfg, model, g = build(hip, dtype)
     assert model._flat.bn_shards is not None
     model.train()
