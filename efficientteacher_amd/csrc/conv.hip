@@ -386,7 +386,9 @@ __device__ __forceinline__ void conv_epilogue_act(f32x16 (&acc)[BM / WM / 32][BN
     const bool bnb = MODE == 1 ? false : ep.bn_y != nullptr;
     const void* const ep_res = MODE == 1 ? nullptr : ep.res;
     const bool ep_accumulate = MODE == 1 ? false : (bool)ep.accumulate;
-    const bool lean = ident && !bnb && ep_res == nullptr && !ep_accumulate && m0 + BM <= g.M && n0 + BN <= g.Cout;   // uniform
+    // (wave-uniform is enough: the store pass has no workgroup barrier.  Per wave since r05: the waves of a ragged tile whose own rows
+    // are all inside keep the fast pass)
+    const bool lean = ident && !bnb && ep_res == nullptr && !ep_accumulate && m0 + (wm + 1) * (BM / WM) <= g.M && n0 + BN <= g.Cout;
     float bsc[8], bsh[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { bsc[e] = 1.f; bsh[e] = 0.f; }
