@@ -75,6 +75,36 @@ class UnitScaler:
         pass
 
 
+class AmpScaler(UnitScaler):
+    """the reference's own recipe -- ``amp.GradScaler`` around fp16 autocast (trainer.py:248,348,399-401) -- on this path: fp16 compute
+    mode with ``optim.DeviceGradScaler`` (scale / found-inf / growth tracker in device memory, skip and unscale inside the optimizer
+    kernels).  ``scale(loss).backward()`` multiplies by the device scale and, as the unit scaler does, completes the data-parallel
+    all-reduce, so ``step`` scans the AVERAGED gradient arena: every rank takes the same skip decision without a collective of its own."""
+
+    def __init__(self, trainer, device):
+        from ..optim import DeviceGradScaler
+        super().__init__(trainer)
+        self.dev = DeviceGradScaler(device, enabled=True)
+
+    def scale(self, loss):
+        return _ReducedLoss(self.dev.scale(loss), self._t)
+
+    def step(self, optimizer):
+        return self.dev.step(optimizer)
+
+    def update(self):
+        self.dev.update()
+
+    def get_scale(self):
+        return self.dev.get_scale()
+
+    def state_dict(self):
+        return self.dev.state_dict()
+
+    def load_state_dict(self, sd):
+        self.dev.load_state_dict(sd)
+
+
 def _intersect(csd, msd, exclude=()):
     # reference utils/torch_utils.py intersect_dicts: same name, same shape, not excluded
     return {k: v for k, v in csd.items() if k in msd and not any(x in k for x in exclude) and tuple(v.shape) == tuple(msd[k].shape)}
@@ -83,12 +113,15 @@ def _intersect(csd, msd, exclude=()):
 class _HotPath:
     """mixin over the reference's Trainer (methods resolved before the reference's through the MRO)"""
     ET_MODEL_MODULE = "efficientteacher_amd.models.detector.yolo"
+    # compute dtype on a GPU (hot_path_trainers(compute_dtype=...)): bfloat16 = no loss scaling; float16 = the reference's autocast
+    # dtype with the device-resident GradScaler (AmpScaler); float32 = parity mode
+    ET_COMPUTE_DTYPE = torch.bfloat16
 
     def _et_model(self, cfg, device):
         import importlib
         model = importlib.import_module(self.ET_MODEL_MODULE).Model(cfg).to(device)
         cuda = torch.device(device).type != "cpu"
-        model.set_compute_dtype(torch.bfloat16 if cuda else torch.float32)
+        model.set_compute_dtype(self.ET_COMPUTE_DTYPE if (cuda or self.ET_COMPUTE_DTYPE == torch.float16) else torch.float32)
         return model
 
     def _et_load_weights(self, cfg, device):
@@ -154,7 +187,9 @@ class _HotPath:
             self.lf = lambda x: ((1 - math.cos(x * math.pi / self.epochs)) / 2) * (cfg.hyp.lrf - 1) + 1   # one_cycle(1, lrf, epochs)
         self.scheduler = lr_scheduler.LambdaLR(self.optimizer, lr_lambda=self.lf)
         self.scheduler.last_epoch = self.epoch - 1
-        self.scaler = UnitScaler(self)
+        inner = self.model.module if is_parallel(self.model) else self.model
+        fp16 = inner.flat_state().compute_dtype == torch.float16
+        self.scaler = AmpScaler(self, next(inner.parameters()).device) if fp16 else UnitScaler(self)
         if ckpt is not None and ckpt.get('optimizer') is not None:
             try:
                 self.optimizer.load_state_dict(ckpt['optimizer'])
@@ -316,12 +351,17 @@ class _SsodHotPath(_HotPath):
     teacher_after = "p2"
 
 
-def hot_path_trainers(ref_trainer=None, ref_ssod_trainer=None):
+def hot_path_trainers(ref_trainer=None, ref_ssod_trainer=None, compute_dtype=torch.bfloat16):
     """(Trainer, SSODTrainer): subclasses of the reference's trainers -- taken from the tree this is called in
-    (``trainer.trainer.Trainer`` / ``trainer.ssod_trainer.SSODTrainer``) unless passed explicitly."""
+    (``trainer.trainer.Trainer`` / ``trainer.ssod_trainer.SSODTrainer``) unless passed explicitly.
+    compute_dtype: torch.bfloat16 (default: no loss scaling), torch.float16 (the reference's autocast dtype; ``self.scaler`` is then
+    the device-resident GradScaler the reference's ``update_optimizer`` drives unchanged) or torch.float32 (parity mode)."""
+    if compute_dtype not in (torch.bfloat16, torch.float16, torch.float32):
+        raise ValueError(f"compute_dtype {compute_dtype}")
     if ref_trainer is None or ref_ssod_trainer is None:
         from trainer.ssod_trainer import SSODTrainer as ref_ssod_trainer       # noqa: N813  (the user's tree)
         from trainer.trainer import Trainer as ref_trainer                     # noqa: N813
-    hot = type("Trainer", (_HotPath, ref_trainer), {"__doc__": "reference Trainer with the MI355X hot path"})
-    ssod = type("SSODTrainer", (_SsodHotPath, ref_ssod_trainer), {"__doc__": "reference SSODTrainer with the MI355X hot path"})
+    hot = type("Trainer", (_HotPath, ref_trainer), {"__doc__": "reference Trainer with the MI355X hot path", "ET_COMPUTE_DTYPE": compute_dtype})
+    ssod = type("SSODTrainer", (_SsodHotPath, ref_ssod_trainer), {"__doc__": "reference SSODTrainer with the MI355X hot path",
+                                                                   "ET_COMPUTE_DTYPE": compute_dtype})
     return hot, ssod

@@ -113,6 +113,31 @@ def test_reference_epoch_loop_drives_the_hot_path_supervised(emu, ref_callbacks)
         assert t.ema.updates >= 1
 
 
+def test_reference_epoch_loop_in_fp16_mode_uses_the_device_grad_scaler(emu, ref_callbacks):
+    """hot_path_trainers(compute_dtype=torch.float16): the reference's own update_optimizer (scaler.scale(loss).backward();
+    scaler.step(optimizer); scaler.update() -- trainer.py:399-401) drives the device-resident scaler: every iteration either moves
+    the parameters or halves the scale, and nothing becomes non-finite"""
+    from efficientteacher_amd.trainer.adapters import AmpScaler, hot_path_trainers
+    Trainer, _ = hot_path_trainers(compute_dtype=torch.float16)
+    rng = np.random.default_rng(0)
+    with tempfile.TemporaryDirectory() as d:
+        t = _mk(Trainer, rng, False)(_cfg(d, False), torch.device("cpu"), ref_callbacks, -1, -1, 1)
+        assert t.model.flat_state().compute_dtype == torch.float16 and isinstance(t.scaler, AmpScaler)
+        s0 = t.scaler.get_scale()
+        p0 = t.model.flat_state().params.clone()
+        t.last_opt_step = -1
+        t.plots = False
+        t.before_epoch()
+        t.train_in_epoch(ref_callbacks)
+        assert torch.isfinite(t.model.flat_state().params).all()
+        moved = not torch.equal(p0, t.model.flat_state().params)
+        assert moved or t.scaler.get_scale() < s0, (moved, s0, t.scaler.get_scale())
+        assert t.scaler.get_scale() in (s0, s0 / 2, s0 / 4)
+        sd = t.scaler.state_dict()
+        t.scaler.load_state_dict(sd)
+        assert t.scaler.get_scale() == float(sd["state"][0])
+
+
 def test_reference_epoch_loop_drives_the_hot_path_ssod(emu, ref_callbacks):
     from efficientteacher_amd.trainer.adapters import hot_path_trainers
     from efficientteacher_amd.models.detector.yolo_ssod import Model as EtModel
