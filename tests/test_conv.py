@@ -311,6 +311,21 @@ def test_stream_kernel_tile_loop_under_adversarial_schedules(emu, dma_late, seed
     if seed == 3:        # the FULL epilogue (residual + BN-backward sums accumulated over the tiles of a workgroup), one schedule
         for case in ((2, 9, 11, 256, 256, 1), (1, 13, 13, 128, 128, 1), (2, 9, 9, 64, 64, 1)):
             test_dgrad_with_fused_bn_backward_sums(emu, case, torch.bfloat16)
+    # the sharded statistics tail (r05): the wave rows of a workgroup meet in the chunk ring's LDS after the last tile -- a wave still
+    # reading the ring, or a sum read before every wave has written its row, shows under these schedules
+    from efficientteacher_amd import ops
+    from efficientteacher_amd.flat_state import BN_SHARDS
+    for (N, H, W, Cin, Cout) in ((2, 9, 11, 128, 128), (1, 13, 13, 64, 64), (2, 9, 9, 256, 256)):
+        x = _mk(emu, (N, H, W, Cin), torch.bfloat16, 601)
+        w = (_mk(emu, (Cout, 1, 1, Cin), torch.bfloat16, 602) * Cin ** -0.5).to(torch.bfloat16)
+        assert kn("fwd", torch.bfloat16, N, H, W, Cin, Cout, 1, 1, 0).startswith("conv1x1_stream_kernel")
+        y0, stats = ops.conv2d_fwd(x, w, 1, 0, want_stats=True)
+        full = torch.zeros((BN_SHARDS, 2, Cout + 24), dtype=torch.float32)
+        y1 = ops.conv2d_fwd(x, w, 1, 0, shards=(full.view(-1)[16:], Cout + 24))
+        assert torch.equal(y0, y1)
+        ref = stats.double().sum(0)
+        assert torch.allclose(full.sum(0)[:, 16:16 + Cout].double(), ref, rtol=2e-5, atol=1e-4 * ref.abs().max().item())
+        assert torch.count_nonzero(full[:, :, :16]) == 0 and torch.count_nonzero(full[:, :, 16 + Cout:]) == 0
 
 
 def test_stream_kernel_statistics_rows_follow_the_grid(hip, monkeypatch):
