@@ -30,6 +30,8 @@ SIGNATURES = {
                                  P, c_float, P, c_int64, c_int64, P]),
     "et_ema_update": (c_int, [P, P, c_int64, c_float, c_float, P]),
     "et_adamw": (c_int, [P, P, P, P, P, c_int, c_int64, c_float, c_float, c_float, c_float, c_float, c_int, c_float, P, P]),
+    "et_adamw_tick": (c_int, [P, c_float, c_float, P, P]),
+    "et_adamw_dev": (c_int, [P, P, P, P, P, c_int, c_int64, c_float, c_float, c_float, c_float, c_float, P, c_float, P, P]),
     "et_sgd_nesterov": (c_int, [P, P, P, P, c_int, c_int64, c_float, c_float, c_float, c_int, c_float, P, P]),
     "et_cast_f32_to_lp": (c_int, [P, P, c_int, c_int64, P]),
     "et_scaler_check": (c_int, [P, c_int64, P, P]),

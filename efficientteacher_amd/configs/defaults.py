@@ -18,4 +18,8 @@ def get_cfg():
     if _C is None:
         with open(os.path.join(_HERE, "defaults.yaml")) as f:
             _C = CfgNode(yaml.safe_load(f))
+        # EXTENSION keys of this package (not in the reference's tree; reference yaml files merge unchanged):
+        #   Model.deterministic_bn  True = bit-reproducible BatchNorm statistics in the bf16 / fp16 compute modes (partial rows + fp64
+        #                           finalize, the fp32 parity mode's path) instead of the sharded fp32 atomics (FlatState(deterministic=))
+        _C.Model.deterministic_bn = False
     return _C.clone()

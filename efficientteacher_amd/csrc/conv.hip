@@ -126,8 +126,9 @@ struct Epilogue {
     const float* bn_shift;
     int bn_act;
     // stats_ld != 0: `stats` is a SHARDED accumulator [ET_BN_SHARDS][2][stats_ld] (zero before the launch) instead of partial rows:
-    // every wave ADDS its sums into shard blockIdx.x % ET_BN_SHARDS (= the XCD the workgroup runs on) with hardware fp32 atomics,
-    // and the consumer (et_bn_act_fwd_sharded / et_bn_act_bwd_sharded) folds the 8 shards itself -- no finalize launch per layer
+    // every wave ADDS its sums into shard blockIdx.x % ET_BN_SHARDS (16 shards: workgroups are dealt round-robin to the 8 XCDs, so a
+    // shard is touched from ONE XCD and two shards share an XCD) with hardware fp32 atomics, and the consumer
+    // (et_bn_act_fwd_sharded / et_bn_act_bwd_sharded) folds the ET_BN_SHARDS shards itself -- no finalize launch per layer
     int stats_ld;
 };
 

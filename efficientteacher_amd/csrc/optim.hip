@@ -142,11 +142,17 @@ extern "C" int et_sgd_nesterov(float* p, const float* grad, float* momentum_buf,
 // weight decay), same operation order as torch's single-tensor implementation:
 //   p *= 1 - lr * wd ; m = lerp(m, g, 1 - b1) ; v = v * b2 + (1 - b2) g^2 ; p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)
 // bc1 = 1 - b1^t, bc2 = 1 - b2^t are computed on the host in double and passed as floats (step_size, 1/sqrt(bc2)).
+template <bool DEV>
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, uint16_t* __restrict__ shadow, int shadow_dtype, long long n,
                                                     float lr_wd, float b1, float b2, float step_size, float inv_sqrt_bc2, float eps,
-                                                    float inv_scale_host, const float* __restrict__ scaler) {
+                                                    float inv_scale_host, const float* __restrict__ scaler, float lr,
+                                                    const double* __restrict__ tick) {
     if (ET_SCALER_SKIP(scaler)) return;
+    if constexpr (DEV) {                                   // bias corrections of the device-resident step count (et_adamw_tick)
+        step_size = (float)((double)lr / tick[1]);
+        inv_sqrt_bc2 = (float)(1.0 / sqrt(tick[2]));
+    }
     const float inv_scale = inv_scale_host * ET_SCALER_INV(scaler);
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -170,9 +176,39 @@ extern "C" int et_adamw(float* p, const float* grad, float* exp_avg, float* exp_
     if (n < 0 || step < 1 || (lp_shadow && shadow_dtype != ET_BF16 && shadow_dtype != ET_F16)) return -2;
     if (n == 0) return 0;
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-    hipLaunchKernelGGL(adamw_kernel, dim3(et_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, p, grad, exp_avg, exp_avg_sq,
+    hipLaunchKernelGGL(adamw_kernel<false>, dim3(et_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, p, grad, exp_avg, exp_avg_sq,
                        (uint16_t*)lp_shadow, shadow_dtype, (long long)n, lr * weight_decay, beta1, beta2, (float)((double)lr / bc1),
-                       (float)(1.0 / sqrt(bc2)), eps, inv_scale, scaler);
+                       (float)(1.0 / sqrt(bc2)), eps, inv_scale, scaler, lr, (const double*)nullptr);
+    ET_CHECK_LAUNCH();
+    return 0;
+}
+
+// AdamW's step count under the loss scaler: torch's GradScaler.step does not call optimizer.step() on an overflow, so a
+// skipped step must not advance the bias corrections -- and whether a step is skipped is only known on the device (found_inf).  The
+// count lives in device memory: tick = {t, 1 - beta1^t, 1 - beta2^t} (doubles); one single-thread launch per optimizer step advances it
+// unless found_inf is set, and the update kernels of that step form lr / bc1 and 1 / sqrt(bc2) from it.
+__global__ void adamw_tick_kernel(double* __restrict__ tick, double b1, double b2, const float* __restrict__ scaler) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (ET_SCALER_SKIP(scaler)) return;
+    const double t = tick[0] + 1.0;
+    tick[0] = t; tick[1] = 1.0 - pow(b1, t); tick[2] = 1.0 - pow(b2, t);
+}
+extern "C" int et_adamw_tick(double* tick, float beta1, float beta2, const float* scaler, et_stream_t stream) {
+    if (!tick) return -1;
+    if (!(beta1 >= 0.0f && beta1 < 1.0f) || !(beta2 >= 0.0f && beta2 < 1.0f)) return -2;
+    hipLaunchKernelGGL(adamw_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, tick, (double)beta1, (double)beta2, scaler);
+    ET_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int et_adamw_dev(float* p, const float* grad, float* exp_avg, float* exp_avg_sq, void* lp_shadow, int shadow_dtype, int64_t n,
+                            float lr, float beta1, float beta2, float eps, float weight_decay, const double* tick, float inv_scale,
+                            const float* scaler, et_stream_t stream) {
+    if (!p || !grad || !exp_avg || !exp_avg_sq || !tick) return -1;
+    if (n < 0 || (lp_shadow && shadow_dtype != ET_BF16 && shadow_dtype != ET_F16)) return -2;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(adamw_kernel<true>, dim3(et_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, p, grad, exp_avg, exp_avg_sq,
+                       (uint16_t*)lp_shadow, shadow_dtype, (long long)n, lr * weight_decay, beta1, beta2, 0.0f, 0.0f, eps, inv_scale,
+                       scaler, lr, tick);
     ET_CHECK_LAUNCH();
     return 0;
 }

@@ -79,8 +79,13 @@ class BnSlot:
 
 
 class FlatState:
-    def __init__(self, model, compute_dtype=torch.float32):
+    def __init__(self, model, compute_dtype=torch.float32, deterministic=False):
+        """deterministic: BatchNorm statistics of the 16-bit modes through the partial-row form (et_conv2d_fwd stats_ld == 0 +
+        fp64 finalize: the fp32 parity mode's path, bit-reproducible sums, one more launch per layer and pass) instead of the sharded
+        fp32 accumulators, whose last bits depend on the arrival order of hardware atomics.  Selected by Model.set_deterministic() /
+        cfg.Model.deterministic_bn / hot_path_trainers(deterministic=True); ~+0.6 ms on the YOLOv5l 32 + 32 step."""
         self.compute_dtype = compute_dtype
+        self.deterministic = bool(deterministic)
         dev = next(model.parameters()).device
         convs = [m for m in model.modules() if isinstance(m, nn.Conv2d)]
         bns = [m for m in model.modules() if isinstance(m, nn.BatchNorm2d)]
@@ -166,7 +171,7 @@ class FlatState:
         bw0 = seg["bn_weight"][0]
         self._bn_gen = [0]
         self.bn_shards = (torch.zeros((2, BN_SHARDS, 2, max(bn_total, 1)), dtype=torch.float32, device=dev)
-                          if compute_dtype != torch.float32 else None)
+                          if compute_dtype != torch.float32 and not self.deterministic else None)
         for b, o in zip(bns, self.bn_off):
             c = b.num_features
             s = BnSlot()
@@ -217,6 +222,7 @@ class FlatState:
         # the padding lanes of running_var must not be 0 (1/sqrt(0 + eps) is finite, fine) -- nothing to do
         self.momentum_buf = None
         self.weights_dirty = False
+        self.zero_gen = 0
         self.sync_shadow()
 
     # ---- maintenance ------------------------------------------------------------------------------------------
@@ -265,6 +271,7 @@ class FlatState:
 
     def zero_grad(self):
         self.grads.zero_()
+        self.zero_gen += 1               # parallel.FlatDataParallel: "the arena has been zeroed since ..."
 
     def group_ranges(self):
         """[(offset, numel)] of the optimizer groups in the reference's order [biases, weights, BN weights]."""

@@ -47,6 +47,8 @@ class Model(nn.Module):
         initialize_weights(self)
         self._flat = None
         self._compute_dtype = torch.float32
+        # extension key (configs/defaults.py): reproducible BatchNorm statistics in the 16-bit modes (FlatState(deterministic=))
+        self._deterministic = bool(getattr(cfg.Model, "deterministic_bn", False)) if hasattr(cfg, "Model") else False
 
     def _build_extra(self, cfg):
         pass
@@ -105,6 +107,14 @@ class Model(nn.Module):
         self.rebuild_flat()
         return self
 
+    def set_deterministic(self, flag=True):
+        """True: BatchNorm statistics of the bf16 / fp16 modes on the bit-reproducible partial-row path (fp64 finalize) instead of
+        the sharded fp32 accumulators (order of hardware atomics); the fp32 parity mode is always on that path.  Rebuilds the arenas
+        like set_compute_dtype (create the optimizer afterwards)."""
+        self._deterministic = bool(flag)
+        self.rebuild_flat()
+        return self
+
     def rebuild_flat(self):
         for m in self.modules():
             m.__dict__.pop("_et_slot", None)
@@ -114,7 +124,7 @@ class Model(nn.Module):
         on_dev = all(p.is_cuda for p in ps) or (_lib.is_emulated() and all(p.device.type == 'cpu' for p in ps))
         if ps and on_dev and all(p.dtype == torch.float32 for p in ps):
             req = [p.requires_grad for p in ps]
-            self._flat = FlatState(self, self._compute_dtype)
+            self._flat = FlatState(self, self._compute_dtype, deterministic=getattr(self, "_deterministic", False))
             for p, r in zip(ps, req):
                 p.requires_grad_(r)
                 if not r:

@@ -882,6 +882,18 @@ def adamw(p, g, exp_avg, exp_avg_sq, shadow, lr, beta1, beta2, eps, weight_decay
                                     float(inv_scale), _lib.ptr(scaler), _lib.stream(p)), "et_adamw")
 
 
+def adamw_tick(tick, beta1, beta2, scaler):
+    """advance AdamW's device-resident step count {t, 1 - b1^t, 1 - b2^t} (float64[3]) unless the scaler's found_inf is set"""
+    assert tick.dtype == torch.float64 and tick.numel() == 3
+    _lib.check(_lib.load().et_adamw_tick(_lib.ptr(tick), float(beta1), float(beta2), _lib.ptr(scaler), _lib.stream(tick)), "et_adamw_tick")
+
+
+def adamw_dev(p, g, exp_avg, exp_avg_sq, shadow, lr, beta1, beta2, eps, weight_decay, tick, inv_scale=1.0, scaler=None):
+    _lib.check(_lib.load().et_adamw_dev(_lib.ptr(p), _lib.ptr(g), _lib.ptr(exp_avg), _lib.ptr(exp_avg_sq), _lib.ptr(shadow), _shadow_dt(shadow),
+                                        p.numel(), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), _lib.ptr(tick),
+                                        float(inv_scale), _lib.ptr(scaler), _lib.stream(p)), "et_adamw_dev")
+
+
 def sgd_nesterov(p, g, buf, shadow, lr, momentum, weight_decay, first_step, inv_scale=1.0, scaler=None):
     _lib.check(_lib.load().et_sgd_nesterov(_lib.ptr(p), _lib.ptr(g), _lib.ptr(buf), _lib.ptr(shadow), _shadow_dt(shadow), p.numel(),
                                            float(lr), float(momentum), float(weight_decay), int(bool(first_step)),

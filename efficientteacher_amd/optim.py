@@ -158,12 +158,21 @@ class FlatAdamW(torch.optim.Optimizer):
         self.exp_avg = torch.zeros_like(self.flat.params)
         self.exp_avg_sq = torch.zeros_like(self.flat.params)
         self.steps = 0
+        # under a DeviceGradScaler the count lives on the device ({t, 1 - b1^t, 1 - b2^t}, et_adamw_tick): a step the scaler skips
+        # (found_inf, known only there) must not advance the bias corrections -- torch's GradScaler.step does not call step() then
+        self.tick = None
+
+    def _steps_now(self):
+        """the update count (reads the device copy back when the scaler path owns it: checkpoints / tests only)"""
+        if self.tick is not None:
+            self.steps = int(round(float(self.tick[0].item())))
+        return self.steps
 
     def state_dict(self):
         sd = super().state_dict()
         sd["flat_exp_avg"] = self.exp_avg.detach().cpu().clone()
         sd["flat_exp_avg_sq"] = self.exp_avg_sq.detach().cpu().clone()
-        sd["flat_steps"] = int(self.steps)
+        sd["flat_steps"] = int(self._steps_now())
         return sd
 
     def load_state_dict(self, sd):
@@ -177,6 +186,7 @@ class FlatAdamW(torch.optim.Optimizer):
             g["range"] = r
         self.exp_avg.copy_(m.to(self.exp_avg.device)); self.exp_avg_sq.copy_(v.to(self.exp_avg_sq.device))
         self.steps = int(n)
+        self.tick = None
 
     @torch.no_grad()
     def step(self, closure=None, inv_scale=1.0, scaler=None):
@@ -185,12 +195,26 @@ class FlatAdamW(torch.optim.Optimizer):
             raise RuntimeError("the model's arenas were rebuilt after this optimizer was created")
         assert not ops.WGRAD_QUEUE.pending, "weight gradients still queued: backward() did not finish"
         ops.WGRAD_QUEUE.join()
-        self.steps += 1
+        if scaler is not None:
+            b1, b2 = self.param_groups[0]['betas']
+            if any(tuple(g['betas']) != (b1, b2) for g in self.param_groups):
+                raise NotImplementedError("per-group betas under the loss scaler (the reference builds one pair, trainer.py:212)")
+            if self.tick is None:
+                t = float(self.steps)
+                self.tick = torch.tensor([t, 1.0 - b1 ** t, 1.0 - b2 ** t], dtype=torch.float64, device=f.params.device)
+            ops.adamw_tick(self.tick, b1, b2, scaler)
+        else:
+            self.steps = self._steps_now() + 1
+            self.tick = None
         for g in self.param_groups:
             o, n = g['range']
             shadow = f.shadow if (f.shadow is not None and (o, n) == tuple(f.w_range)) else None
-            ops.adamw(f.params[o:o + n], f.grads[o:o + n], self.exp_avg[o:o + n], self.exp_avg_sq[o:o + n], shadow, g['lr'],
-                      g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'], self.steps, inv_scale, scaler)
+            if scaler is not None:
+                ops.adamw_dev(f.params[o:o + n], f.grads[o:o + n], self.exp_avg[o:o + n], self.exp_avg_sq[o:o + n], shadow, g['lr'],
+                              g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'], self.tick, inv_scale, scaler)
+            else:
+                ops.adamw(f.params[o:o + n], f.grads[o:o + n], self.exp_avg[o:o + n], self.exp_avg_sq[o:o + n], shadow, g['lr'],
+                          g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'], self.steps, inv_scale, scaler)
         f.w_version += 1
 
     def zero_grad(self, set_to_none=False):

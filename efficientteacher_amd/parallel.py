@@ -59,7 +59,10 @@ class FlatDataParallel(nn.Module):
             chunk_mb = float(os.environ.get("ET_ALLREDUCE_CHUNK_MB", "48"))
         self.chunk = int(chunk_mb * (1 << 20) // 4)
         if grad_dtype is None:                       # transport setting, like the chunk size: ET_ALLREDUCE_DTYPE=bf16 | fp32 (default)
-            grad_dtype = {"bf16": torch.bfloat16, "fp32": torch.float32, "": torch.float32}[os.environ.get("ET_ALLREDUCE_DTYPE", "").lower()]
+            env = os.environ.get("ET_ALLREDUCE_DTYPE", "").strip().lower()
+            if env not in ("", "fp32", "bf16"):
+                raise ValueError(f"ET_ALLREDUCE_DTYPE={env!r}: expected 'fp32' (default) or 'bf16'")
+            grad_dtype = torch.bfloat16 if env == "bf16" else torch.float32
         if grad_dtype not in (torch.float32, torch.bfloat16):
             raise ValueError(f"grad_dtype {grad_dtype}: float32 (default) or bfloat16")
         self.grad_dtype = grad_dtype
@@ -73,6 +76,8 @@ class FlatDataParallel(nn.Module):
         self._works = []
         self._launched = set()
         self._dirty = False              # a backward has moved the per-chunk counters since the last reduce_gradients()
+        self._dirty_gen = -1             # FlatState.zero_gen when that backward started
+        self._stale_gen = None           # set by forward() after an aborted backward whose partial gradients are still in the arena
         self.timing = False              # bench.py: HIP events around the collective phase of a step
         self.last_timing = None          # (first launch -> all complete, exposed wait after backward) in ms
         self._ev0 = None
@@ -142,6 +147,8 @@ class FlatDataParallel(nn.Module):
         ci = self._slot_chunk.get(slot.index)
         if ci is None or ci in self._launched:
             return
+        if not self._dirty:
+            self._dirty_gen = self.module.flat_state().zero_gen
         self._dirty = True                    # counters no longer at their start values (cleared by reduce_gradients)
         self._remaining[ci] -= 1
         if self._remaining[ci] == 0:
@@ -165,7 +172,13 @@ class FlatDataParallel(nn.Module):
             import warnings
             warnings.warn("FlatDataParallel: the previous backward did not finish (no collective had been launched); "
                           "per-chunk counters reset, gradients of that pass are NOT reduced")
+            # ... and unless the arena has been zeroed since that backward started, it still holds this rank's partial, UNREDUCED
+            # gradients: the next reduce_gradients() refuses to average them into the step (ranks would diverge silently) until
+            # zero_grad() has run
+            stale = self.module.flat_state().zero_gen == self._dirty_gen
             self.abort_step()
+            if stale:
+                self._stale_gen = self._dirty_gen
         if self.active and self.broadcast_buffers and self.module.training:
             # DDP broadcast_buffers=True: rank 0's BN running stats / anchors at every forward, on the compute stream, in front of the
             # forward.  r04 moved it to a side stream (joined before the first running-statistics update) and took that back: the
@@ -194,6 +207,11 @@ class FlatDataParallel(nn.Module):
         DistributedDataParallel accumulates in .grad."""
         if not self.active:
             return
+        if self._stale_gen is not None:
+            if self.module.flat_state().zero_gen == self._stale_gen:
+                raise RuntimeError("FlatDataParallel: the gradient arena still holds the unreduced partial gradients of an aborted "
+                                   "backward (see the earlier warning): call zero_grad() and redo the step before reducing")
+            self._stale_gen = None
         g = self.module.flat_state().grads
         wo, wn = self.module.flat_state().w_range
         for ci, (o, n, _) in enumerate(self._chunks):      # chunks whose layers did not all run (frozen / unused)

@@ -116,10 +116,14 @@ class _HotPath:
     # compute dtype on a GPU (hot_path_trainers(compute_dtype=...)): bfloat16 = no loss scaling; float16 = the reference's autocast
     # dtype with the device-resident GradScaler (AmpScaler); float32 = parity mode
     ET_COMPUTE_DTYPE = torch.bfloat16
+    # hot_path_trainers(deterministic=True): bit-reproducible BatchNorm statistics in the 16-bit modes (Model.set_deterministic)
+    ET_DETERMINISTIC = False
 
     def _et_model(self, cfg, device):
         import importlib
         model = importlib.import_module(self.ET_MODEL_MODULE).Model(cfg).to(device)
+        if self.ET_DETERMINISTIC:
+            model._deterministic = True          # picked up by the rebuild inside set_compute_dtype below
         cuda = torch.device(device).type != "cpu"
         model.set_compute_dtype(self.ET_COMPUTE_DTYPE if (cuda or self.ET_COMPUTE_DTYPE == torch.float16) else torch.float32)
         return model
@@ -351,17 +355,19 @@ class _SsodHotPath(_HotPath):
     teacher_after = "p2"
 
 
-def hot_path_trainers(ref_trainer=None, ref_ssod_trainer=None, compute_dtype=torch.bfloat16):
+def hot_path_trainers(ref_trainer=None, ref_ssod_trainer=None, compute_dtype=torch.bfloat16, deterministic=False):
     """(Trainer, SSODTrainer): subclasses of the reference's trainers -- taken from the tree this is called in
     (``trainer.trainer.Trainer`` / ``trainer.ssod_trainer.SSODTrainer``) unless passed explicitly.
     compute_dtype: torch.bfloat16 (default: no loss scaling), torch.float16 (the reference's autocast dtype; ``self.scaler`` is then
-    the device-resident GradScaler the reference's ``update_optimizer`` drives unchanged) or torch.float32 (parity mode)."""
+    the device-resident GradScaler the reference's ``update_optimizer`` drives unchanged) or torch.float32 (parity mode).
+    deterministic: BatchNorm statistics of the 16-bit modes on the reproducible partial-row path (FlatState(deterministic=True))."""
     if compute_dtype not in (torch.bfloat16, torch.float16, torch.float32):
         raise ValueError(f"compute_dtype {compute_dtype}")
     if ref_trainer is None or ref_ssod_trainer is None:
         from trainer.ssod_trainer import SSODTrainer as ref_ssod_trainer       # noqa: N813  (the user's tree)
         from trainer.trainer import Trainer as ref_trainer                     # noqa: N813
-    hot = type("Trainer", (_HotPath, ref_trainer), {"__doc__": "reference Trainer with the MI355X hot path", "ET_COMPUTE_DTYPE": compute_dtype})
+    hot = type("Trainer", (_HotPath, ref_trainer), {"__doc__": "reference Trainer with the MI355X hot path", "ET_COMPUTE_DTYPE": compute_dtype,
+                                                      "ET_DETERMINISTIC": bool(deterministic)})
     ssod = type("SSODTrainer", (_SsodHotPath, ref_ssod_trainer), {"__doc__": "reference SSODTrainer with the MI355X hot path",
-                                                                   "ET_COMPUTE_DTYPE": compute_dtype})
+                                                                   "ET_COMPUTE_DTYPE": compute_dtype, "ET_DETERMINISTIC": bool(deterministic)})
     return hot, ssod

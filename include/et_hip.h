@@ -31,7 +31,7 @@ enum { ET_F32 = 0, ET_BF16 = 1, ET_F16 = 2 };   /* ET_F16 (r05): IEEE half stora
  * for ("gfx950") and the ABI version.  ET_ABI_VERSION changes whenever an entry point is added or a signature / workspace
  * contract changes; a binding must refuse a library whose et_abi_version() differs from the header it was written against
  * (efficientteacher_amd/_lib.py does): a stale libet_hip.so would otherwise read e.g. a new int argument as the stream. */
-#define ET_ABI_VERSION 5
+#define ET_ABI_VERSION 6
 const char* et_build_arch(void);
 int et_abi_version(void);
 
@@ -86,6 +86,14 @@ int et_ema_update(float* ema, const float* model, int64_t n, float d, float one_
 int et_adamw(float* p, const float* grad, float* exp_avg, float* exp_avg_sq, void* lp_shadow, int shadow_dtype, int64_t n, float lr,
              float beta1, float beta2, float eps, float weight_decay, int step, float inv_scale, const float* scaler,
              et_stream_t stream);
+/* AdamW under the loss scaler (fp16 mode): the update count lives in device memory, tick = 3 doubles {t, 1 - beta1^t, 1 - beta2^t},
+ * because GradScaler.step (trainer/trainer.py:400) does not call optimizer.step() on an overflow -- a skipped step must not
+ * advance the bias corrections, and found_inf is only known on the device.  et_adamw_tick: once per optimizer step, advances the
+ * count unless scaler's found_inf is set; et_adamw_dev: et_adamw with lr / bc1 and 1 / sqrt(bc2) formed from `tick`.              */
+int et_adamw_tick(double* tick, float beta1, float beta2, const float* scaler, et_stream_t stream);
+int et_adamw_dev(float* p, const float* grad, float* exp_avg, float* exp_avg_sq, void* lp_shadow, int shadow_dtype, int64_t n, float lr,
+                 float beta1, float beta2, float eps, float weight_decay, const double* tick, float inv_scale, const float* scaler,
+                 et_stream_t stream);
 int et_sgd_nesterov(float* p, const float* grad, float* momentum_buf, void* lp_shadow, int shadow_dtype, int64_t n,
                     float lr, float momentum, float weight_decay, int first_step, float inv_scale, const float* scaler,
                     et_stream_t stream);

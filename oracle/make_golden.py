@@ -66,6 +66,8 @@ def case_nms():
         "c": (synth_pred(rng, 2, 300, 5, obj_pow=8), 0.25, 0.45),
         "empty": (synth_pred(rng, 2, 64, 4) * np.float32(0.05), 0.1, 0.65),
     }
+    # (ORACLE-DERIVED case: with torchvision absent, the reference's torchvision.ops.nms below IS oracle.nms.nms_torch -- the
+    # `ref == mine` assertion of this function then compares the restatement with itself for the tie rule; oracle/nms.py header)
     # exact tie at the threshold: IoU == fp32(0.6) -- xyxy [100,100,110,110] (area 100) against [100,100,106,110] (inside it, area 60):
     # inter / union = 60 / 100, and the correctly rounded fp32 quotient IS fp32(0.6).  The pinned compare (torchvision's CUDA kernel,
     # fp32 threshold: oracle/nms.py header) KEEPS the second box, the CPU kernel's double compare would drop it; rows 2-3 / 4-5 are

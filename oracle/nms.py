@@ -19,7 +19,14 @@ Restates, in numpy fp32:
     an exact tie, the CUDA rule keeps it), 0.65 (SSOD.nms_iou_thres) and 0.45 are
     not.  ``nms(..., thr_compare="cpu_double")`` restates the other rule; the
     golden case ``tie06`` (tests/golden/nms.npz) holds an exact tie at 0.6 and the
-    keep set under the pinned (CUDA) rule.
+    keep set under that rule.  ``tie06`` is ORACLE-DERIVED, not a reference output:
+    torchvision is installed neither in the build container nor on the GPU box, so
+    when oracle/make_golden.py runs the reference, ``torchvision.ops.nms`` is THIS
+    restatement (oracle/ref_loader.py) and its ``ref == mine`` check compares the
+    restatement with itself.  The rule above is a reading of torchvision's source,
+    UNVERIFIED against a real torchvision; tests/test_nms_torchvision.py is the pin
+    and reports SKIPPED wherever torchvision is absent (parity
+    unpinned at this boundary).
   * ``non_max_suppression_ssod``  utils/general.py:887-992
   * ``non_max_suppression``       utils/general.py:994-1100  (val.py path, row f-1)
   * ``xywh2xyxy`` / ``xyxy2xywh`` utils/general.py:630-637 / 549-556

@@ -99,6 +99,51 @@ def test_optimizer_skips_on_found_inf_and_unscales_otherwise(hip, opt_name):
     assert st[0].item() == S * 0.5 and st[2].item() == 0.0 and st[3].item() == 0.0
 
 
+def test_adamw_under_the_scaler_does_not_count_skipped_steps(hip):
+    """torch's GradScaler.step does not call optimizer.step() on an overflow, so AdamW's bias corrections stay put; here
+    the count is device resident (et_adamw_tick) and advances only when found_inf is clear.  Sequence: overflow, overflow, three clean
+    steps -- against torch.optim.AdamW stepped three times on the unscaled gradients (the reference's fp16 + Adam recipe,
+    trainer/trainer.py:212,400-401); then the count survives a state_dict round trip and an unscaled (host-counted) step."""
+    from efficientteacher_amd.optim import DeviceGradScaler, FlatAdamW
+    cfg, model, _ = build(hip, torch.float16)
+    opt = FlatAdamW(model, lr=1e-2, betas=(0.937, 0.999), weight_decay=5e-4)
+    f = model.flat_state()
+    p0 = f.params.detach().cpu().clone()
+    ref_p = p0.clone().requires_grad_(True)
+    ref = torch.optim.AdamW([ref_p], lr=1e-2, betas=(0.937, 0.999), weight_decay=0.0)
+    # one decay for the whole arena would not be the three groups: compare a range that lies in ONE group (the conv weights)
+    o, n = f.w_range
+    ref.param_groups[0]["weight_decay"] = 5e-4
+    S = 65536.0
+    sc = DeviceGradScaler(hip.device, init_scale=S)
+    gen = torch.Generator().manual_seed(3)
+    scale = S
+    for i, bad in enumerate([True, True, False, False, False]):
+        g = torch.randn(p0.numel(), generator=gen) * 1e-2
+        f.grads.copy_((g * scale).to(hip.device))
+        if bad:
+            f.grads[o + 17] = float("inf")
+        else:
+            ref_p.grad = g.clone()
+            ref.step()
+        sc.step(opt)
+        sc.update()
+        if bad:
+            scale *= 0.5
+    assert opt._steps_now() == 3 and sc.get_scale() == S * 0.25
+    mine, want = f.params[o:o + n].detach().cpu(), ref_p.detach()[o:o + n]
+    assert torch.allclose(mine, want, rtol=2e-5, atol=1e-7), (mine - want).abs().max()
+    # had the skipped steps been counted, the first real update would have used bc1 = 1 - b1^3 instead of 1 - b1: 2.8x smaller
+    sd = opt.state_dict()
+    assert sd["flat_steps"] == 3
+    opt2 = FlatAdamW(model, lr=1e-2, betas=(0.937, 0.999), weight_decay=5e-4)
+    opt2.load_state_dict(sd)
+    assert opt2.steps == 3 and opt2.tick is None
+    f.grads.zero_()
+    opt2.step()                                   # no scaler: the host count continues from the restored value
+    assert opt2._steps_now() == 4
+
+
 def test_fp16_eval_forward_close_to_reference_golden(hip):
     """fp16 storage, fp32 accumulation: within 1e-2 of the reference's fp32 eval output (bf16 mode: 3e-2, tests/test_model.py)"""
     cfg, model, g = build(hip, torch.float16)

@@ -23,8 +23,10 @@ def test_nms_oracle_vs_golden():
 
 
 def test_nms_threshold_compare_rule_is_the_cuda_kernels():
-    """tie06: IoU == fp32(0.6) exactly.  Pinned = torchvision's CUDA kernel (fp32 threshold: the tie survives); the CPU kernel's double
-    compare would suppress it (oracle/nms.py header) -- the golden holds the pinned rule and the two rules must differ on this case"""
+    """tie06 (ORACLE-DERIVED golden, not a reference output: torchvision is absent here, oracle/nms.py header): IoU == fp32(0.6) exactly.
+    The chosen rule = our reading of torchvision's CUDA kernel (fp32 threshold: the tie survives); the CPU kernel's double compare would
+    suppress it -- the golden holds the chosen rule and the two rules must differ on this case.  Verification against a real torchvision:
+    tests/test_nms_torchvision.py (SKIPPED in both tiers of this environment)."""
     g = golden("nms")
     bx = o_nms.xywh2xyxy(g["tie06_pred"][0, :, :4])
     sc = g["tie06_pred"][0, :, 4]

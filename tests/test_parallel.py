@@ -134,8 +134,25 @@ def _worker_bf16(rank, world, port, emu_path, out_dir):
                     ddp.train()
             assert any("did not finish" in str(w.message) for w in wl)
             assert not ddp._dirty and ddp._remaining == [c[2] for c in ddp._chunks]
+            # ... and the arena still holds that pass's unreduced partial gradients: reducing them into a step is refused until the
+            # arena has been zeroed -- checked without a collective: the refusal comes first, the peer is not involved
+            try:
+                ddp.reduce_gradients()
+                raise AssertionError("reduce_gradients() accepted the stale arena")
+            except RuntimeError as e:
+                assert "zero_grad" in str(e)
+            model.zero_grad()
+            assert ddp._stale_gen is not None and model.flat_state().zero_gen != ddp._stale_gen
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), local=local.numpy(), g16=g16.numpy(), stage_bytes=stage_bytes)
     dist.destroy_process_group()
+
+
+def test_allreduce_dtype_env_is_validated(monkeypatch):
+    """a typo in ET_ALLREDUCE_DTYPE is a ValueError naming the accepted values, not a bare KeyError"""
+    from efficientteacher_amd.parallel import FlatDataParallel
+    monkeypatch.setenv("ET_ALLREDUCE_DTYPE", "fp8")
+    with pytest.raises(ValueError, match="ET_ALLREDUCE_DTYPE"):
+        FlatDataParallel(torch.nn.Identity())
 
 
 def test_two_rank_bf16_wire_format_gloo(emu_lib_path):
