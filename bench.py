@@ -473,6 +473,10 @@ def measure(a, wl_name, per_rank, device, rank, world, dev_index, full=True):
     Bl = Bu = per_rank
     if ssod:
         imgs, targets, u_str, u_ori, M_s = make_batch(rng, Bl, Bu, S, device)
+        if not a.float_inputs:
+            # resident inputs = what the loaders deliver (uint8 NCHW): the `/ 255` of ssod_trainer.py:694 then runs INSIDE
+            # the timed step (the pack kernel's IEEE division, bit-equal to torch's), as it does for the supervised workloads below
+            imgs, u_str, u_ori = [(t * 255).round().to(torch.uint8) for t in (imgs, u_str, u_ori)]
         g = torch.Generator(device="cpu").manual_seed(99 + rank)
         synth = synth_teacher_scores(cfg, Bu, S, g).to(device)
 
@@ -494,7 +498,7 @@ def measure(a, wl_name, per_rank, device, rank, world, dev_index, full=True):
     feed = None
     if a.host_inputs and ssod:  # what a data loader hands over: uint8 NCHW batches in host memory, every step
         from efficientteacher_amd.utils.prefetch import DevicePrefetcher
-        host = [(t * 255).round().to(torch.uint8).cpu() for t in (imgs, u_str, u_ori)]
+        host = [(t if t.dtype == torch.uint8 else (t * 255).round().to(torch.uint8)).cpu() for t in (imgs, u_str, u_ori)]
 
         def batches():
             while True:
@@ -777,6 +781,8 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the step as one captured HIP graph (trainer/graph_step.py) instead of "
                     "issuing every launch from Python (A/B: the 32+32 step is GPU-bound; default ON for per-rank batches < 32)")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--float-inputs", action="store_true", help="A/B: resident fp32 images already divided by 255 (the form until r05) instead "
+                    "of the loaders' uint8 batches")
     ap.add_argument("--host-inputs", action="store_true", help="PCIe-inclusive variant: every step receives its three "
                     "uint8 image batches from pinned host memory (never the reported `value`; noted in DESIGN.md)")
     ap.add_argument("--dump-launches", default=None, help="write (kernel, flops, bytes, ms) of every timed conv launch of the "
@@ -886,7 +892,9 @@ def main():
                                           replay_probe=(dict(zip(("replay_ms", "eager_ms", "slow_captures"), res["graph_probe"]))
                                                         if res.get("graph_probe") else None),
                                           eager_instrumented_steps=res["n_timed"]),
-                       "inputs": "host uint8 (PCIe inclusive)" if a.host_inputs else "resident in HBM"},
+                       "inputs": "host uint8 (PCIe inclusive)" if a.host_inputs else
+                                 ("resident in HBM (fp32, pre-divided by 255)" if a.float_inputs else
+                                  "resident in HBM (uint8 NCHW as the loaders deliver; / 255 inside the timed step)")},
             "roofline": roof,
             "roofline_hbm": roofline_hbm(a.workload, per_rank, dt / a.steps),
             "kernel_ms_by_family": res.get("families"),

@@ -40,6 +40,7 @@ SIGNATURES = {
     "et_sgd_nesterov_dev": (c_int, [P, P, P, P, c_int, c_int64, P, c_int, P, P]),
     "et_conv2d_stats_rows": (c_int, [c_int, c_int, c_int]),
     "et_conv2d_stats_rows_for": (c_int, [c_int] * 12),
+    "et_conv2d_stats_adds_for": (c_int, [c_int] * 12),
     "et_conv2d_fwd": (c_int, [P, P, P, c_int] + [c_int] * 11 + [P, P, c_int, P, c_int, P, c_int, P, P]),
     "et_conv2d_dgrad": (c_int, [P, P, P, c_int] + [c_int] * 11 + [c_int, P, c_int, P, P]),
     "et_conv2d_dgrad_bn": (c_int, [P, P, P, c_int] + [c_int] * 10 + [P, c_int, P, c_int, P, P, c_int, P, c_int, P, P]),

@@ -308,13 +308,17 @@ __device__ __forceinline__ void conv_epilogue_write_stats(EpiSums<BN / WN / 32>&
     }
 }
 
-// Sharded statistics of a PERSISTENT workgroup (Epilogue::stats_ld != 0): the sums of its WM wave rows meet in LDS first, then one
-// atomic per channel and workgroup.  The workgroups of a persistent grid finish together, so their atomics arrive together and
-// queue per address in the memory-side atomic units (~25 ns each, r05): gridDim.x / ET_BN_SHARDS deep instead of WM times that.
+// Sharded statistics of a workgroup (Epilogue::stats_ld != 0): the sums of its WM wave rows meet in LDS first, then ONE atomic per
+// channel and workgroup (et_conv2d_stats_adds_for counts them).  The workgroups of a persistent grid finish together, so their
+// atomics arrive together and queue per address in the memory-side atomic units (~25 ns each, r05): gridDim.x / ET_BN_SHARDS deep
+// instead of WM times that.  r06: the tiled kernels end their epilogue with the same pre-reduction (n0 = the tile's first channel) --
+// the barrier sits AFTER every wave's store passes, where a wave that is done could only idle until its workgroup retires anyway --
+// which halves the additions per address of the 2-wave-row tiles and brings the 3200-tile layers (128 -> 128 3x3 @80, 512 -> 128 @80)
+// under the sharding threshold: 21 of the step's 28 remaining finalize launches go away.
 // red: LDS, WM * 2 * BN floats, free to use once every wave has passed the barrier inside.
 template <int BN, int WN, int WM, int MODE>
 __device__ __forceinline__ void conv_stats_add_sharded_wg(EpiSums<BN / WN / 32>& st, const GatherGeom& g, const Epilogue& ep, int tid, int lane,
-                                                          int wm, int wn, float* red) {
+                                                          int wm, int wn, float* red, int n0 = 0) {
     constexpr int TN = BN / WN / 32, WCOLS = BN / WN, CVN = WCOLS / 8;
     const int l31 = lane & 31, hi = lane >> 5;
     const bool bnb = MODE == 1 ? false : ep.bn_y != nullptr;
@@ -338,13 +342,13 @@ __device__ __forceinline__ void conv_stats_add_sharded_wg(EpiSums<BN / WN / 32>&
         }
     }
     __syncthreads();
-    float* const dst = ep.stats + ((size_t)(blockIdx.x % ET_BN_SHARDS) * 2) * ep.stats_ld;
+    float* const dst = ep.stats + ((size_t)(blockIdx.x % ET_BN_SHARDS) * 2) * ep.stats_ld + n0;
     for (int i = tid; i < 2 * BN; i += 64 * WM * WN) {
         const int t = i / BN, c = i % BN;
         float v = 0.f;
 #pragma unroll
         for (int w = 0; w < WM; ++w) v += red[(w * 2 + t) * BN + c];
-        if (c < g.Cout) unsafeAtomicAdd(dst + (size_t)t * ep.stats_ld + c, v);
+        if (n0 + c < g.Cout) unsafeAtomicAdd(dst + (size_t)t * ep.stats_ld + c, v);
     }
 }
 
@@ -581,7 +585,9 @@ __device__ __forceinline__ void conv_epilogue_act(f32x16 (&acc)[BM / WM / 32][BN
             // operands, so they add nothing.
             constexpr int RPW = (BM / WM) / 64;                      // 64-row blocks per wave
             static_assert((BM / WM) % 64 == 0, "wave tiles are whole 64-row blocks");
-            conv_epilogue_write_stats<BN, WN, MODE>(st, g, ep, n0, lane, wn, (m0 + wm * (BM / WM)) / 64, RPW - 1, (g.M + 63) / 64);
+            // sharded accumulator: one addition per channel and WORKGROUP (the wave rows meet in LDS behind the store passes)
+            if (ep.stats_ld) conv_stats_add_sharded_wg<BN, WN, WM, MODE>(st, g, ep, tid, lane, wm, wn, (float*)lds_raw, n0);
+            else conv_epilogue_write_stats<BN, WN, MODE>(st, g, ep, n0, lane, wn, (m0 + wm * (BM / WM)) / 64, RPW - 1, (g.M + 63) / 64);
         }
     }
 }
@@ -3003,6 +3009,37 @@ extern "C" int et_conv2d_stats_rows_for(int op, int dtype, int N, int IH, int IW
     const GemmPlan p = plan_gemm(g, eb, have_zero_page != 0, op == 1 || fwd_full);
     if (p.kind == GEMM_S1) return s1_grid((g.M + p.BM - 1) / p.BM, p) * p.WM;
     return (g.M + 63) / 64;
+}
+
+extern "C" int et_conv2d_stats_adds_for(int op, int dtype, int N, int IH, int IW, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                                        int have_zero_page) {
+    // fp32 atomic additions PER CHANNEL (all shards together) of the same call with a SHARDED accumulator (stats_ld > 0): every
+    // kernel adds once per workgroup that covers the channel -- the persistent kernels (stem, 1x1 stream) once per resident
+    // workgroup, the tiled kernels once per row tile (conv_stats_add_sharded_wg).  adds / ET_BN_SHARDS of them meet on one address.
+    if (KH * KW > CONV_MAX_TAPS || stride < 1 || N <= 0 || op < 0 || op > 2) return -2;
+    const bool fwd_full = op == 2;
+    if (fwd_full) op = 0;
+    const int eb = dtype == ET_F32 ? 4 : 2, vec = dtype == ET_F32 ? 4 : 8;
+    GatherGeom g;
+    int rc;
+    if (op == 0) {
+        if (!fwd_full && try_launch_stem(nullptr, nullptr, nullptr, dtype, N, IH, IW, Cin, Cin, Cout, KH, KW, stride, pad, Cout, nullptr, nullptr, 0, nullptr,
+                                         nullptr, 0, have_zero_page ? (const void*)&g : nullptr, nullptr, false)) {
+            const int OH = (IH + 2 * pad - KH) / stride + 1, OW = (IW + 2 * pad - KW) / stride + 1;
+            const int ntiles = N * ((OH + STEM_TR - 1) / STEM_TR) * ((OW + STEM_TC - 1) / STEM_TC);
+            int grid = env_int("ET_CONV_STEM_WGS", 2 * device_cus());
+            if (grid < 1) grid = 1;
+            return grid < ntiles ? grid : ntiles;
+        }
+        rc = fwd_geom(g, N, IH, IW, Cin, Cin, Cout, KH, KW, stride, pad, Cout, vec);
+    } else {
+        if (stride != 1) return -2;
+        rc = dgrad_geom(g, 0, 0, N, IH, IW, Cin, Cin, Cout, KH, KW, 1, pad, Cout, vec);
+    }
+    if (rc) return rc < 0 ? rc : -2;
+    const GemmPlan p = plan_gemm(g, eb, have_zero_page != 0, op == 1 || fwd_full);
+    if (p.kind == GEMM_S1) return s1_grid((g.M + p.BM - 1) / p.BM, p);
+    return (g.M + p.BM - 1) / p.BM;
 }
 
 extern "C" int et_conv2d_fwd(const void* x, const void* w, void* y, int dtype, int N, int IH, int IW, int Cin,

@@ -108,11 +108,23 @@ def stats_rows(op, dtype, N, IH, IW, Cin, Cout, k, stride, pad, zero_page=True):
     return rows
 
 
-# Sharded statistics pay when the producer writes FEW partial rows (the persistent 1x1 kernel: one per wave row of its <= 512
-# workgroups; any kernel on the small maps): every row becomes one fp32 atomic per channel, rows / BN_SHARDS of them on one address.
-# Above this many rows the atomics serialise in the memory-side atomic units for longer than the finalize launch they replace
-# (r05: every conv sharded = +5.3 ms of conv time against -1.6 ms of BatchNorm time per step).
-SHARD_MAX_ROWS = 2048
+def stats_adds(op, dtype, N, IH, IW, Cin, Cout, k, stride, pad, zero_page=True):
+    """fp32 atomic additions per channel (all shards together) of the same call with a SHARDED accumulator: one per workgroup that
+    covers the channel (et_conv2d_stats_adds_for)"""
+    dt = _ET_OF[dtype]
+    n = _lib.load().et_conv2d_stats_adds_for({"fwd": 0, "dgrad_bn": 1, "fwd_res": 2}[op], dt, N, IH, IW, Cin, Cout, k, k, stride, pad, int(bool(zero_page)))
+    if n <= 0:
+        raise _lib.EtHipError(f"et_conv2d_stats_adds_for failed with code {n}")
+    return n
+
+
+# Sharded statistics pay when the producer ADDS FEW times per channel (the persistent kernels: once per resident workgroup; the
+# tiled kernels: once per row tile since r06, their wave rows meet in LDS first): every addition is one fp32 atomic per channel,
+# adds / BN_SHARDS of them on one address.  Above the threshold the atomics serialise in the memory-side atomic units for longer than
+# the finalize launch they replace (r05: every conv sharded = +5.3 ms of conv time against -1.6 ms of BatchNorm time per step; the
+# 12800-tile layers of the 160 x 160 maps stay on partial rows).  3200 = the 128-row tiles of the 80 x 80 maps at 64 images
+# (profiles/r06_bn_shard_threshold_ab.txt).
+SHARD_MAX_ADDS = 3200
 _FEW_ROWS = {}
 
 
@@ -120,14 +132,14 @@ def few_rows(op, dtype, N, IH, IW, Cin, Cout, k, stride, pad):
     key = (op, dtype, N, IH, IW, Cin, Cout, k, stride, pad)
     r = _FEW_ROWS.get(key)
     if r is None:
-        r = _FEW_ROWS[key] = stats_rows(op, dtype, N, IH, IW, Cin, Cout, k, stride, pad)
-    return r <= SHARD_MAX_ROWS
+        r = _FEW_ROWS[key] = stats_adds(op, dtype, N, IH, IW, Cin, Cout, k, stride, pad)
+    return r <= SHARD_MAX_ADDS
 
 
 def few_reduce_rows(y):
-    """the same question for the separate reduce pass of the BatchNorm backward (one row per workgroup)"""
+    """the same question for the separate reduce pass of the BatchNorm backward (one addition per workgroup)"""
     N, H, W, C = y.shape
-    return _lib.load().et_bn_reduce_rows(N * H * W, C, et_dtype(y)) <= SHARD_MAX_ROWS
+    return _lib.load().et_bn_reduce_rows(N * H * W, C, et_dtype(y)) <= SHARD_MAX_ADDS
 
 
 def env_knobs():

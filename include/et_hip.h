@@ -144,10 +144,15 @@ int et_conv2d_stats_rows(int N, int OH, int OW);
  * call passes zero16.  Host only. */
 int et_conv2d_stats_rows_for(int op, int dtype, int N, int IH, int IW, int Cin, int Cout, int KH, int KW, int stride, int pad,
                              int have_zero_page);
+/* the same question for a SHARDED call (stats_ld > 0): fp32 atomic additions per channel (all shards together) -- one per workgroup
+ * that covers the channel (row tiles of the tiled kernels, resident workgroups of the persistent ones).  The caller decides with it
+ * whether sharding pays (additions / ET_BN_SHARDS meet on one address and serialise in the memory-side atomic units).  Host only. */
+int et_conv2d_stats_adds_for(int op, int dtype, int N, int IH, int IW, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                             int have_zero_page);
 /* stats_partial with stats_ld == 0: partial rows (et_conv2d_stats_rows_for(...), 2, Cout), every row written -- the exact path
  * (fp64 combine in et_bn_finalize, bit-reproducible).  stats_ld > 0: stats_partial is a SHARDED ACCUMULATOR
- * [ET_BN_SHARDS][2][stats_ld] fp32 that must be ZERO before the launch; every wave adds its column sums into shard
- * (workgroup index % ET_BN_SHARDS) with hardware fp32 atomics, channel c at [shard][t][c].  et_bn_act_fwd_sharded folds the shards
+ * [ET_BN_SHARDS][2][stats_ld] fp32 that must be ZERO before the launch; every WORKGROUP adds its column sums (its wave rows meet in
+ * LDS first) into shard (workgroup index % ET_BN_SHARDS) with hardware fp32 atomics, channel c at [shard][t][c].  et_bn_act_fwd_sharded folds the shards
  * itself, so a Conv block is two launches (conv, normalise) instead of three, and one memset per STEP zeroes every layer's shards
  * when they live in one arena.  Sums are then order-dependent in the last fp32 bits (the 16-bit training modes use this form). */
 #define ET_BN_SHARDS 16

@@ -14,7 +14,7 @@ dev = torch.device("cuda:0")
 for dtype in (torch.float16, torch.bfloat16):
     for sharded, rows in ((False, 0), (True, 2048), (True, 10 ** 9), (False, 0), (True, 2048)):
         autograd.SHARDED_BN = sharded
-        ops.SHARD_MAX_ROWS = rows
+        ops.SHARD_MAX_ADDS = rows
         for _ in range(2):
             r = run_ssod_step_parity(dev, dtype, Bl=2, Bu=2, amp_calibration=False)
             print(str(dtype)[6:], "sharded" if sharded else "rows   ", rows, {k: round(v, 5) for k, v in r["loss_rel"].items()}, flush=True)
