@@ -3179,6 +3179,10 @@ static WgradPlan plan_wgrad(const WgradGeom& g, int elem_bytes, bool have_zero_p
         // (691-765 TFLOP/s vs ~600), 128x256 on the 128-channel stride-1 3x3 layers; 1x1 layers keep 128^2
         if (g.T > 1 && g.Cout >= 256 && g.NC >= 256) { p.bm = 256; p.bn = 256; }
         else if (g.T > 1 && g.isy == 1 && g.NC >= 256 && g.Cout == 128) p.bn = 256;
+        // 1x1 layers with >= 512 channels on both sides (MFMA-bound: 256 flop per byte) take the 256^2 tile as well; below that the
+        // layers are HBM-bound and 128^2 (two workgroups per CU) wins.  Same-box A/B on the step (profiles/r06_wgrad_1x1_tile_ab.txt):
+        // wgrad family 9.74 / 9.79 -> 9.67 / 9.67 ms; 256^2 from 256 channels 9.82 / 9.78, 128 x 256 9.95, 256 x 128 9.98
+        else if (g.T == 1 && g.Cout >= 512 && g.NC >= 512) { p.bm = 256; p.bn = 256; }
     }
     // 3x3 stride-1 pad-1 layers: the three taps of a kernel row share both staged operands (conv_wgrad_rs_kernel)
     if (p.tr && g.T == 9 && g.isy == 1 && g.isx == 1 && g.dy[0] == -1 && g.dx[0] == -1 && g.dy[8] == 1 && g.dx[8] == 1 &&

@@ -209,7 +209,7 @@ SELECT = [
      [GLDS + "128, 128, 2, 2, 4, 3, true>", GLDS + "128, 128, 2, 2, 8, 2, true>", GLDS + "128, 128, 2, 2, 8, 2, true>",
       GLDS + "128, 128, 2, 2, 8, 2, true>"], "conv_wgrad_tr_kernel<256, 256, 2, 4>"),
     ((2, 20, 20, 512, 512, 1, 1, 0), GLDS + "128, 128, 2, 2, 8, 2, true>", [GLDS + "128, 128, 2, 2, 8, 2, true>"],
-     "conv_wgrad_tr_kernel<128, 128, 2, 2>"),
+     "conv_wgrad_tr_kernel<256, 256, 2, 4>"),                                                  # r06: >= 512-channel 1x1 layers on the 256^2 tile (identity X rows)
     ((1, 9, 11, 64, 40, 3, 1, 1), RS64, [GLDS + "128, 64, 2, 2, 4, 2, false>"],                # ragged M, 11-pixel rows
      "conv_wgrad_rs_kernel<64, 64, 2, 2>"),
     ((2, 12, 12, 64, 128, 1, 1, 0), S1, [S1], "conv_wgrad_tr_kernel<128, 64, 2, 2>"),
