@@ -219,7 +219,16 @@ def ptr(t):
     return t.data_ptr()
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream(t=None):
+    """the current HIP stream handle of t's device.  Through torch's raw-stream accessor where it exists: constructing a
+    torch.cuda.Stream object per launch (current_stream().cuda_stream) cost 4.7 us x 340 launches = 1.6 ms of host time per SSOD step
+    (profiles/r06_adapter_host_cost.txt)"""
     if _emulated:
         return None
+    if _RAW_STREAM is not None:
+        idx = t.device.index if t is not None else None
+        return _RAW_STREAM(torch.cuda.current_device() if idx is None else idx)
     return torch.cuda.current_stream(t.device if t is not None else None).cuda_stream

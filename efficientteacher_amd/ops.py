@@ -530,12 +530,16 @@ def bn_act_fwd_sharded(y, shards, count, gamma, beta, eps, momentum, running_mea
         aff = torch.empty((4, C), dtype=torch.float32, device=y.device)
     ldr = _nhwc(residual) if residual is not None else 0
     sh, ld = shards
+    a0 = _lib.ptr(aff)                                  # rows of the (4, C) block by address: four view tensors per call were host time
+    rs = aff.stride(0) * 4
+    assert aff.stride(1) == 1 and aff.dtype == torch.float32
     _lib.check(_lib.load().et_bn_act_fwd_sharded(_lib.ptr(y), _nhwc(y), _lib.ptr(out), _nhwc(out), _lib.ptr(residual), ldr, et_dtype(y),
                                                  N * H * W, C, _lib.ptr(sh), ld, float(count), _lib.ptr(gamma), _lib.ptr(beta), eps,
-                                                 momentum, _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(aff[0]),
-                                                 _lib.ptr(aff[1]), _lib.ptr(aff[2]), _lib.ptr(aff[3]), act, _lib.stream(y)),
+                                                 momentum, _lib.ptr(running_mean), _lib.ptr(running_var), a0, a0 + rs, a0 + 2 * rs,
+                                                 a0 + 3 * rs, act, _lib.stream(y)),
                "et_bn_act_fwd_sharded")
-    return out, aff[0], aff[1], aff[2], aff[3]
+    sc, shf, mean, invstd = aff.unbind(0)
+    return out, sc, shf, mean, invstd
 
 
 def bn_act_bwd(dz, y, gamma, scale, shift, mean, invstd, act, dgamma, dbeta, out=None, partial=None, shards=None):
