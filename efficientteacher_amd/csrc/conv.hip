@@ -1134,6 +1134,10 @@ template <int N> __device__ __forceinline__ void et_wait_vmem_le_pp() {
     __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 0xF) | ((N >> 4) << 14));
 }
 
+// (r06: the buffer-descriptor form of the LDS-DMA pieces that conv_gemm_pprs_kernel uses was built for this kernel too -- per-tap
+// validity as one mask bit per pixel, no VALU for a weight piece: -4.3 % cycles per launch, -2 % per-launch time, and the STEP 0.2-0.4 ms
+// SLOWER: the chip runs this step at its power limit and the denser kernel lowers the clock of every other MFMA kernel by 1.3-1.7 %
+// (profiles/r06_power_limit.txt); tools/probe/pp_buffer_dma.patch keeps the code.)
 template <typename T>
 __global__ __launch_bounds__(512, 2) void conv_gemm_pp_kernel(const T* __restrict__ X, const T* __restrict__ W,
                                                               T* __restrict__ Y, const T* __restrict__ ZERO,
@@ -1342,11 +1346,15 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_pp_kernel(const T* __restric
 //   end of ph0's load section: vmcnt(1) if the previous phase 3 issued a piece, else vmcnt(0) -> B1 of this chunk has landed
 // RAW / WAR as in conv_gemm_pp_kernel (its header): the weight schedule is unchanged, the activation unit is written two
 // units before... no: ONE unit before it is read (buffer (u+1)&1 during unit u; its last reader was unit u-1).
+// BUF (r06): the LDS-DMA pieces go through BUFFER descriptors (et_bufdma16) instead of flat 64-bit addresses.  A padding lane is an
+// out-of-range voffset (the hardware writes zeros: no zero page, no exec-masked 64-bit select), weight rows beyond Cout fall out of the
+// descriptor's range by themselves, and everything wave-uniform about an address (tap, channel chunk, row block of the half-tile, the
+// image-row step of the kernel row) is ONE SGPR: a weight piece costs no VALU at all, an activation piece two (v_bfe_u32 + v_lshl_or_b32)
+// against nine to ten instructions per piece with an exec-mask round trip in the flat form.  Host: both operands < 2^31 bytes.
 #define PPRS_ROWS 320
-template <typename T>
-__global__ __launch_bounds__(512, 2) void conv_gemm_pprs_kernel(const T* __restrict__ X, const T* __restrict__ W,
-                                                                T* __restrict__ Y, const T* __restrict__ ZERO,
-                                                                GatherGeom g, Epilogue ep) {
+template <typename T, bool BUF>
+__device__ __forceinline__ void conv_gemm_pprs_body(const T* __restrict__ X, const T* __restrict__ W, T* __restrict__ Y,
+                                                    const T* __restrict__ ZERO, const GatherGeom& g, const Epilogue& ep) {
     constexpr int BM = 256, BN = 256, WM = 2, WN = 4, BKV = 8, VEC = 8;
     constexpr int HALF_VEC = 128 * BKV;            // one weight half-tile in 16-byte vectors (16 KB)
     constexpr int A_VEC = PPRS_ROWS * BKV;         // one activation unit (40 KB)
@@ -1384,11 +1392,25 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_pprs_kernel(const T* __restr
         const int iy = ygc - fdiv(ygc, g.dQH) * g.QH;
         a_off[q] = (ok ? pix : 0) * g.ldx;
         a_okm |= ok ? ((iy > 0 ? 1u : 0u) | 2u | (iy + 1 < g.IH ? 4u : 0u)) << (3 * q) : 0u;
+        // BUF: this lane's byte offset of piece q behind the descriptor base (one image row in FRONT of the tensor, so that the
+        // kernel-row step (dy + 1) * IW * ldx is never negative); a pixel that does not exist is out of range for good (bit 31)
+        if constexpr (BUF) a_off[q] = ok ? (int)((a_off[q] + lv * VEC) * (int)sizeof(T)) : (int)0x80000000;
     }
+    const unsigned a_nokm = ~a_okm;                // BUF: bit 3q+1+dy SET = piece q has no row at dy for this lane
     // weight rows: half-tile j, piece jj, LDS row jj*64 + lrow <-> output channel co0 + jj*128 + j*32 (one base + uniform steps)
     const int co0 = n0 + (lrow >> 5) * 64 + (lrow & 31);
     const int wrow = g.TT * g.Cin;                 // elements per weight row (uniform)
     const int b_off0 = co0 * wrow;
+    // BUF descriptors: X from one image row before its first byte (see above) over the whole tensor, W over exactly Cout rows -- a row
+    // beyond Cout (ragged column tile) is out of range and lands as zeros without a mask
+    const int rowstep = g.IW * g.ldx;              // elements per image row of X
+    et_rsrc rsX, rsW;
+    unsigned voffB = 0;
+    if constexpr (BUF) {
+        rsX = et_make_rsrc((const char*)X - (size_t)rowstep * sizeof(T), (unsigned)(((size_t)g.N * g.IH * g.IW * g.ldx + rowstep) * sizeof(T)));
+        rsW = et_make_rsrc(W, (unsigned)((size_t)g.Cout * wrow * sizeof(T)));
+        voffB = (unsigned)((b_off0 + lv * VEC) * (int)sizeof(T));
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -1421,14 +1443,23 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_pprs_kernel(const T* __restr
     auto stage_a_piece = [&](int q, int ub, int j, int cv) {
         u32x4* const wbase = slotA + ub * A_VEC + q * 512 + wave * 64;
         const int dy = sgn * (j - 1);
-        const bool ok = (a_okm >> (3 * q + 1 + dy)) & 1u;
-        et_glds16(ok ? X + (a_off[q] + dy * g.IW * g.ldx + (cv + lv) * VEC) : ZERO, wbase);
+        if constexpr (BUF) {
+            const unsigned bad = (a_nokm >> (3 * q + 1 + dy)) & 1u;
+            et_bufdma16(rsX, (bad << 31) | (unsigned)a_off[q], (unsigned)(((dy + 1) * rowstep + cv * VEC) * (int)sizeof(T)), wbase);
+        } else {
+            const bool ok = (a_okm >> (3 * q + 1 + dy)) & 1u;
+            et_glds16(ok ? X + (a_off[q] + dy * g.IW * g.ldx + (cv + lv) * VEC) : ZERO, wbase);
+        }
     };
     // piece jj (rows 0-63 / 64-127) of weight half-tile j of chunk (tap, cv) into buffer b
     auto stage_b_piece = [&](int j, int b, int jj, int tap, int cv) {
         u32x4* const wbase = slotB + (2 * j + b) * HALF_VEC + wave * 64;
-        const bool ok = (b_okm >> (j * 2 + jj)) & 1u;
-        et_glds16(ok ? W + (b_off0 + (jj * 128 + j * 32) * wrow + tap * g.Cin + (cv + lv) * VEC) : ZERO, wbase + jj * 512);
+        if constexpr (BUF) {
+            et_bufdma16(rsW, voffB, (unsigned)(((jj * 128 + j * 32) * wrow + tap * g.Cin + cv * VEC) * (int)sizeof(T)), wbase + jj * 512);
+        } else {
+            const bool ok = (b_okm >> (j * 2 + jj)) & 1u;
+            et_glds16(ok ? W + (b_off0 + (jj * 128 + j * 32) * wrow + tap * g.Cin + (cv + lv) * VEC) : ZERO, wbase + jj * 512);
+        }
     };
 
     u32x4 af[2][4], bf[4];                         // A fragments of one half (2 row tiles x 4 k-steps), B of one half
@@ -1526,6 +1557,19 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_pprs_kernel(const T* __restr
     conv_epilogue<T, BM, BN, WM, WN, false>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn);
 #undef ET_PP_BAR
 #undef ET_PP_WAIT
+}
+// the kernel rocprofv3 shows (buffer-descriptor LDS-DMA) and its flat-address twin for operands of 2^31 bytes and more
+template <typename T>
+__global__ __launch_bounds__(512, 2) void conv_gemm_pprs_kernel(const T* __restrict__ X, const T* __restrict__ W,
+                                                                T* __restrict__ Y, const T* __restrict__ ZERO,
+                                                                GatherGeom g, Epilogue ep) {
+    conv_gemm_pprs_body<T, true>(X, W, Y, ZERO, g, ep);
+}
+template <typename T>
+__global__ __launch_bounds__(512, 2) void conv_gemm_pprs_flat_kernel(const T* __restrict__ X, const T* __restrict__ W,
+                                                                     T* __restrict__ Y, const T* __restrict__ ZERO,
+                                                                     GatherGeom g, Epilogue ep) {
+    conv_gemm_pprs_body<T, false>(X, W, Y, ZERO, g, ep);
 }
 
 // ---- 1x1 stride-1 layers with <= 256 input and <= 256 output channels: persistent streaming GEMM ---------------------------
@@ -2935,7 +2979,17 @@ static int launch_gemm(const void* X, const void* W, void* Y, const void* zero16
     }
     if (p.kind == GEMM_PPRS) {
         if constexpr (sizeof(T) == 2) {
-            hipLaunchKernelGGL((conv_gemm_pprs_kernel<T>), grid, block, 0, s, x, w, y, z, g, ep);
+            {
+                // buffer-descriptor LDS-DMA (BUF) wherever both operands sit below 2^31 bytes (bit 31 of a lane's offset = "out of range");
+                // the flat-address form remains for larger tensors.  Same-box A/B on the step: -0.13 ms in 20-step and in 200-step runs
+                // (profiles/r06_pprs_buffer_dma_ab.txt)
+                const size_t xb = ((size_t)g.N * g.IH * g.IW * g.ldx + (size_t)g.IW * g.ldx) * sizeof(T), wb = (size_t)g.Cout * g.TT * g.Cin * sizeof(T);
+                // (ET_CONV_PPRS_FLAT=1: test hook, read per call -- the flat form on shapes that do not need it)
+                if (xb < (1ull << 31) && wb < (1ull << 31) && !env_int("ET_CONV_PPRS_FLAT", 0))
+                    hipLaunchKernelGGL((conv_gemm_pprs_kernel<T>), grid, block, 0, s, x, w, y, z, g, ep);
+                else
+                    hipLaunchKernelGGL((conv_gemm_pprs_flat_kernel<T>), grid, block, 0, s, x, w, y, z, g, ep);
+            }
             return 0;
         }
         return -2;
@@ -3439,9 +3493,9 @@ extern "C" int et_conv2d_kernel_name(int op, int dtype, int N, int IH, int IW, i
 
 extern "C" int et_env_knobs(char* buf, int buflen) {
     // every ET_* runtime knob that is SET in this process's environment, as "NAME=value;..." (bench.py records it).  The complete list:
-    // three test hooks (persistent-grid sizes, the BatchNorm finalize form), the opt-in arms that change WHAT runs beside what (step
+    // four test hooks (persistent-grid sizes, the BatchNorm finalize form, the flat-address twin of the dominant kernel), the opt-in arms that change WHAT runs beside what (step
     // graph, weight-gradient stream), the data-parallel transport settings, and the experiment-library path.
-    static const char* names[] = {"ET_CONV_S1_WGS", "ET_CONV_STEM_WGS", "ET_BN_FIN_SMALL", "ET_STEP_GRAPH", "ET_WGRAD_STREAM",
+    static const char* names[] = {"ET_CONV_S1_WGS", "ET_CONV_STEM_WGS", "ET_CONV_PPRS_FLAT", "ET_BN_FIN_SMALL", "ET_STEP_GRAPH", "ET_WGRAD_STREAM",
                                   "ET_ALLREDUCE_CHUNK_MB", "ET_ALLREDUCE_DTYPE", "ET_RCCL_CHANNELS", "ET_DP_SINGLE_RANK", "ET_HIP_LIB"};
     if (!buf || buflen < 1) return -1;
     int off = 0;

@@ -138,5 +138,18 @@ __device__ __forceinline__ void et_glds16_nt(const void* g, void* lds_wave_base)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 2);
 }
+// LDS-DMA through a BUFFER descriptor (buffer_load_dwordx4 ... offen lds): address = base + soffset (SGPR, wave-uniform) + voffset
+// (VGPR, per lane, unsigned bytes); a lane whose voffset + soffset + 16 exceeds num_records is OUT OF RANGE and the hardware writes
+// ZEROS into its LDS slot (probed on gfx950, tools/probe/probe_bufdma.py, profiles/r06_probe_bufdma.txt: soffset IS part of the range
+// check, per dword; a negative voffset is out of range).  Against the flat form (et_glds16) a padding / tail lane needs no zero
+// page and no 64-bit select: an all-ones voffset; rows beyond a tensor's end fall out of range by themselves; and the wave-uniform
+// part of the address (tap, channel chunk, half-tile row block) travels in an SGPR instead of per-lane VALU.
+typedef __amdgpu_buffer_rsrc_t et_rsrc;
+__device__ __forceinline__ et_rsrc et_make_rsrc(const void* base, unsigned num_bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, num_bytes, 0x00020000);
+}
+__device__ __forceinline__ void et_bufdma16(et_rsrc r, unsigned voff, unsigned soff, void* lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, (int)soff, 0, 0);
+}
 // s_waitcnt vmcnt(0): all of this wave's LDS-DMA writes have landed (expcnt / lgkmcnt left at max)
 __device__ __forceinline__ void et_wait_vmem() { __builtin_amdgcn_s_waitcnt(0x0F70); }

@@ -271,6 +271,25 @@ static inline void emu_global_load_lds(const void* g, void* l, unsigned size, in
     b.dmaq[b.cur->lin].push_back(d);
 }
 #define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) emu_global_load_lds((const void*)(g), (void*)(l), (size), (off))
+// the same through a buffer descriptor (buffer_load_dwordx4 ... offen lds), semantics PROBED on hardware (tools/probe/probe_bufdma.py):
+// byte offset = voffset + soffset + inst offset (unsigned); a dword whose end lies beyond num_records reads as ZERO -- and the zero IS
+// written to LDS; a "negative" voffset is a huge unsigned one, i.e. out of range
+struct emu_buffer_rsrc { const char* base; unsigned num_records; };
+typedef emu_buffer_rsrc __amdgpu_buffer_rsrc_t;
+static inline emu_buffer_rsrc __builtin_amdgcn_make_buffer_rsrc(void* p, short stride, unsigned num, unsigned flags) {
+    (void)stride; (void)flags;
+    return emu_buffer_rsrc{(const char*)p, num};
+}
+static inline void emu_buffer_load_lds(emu_buffer_rsrc r, void* l, unsigned size, int voff, int soff, int ioff) {
+    unsigned char tmp[16];
+    const unsigned long long off = (unsigned long long)(unsigned)voff + (unsigned long long)(unsigned)soff + (unsigned long long)(unsigned)ioff;
+    for (unsigned d = 0; d < size / 4; ++d) {
+        if (off + 4ull * (d + 1) <= (unsigned long long)r.num_records) memcpy(tmp + 4 * d, r.base + off + 4 * d, 4);
+        else memset(tmp + 4 * d, 0, 4);
+    }
+    emu_global_load_lds(tmp, l, size, 0);
+}
+#define __builtin_amdgcn_raw_ptr_buffer_load_lds(r, l, size, voff, soff, ioff, aux) emu_buffer_load_lds((r), (void*)(l), (size), (voff), (soff), (ioff))
 // s_waitcnt immediate (gfx9): vmcnt = bits [3:0] | bits [15:14] << 4; only the LDS-DMA queue is modelled
 #define __builtin_amdgcn_s_waitcnt(x) emu::dma_retire((int)(((x) & 0xF) | ((((x) >> 14) & 3) << 4)))
 
