@@ -334,8 +334,10 @@ def cpu_baseline_ssod(cfg, device, seconds=25.0, Bl=2, Bu=2):
             vals = sorted(cos.values())
             parity["fp16"]["conv_grad_cosine_vs_fp32_oracle"] = dict(
                 at="conditioned init (BatchNorm weights 0.3), loss scale 256, reproducible BatchNorm path", tensors=len(vals),
-                min=vals[0], median=vals[len(vals) // 2], worst_tensor=min(cos, key=cos.get), bound=0.999,
-                within_bound=bool(vals[0] >= 0.999))
+                min=vals[0], median=vals[len(vals) // 2], worst_tensor=min(cos, key=cos.get), bound=0.995,
+                within_bound=bool(vals[0] >= 0.995),
+                note="bound = tests/test_step_fullsize.py::test_yolov5l_640_ssod_step_fp16_gradients_vs_oracle (measured 0.9990 +- 1e-4 "
+                     "from run to run: fp32 atomics of the weight-gradient split-K); the bf16 mode's bound at the same point is 0.95")
             del st2, te2, grads
         except Exception as e:              # the gradient leg must never cost the line its throughput number
             parity["fp16"]["conv_grad_cosine_vs_fp32_oracle"] = dict(error=f"{type(e).__name__}: {e}"[:300])
@@ -620,12 +622,18 @@ def measure(a, wl_name, per_rank, device, rank, world, dev_index, full=True):
         by_stream = ft.summary()
         span = e0.elapsed_time(e1)
         main = by_stream.pop(main_id, {})
+        wq_side = ops.WGRAD_QUEUE._side.get(device) if hasattr(ops.WGRAD_QUEUE, "_side") else None
+        wgrad_side = by_stream.pop(wq_side.cuda_stream, {}) if wq_side is not None else {}
         side = {}
         for d in by_stream.values():
             for k, v in d.items():
                 side[k] = side.get(k, 0.0) + v
         fam = dict(main_stream={k: round(v, 3) for k, v in sorted(main.items())},
                    teacher_stream={k: round(v, 3) for k, v in sorted(side.items())},
+                   wgrad_stream={k: round(v, 3) for k, v in sorted(wgrad_side.items())},
+                   wgrad_stream_note="the deferred, grouped weight-gradient launches run on their own HIP stream beside the dgrad / BatchNorm-"
+                                     "backward chain (ops.WgradQueue, default since r06; ET_WGRAD_STREAM=0 puts them back on the main stream: "
+                                     "profiles/r06_wgrad_side_stream_ab.txt); durations under contention, like the teacher stream's",
                    main_stream_span_ms=round(span, 3), main_stream_busy_ms=round(sum(main.values()), 3),
                    teacher_stream_ms=round(sum(side.values()), 3),
                    aten_and_gaps_ms=round(span - sum(main.values()), 3),
@@ -640,20 +648,24 @@ def measure(a, wl_name, per_rank, device, rank, world, dev_index, full=True):
         if ssod:
             tr.use_graph = graph_default
     res["families"] = fam
-    # ONE instrumented step with the teacher on the main stream (no kernel shares the GPU with the timed one): the same
-    # launches' durations without the inflation the overlapped teacher stream causes
+    # ONE instrumented step with the teacher AND the weight gradients on the main stream (no kernel shares the GPU with the timed one):
+    # the same launches' durations without the inflation the co-resident streams cause
     solo = None
     if ssod:
+        keep_side = ops.WGRAD_QUEUE.use_side
         try:
             t_solo = ops.KernelTimer()
             keep_overlap = tr.overlap_teacher
             tr.overlap_teacher, ops.TIMER, tr.use_graph = False, t_solo, False
+            ops.WGRAD_QUEUE.use_side = 0
             step(a.warmup + a.steps + 4)
+            ops.WGRAD_QUEUE.use_side = keep_side
             ops.TIMER, tr.overlap_teacher, tr.use_graph = None, keep_overlap, graph_default
             torch.cuda.synchronize()
             solo = t_solo.summary()
         except Exception:
             ops.TIMER = None
+            ops.WGRAD_QUEUE.use_side = keep_side
     res["solo"] = solo
     # ... and the teacher's forward + decode ALONE on the GPU (in the step it shares the CUs with the student's forward, so the
     # teacher_stream figures above are durations under contention, not cost)
@@ -728,11 +740,13 @@ def roofline_of(res, dump=None):
     solo = res.get("solo")
     if solo and dom in solo:
         sd = solo[dom]
-        roof["same_kernel_teacher_not_overlapped"] = dict(
+        roof["same_kernel_nothing_co_resident"] = dict(
             avg_launch_us=sd["ms"] * 1e3 / sd["launches"], frac=sd["flops"] / (sd["ms"] * 1e-3) / PEAK_BF16,
             all_conv_ms=sum(v["ms"] for v in solo.values()),
-            note="one extra step outside the timed region with the teacher forward on the main stream: in the timed "
-                 "region the teacher's launches share the GPU with the student's and lengthen them")
+            note="one extra step outside the timed region with the teacher forward AND the weight gradients on the main stream: in the "
+                 "timed region their launches share the GPU with the student's forward / dgrad chain and lengthen them (the step is faster "
+                 "with them side by side)")
+        roof["same_kernel_teacher_not_overlapped"] = roof["same_kernel_nothing_co_resident"]      # the key of rounds 2-5
     return roof, conv_fl
 
 

@@ -251,8 +251,12 @@ class WgradQueue:
     58.13 / 58.10 ms against 58.77 / 58.75 ms -- about 1 %.  The GPU is close to work-conserving here: with the 12.6 ms of wgrad
     kernels off the main stream its own kernels stretch by ~6 ms (BatchNorm passes 14.1 -> 17.2 ms, gather-GEMMs 26.0 -> 29.2 ms),
     which is why the gain is 0.6 ms and not 12 -- and why the PER-LAUNCH figures get worse while the step gets faster (the
-    dominant gather-GEMM's HIP-event duration 132 -> 149 us, bench.py `roofline.frac` 0.23 -> 0.21).  The default therefore keeps
-    the launches on the launching stream; the side stream is an opt-in for throughput.  Ordering: the side stream waits for the
+    dominant gather-GEMM's HIP-event duration 132 -> 149 us, bench.py `roofline.frac` 0.23 -> 0.21).  r03-r05 therefore kept the
+    launches on the launching stream.  r06: the DEFAULT is the side stream (ET_WGRAD_STREAM=0 restores the launching stream) -- re-measured
+    at the current kernels, 50.43 -> 50.10 ms over 100-step runs and 49.81 -> 49.55 ms over 20-step runs, alternating on one box
+    (profiles/r06_wgrad_side_stream_ab.txt): the step runs at the chip's power limit (profiles/r06_power_limit.txt), where what a change is
+    worth is decided on the step, not per launch; bench.py reports the dominant kernel's uncontended duration beside the in-region one
+    (`roofline.same_kernel_nothing_co_resident`: one extra step with the teacher and the weight gradients on the main stream).  Ordering: the side stream waits for the
     launching stream at every group launch (dy and x are complete), the launching stream joins the side stream at the end of
     backward (before the optimizer / the final all-reduces); gradient-ready hooks run with the side stream current, so an RCCL
     all-reduce they start is ordered behind the wgrads it covers."""
@@ -265,7 +269,7 @@ class WgradQueue:
         self.last = {}
         self.tick = 0
         self._cb_armed = False
-        self.use_side = int(os.environ.get("ET_WGRAD_STREAM", "0") or 0)     # 0 off, 1 every group, 2 only the 1x1 layers, 3 only k > 1
+        self.use_side = int(os.environ.get("ET_WGRAD_STREAM", "1") or 0)     # 0 launching stream, 1 every group (default), 2 only the 1x1 layers, 3 only k > 1
         self._side = {}              # device -> side stream
         self._dirty = set()          # devices whose side stream holds work the launching stream has not joined yet
 
