@@ -938,10 +938,11 @@ __global__ __launch_bounds__(64 * WM * WN, (NS == 3 && BKV == 4 && BM == 128) ? 
 // Only the weight tile is staged per step: (BM + 16) + 3 * BN instead of 3 * (BM + BN) rows per unit of L2->LDS traffic.
 // Ring: two A-unit slots + two B-step slots; B(s+1) is issued at the start of step s, A(u+1) at the first step of unit u, BEHIND
 // that step's B so that the counted vmcnt wait of the next step releases B while A is still in flight.
-template <typename T, int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN, BN <= 64 ? 3 : 2) void conv_gemm_rs_kernel(const T* __restrict__ X, const T* __restrict__ W,
-                                                                       T* __restrict__ Y, const T* __restrict__ ZERO,
-                                                                       GatherGeom g, Epilogue ep) {
+// BUF (r06): LDS-DMA through buffer descriptors as in conv_gemm_pprs_kernel (its header): out-of-range lanes land as zeros, the kernel-row
+// step and the channel cursor travel in the SGPR offset.
+template <typename T, int BM, int BN, int WM, int WN, bool BUF>
+__device__ __forceinline__ void conv_gemm_rs_body(const T* __restrict__ X, const T* __restrict__ W, T* __restrict__ Y,
+                                                  const T* __restrict__ ZERO, const GatherGeom& g, const Epilogue& ep) {
     constexpr int VEC = 8, BKV = 8;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int NW = WM * WN, NT = 64 * NW;
@@ -986,6 +987,20 @@ __global__ __launch_bounds__(64 * WM * WN, BN <= 64 ? 3 : 2) void conv_gemm_rs_k
         a_off[q] = (a_ok[q] ? pix : 0) * g.ldx;
         a_lv[q] = lvec ^ lds_swz<BKV>(rho);
     }
+    // BUF: byte offsets behind the descriptor bases (X: one image row in front of the tensor) and, per piece, which of the three kernel
+    // rows leave the image (bit 3q + 1 + dy); a pixel that does not exist carries bit 31 for good
+    const int rowstep = g.IW * g.ldx;
+    unsigned a_nokm = 0u;
+    et_rsrc rsX, rsW;
+    if constexpr (BUF) {
+        rsX = et_make_rsrc((const char*)X - (size_t)rowstep * sizeof(T), (unsigned)(((size_t)g.N * g.IH * g.IW * g.ldx + rowstep) * sizeof(T)));
+        rsW = et_make_rsrc(W, (unsigned)((size_t)g.Cout * g.TT * g.Cin * sizeof(T)));
+#pragma unroll
+        for (int q = 0; q < RA; ++q) {
+            a_nokm |= ((a_iy[q] > 0 ? 0u : 1u) | (a_iy[q] + 1 < g.IH ? 0u : 4u)) << (3 * q);
+            a_off[q] = a_ok[q] ? (int)((a_off[q] + a_lv[q] * VEC) * (int)sizeof(T)) : (int)0x80000000;
+        }
+    }
     int b_off[RB], b_lv[RB];
     bool b_ok[RB];
 #pragma unroll
@@ -995,6 +1010,8 @@ __global__ __launch_bounds__(64 * WM * WN, BN <= 64 ? 3 : 2) void conv_gemm_rs_k
         b_ok[q] = co < g.Cout;
         b_off[q] = (b_ok[q] ? co : 0) * g.TT * g.Cin;
         b_lv[q] = lvec ^ lds_swz<BKV>(rl);
+        // BUF: the UNCLAMPED row -- a row beyond Cout lies beyond the weight descriptor's range and lands as zeros
+        if constexpr (BUF) b_off[q] = (int)((co * g.TT * g.Cin + b_lv[q] * VEC) * (int)sizeof(T));
     }
     // byte offset (inside an A unit) of this lane's k-step-0 fragment of row tile tm at step shift s; a k-step XORs bits 5-6 of it
     // (the swizzle is an XOR on the K-vector slot): one v_xor per fragment read instead of a swizzle computation
@@ -1026,9 +1043,14 @@ __global__ __launch_bounds__(64 * WM * WN, BN <= 64 ? 3 : 2) void conv_gemm_rs_k
 #pragma unroll
         for (int q = 0; q < RA; ++q) {
             if (q == RAF && wave >= XW) continue;        // wave-uniform: the short last pass
-            const bool ok = a_ok[q] && (unsigned)(a_iy[q] + dy) < (unsigned)g.IH;
-            const T* src = ok ? X + (a_off[q] + roff + a_lv[q] * VEC) : ZERO;
-            et_glds16(src, wbase + q * NT);
+            if constexpr (BUF) {
+                const unsigned bad = (a_nokm >> (3 * q + 1 + dy)) & 1u;
+                et_bufdma16(rsX, (bad << 31) | (unsigned)a_off[q], (unsigned)(((dy + 1) * rowstep + cv_c * VEC) * (int)sizeof(T)), wbase + q * NT);
+            } else {
+                const bool ok = a_ok[q] && (unsigned)(a_iy[q] + dy) < (unsigned)g.IH;
+                const T* src = ok ? X + (a_off[q] + roff + a_lv[q] * VEC) : ZERO;
+                et_glds16(src, wbase + q * NT);
+            }
         }
     };
     auto stage_b = [&](u32x4* dst, int tap, int cv_c) {
@@ -1036,8 +1058,12 @@ __global__ __launch_bounds__(64 * WM * WN, BN <= 64 ? 3 : 2) void conv_gemm_rs_k
         const int woff = tap * g.Cin + cv_c * VEC;
 #pragma unroll
         for (int q = 0; q < RB; ++q) {
-            const T* src = b_ok[q] ? W + (b_off[q] + woff + b_lv[q] * VEC) : ZERO;
-            et_glds16(src, wbase + q * NT);
+            if constexpr (BUF) {
+                et_bufdma16(rsW, (unsigned)b_off[q], (unsigned)(woff * (int)sizeof(T)), wbase + q * NT);
+            } else {
+                const T* src = b_ok[q] ? W + (b_off[q] + woff + b_lv[q] * VEC) : ZERO;
+                et_glds16(src, wbase + q * NT);
+            }
         }
     };
     // one step: TM x TN x 4 MFMAs, A fragments from the unit at row offset SFT
@@ -1104,6 +1130,18 @@ __global__ __launch_bounds__(64 * WM * WN, BN <= 64 ? 3 : 2) void conv_gemm_rs_k
     }
     __syncthreads();                                     // the epilogue reuses the ring as its staging area
     conv_epilogue<T, BM, BN, WM, WN>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn);
+}
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, BN <= 64 ? 3 : 2) void conv_gemm_rs_flat_kernel(const T* __restrict__ X, const T* __restrict__ W,
+                                                                            T* __restrict__ Y, const T* __restrict__ ZERO,
+                                                                            GatherGeom g, Epilogue ep) {
+    conv_gemm_rs_body<T, BM, BN, WM, WN, false>(X, W, Y, ZERO, g, ep);       // flat-address twin: operands of 2^31 bytes and more
+}
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, BN <= 64 ? 3 : 2) void conv_gemm_rs_kernel(const T* __restrict__ X, const T* __restrict__ W,
+                                                                       T* __restrict__ Y, const T* __restrict__ ZERO,
+                                                                       GatherGeom g, Epilogue ep) {
+    conv_gemm_rs_body<T, BM, BN, WM, WN, true>(X, W, Y, ZERO, g, ep);
 }
 
 // ---- forward / dgrad gather-GEMM, 256x256 tile, two wave groups in anti-phase ("ping-pong") ----------------
@@ -2984,8 +3022,8 @@ static int launch_gemm(const void* X, const void* W, void* Y, const void* zero16
                 // the flat-address form remains for larger tensors.  Same-box A/B on the step: -0.13 ms in 20-step and in 200-step runs
                 // (profiles/r06_pprs_buffer_dma_ab.txt)
                 const size_t xb = ((size_t)g.N * g.IH * g.IW * g.ldx + (size_t)g.IW * g.ldx) * sizeof(T), wb = (size_t)g.Cout * g.TT * g.Cin * sizeof(T);
-                // (ET_CONV_PPRS_FLAT=1: test hook, read per call -- the flat form on shapes that do not need it)
-                if (xb < (1ull << 31) && wb < (1ull << 31) && !env_int("ET_CONV_PPRS_FLAT", 0))
+                // (ET_CONV_FLAT_DMA=1: test hook, read per call -- the flat form on shapes that do not need it)
+                if (xb < (1ull << 31) && wb < (1ull << 31) && !env_int("ET_CONV_FLAT_DMA", 0))
                     hipLaunchKernelGGL((conv_gemm_pprs_kernel<T>), grid, block, 0, s, x, w, y, z, g, ep);
                 else
                     hipLaunchKernelGGL((conv_gemm_pprs_flat_kernel<T>), grid, block, 0, s, x, w, y, z, g, ep);
@@ -2996,8 +3034,15 @@ static int launch_gemm(const void* X, const void* W, void* Y, const void* zero16
     }
     if (p.kind == GEMM_RS) {
         if constexpr (sizeof(T) == 2) {
-            if (p.BN == 128) hipLaunchKernelGGL((conv_gemm_rs_kernel<T, 128, 128, 2, 2>), grid, block, 0, s, x, w, y, z, g, ep);
-            else hipLaunchKernelGGL((conv_gemm_rs_kernel<T, 128, 64, 2, 2>), grid, block, 0, s, x, w, y, z, g, ep);
+            const size_t xb = ((size_t)g.N * g.IH * g.IW * g.ldx + (size_t)g.IW * g.ldx) * sizeof(T), wb = (size_t)g.Cout * g.TT * g.Cin * sizeof(T);
+            // buffer-descriptor LDS-DMA below 2^31 bytes per operand (isolated -8...-10 % on 128 -> 128 @80x80; the step: neutral, 50.26 vs
+            // 50.22 ms over 100-step runs -- the power limit, profiles/r06_power_limit.txt -- adopted for the per-launch cost and because it
+            // needs no zero page); ET_CONV_FLAT_DMA=1: test hook for the flat twin
+            if (xb < (1ull << 31) && wb < (1ull << 31) && !env_int("ET_CONV_FLAT_DMA", 0)) {
+                if (p.BN == 128) hipLaunchKernelGGL((conv_gemm_rs_kernel<T, 128, 128, 2, 2>), grid, block, 0, s, x, w, y, z, g, ep);
+                else hipLaunchKernelGGL((conv_gemm_rs_kernel<T, 128, 64, 2, 2>), grid, block, 0, s, x, w, y, z, g, ep);
+            } else if (p.BN == 128) hipLaunchKernelGGL((conv_gemm_rs_flat_kernel<T, 128, 128, 2, 2>), grid, block, 0, s, x, w, y, z, g, ep);
+            else hipLaunchKernelGGL((conv_gemm_rs_flat_kernel<T, 128, 64, 2, 2>), grid, block, 0, s, x, w, y, z, g, ep);
             return 0;
         }
         return -2;
@@ -3493,9 +3538,9 @@ extern "C" int et_conv2d_kernel_name(int op, int dtype, int N, int IH, int IW, i
 
 extern "C" int et_env_knobs(char* buf, int buflen) {
     // every ET_* runtime knob that is SET in this process's environment, as "NAME=value;..." (bench.py records it).  The complete list:
-    // four test hooks (persistent-grid sizes, the BatchNorm finalize form, the flat-address twin of the dominant kernel), the opt-in arms that change WHAT runs beside what (step
+    // four test hooks (persistent-grid sizes, the BatchNorm finalize form, the flat-address twins of the row-shift kernels), the opt-in arms that change WHAT runs beside what (step
     // graph, weight-gradient stream), the data-parallel transport settings, and the experiment-library path.
-    static const char* names[] = {"ET_CONV_S1_WGS", "ET_CONV_STEM_WGS", "ET_CONV_PPRS_FLAT", "ET_BN_FIN_SMALL", "ET_STEP_GRAPH", "ET_WGRAD_STREAM",
+    static const char* names[] = {"ET_CONV_S1_WGS", "ET_CONV_STEM_WGS", "ET_CONV_FLAT_DMA", "ET_BN_FIN_SMALL", "ET_STEP_GRAPH", "ET_WGRAD_STREAM",
                                   "ET_ALLREDUCE_CHUNK_MB", "ET_ALLREDUCE_DTYPE", "ET_RCCL_CHANNELS", "ET_DP_SINGLE_RANK", "ET_HIP_LIB"};
     if (!buf || buflen < 1) return -1;
     int off = 0;

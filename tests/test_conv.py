@@ -249,7 +249,7 @@ SELECT = [
     ((1, 10, 11, 64, 256, 1, 1, 0), S1, [GLDS + "128, 64, 2, 2, 4, 3, true>"], "conv_wgrad_tr_kernel<128, 64, 2, 2>"),
 ]
 STREAM_CASES = [c for c in SELECT if c[1].startswith(S1)]
-PPRS_CASES = [c for c in SELECT if c[1] == "conv_gemm_pprs_kernel" or (c[2] and "conv_gemm_pprs_kernel" in c[2])]
+PPRS_CASES = [c for c in SELECT if c[1] in ("conv_gemm_pprs_kernel", RS128, RS64) or (c[2] and any(k in ("conv_gemm_pprs_kernel", RS128, RS64) for k in c[2]))]
 
 
 @pytest.mark.parametrize("case,kf,kd,kw", SELECT, ids=[str(c[0]) for c in SELECT])
@@ -260,13 +260,13 @@ def test_bench_instantiations_elementwise(hip, case, kf, kd, kw):
 
 
 @pytest.mark.parametrize("case,kf,kd,kw", PPRS_CASES, ids=[str(c[0]) for c in PPRS_CASES])
-def test_pprs_flat_address_twin(hip, case, kf, kd, kw, monkeypatch):
-    """conv_gemm_pprs_kernel stages through buffer descriptors (r06: out-of-range lanes land as zeros, no zero page) wherever both
-    operands sit below 2^31 bytes -- every shape of the model.  Its flat-address twin (conv_gemm_pprs_flat_kernel: the r05 form, kept for
-    larger tensors) is the same loop with the other addressing: run the same element-wise checks on it (ET_CONV_PPRS_FLAT=1, a test
-    hook read per launch)."""
-    assert len(PPRS_CASES) >= 3
-    monkeypatch.setenv("ET_CONV_PPRS_FLAT", "1")
+def test_row_shift_flat_address_twins(hip, case, kf, kd, kw, monkeypatch):
+    """conv_gemm_pprs_kernel / conv_gemm_rs_kernel stage through buffer descriptors (r06: out-of-range lanes land as zeros, no zero page)
+    wherever both operands sit below 2^31 bytes -- every shape of the model.  Their flat-address twins (conv_gemm_*_flat_kernel: the r05
+    form, kept for larger tensors) are the same loops with the other addressing: run the same element-wise checks on them
+    (ET_CONV_FLAT_DMA=1, a test hook read per launch)."""
+    assert len(PPRS_CASES) >= 6
+    monkeypatch.setenv("ET_CONV_FLAT_DMA", "1")
     _check_instantiation(hip, case, kf, kd, kw)
 
 
