@@ -276,3 +276,23 @@ def test_deterministic_switch_selects_the_partial_row_path_and_is_bit_reproducib
     assert m2._flat.deterministic and m2._flat.bn_shards is None
     model.set_deterministic(False)
     assert model._flat.bn_shards is not None
+
+
+def test_additions_per_channel_follow_the_selected_kernel(hip):
+    """et_conv2d_stats_adds_for: what decides whether a layer's statistics are sharded (ops.SHARD_MAX_ADDS) -- one fp32 atomic addition per
+    channel and WORKGROUP that covers it (r06: the tiled kernels pre-reduce their wave rows in LDS): row tiles of the tiled kernels, resident
+    workgroups of the persistent ones; never more than the partial rows of the same call."""
+    from efficientteacher_amd import ops
+    dt = torch.bfloat16
+    # 128 -> 128 3x3 @80x80, 64 images: 128-row tiles -> 3200 additions (the layers r06 brought under the threshold), 6400 partial rows
+    assert ops.kernel_name("fwd", dt, 64, 80, 80, 128, 128, 3, 1, 1).startswith("conv_gemm_rs_kernel")
+    assert ops.stats_adds("fwd", dt, 64, 80, 80, 128, 128, 3, 1, 1) == 3200 and ops.stats_rows("fwd", dt, 64, 80, 80, 128, 128, 3, 1, 1) == 6400
+    assert ops.few_rows("fwd", dt, 64, 80, 80, 128, 128, 3, 1, 1) and ops.few_rows("dgrad_bn", dt, 64, 80, 80, 128, 128, 3, 1, 1)
+    # 256-row ping-pong tiles: one addition per 256 output pixels
+    assert ops.stats_adds("fwd", dt, 64, 40, 40, 256, 256, 3, 1, 1) == 400
+    # 64 -> 64 3x3 @160x160: 12800 row tiles -> stays on partial rows + finalize
+    assert ops.stats_adds("fwd", dt, 64, 160, 160, 64, 64, 3, 1, 1) == 12800 and not ops.few_rows("fwd", dt, 64, 160, 160, 64, 64, 3, 1, 1)
+    # persistent kernels: the resident grid, whatever the tensor size
+    assert ops.stats_adds("fwd", dt, 64, 160, 160, 64, 64, 1, 1, 0) <= 512 and ops.stats_adds("fwd", dt, 64, 640, 640, 8, 64, 6, 2, 2) <= 512
+    for a in [(2, 24, 24, 64, 128, 3, 2, 1), (1, 9, 11, 64, 40, 3, 1, 1), (2, 13, 13, 128, 128, 1, 1, 0)]:
+        assert 1 <= ops.stats_adds("fwd", dt, *a) <= ops.stats_rows("fwd", dt, *a)
