@@ -750,6 +750,27 @@ def roofline_of(res, dump=None):
     return roof, conv_fl
 
 
+def roofline_power(executed_flops, hbm_bytes, step_s):
+    """The third roofline of this part: ENERGY.  The step runs with the package power tracker as its active limiter (profiles/
+    r06_power_limit.txt: amd-smi PPT violations accumulate, no thermal ones; 1.15-1.28 kW sampled), so its floor is
+    (executed FLOPs x energy per MFMA flop + HBM bytes x energy per byte) / (power cap - idle power), with the per-operation energies
+    MEASURED on the part (profiles/energy_model.json <- tools/probe/kernel_power.py).  `frac` = that floor / the measured step;
+    `implied_mean_power_w` = the package power the same energy needs at the measured step time (compare with rocm-smi's samples)."""
+    try:
+        m = json.load(open(os.path.join(ROOT, "profiles", "energy_model.json")))
+        e = executed_flops * m["pj_per_mfma_flop"] * 1e-12 + (hbm_bytes or 0.0) * m["pj_per_hbm_byte"] * 1e-12
+        floor = e / (m["cap_w"] - m["idle_w"])
+        return dict(bound="power", energy_j_per_step=round(e, 2), mfma_j=round(executed_flops * m["pj_per_mfma_flop"] * 1e-12, 2),
+                    hbm_j=round((hbm_bytes or 0.0) * m["pj_per_hbm_byte"] * 1e-12, 2), cap_w=m["cap_w"], idle_w=m["idle_w"],
+                    floor_ms=round(floor * 1e3, 2), frac=round(floor / step_s, 4),
+                    implied_mean_power_w=round(e / step_s + m["idle_w"], 0),
+                    pj_per_mfma_flop=m["pj_per_mfma_flop"], pj_per_hbm_byte=m["pj_per_hbm_byte"], source="profiles/energy_model.json",
+                    note="energy floor of the step at the package power cap; the step's clock (2.04-2.09 GHz of 2.4) is set by this limiter, "
+                         "so roofline.frac against 2.5 PFLOP/s and this figure describe the same distance from two sides")
+    except Exception as ex:
+        return dict(bound="power", error=f"{type(ex).__name__}: {ex}"[:200])
+
+
 def roofline_hbm(workload, per_rank, step_s):
     """the HBM side of the step: bytes moved per step (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over EVERY kernel of this very
     command, separate passes, FETCH doubled per the gfx950 note: profiles/pmc_traffic.json, tools/pmc_to_traffic.py) divided by
@@ -913,6 +934,7 @@ def main():
             "roofline_hbm": roofline_hbm(a.workload, per_rank, dt / a.steps),
             "kernel_ms_by_family": res.get("families"),
         }
+        out["roofline_power"] = roofline_power(step_flop, (out["roofline_hbm"] or {}).get("traffic"), dt / a.steps)
         if ssod and world == 8 and per_rank == 16:
             out["scaling_note"] = ("BASELINE configs[3]: the global batch equals that of 4 ranks at configs[2]'s per-GPU batch (strong "
                                    "scaling 4 -> 8); the per-GPU-work-fixed point of the same 8 ranks is `weak_scaling_point`")
