@@ -108,7 +108,14 @@ __device__ __forceinline__ Slot eval_slot(const LossArgs& A, const LossLevel& L,
     return r;
 }
 
-__global__ __launch_bounds__(256) void loss_count_kernel(LossArgs A, LossLevel L, int level) {
+// r06: the pyramid levels of one loss run in ONE launch per kernel (blockIdx.z = level; they are independent of each other, count ->
+// pos -> obj is the only order that matters): 8 launches per loss instead of 14 in the low-power gap between the step's forward and
+// backward (profiles/r06_loss_levels_one_launch_ab.txt)
+struct LossLevels { LossLevel l[LOSS_MAXL]; float fixed_n[LOSS_MAXL]; };
+
+__global__ __launch_bounds__(256) void loss_count_kernel(LossArgs A, LossLevels Ls) {
+    const int level = blockIdx.z;
+    const LossLevel& L = Ls.l[level];
     const int nslot = 5 * A.na * A.NT;
     const int s = blockIdx.x * 256 + threadIdx.x;
     const int pass = blockIdx.y;
@@ -244,7 +251,9 @@ __device__ __forceinline__ float loss_class_walk(const LossArgs& A, const LossLe
     return cls_sum;
 }
 
-__global__ __launch_bounds__(256) void loss_pos_kernel(LossArgs A, LossLevel L, int level) {
+__global__ __launch_bounds__(256) void loss_pos_kernel(LossArgs A, LossLevels Ls) {
+    const int level = blockIdx.z;
+    const LossLevel& L = Ls.l[level];
     const int nslot = 5 * A.na * A.NT;
     const int s = blockIdx.x * 256 + threadIdx.x;
     const int pass = blockIdx.y;
@@ -318,7 +327,10 @@ __global__ __launch_bounds__(256) void loss_pos_kernel(LossArgs A, LossLevel L, 
 }
 
 // mode 0: count non-ignored cells only; mode 1: loss sum + gradient (denominator read from acc)
-__global__ __launch_bounds__(256) void loss_obj_kernel(LossArgs A, LossLevel L, int level, int mode, float fixed_n) {
+__global__ __launch_bounds__(256) void loss_obj_kernel(LossArgs A, LossLevels Ls, int mode) {
+    const int level = blockIdx.z;
+    const LossLevel& L = Ls.l[level];
+    const float fixed_n = Ls.fixed_n[level];
     // grid-stride over the cells, ONE atomic per workgroup: with a thread per cell and an atomic per wave the 80x80 level
     // sent 9600 adds to the same address (tools/probe/probe_stat_atomics: same-address atomics serialise at ~20-100 ns each)
     const unsigned ncell = (unsigned)A.B * A.na * L.ny * L.nx;          // host: < 2^31
@@ -326,6 +338,7 @@ __global__ __launch_bounds__(256) void loss_obj_kernel(LossArgs A, LossLevel L, 
     float lsum = 0.f, cnt = 0.f;
     const float n = (mode == 1) ? (fixed_n > 0.f ? fixed_n : A.acc[level * 16 + ACC_OBJN]) : 1.f;
     const float bal = (mode == 1) ? (A.balance_dev ? A.balance_dev[level] : L.balance) : 0.f;
+    if (blockIdx.x * 256u >= ncell) return;            // the launch is sized for the largest level: workgroups beyond this level's cells
     for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < ncell; i += gridDim.x * 256u) {
         const unsigned long long w = L.tobj[i];
         const float t = w ? __uint_as_float((unsigned)(w & 0xffffffffull)) : 0.0f;
@@ -785,29 +798,34 @@ extern "C" int et_yolo_loss(const et_loss_desc* d, et_stream_t stream) {
     (void)hipMemsetAsync(d->acc_ws, 0, sizeof(float) * 16 * LOSS_MAXL, s);
     float bal[4] = {0, 0, 0, 0};
     long long ncell[4] = {0, 0, 0, 0};
+    LossLevels Ls;
+    long long ob_max = 1;
     for (int l = 0; l < d->nl; ++l) {
         const et_loss_level* e = &d->level[l];
         if (!e->p || !e->dp || !e->tobj_ws) return -1;
-        LossLevel L;
+        LossLevel& L = Ls.l[l];
         L.p = e->p; L.dp = e->dp; L.tobj = (unsigned long long*)e->tobj_ws;
         L.sb = e->sb; L.sa = e->sa; L.sy = e->sy; L.sx = e->sx; L.ny = e->ny; L.nx = e->nx;
         for (int a = 0; a < d->na; ++a) { L.anchors[a][0] = e->anchors[2 * a]; L.anchors[a][1] = e->anchors[2 * a + 1]; }
         L.balance = e->balance;
         bal[l] = e->balance;
         ncell[l] = (long long)d->B * d->na * e->ny * e->nx;
-        (void)hipMemsetAsync(e->tobj_ws, 0, (size_t)ncell[l] * 8, s);
-        const int nslot = 5 * d->na * d->NT;
-        if (nslot > 0) {
-            const dim3 grid((nslot + 255) / 256, LOSS_NPASS);
-            hipLaunchKernelGGL(loss_count_kernel, grid, dim3(256), 0, s, A, L, l);
-            hipLaunchKernelGGL(loss_pos_kernel, grid, dim3(256), 0, s, A, L, l);
-        }
         if (ncell[l] >= (1ll << 31)) return -2;
+        Ls.fixed_n[l] = d->ignore_obj ? 0.f : (float)ncell[l];
         const long long ob = et_cdiv(ncell[l], 256);
-        const dim3 og((unsigned)(ob < 512 ? ob : 512));              // two workgroups per CU, grid-stride
-        if (d->ignore_obj) hipLaunchKernelGGL(loss_obj_kernel, og, dim3(256), 0, s, A, L, l, 0, 0.f);
-        hipLaunchKernelGGL(loss_obj_kernel, og, dim3(256), 0, s, A, L, l, 1, d->ignore_obj ? 0.f : (float)ncell[l]);
+        ob_max = ob > ob_max ? ob : ob_max;
+        (void)hipMemsetAsync(e->tobj_ws, 0, (size_t)ncell[l] * 8, s);
     }
+    for (int l = d->nl; l < LOSS_MAXL; ++l) { Ls.l[l] = Ls.l[0]; Ls.fixed_n[l] = 0.f; }
+    const int nslot = 5 * d->na * d->NT;
+    if (nslot > 0) {
+        const dim3 grid((nslot + 255) / 256, LOSS_NPASS, d->nl);
+        hipLaunchKernelGGL(loss_count_kernel, grid, dim3(256), 0, s, A, Ls);
+        hipLaunchKernelGGL(loss_pos_kernel, grid, dim3(256), 0, s, A, Ls);
+    }
+    const dim3 og((unsigned)(ob_max < 512 ? ob_max : 512), 1, d->nl);     // two workgroups per CU and level, grid-stride
+    if (d->ignore_obj) hipLaunchKernelGGL(loss_obj_kernel, og, dim3(256), 0, s, A, Ls, 0);
+    hipLaunchKernelGGL(loss_obj_kernel, og, dim3(256), 0, s, A, Ls, 1);
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, s, A, bal[0], bal[1], bal[2], bal[3], ncell[0], ncell[1],
                        ncell[2], ncell[3], d->out);
     ET_CHECK_LAUNCH();
