@@ -1132,13 +1132,13 @@ __device__ __forceinline__ void conv_gemm_rs_body(const T* __restrict__ X, const
     conv_epilogue<T, BM, BN, WM, WN>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn);
 }
 template <typename T, int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN, BN <= 64 ? 3 : 2) void conv_gemm_rs_flat_kernel(const T* __restrict__ X, const T* __restrict__ W,
-                                                                            T* __restrict__ Y, const T* __restrict__ ZERO,
-                                                                            GatherGeom g, Epilogue ep) {
-    conv_gemm_rs_body<T, BM, BN, WM, WN, false>(X, W, Y, ZERO, g, ep);       // flat-address twin: operands of 2^31 bytes and more
+__global__ __launch_bounds__(64 * WM * WN, BN <= 64 ? 3 : 2) void conv_gemm_rs_kernel(const T* __restrict__ X, const T* __restrict__ W,
+                                                                       T* __restrict__ Y, const T* __restrict__ ZERO,
+                                                                       GatherGeom g, Epilogue ep) {
+    conv_gemm_rs_body<T, BM, BN, WM, WN, false>(X, W, Y, ZERO, g, ep);       // flat addresses: the default
 }
 template <typename T, int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN, BN <= 64 ? 3 : 2) void conv_gemm_rs_kernel(const T* __restrict__ X, const T* __restrict__ W,
+__global__ __launch_bounds__(64 * WM * WN, BN <= 64 ? 3 : 2) void conv_gemm_rs_buf_kernel(const T* __restrict__ X, const T* __restrict__ W,
                                                                        T* __restrict__ Y, const T* __restrict__ ZERO,
                                                                        GatherGeom g, Epilogue ep) {
     conv_gemm_rs_body<T, BM, BN, WM, WN, true>(X, W, Y, ZERO, g, ep);
@@ -1596,18 +1596,18 @@ __device__ __forceinline__ void conv_gemm_pprs_body(const T* __restrict__ X, con
 #undef ET_PP_BAR
 #undef ET_PP_WAIT
 }
-// the kernel rocprofv3 shows (buffer-descriptor LDS-DMA) and its flat-address twin for operands of 2^31 bytes and more
+// the default (flat addresses) and the experimental buffer-descriptor twin (ET_CONV_BUF_DMA=1)
 template <typename T>
 __global__ __launch_bounds__(512, 2) void conv_gemm_pprs_kernel(const T* __restrict__ X, const T* __restrict__ W,
                                                                 T* __restrict__ Y, const T* __restrict__ ZERO,
                                                                 GatherGeom g, Epilogue ep) {
-    conv_gemm_pprs_body<T, true>(X, W, Y, ZERO, g, ep);
+    conv_gemm_pprs_body<T, false>(X, W, Y, ZERO, g, ep);
 }
 template <typename T>
-__global__ __launch_bounds__(512, 2) void conv_gemm_pprs_flat_kernel(const T* __restrict__ X, const T* __restrict__ W,
-                                                                     T* __restrict__ Y, const T* __restrict__ ZERO,
-                                                                     GatherGeom g, Epilogue ep) {
-    conv_gemm_pprs_body<T, false>(X, W, Y, ZERO, g, ep);
+__global__ __launch_bounds__(512, 2) void conv_gemm_pprs_buf_kernel(const T* __restrict__ X, const T* __restrict__ W,
+                                                                    T* __restrict__ Y, const T* __restrict__ ZERO,
+                                                                    GatherGeom g, Epilogue ep) {
+    conv_gemm_pprs_body<T, true>(X, W, Y, ZERO, g, ep);
 }
 
 // ---- 1x1 stride-1 layers with <= 256 input and <= 256 output channels: persistent streaming GEMM ---------------------------
@@ -3018,15 +3018,15 @@ static int launch_gemm(const void* X, const void* W, void* Y, const void* zero16
     if (p.kind == GEMM_PPRS) {
         if constexpr (sizeof(T) == 2) {
             {
-                // buffer-descriptor LDS-DMA (BUF) wherever both operands sit below 2^31 bytes (bit 31 of a lane's offset = "out of range");
-                // the flat-address form remains for larger tensors.  Same-box A/B on the step: -0.13 ms in 20-step and in 200-step runs
-                // (profiles/r06_pprs_buffer_dma_ab.txt)
+                // ET_CONV_BUF_DMA=1 (EXPERIMENT, off by default): buffer-descriptor LDS-DMA, operands below 2^31 bytes (bit 31 of a lane's
+                // offset = "out of range").  -0.13 ms on the step here (profiles/r06_pprs_buffer_dma_ab.txt) and every test of this kernel
+                // green -- but the same addressing form produced wrong tiles in conv_gemm_rs_kernel<128, 64> on the hardware for one map
+                // width (profiles/r06_buffer_dma_mismatch.txt) for a reason not understood, so nothing ships on it
                 const size_t xb = ((size_t)g.N * g.IH * g.IW * g.ldx + (size_t)g.IW * g.ldx) * sizeof(T), wb = (size_t)g.Cout * g.TT * g.Cin * sizeof(T);
-                // (ET_CONV_FLAT_DMA=1: test hook, read per call -- the flat form on shapes that do not need it)
-                if (xb < (1ull << 31) && wb < (1ull << 31) && !env_int("ET_CONV_FLAT_DMA", 0))
-                    hipLaunchKernelGGL((conv_gemm_pprs_kernel<T>), grid, block, 0, s, x, w, y, z, g, ep);
+                if (env_int("ET_CONV_BUF_DMA", 0) && xb < (1ull << 31) && wb < (1ull << 31))
+                    hipLaunchKernelGGL((conv_gemm_pprs_buf_kernel<T>), grid, block, 0, s, x, w, y, z, g, ep);
                 else
-                    hipLaunchKernelGGL((conv_gemm_pprs_flat_kernel<T>), grid, block, 0, s, x, w, y, z, g, ep);
+                    hipLaunchKernelGGL((conv_gemm_pprs_kernel<T>), grid, block, 0, s, x, w, y, z, g, ep);
             }
             return 0;
         }
@@ -3035,14 +3035,15 @@ static int launch_gemm(const void* X, const void* W, void* Y, const void* zero16
     if (p.kind == GEMM_RS) {
         if constexpr (sizeof(T) == 2) {
             const size_t xb = ((size_t)g.N * g.IH * g.IW * g.ldx + (size_t)g.IW * g.ldx) * sizeof(T), wb = (size_t)g.Cout * g.TT * g.Cin * sizeof(T);
-            // buffer-descriptor LDS-DMA below 2^31 bytes per operand (isolated -8...-10 % on 128 -> 128 @80x80; the step: neutral, 50.26 vs
-            // 50.22 ms over 100-step runs -- the power limit, profiles/r06_power_limit.txt -- adopted for the per-launch cost and because it
-            // needs no zero page); ET_CONV_FLAT_DMA=1: test hook for the flat twin
-            if (xb < (1ull << 31) && wb < (1ull << 31) && !env_int("ET_CONV_FLAT_DMA", 0)) {
-                if (p.BN == 128) hipLaunchKernelGGL((conv_gemm_rs_kernel<T, 128, 128, 2, 2>), grid, block, 0, s, x, w, y, z, g, ep);
-                else hipLaunchKernelGGL((conv_gemm_rs_kernel<T, 128, 64, 2, 2>), grid, block, 0, s, x, w, y, z, g, ep);
-            } else if (p.BN == 128) hipLaunchKernelGGL((conv_gemm_rs_flat_kernel<T, 128, 128, 2, 2>), grid, block, 0, s, x, w, y, z, g, ep);
-            else hipLaunchKernelGGL((conv_gemm_rs_flat_kernel<T, 128, 64, 2, 2>), grid, block, 0, s, x, w, y, z, g, ep);
+            // ET_CONV_BUF_DMA=1 (EXPERIMENT, off by default): the buffer-descriptor form of the LDS-DMA pieces.  Isolated -8...-10 % on
+            // 128 -> 128 @80x80, step-neutral (the power limit) -- and WRONG on the hardware for conv_gemm_rs_kernel<128, 64> on 160-pixel-wide
+            // maps with several workgroups per CU (scattered 64-pixel x 32-channel wave tiles differ from the flat form from run to run;
+            // the emulator, every other shape and the 128-wide tile agree bit for bit): profiles/r06_buffer_dma_mismatch.txt
+            if (env_int("ET_CONV_BUF_DMA", 0) && xb < (1ull << 31) && wb < (1ull << 31)) {
+                if (p.BN == 128) hipLaunchKernelGGL((conv_gemm_rs_buf_kernel<T, 128, 128, 2, 2>), grid, block, 0, s, x, w, y, z, g, ep);
+                else hipLaunchKernelGGL((conv_gemm_rs_buf_kernel<T, 128, 64, 2, 2>), grid, block, 0, s, x, w, y, z, g, ep);
+            } else if (p.BN == 128) hipLaunchKernelGGL((conv_gemm_rs_kernel<T, 128, 128, 2, 2>), grid, block, 0, s, x, w, y, z, g, ep);
+            else hipLaunchKernelGGL((conv_gemm_rs_kernel<T, 128, 64, 2, 2>), grid, block, 0, s, x, w, y, z, g, ep);
             return 0;
         }
         return -2;
@@ -3538,9 +3539,9 @@ extern "C" int et_conv2d_kernel_name(int op, int dtype, int N, int IH, int IW, i
 
 extern "C" int et_env_knobs(char* buf, int buflen) {
     // every ET_* runtime knob that is SET in this process's environment, as "NAME=value;..." (bench.py records it).  The complete list:
-    // four test hooks (persistent-grid sizes, the BatchNorm finalize form, the flat-address twins of the row-shift kernels), the opt-in arms that change WHAT runs beside what (step
+    // three test hooks (persistent-grid sizes, the BatchNorm finalize form), the experimental buffer-descriptor staging of the row-shift kernels, the opt-in arms that change WHAT runs beside what (step
     // graph, weight-gradient stream), the data-parallel transport settings, and the experiment-library path.
-    static const char* names[] = {"ET_CONV_S1_WGS", "ET_CONV_STEM_WGS", "ET_CONV_FLAT_DMA", "ET_BN_FIN_SMALL", "ET_STEP_GRAPH", "ET_WGRAD_STREAM",
+    static const char* names[] = {"ET_CONV_S1_WGS", "ET_CONV_STEM_WGS", "ET_CONV_BUF_DMA", "ET_BN_FIN_SMALL", "ET_STEP_GRAPH", "ET_WGRAD_STREAM",
                                   "ET_ALLREDUCE_CHUNK_MB", "ET_ALLREDUCE_DTYPE", "ET_RCCL_CHANNELS", "ET_DP_SINGLE_RANK", "ET_HIP_LIB"};
     if (!buf || buflen < 1) return -1;
     int off = 0;

@@ -260,13 +260,13 @@ def test_bench_instantiations_elementwise(hip, case, kf, kd, kw):
 
 
 @pytest.mark.parametrize("case,kf,kd,kw", PPRS_CASES, ids=[str(c[0]) for c in PPRS_CASES])
-def test_row_shift_flat_address_twins(hip, case, kf, kd, kw, monkeypatch):
-    """conv_gemm_pprs_kernel / conv_gemm_rs_kernel stage through buffer descriptors (r06: out-of-range lanes land as zeros, no zero page)
-    wherever both operands sit below 2^31 bytes -- every shape of the model.  Their flat-address twins (conv_gemm_*_flat_kernel: the r05
-    form, kept for larger tensors) are the same loops with the other addressing: run the same element-wise checks on them
-    (ET_CONV_FLAT_DMA=1, a test hook read per launch)."""
+def test_row_shift_buffer_descriptor_twins(hip, case, kf, kd, kw, monkeypatch):
+    """EXPERIMENTAL arm (ET_CONV_BUF_DMA=1, off by default): conv_gemm_pprs_buf_kernel / conv_gemm_rs_buf_kernel stage their LDS-DMA
+    pieces through buffer descriptors (out-of-range lanes land as zeros: no zero page).  Same loops, other addressing: the same
+    element-wise checks.  These shapes are green on the hardware too; what is NOT is conv_gemm_rs_buf_kernel<128, 64> on 160-pixel-wide
+    maps with several workgroups per CU (profiles/r06_buffer_dma_mismatch.txt) -- the reason the arm is not the default."""
     assert len(PPRS_CASES) >= 6
-    monkeypatch.setenv("ET_CONV_FLAT_DMA", "1")
+    monkeypatch.setenv("ET_CONV_BUF_DMA", "1")
     _check_instantiation(hip, case, kf, kd, kw)
 
 
