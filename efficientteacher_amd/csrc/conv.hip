@@ -314,7 +314,7 @@ __device__ __forceinline__ void conv_epilogue_write_stats(EpiSums<BN / WN / 32>&
 // instead of WM times that.  r06: the tiled kernels end their epilogue with the same pre-reduction (n0 = the tile's first channel) --
 // the barrier sits AFTER every wave's store passes, where a wave that is done could only idle until its workgroup retires anyway --
 // which halves the additions per address of the 2-wave-row tiles and brings the 3200-tile layers (128 -> 128 3x3 @80, 512 -> 128 @80)
-// under the sharding threshold: 21 of the step's 28 remaining finalize launches go away.
+// under the sharding threshold (ops.SHARD_MAX_ADDS): the step's 28 remaining finalize launches go away.
 // red: LDS, WM * 2 * BN floats, free to use once every wave has passed the barrier inside.
 template <int BN, int WN, int WM, int MODE>
 __device__ __forceinline__ void conv_stats_add_sharded_wg(EpiSums<BN / WN / 32>& st, const GatherGeom& g, const Epilogue& ep, int tid, int lane,

@@ -122,9 +122,10 @@ def stats_adds(op, dtype, N, IH, IW, Cin, Cout, k, stride, pad, zero_page=True):
 # tiled kernels: once per row tile since r06, their wave rows meet in LDS first): every addition is one fp32 atomic per channel,
 # adds / BN_SHARDS of them on one address.  Above the threshold the atomics serialise in the memory-side atomic units for longer than
 # the finalize launch they replace (r05: every conv sharded = +5.3 ms of conv time against -1.6 ms of BatchNorm time per step; the
-# 12800-tile layers of the 160 x 160 maps stay on partial rows).  3200 = the 128-row tiles of the 80 x 80 maps at 64 images
-# (profiles/r06_bn_shard_threshold_ab.txt).
-SHARD_MAX_ADDS = 3200
+# threshold was 2048 partial ROWS then, with every wave adding).  12800 = the 128-row tiles of the 160 x 160 maps at 64 images: with one
+# addition per workgroup EVERY layer of the YOLOv5l step is under it -- no finalize launch left in a 16-bit step (3200 -> 12800: -0.05 ms,
+# inside the noise, profiles/r06_bn_shard_threshold_ab.txt; larger problems fall back to partial rows + finalize).
+SHARD_MAX_ADDS = 12800
 _FEW_ROWS = {}
 
 
