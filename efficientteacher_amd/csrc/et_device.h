@@ -150,6 +150,11 @@ __device__ __forceinline__ et_rsrc et_make_rsrc(const void* base, unsigned num_b
 }
 __device__ __forceinline__ void et_bufdma16(et_rsrc r, unsigned voff, unsigned soff, void* lds_wave_base) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, (int)soff, 0, 0);
+#ifdef ET_BUFDMA_NOPS
+    __builtin_amdgcn_sched_barrier(0);           // PROBE: keep the next M0 write ET_BUFDMA_NOPS + 1 wait states away from this instruction
+    asm volatile("s_nop %0" ::"n"(ET_BUFDMA_NOPS));
+    __builtin_amdgcn_sched_barrier(0);
+#endif
 }
 // s_waitcnt vmcnt(0): all of this wave's LDS-DMA writes have landed (expcnt / lgkmcnt left at max)
 __device__ __forceinline__ void et_wait_vmem() { __builtin_amdgcn_s_waitcnt(0x0F70); }
