@@ -25,7 +25,7 @@ def _rnd(shape, dev, seed, scale=1.0, dtype=torch.bfloat16):
 
 
 @pytest.mark.parametrize("cin,cout,k,s,h", [(256, 256, 3, 1, 40), (128, 256, 3, 2, 80), (512, 512, 1, 1, 20),
-                                            (64, 64, 3, 1, 160), (256, 128, 1, 1, 80)])
+                                            (64, 64, 3, 1, 160), (256, 128, 1, 1, 80), (128, 128, 3, 1, 80)])
 def test_conv_adjoint_and_linearity_full_size(dev, cin, cout, k, s, h):
     """<conv(x), dy> == <x, dgrad(dy)> == <w, wgrad(x, dy)>  (bf16 operands, fp32 accumulation) and
     conv(2*x1 - x2) == 2*conv(x1) - conv(x2) up to bf16 rounding, at B = 64."""
@@ -50,6 +50,25 @@ def test_conv_adjoint_and_linearity_full_size(dev, cin, cout, k, s, h):
     rhs = 2 * y.float() - ops.conv2d_fwd(x2, w, s, p).float()
     err = (lhs - rhs).abs().max().item()
     assert err <= 0.05 * max(1.0, rhs.abs().max().item()), err
+
+
+@pytest.mark.parametrize("cin,cout,k,s,h", [(64, 64, 3, 1, 160), (128, 128, 3, 1, 80), (256, 256, 3, 1, 40), (1024, 1024, 1, 1, 20), (128, 128, 1, 1, 80)])
+def test_forward_and_dgrad_repeat_bit_equal_full_size(dev, cin, cout, k, s, h):
+    """idempotence at B = 64: forward and dgrad launches have no atomics, so 25 launches on the same operands give 25 bit-equal outputs.
+    (r06: the property that exposes a staging race -- the experimental buffer-descriptor form of conv_gemm_rs_kernel<128, 64> failed it on the
+    160 x 160 maps in most processes, profiles/r06_buffer_dma_mismatch.txt; the shipped flat-address kernels: 0 of 4400 launches differ,
+    profiles/r06_flat_kernels_repeat_bit_equal.txt)"""
+    from efficientteacher_amd import ops
+    B, p = 64, k // 2
+    x = _rnd((B, h, h, cin), dev, 1)
+    w = _rnd((cout, k, k, cin), dev, 2, 0.05)
+    ref = ops.conv2d_fwd(x, w, s, p)
+    dy = _rnd(tuple(ref.shape), dev, 3)
+    wT = ops.weight_transpose(w)
+    dref = ops.conv2d_dgrad(dy, wT, (h, h), s, p)
+    for _ in range(25):
+        assert torch.equal(ops.conv2d_fwd(x, w, s, p), ref)
+        assert torch.equal(ops.conv2d_dgrad(dy, wT, (h, h), s, p), dref)
 
 
 def test_bn_invariants_full_size(dev):
