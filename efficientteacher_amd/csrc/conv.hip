@@ -768,11 +768,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const T* __restrict__ X,
 // fetches the logical K-vector  slot ^ swz(row)  (same 128-byte global segment, so coalescing is
 // unchanged) and the fragment reads keep using  physical = logical ^ swz(row).  Out-of-image taps, rows
 // beyond M and channels beyond Cout fetch from a 16-byte zero page instead of branching.
-// s_waitcnt vmcnt(N): at most N of this wave's vector-memory operations (here: LDS-DMA loads) still in flight
-template <int N> __device__ __forceinline__ void et_wait_vmem_le() {
-    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
-    __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 0xF) | ((N >> 4) << 14));
-}
+// (the counted waits -- s_waitcnt vmcnt(N): at most N of this wave's LDS-DMA loads still in flight -- are et_device.h's)
 
 // NS = depth of the LDS ring of K-chunks.  Chunk c+NS-1 is issued while chunk c is being multiplied, so up to
 // NS-1 chunks per workgroup are in flight all the time.  What bounds this kernel is bytes in flight per CU
@@ -904,13 +900,14 @@ __global__ __launch_bounds__(64 * WM * WN, (NS == 3 && BKV == 4 && BM == 128) ? 
     for (int c = 0; c < nchunks; ++c) {
         // chunk c has landed once at most `ahead` younger chunks of this wave are still in flight
         const int ahead = min(NS - 2, nchunks - 1 - c);
+        // (and lgkmcnt(0): this wave's reads of slot `wr` have COMPLETED, not merely been issued -- et_device.h)
         if constexpr (!UTAP) {
-            et_wait_vmem();                        // table loads share vmcnt on this path: no partial waits
+            et_wait_vmem_lds_read_done();          // table loads share vmcnt on this path: no partial waits
         } else {
-            if (NS >= 5 && ahead == 3) et_wait_vmem_le<(NS >= 5 ? 3 : 0) * PER>();
-            else if (NS >= 4 && ahead == 2) et_wait_vmem_le<(NS >= 4 ? 2 : 0) * PER>();
-            else if (NS >= 3 && ahead == 1) et_wait_vmem_le<(NS >= 3 ? 1 : 0) * PER>();
-            else et_wait_vmem();
+            if (NS >= 5 && ahead == 3) et_wait_vmem_le_lds_read_done<(NS >= 5 ? 3 : 0) * PER>();
+            else if (NS >= 4 && ahead == 2) et_wait_vmem_le_lds_read_done<(NS >= 4 ? 2 : 0) * PER>();
+            else if (NS >= 3 && ahead == 1) et_wait_vmem_le_lds_read_done<(NS >= 3 ? 1 : 0) * PER>();
+            else et_wait_vmem_lds_read_done();
         }
         // ... for every wave; and all reads of slot `wr` (chunk c-1) are done.  With younger chunks in flight the
         // barrier must be the bare s_barrier: __syncthreads() carries a fence that waits vmcnt(0), i.e. drains
@@ -938,8 +935,10 @@ __global__ __launch_bounds__(64 * WM * WN, (NS == 3 && BKV == 4 && BM == 128) ? 
 // Only the weight tile is staged per step: (BM + 16) + 3 * BN instead of 3 * (BM + BN) rows per unit of L2->LDS traffic.
 // Ring: two A-unit slots + two B-step slots; B(s+1) is issued at the start of step s, A(u+1) at the first step of unit u, BEHIND
 // that step's B so that the counted vmcnt wait of the next step releases B while A is still in flight.
-// BUF (r06): LDS-DMA through buffer descriptors as in conv_gemm_pprs_kernel (its header): out-of-range lanes land as zeros, the kernel-row
-// step and the channel cursor travel in the SGPR offset.
+// BUF (r06, the default form): LDS-DMA through buffer descriptors as in conv_gemm_pprs_kernel (its header): out-of-range lanes land as
+// zeros, the kernel-row step and the channel cursor travel in the SGPR offset.  One barrier per step hands the B slot the previous
+// step read back to the DMA: the wait in front of it includes lgkmcnt(0) (et_device.h et_wait_vmem_le_lds_read_done -- the race this
+// kernel's buffer form exposed).
 template <typename T, int BM, int BN, int WM, int WN, bool BUF>
 __device__ __forceinline__ void conv_gemm_rs_body(const T* __restrict__ X, const T* __restrict__ W, T* __restrict__ Y,
                                                   const T* __restrict__ ZERO, const GatherGeom& g, const Epilogue& ep) {
@@ -1111,10 +1110,11 @@ __device__ __forceinline__ void conv_gemm_rs_body(const T* __restrict__ X, const
         auto step = [&](auto ktag) {
             constexpr int k = decltype(ktag)::value;
             // B(s) has landed (and A(u) at k == 0); at k == 1 the A unit issued behind B(s) may still be in flight
+            // (and lgkmcnt(0): the previous step's reads of the B slot rewritten below have COMPLETED -- et_device.h)
             if (k == 1 && more_units) {
-                if (wave < XW) et_wait_vmem_le<RA>(); else et_wait_vmem_le<RAF>();
+                if (wave < XW) et_wait_vmem_le_lds_read_done<RA>(); else et_wait_vmem_le_lds_read_done<RAF>();
             } else {
-                et_wait_vmem();
+                et_wait_vmem_lds_read_done();
             }
             __builtin_amdgcn_s_barrier();                // ... for every wave; all reads of the slots rewritten below are done
             constexpr int kn = k < 2 ? k + 1 : 0;
@@ -1131,17 +1131,19 @@ __device__ __forceinline__ void conv_gemm_rs_body(const T* __restrict__ X, const
     __syncthreads();                                     // the epilogue reuses the ring as its staging area
     conv_epilogue<T, BM, BN, WM, WN>(acc, lds_raw, Y, g, ep, bx, m0, n0, tid, lane, wm, wn);
 }
+// conv_gemm_rs_kernel: the buffer-descriptor pieces (the default); conv_gemm_rs_flat_kernel: the same loops on flat 64-bit addresses, for
+// an operand of 2^31 bytes or more (a voffset's bit 31 means "out of range") and for ET_CONV_BUF_DMA=0
 template <typename T, int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(64 * WM * WN, BN <= 64 ? 3 : 2) void conv_gemm_rs_kernel(const T* __restrict__ X, const T* __restrict__ W,
                                                                        T* __restrict__ Y, const T* __restrict__ ZERO,
                                                                        GatherGeom g, Epilogue ep) {
-    conv_gemm_rs_body<T, BM, BN, WM, WN, false>(X, W, Y, ZERO, g, ep);       // flat addresses: the default
+    conv_gemm_rs_body<T, BM, BN, WM, WN, true>(X, W, Y, ZERO, g, ep);
 }
 template <typename T, int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN, BN <= 64 ? 3 : 2) void conv_gemm_rs_buf_kernel(const T* __restrict__ X, const T* __restrict__ W,
+__global__ __launch_bounds__(64 * WM * WN, BN <= 64 ? 3 : 2) void conv_gemm_rs_flat_kernel(const T* __restrict__ X, const T* __restrict__ W,
                                                                        T* __restrict__ Y, const T* __restrict__ ZERO,
                                                                        GatherGeom g, Epilogue ep) {
-    conv_gemm_rs_body<T, BM, BN, WM, WN, true>(X, W, Y, ZERO, g, ep);
+    conv_gemm_rs_body<T, BM, BN, WM, WN, false>(X, W, Y, ZERO, g, ep);
 }
 
 // ---- forward / dgrad gather-GEMM, 256x256 tile, two wave groups in anti-phase ("ping-pong") ----------------
@@ -1596,18 +1598,19 @@ __device__ __forceinline__ void conv_gemm_pprs_body(const T* __restrict__ X, con
 #undef ET_PP_BAR
 #undef ET_PP_WAIT
 }
-// the default (flat addresses) and the experimental buffer-descriptor twin (ET_CONV_BUF_DMA=1)
+// conv_gemm_pprs_kernel: the buffer-descriptor pieces (the default); conv_gemm_pprs_flat_kernel: flat 64-bit addresses, for an operand
+// of 2^31 bytes or more and for ET_CONV_BUF_DMA=0
 template <typename T>
 __global__ __launch_bounds__(512, 2) void conv_gemm_pprs_kernel(const T* __restrict__ X, const T* __restrict__ W,
                                                                 T* __restrict__ Y, const T* __restrict__ ZERO,
                                                                 GatherGeom g, Epilogue ep) {
-    conv_gemm_pprs_body<T, false>(X, W, Y, ZERO, g, ep);
+    conv_gemm_pprs_body<T, true>(X, W, Y, ZERO, g, ep);
 }
 template <typename T>
-__global__ __launch_bounds__(512, 2) void conv_gemm_pprs_buf_kernel(const T* __restrict__ X, const T* __restrict__ W,
-                                                                    T* __restrict__ Y, const T* __restrict__ ZERO,
-                                                                    GatherGeom g, Epilogue ep) {
-    conv_gemm_pprs_body<T, true>(X, W, Y, ZERO, g, ep);
+__global__ __launch_bounds__(512, 2) void conv_gemm_pprs_flat_kernel(const T* __restrict__ X, const T* __restrict__ W,
+                                                                     T* __restrict__ Y, const T* __restrict__ ZERO,
+                                                                     GatherGeom g, Epilogue ep) {
+    conv_gemm_pprs_body<T, false>(X, W, Y, ZERO, g, ep);
 }
 
 // ---- 1x1 stride-1 layers with <= 256 input and <= 256 output channels: persistent streaming GEMM ---------------------------
@@ -1762,13 +1765,13 @@ __global__ __launch_bounds__(64 * WM * WN, WGS) void conv1x1_stream_kernel(const
             // stages nothing has nothing to wait for
             const int ahead = min(NS - 2, total - 1 - q);
             switch (ahead) {             // uniform; NS <= 16
-#define ET_S1_WAIT(A) case A: et_wait_vmem_le<((A) <= NS - 2 ? (A) : 0) * PER>(); break;
+#define ET_S1_WAIT(A) case A: et_wait_vmem_le_lds_read_done<((A) <= NS - 2 ? (A) : 0) * PER>(); break;
                 ET_S1_WAIT(1) ET_S1_WAIT(2) ET_S1_WAIT(3) ET_S1_WAIT(4) ET_S1_WAIT(5) ET_S1_WAIT(6) ET_S1_WAIT(7)
                 ET_S1_WAIT(8) ET_S1_WAIT(9) ET_S1_WAIT(10) ET_S1_WAIT(11) ET_S1_WAIT(12) ET_S1_WAIT(13) ET_S1_WAIT(14)
 #undef ET_S1_WAIT
-                default: et_wait_vmem(); break;
+                default: et_wait_vmem_lds_read_done(); break;
             }
-            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_barrier();                // (lgkmcnt(0) above: issue() rewrites the slot the previous chunk read -- et_device.h)
             if (issued < total) issue();
             const char* const sa = (const char*)(ring + rd * CH_VEC);
             u32x4 af[2][TM];
@@ -3015,35 +3018,25 @@ static int launch_gemm(const void* X, const void* W, void* Y, const void* zero16
         }
         return -2;
     }
-    if (p.kind == GEMM_PPRS) {
+    if (p.kind == GEMM_PPRS || p.kind == GEMM_RS) {
         if constexpr (sizeof(T) == 2) {
-            {
-                // ET_CONV_BUF_DMA=1 (EXPERIMENT, off by default): buffer-descriptor LDS-DMA, operands below 2^31 bytes (bit 31 of a lane's
-                // offset = "out of range").  -0.13 ms on the step here (profiles/r06_pprs_buffer_dma_ab.txt) and every test of this kernel
-                // green -- but the same addressing form produced wrong tiles in conv_gemm_rs_kernel<128, 64> on the hardware for one map
-                // width (profiles/r06_buffer_dma_mismatch.txt) for a reason not understood, so nothing ships on it
-                const size_t xb = ((size_t)g.N * g.IH * g.IW * g.ldx + (size_t)g.IW * g.ldx) * sizeof(T), wb = (size_t)g.Cout * g.TT * g.Cin * sizeof(T);
-                if (env_int("ET_CONV_BUF_DMA", 0) && xb < (1ull << 31) && wb < (1ull << 31))
-                    hipLaunchKernelGGL((conv_gemm_pprs_buf_kernel<T>), grid, block, 0, s, x, w, y, z, g, ep);
-                else
-                    hipLaunchKernelGGL((conv_gemm_pprs_kernel<T>), grid, block, 0, s, x, w, y, z, g, ep);
-            }
-            return 0;
-        }
-        return -2;
-    }
-    if (p.kind == GEMM_RS) {
-        if constexpr (sizeof(T) == 2) {
+            // LDS-DMA pieces through buffer descriptors (et_bufdma16) unless an operand reaches 2^31 bytes (bit 31 of a lane's offset means
+            // "out of range") or ET_CONV_BUF_DMA=0 asks for the flat-address twins.  On the step: -0.4 ms in 20- and 100-step runs
+            // (profiles/r06_buffer_dma_default_ab.txt).  (The arm was withdrawn for a day of this round: conv_gemm_rs_kernel<128, 64> produced
+            // wrong wave tiles with it -- an LDS-ring WAR race of the single-barrier kernels that the faster piece issue exposed, not a
+            // property of the addressing form: et_device.h et_wait_vmem_le_lds_read_done, profiles/r06_lds_ring_war_race.txt.)
             const size_t xb = ((size_t)g.N * g.IH * g.IW * g.ldx + (size_t)g.IW * g.ldx) * sizeof(T), wb = (size_t)g.Cout * g.TT * g.Cin * sizeof(T);
-            // ET_CONV_BUF_DMA=1 (EXPERIMENT, off by default): the buffer-descriptor form of the LDS-DMA pieces.  Isolated -8...-10 % on
-            // 128 -> 128 @80x80, step-neutral (the power limit) -- and WRONG on the hardware for conv_gemm_rs_kernel<128, 64> on 160-pixel-wide
-            // maps with several workgroups per CU (scattered 64-pixel x 32-channel wave tiles differ from the flat form from run to run;
-            // the emulator, every other shape and the 128-wide tile agree bit for bit): profiles/r06_buffer_dma_mismatch.txt
-            if (env_int("ET_CONV_BUF_DMA", 0) && xb < (1ull << 31) && wb < (1ull << 31)) {
-                if (p.BN == 128) hipLaunchKernelGGL((conv_gemm_rs_buf_kernel<T, 128, 128, 2, 2>), grid, block, 0, s, x, w, y, z, g, ep);
-                else hipLaunchKernelGGL((conv_gemm_rs_buf_kernel<T, 128, 64, 2, 2>), grid, block, 0, s, x, w, y, z, g, ep);
-            } else if (p.BN == 128) hipLaunchKernelGGL((conv_gemm_rs_kernel<T, 128, 128, 2, 2>), grid, block, 0, s, x, w, y, z, g, ep);
-            else hipLaunchKernelGGL((conv_gemm_rs_kernel<T, 128, 64, 2, 2>), grid, block, 0, s, x, w, y, z, g, ep);
+            const bool buf = env_int("ET_CONV_BUF_DMA", 1) && xb < (1ull << 31) && wb < (1ull << 31);
+            if (p.kind == GEMM_PPRS) {
+                if (buf) hipLaunchKernelGGL((conv_gemm_pprs_kernel<T>), grid, block, 0, s, x, w, y, z, g, ep);
+                else hipLaunchKernelGGL((conv_gemm_pprs_flat_kernel<T>), grid, block, 0, s, x, w, y, z, g, ep);
+            } else if (p.BN == 128) {
+                if (buf) hipLaunchKernelGGL((conv_gemm_rs_kernel<T, 128, 128, 2, 2>), grid, block, 0, s, x, w, y, z, g, ep);
+                else hipLaunchKernelGGL((conv_gemm_rs_flat_kernel<T, 128, 128, 2, 2>), grid, block, 0, s, x, w, y, z, g, ep);
+            } else {
+                if (buf) hipLaunchKernelGGL((conv_gemm_rs_kernel<T, 128, 64, 2, 2>), grid, block, 0, s, x, w, y, z, g, ep);
+                else hipLaunchKernelGGL((conv_gemm_rs_flat_kernel<T, 128, 64, 2, 2>), grid, block, 0, s, x, w, y, z, g, ep);
+            }
             return 0;
         }
         return -2;

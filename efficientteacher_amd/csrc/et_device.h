@@ -150,11 +150,21 @@ __device__ __forceinline__ et_rsrc et_make_rsrc(const void* base, unsigned num_b
 }
 __device__ __forceinline__ void et_bufdma16(et_rsrc r, unsigned voff, unsigned soff, void* lds_wave_base) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, (int)soff, 0, 0);
-#ifdef ET_BUFDMA_NOPS
-    __builtin_amdgcn_sched_barrier(0);           // PROBE: keep the next M0 write ET_BUFDMA_NOPS + 1 wait states away from this instruction
-    asm volatile("s_nop %0" ::"n"(ET_BUFDMA_NOPS));
-    __builtin_amdgcn_sched_barrier(0);
-#endif
 }
 // s_waitcnt vmcnt(0): all of this wave's LDS-DMA writes have landed (expcnt / lgkmcnt left at max)
 __device__ __forceinline__ void et_wait_vmem() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+// The wait in front of a bare s_barrier that hands an LDS slot BACK to the LDS-DMA (the single-barrier rings: the slot one step read is
+// rewritten by the pieces issued right behind the NEXT step's barrier): vmcnt <= N AND lgkmcnt(0).  Program order is not enough there:
+// s_barrier orders the ISSUE of the ds_reads in front of it, not their completion, and the scheduler may sink a step's last MFMAs --
+// with the lgkmcnt wait the compiler attaches to them -- below the barrier.  A faster wave then passes the barrier and its piece can
+// land in the slot while this wave's reads of it are still queued in the LDS.  It happened in the buffer-descriptor form of the row-shift
+// kernels (pieces issued two instructions behind the barrier, three workgroups per CU, weight rows hot in the vector L1): one wave's
+// tile computed on stale / foreign weight rows in ~15 % of the launches on 160-pixel-wide maps; 0 of 540 with this wait
+// (profiles/r06_lds_ring_war_race.txt).  The flat-address forms, the K-chunk ring and the 1x1 stream kernel have the same source shape;
+// their compiled code happened to keep the wait in front of the barrier (tests/test_lds_ring_barriers.py reads the disassembly of the
+// built library for exactly this), and they now state it.  Step-neutral (same file).
+template <int N> __device__ __forceinline__ void et_wait_vmem_le_lds_read_done() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    __builtin_amdgcn_s_waitcnt(0x0070 | (N & 0xF) | ((N >> 4) << 14));
+}
+__device__ __forceinline__ void et_wait_vmem_lds_read_done() { __builtin_amdgcn_s_waitcnt(0x0070); }

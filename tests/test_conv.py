@@ -260,13 +260,14 @@ def test_bench_instantiations_elementwise(hip, case, kf, kd, kw):
 
 
 @pytest.mark.parametrize("case,kf,kd,kw", PPRS_CASES, ids=[str(c[0]) for c in PPRS_CASES])
-def test_row_shift_buffer_descriptor_twins(hip, case, kf, kd, kw, monkeypatch):
-    """EXPERIMENTAL arm (ET_CONV_BUF_DMA=1, off by default): conv_gemm_pprs_buf_kernel / conv_gemm_rs_buf_kernel stage their LDS-DMA
-    pieces through buffer descriptors (out-of-range lanes land as zeros: no zero page).  Same loops, other addressing: the same
-    element-wise checks.  These shapes are green on the hardware too; what is NOT is conv_gemm_rs_buf_kernel<128, 64> on 160-pixel-wide
-    maps with several workgroups per CU (profiles/r06_buffer_dma_mismatch.txt) -- the reason the arm is not the default."""
+def test_row_shift_flat_address_twins(hip, case, kf, kd, kw, monkeypatch):
+    """conv_gemm_pprs_kernel / conv_gemm_rs_kernel stage their LDS-DMA pieces through buffer descriptors (out-of-range lanes land as
+    zeros: no zero page); conv_gemm_pprs_flat_kernel / conv_gemm_rs_flat_kernel are the same loops on flat 64-bit addresses, taken for
+    an operand of 2^31 bytes or more and under ET_CONV_BUF_DMA=0: the same element-wise checks on that arm.  (The buffer form is what every
+    other test of these shapes runs; the full-size idempotence / linearity tests of tests/test_fullsize.py are the ones that caught the
+    LDS-ring race it exposed, profiles/r06_lds_ring_war_race.txt.)"""
     assert len(PPRS_CASES) >= 6
-    monkeypatch.setenv("ET_CONV_BUF_DMA", "1")
+    monkeypatch.setenv("ET_CONV_BUF_DMA", "0")
     _check_instantiation(hip, case, kf, kd, kw)
 
 

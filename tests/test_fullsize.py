@@ -55,9 +55,9 @@ def test_conv_adjoint_and_linearity_full_size(dev, cin, cout, k, s, h):
 @pytest.mark.parametrize("cin,cout,k,s,h", [(64, 64, 3, 1, 160), (128, 128, 3, 1, 80), (256, 256, 3, 1, 40), (1024, 1024, 1, 1, 20), (128, 128, 1, 1, 80)])
 def test_forward_and_dgrad_repeat_bit_equal_full_size(dev, cin, cout, k, s, h):
     """idempotence at B = 64: forward and dgrad launches have no atomics, so 25 launches on the same operands give 25 bit-equal outputs.
-    (r06: the property that exposes a staging race -- the experimental buffer-descriptor form of conv_gemm_rs_kernel<128, 64> failed it on the
-    160 x 160 maps in most processes, profiles/r06_buffer_dma_mismatch.txt; the shipped flat-address kernels: 0 of 4400 launches differ,
-    profiles/r06_flat_kernels_repeat_bit_equal.txt)"""
+    (r06: the property that exposes a staging race.  With the buffer-descriptor pieces conv_gemm_rs_kernel<128, 64> failed it on the 160 x 160
+    maps in most processes -- the single-barrier LDS rings handed a slot back to the DMA while a slower wave's reads of it were still
+    queued; since the waits in front of those barriers include lgkmcnt(0): 0 of 540 launches differ, profiles/r06_lds_ring_war_race.txt)"""
     from efficientteacher_amd import ops
     B, p = 64, k // 2
     x = _rnd((B, h, h, cin), dev, 1)

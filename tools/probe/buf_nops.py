@@ -13,8 +13,10 @@ dev = torch.device("cuda:0")
 bad = tot = 0
 for (B, h, cin, cout) in [(64, 160, 64, 64), (8, 160, 128, 64), (4, 320, 64, 64)]:
     g = torch.Generator().manual_seed(1)
-    x = torch.randn((B, h, h, cin), generator=g).to(torch.bfloat16).to(dev)
-    w = (torch.randn((cout, 3, 3, cin), generator=g) * 0.05).to(torch.bfloat16).to(dev)
+    nx, nw = B * h * h * cin, cout * 9 * cin
+    pool = torch.empty(nx + nw + 256, dtype=torch.bfloat16, device=dev)      # one allocation: the one-descriptor probe needs both operands < 2^31 bytes apart
+    x = pool[:nx].view(B, h, h, cin); x.copy_(torch.randn((B, h, h, cin), generator=g).to(torch.bfloat16))
+    w = pool[nx + 128:nx + 128 + nw].view(cout, 3, 3, cin); w.copy_((torch.randn((cout, 3, 3, cin), generator=g) * 0.05).to(torch.bfloat16))
     os.environ["ET_CONV_BUF_DMA"] = "0"
     ref = ops.conv2d_fwd(x, w, 1, 1)
     os.environ["ET_CONV_BUF_DMA"] = "1"
@@ -23,7 +25,8 @@ for (B, h, cin, cout) in [(64, 160, 64, 64), (8, 160, 128, 64), (4, 320, 64, 64)
         tot += 1; bad += int(not torch.equal(y, ref))
 print("launches", tot, "differing from the flat form", bad)
 ''' % ROOT
-for lib in ["default"] + [f"tools/probe/libet_nops{n}.so" for n in (0, 1, 3, 7, 15)]:
+LIBS = os.environ.get("ET_PROBE_LIBS")
+for lib in (LIBS.split(",") if LIBS else ["default"] + [f"tools/probe/libet_nops{n}.so" for n in (0, 1, 3, 7, 15)]):
     env = dict(os.environ)
     if lib != "default":
         env["ET_HIP_LIB"] = os.path.join(ROOT, lib)
