@@ -1642,10 +1642,14 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_pprs_flat_kernel(const T* __
 // Statistics: a lane's sums run over ALL tiles of its (persistent) workgroup and are written ONCE, as partial row
 // blockIdx.x * WM + wm of a (gridDim.x * WM, 2, Cout) buffer (et_conv2d_stats_rows_for reports that row count to the caller): the
 // finalize then reads a few hundred rows instead of one per 64 pixels.
-template <typename T, int KC, int WN, int TN, int WM, int TMW, int NS, int WGS, bool FULL>
-__global__ __launch_bounds__(64 * WM * WN, WGS) void conv1x1_stream_kernel(const T* __restrict__ X, const T* __restrict__ W,
-                                                                          T* __restrict__ Y, const T* __restrict__ ZERO,
-                                                                          GatherGeom g, Epilogue ep) {
+// BUF (r06): the activation pieces through a buffer descriptor over the tensor's rows (et_bufdma16): a piece is ZERO vector
+// instructions -- the lane's part of the address (row inside the tile, swizzled channel slot) is a constant per piece, the tile's
+// first row and the channel chunk travel in the SGPR offset, and a row beyond M lies beyond the descriptor's range and lands as
+// zeros -- against a compare, a 64-bit multiply-add and a select into the zero page per piece in the flat form.
+template <typename T, int KC, int WN, int TN, int WM, int TMW, int NS, int WGS, bool FULL, bool BUF>
+__device__ __forceinline__ void conv1x1_stream_body(const T* __restrict__ X, const T* __restrict__ W,
+                                                    T* __restrict__ Y, const T* __restrict__ ZERO,
+                                                    const GatherGeom& g, const Epilogue& ep) {
     constexpr int BN = 32 * TN * WN, BM = 32 * TMW * WM, BKV = 8, VEC = 8;
     constexpr int TM = TMW;                              // a wave owns 32 * TMW rows x 32 * TN output channels
     constexpr int NT = 64 * WM * WN;
@@ -1685,6 +1689,12 @@ __global__ __launch_bounds__(64 * WM * WN, WGS) void conv1x1_stream_kernel(const
         a_row[j] = lrow + j * RPT;
         a_lv[j] = (lvec ^ lds_swz<BKV>(a_row[j])) * VEC;
     }
+    et_rsrc rsX;
+    if constexpr (BUF) {                                 // [X, end of row M - 1's channels): a row >= M is out of range by itself
+        rsX = et_make_rsrc(X, (unsigned)(((size_t)(g.M - 1) * g.ldx + KC * 64) * sizeof(T)));
+#pragma unroll
+        for (int j = 0; j < PER; ++j) a_row[j] = (a_row[j] * g.ldx + a_lv[j]) * (int)sizeof(T);      // the lane's byte offset inside a tile
+    }
     const int ntiles = g.ntm;
     const int my_tiles = ((int)blockIdx.x < ntiles) ? (ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
     const int total = my_tiles * KC;                     // chunks this workgroup consumes
@@ -1693,15 +1703,24 @@ __global__ __launch_bounds__(64 * WM * WN, WGS) void conv1x1_stream_kernel(const
         if (stager) {
             u32x4* const wbase = ring + is_slot * CH_VEC + wave * 64;
             const int m0i = is_tile * BM;
+            const unsigned soff = (unsigned)(((size_t)m0i * g.ldx + is_kc * 64) * sizeof(T));     // BUF; host: the tensor spans < 2^31 bytes
 #pragma unroll
             for (int j = 0; j < PER; ++j) {
-                const int p = m0i + a_row[j];
-                const T* src = p < g.M ? X + ((size_t)p * g.ldx + is_kc * 64 + a_lv[j]) : ZERO;
+                if constexpr (BUF) {
 #if ET_S1_NT
-                et_glds16_nt(src, wbase + j * DT);
+                    et_bufdma16_nt(rsX, (unsigned)a_row[j], soff, wbase + j * DT);
 #else
-                et_glds16(src, wbase + j * DT);
+                    et_bufdma16(rsX, (unsigned)a_row[j], soff, wbase + j * DT);
 #endif
+                } else {
+                    const int p = m0i + a_row[j];
+                    const T* src = p < g.M ? X + ((size_t)p * g.ldx + is_kc * 64 + a_lv[j]) : ZERO;
+#if ET_S1_NT
+                    et_glds16_nt(src, wbase + j * DT);
+#else
+                    et_glds16(src, wbase + j * DT);
+#endif
+                }
             }
         }
         ++issued;
@@ -1800,6 +1819,20 @@ __global__ __launch_bounds__(64 * WM * WN, WGS) void conv1x1_stream_kernel(const
         if (ep.stats_ld) conv_stats_add_sharded_wg<BN, WN, WM, MODE>(st, g, ep, tid, lane, wm, wn, (float*)ring);
         else conv_epilogue_write_stats<BN, WN, MODE>(st, g, ep, 0, lane, wn, (int)blockIdx.x * WM + wm, 0, (int)gridDim.x * WM);
     }
+}
+// conv1x1_stream_kernel: buffer-descriptor pieces (the default); conv1x1_stream_flat_kernel: flat addresses, for a tensor of 2^31 bytes or
+// more and for ET_CONV_BUF_DMA=0
+template <typename T, int KC, int WN, int TN, int WM, int TMW, int NS, int WGS, bool FULL>
+__global__ __launch_bounds__(64 * WM * WN, WGS) void conv1x1_stream_kernel(const T* __restrict__ X, const T* __restrict__ W,
+                                                                          T* __restrict__ Y, const T* __restrict__ ZERO,
+                                                                          GatherGeom g, Epilogue ep) {
+    conv1x1_stream_body<T, KC, WN, TN, WM, TMW, NS, WGS, FULL, true>(X, W, Y, ZERO, g, ep);
+}
+template <typename T, int KC, int WN, int TN, int WM, int TMW, int NS, int WGS, bool FULL>
+__global__ __launch_bounds__(64 * WM * WN, WGS) void conv1x1_stream_flat_kernel(const T* __restrict__ X, const T* __restrict__ W,
+                                                                               T* __restrict__ Y, const T* __restrict__ ZERO,
+                                                                               GatherGeom g, Epilogue ep) {
+    conv1x1_stream_body<T, KC, WN, TN, WM, TMW, NS, WGS, FULL, false>(X, W, Y, ZERO, g, ep);
 }
 
 // ---- the stem: 6x6 stride-2 pad-2 convolution of the packed image (8 channels, 3 used) ----------------------------
@@ -2985,8 +3018,12 @@ static int launch_gemm(const void* X, const void* W, void* Y, const void* zero16
     if (p.kind == GEMM_S1) {
         if constexpr (sizeof(T) == 2) {
             const dim3 sgrid(s1_grid(g.ntm, p));
-#define ET_S1(KC_, WN_, TN_, WM_, TMW_, NS_, WGS_, FULL_) \
-    hipLaunchKernelGGL((conv1x1_stream_kernel<T, KC_, WN_, TN_, WM_, TMW_, NS_, WGS_, FULL_>), sgrid, block, 0, s, x, w, y, z, g, ep)
+            const bool s1buf = env_int("ET_CONV_BUF_DMA", 1) && (size_t)g.M * g.ldx * sizeof(T) < (1ull << 31);
+#define ET_S1(KC_, WN_, TN_, WM_, TMW_, NS_, WGS_, FULL_)                                                                                     \
+    do {                                                                                                                                      \
+        if (s1buf) hipLaunchKernelGGL((conv1x1_stream_kernel<T, KC_, WN_, TN_, WM_, TMW_, NS_, WGS_, FULL_>), sgrid, block, 0, s, x, w, y, z, g, ep);       \
+        else hipLaunchKernelGGL((conv1x1_stream_flat_kernel<T, KC_, WN_, TN_, WM_, TMW_, NS_, WGS_, FULL_>), sgrid, block, 0, s, x, w, y, z, g, ep);   \
+    } while (0)
             switch ((p.full ? 10000 : 0) + p.kc * 1000 + p.BN) {
                 //            K/64 WN TN WM TMW NS WGS
                 case 4256: ET_S1(4, 4, 2, 1, 1, 8, 2, false); return 0;

@@ -151,6 +151,10 @@ __device__ __forceinline__ et_rsrc et_make_rsrc(const void* base, unsigned num_b
 __device__ __forceinline__ void et_bufdma16(et_rsrc r, unsigned voff, unsigned soff, void* lds_wave_base) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, (int)soff, 0, 0);
 }
+// the same with the non-temporal cache policy (aux = 2), as et_glds16_nt
+__device__ __forceinline__ void et_bufdma16_nt(et_rsrc r, unsigned voff, unsigned soff, void* lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, (int)soff, 0, 2);
+}
 // s_waitcnt vmcnt(0): all of this wave's LDS-DMA writes have landed (expcnt / lgkmcnt left at max)
 __device__ __forceinline__ void et_wait_vmem() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 // The wait in front of a bare s_barrier that hands an LDS slot BACK to the LDS-DMA (the single-barrier rings: the slot one step read is
