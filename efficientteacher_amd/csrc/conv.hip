@@ -2088,6 +2088,7 @@ struct WgradGeom {
     FastDiv dQW, dQH, dCin, dW1; // dW1: by QW + 1 (conv_wgrad_rs_kernel's padded raster)
     int PP;                      // padded slots N*QH*(QW+1) (conv_wgrad_rs_kernel's GEMM-K)
     int ident;                   // 1 = every tap reads X at the dY pixel itself (1x1, stride 1, pad 0): X row = dY row, no decode
+    int buf;                     // ident layers: stage through buffer descriptors (host: both tensors < 2^31 bytes, ET_CONV_BUF_DMA != 0)
     signed char dy[CONV_MAX_TAPS], dx[CONV_MAX_TAPS];
 };
 
@@ -2368,9 +2369,30 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_tr_kernel(WgradGroup 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
 
+    // 1x1 stride-1 layers, buffer form (g.buf, uniform): descriptors over [tensor, end of this K-slice's last row) -- a row at or beyond
+    // pk_end is out of range and lands as zeros, a channel group beyond the tensor carries bit 31; the chunk's first row travels in the
+    // SGPR offset: no vector instruction per piece (flat form: add, compare, 64-bit multiply-add, select into the zero page)
+    et_rsrc rsDY, rsX;
+    unsigned a_vo[RA], b_vo[RB];
+    if (g.buf) {
+        rsDY = et_make_rsrc(DY, (unsigned)(((size_t)(pk_end - 1) * ldy + g.Cout) * 2));
+        rsX = et_make_rsrc(X, (unsigned)(((size_t)(pk_end - 1) * ldx + g.NC) * 2));
+#pragma unroll
+        for (int j = 0; j < RA; ++j) a_vo[j] = a_ok[j] ? (unsigned)((a_pl[j] * ldy + a_co[j]) * 2) : 0x80000000u;
+#pragma unroll
+        for (int j = 0; j < RB; ++j) b_vo[j] = b_ok[j] ? (unsigned)((b_pl[j] * ldx + b_ci[j]) * 2) : 0x80000000u;
+    }
     auto stage = [&](u32x4* dstA, u32x4* dstB, int pk0) {
         u32x4* const wa = dstA + wave * 64;
         u32x4* const wb = dstB + wave * 64;
+        if (g.buf) {
+            const unsigned sa = (unsigned)((size_t)pk0 * ldy * 2), sb = (unsigned)((size_t)pk0 * ldx * 2);
+#pragma unroll
+            for (int j = 0; j < RA; ++j) et_bufdma16(rsDY, a_vo[j], sa, wa + j * NT);
+#pragma unroll
+            for (int j = 0; j < RB; ++j) et_bufdma16(rsX, b_vo[j], sb, wb + j * NT);
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < RA; ++j) {
             const int p = pk0 + a_pl[j];
@@ -3289,6 +3311,7 @@ static void wgrad_geom(WgradGeom& g, int N, int IH, int IW, int Cin, int ldx, in
     g.dQW = make_fastdiv(OW); g.dQH = make_fastdiv(OH); g.dCin = make_fastdiv(Cin); g.dW1 = make_fastdiv(OW + 1);
     g.PP = N * OH * (OW + 1);
     g.ident = (KH == 1 && KW == 1 && stride == 1 && pad == 0 && OH == IH && OW == IW) ? 1 : 0;
+    g.buf = 0;                   // set per launch (launch_wgrad_tr): needs the group's pixel strides
     for (int ky = 0; ky < KH; ++ky)
         for (int kx = 0; kx < KW; ++kx) {
             g.dy[ky * KW + kx] = (signed char)(ky - pad);
@@ -3412,6 +3435,10 @@ static void launch_wgrad(const WgradGroup& grp, const void* zero16, WgradGeom& g
         if (tr) {
             const dim3 grid(grp.n * g.ntn * g.ntm * sk);
             const uint16_t* z = (const uint16_t*)zero16;
+            // 1x1 stride-1 layers: buffer-descriptor pieces when every tensor of the group spans < 2^31 bytes (conv_wgrad_tr_kernel, g.buf)
+            g.buf = g.ident && env_int("ET_CONV_BUF_DMA", 1);
+            for (int i = 0; i < grp.n && g.buf; ++i)
+                if ((size_t)g.P * grp.it[i].ldx * 2 >= (1ull << 31) || (size_t)g.P * grp.it[i].ldy * 2 >= (1ull << 31)) g.buf = 0;
 #define ET_WG(BM_, BN_, WM_, WN_) hipLaunchKernelGGL((conv_wgrad_tr_kernel<T, BM_, BN_, WM_, WN_>), grid, dim3(64 * WM_ * WN_), 0, s, grp, z, g)
             if (bm == 256) { if (bn == 256) ET_WG(256, 256, 2, 4); else if (bn == 128) ET_WG(256, 128, 4, 2); else ET_WG(256, 64, 4, 1); }
             else if (bm == 128) { if (bn == 256) ET_WG(128, 256, 2, 4); else if (bn == 128) ET_WG(128, 128, 2, 2); else ET_WG(128, 64, 2, 2); }
