@@ -487,6 +487,8 @@ def measure(a, wl_name, per_rank, device, rank, world, dev_index, full=True):
             return tp
         tr.teacher_pred_hook = hook
         tr.overlap_teacher = not a.no_overlap
+        if getattr(a, "teacher_after", None) is not None:
+            tr.teacher_after = "" if a.teacher_after == "start" else a.teacher_after
         if a.graph:
             tr.use_graph = True
         imgs_per_step = Bl + Bu
@@ -813,6 +815,8 @@ def main():
                     "runs: its seven extra forwards would count into the per-step kernel totals)")
     ap.add_argument("--no-weak-point", action="store_true", help="--gpus 8: skip the second (32+32 per rank) measurement")
     ap.add_argument("--no-overlap", action="store_true", help="run the teacher on the main stream (A/B)")
+    ap.add_argument("--teacher-after", default=None, choices=["start", "p1", "p2", "p3", "p4"], help="A/B: where in the student's forward the teacher stream "
+                    "starts (trainer default p3: behind the stride-8 stage)")
     ap.add_argument("--graph", action="store_true", help="replay the step as one captured HIP graph (trainer/graph_step.py) instead of "
                     "issuing every launch from Python (A/B: the 32+32 step is GPU-bound; default ON for per-rank batches < 32)")
     ap.add_argument("--no-graph", action="store_true")

@@ -352,7 +352,7 @@ class _SsodHotPath(_HotPath):
         return self._side
 
     overlap_teacher = True
-    teacher_after = "p2"
+    teacher_after = "p3"
 
 
 def hot_path_trainers(ref_trainer=None, ref_ssod_trainer=None, compute_dtype=torch.bfloat16, deterministic=False):

@@ -59,7 +59,7 @@ class SSODTrainer(Trainer):
         self.extra_teacher_models = []
         self.teacher_pred_hook = None      # optional callable(teacher_pred) -> teacher_pred (bench: synthetic scores)
         self.overlap_teacher = True        # teacher forward + pseudo labels on a second stream
-        self.teacher_after = "p2"          # "" (start of the step) | "p1" | "p2" | "p3" | "p4": see _train_instance_eager
+        self.teacher_after = "p3"          # "" (start of the step) | "p1" | "p2" | "p3" | "p4": see _train_instance_eager
         self._side = None
         # the step as one captured HIP graph (trainer/graph_step.py), opt-in: ET_STEP_GRAPH=1 or use_graph=True.  Measured on
         # MI355X (profiles/r02_graph_step_timing.txt): issuing the ~750 launches of an eager step takes the host 18-24 ms, a
@@ -218,11 +218,11 @@ class SSODTrainer(Trainer):
                 t9, valid = self.pseudo_label_creator.create_pseudo_label_padded(teacher_pred, unlabeled_M, width, height)
                 return t9, valid, valid.any().float()        # has_targets == not invalid_target_shape, as a device flag
 
-        # The teacher stream starts when the student's forward has passed its stride-4 stage (teacher_after = "p2"; p1 / p3 / p4 /
-        # start-of-step are the other measured settings, profiles/r03_teacher_start_ab.txt, r04_knob_combinations_ab.txt), not at the start: both networks begin with their
-        # large, HBM-bound maps, and running those side by side only makes both slower.  Same-box A/B, three alternations
-        # (profiles/r03_teacher_start_ab.txt): 58.64 / 58.74 / 58.74 ms against 59.06 / 58.78 / 59.00 ms, and the dominant
-        # gather-GEMM's in-step roofline fraction 0.240 / 0.242 / 0.240 against 0.232 / 0.229 / 0.232.
+        # The teacher stream starts when the student's forward has passed its stride-8 stage (teacher_after = "p3"), not at the start: both
+        # networks begin with their large, HBM-bound maps, and running those side by side only makes both slower.  Same-box A/B:
+        # r03 / r04 (profiles/r03_teacher_start_ab.txt, r04_knob_combinations_ab.txt, the step at 55-58 ms) chose "p2"; re-tuned at the r06
+        # build (profiles/r06_teacher_start_ab.txt): p2 49.85 / start 49.76 / p1 49.78 / p3 49.60 / p4 50.38 ms over 20 steps, p3 -0.1 ms at
+        # 100 steps and -0.16 ms in fp16 mode.
         after = self.teacher_after if side is not None else ""
         if after:
             from ..models.backbone.yolov5_backbone import YoloV5BackBone
