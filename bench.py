@@ -815,6 +815,8 @@ def main():
                     "runs: its seven extra forwards would count into the per-step kernel totals)")
     ap.add_argument("--no-weak-point", action="store_true", help="--gpus 8: skip the second (32+32 per rank) measurement")
     ap.add_argument("--no-overlap", action="store_true", help="run the teacher on the main stream (A/B)")
+    ap.add_argument("--set", action="append", default=[], metavar="MODULE.NAME=VALUE", help="A/B: set a module-level constant of the package before the "
+                    "trainer is built, e.g. --set autograd.FUSE_BN_BWD_K=7 (int / float / str literals)")
     ap.add_argument("--teacher-after", default=None, choices=["start", "p1", "p2", "p3", "p4"], help="A/B: where in the student's forward the teacher stream "
                     "starts (trainer default p3: behind the stride-8 stage)")
     ap.add_argument("--graph", action="store_true", help="replay the step as one captured HIP graph (trainer/graph_step.py) instead of "
@@ -832,6 +834,14 @@ def main():
                     "asynchronous AVG all-reduce from the gradient-ready hook, graph capture of the collectives) over a ONE-rank "
                     "RCCL group -- the way to execute that path on a single-GPU box")
     a = ap.parse_args()
+    for kv in a.set:
+        import ast
+        import importlib
+        name, val = kv.split("=", 1)
+        mod, attr = name.rsplit(".", 1)
+        m = importlib.import_module("efficientteacher_amd." + mod)
+        assert hasattr(m, attr), f"--set: efficientteacher_amd.{mod} has no {attr}"
+        setattr(m, attr, ast.literal_eval(val))
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         _respawn(a)
@@ -909,7 +919,7 @@ def main():
                                     "backward, which SSOD.with_da_loss False never runs; step_tflops / frac_of_bf16_mfma_peak use EXECUTED",
                        "step_tflops_per_gpu": step_flop / (dt / a.steps) / 1e12,
                        "frac_of_bf16_mfma_peak": step_flop / (dt / a.steps) / PEAK_BF16, "loss_finite": res["loss_ok"], "loss_scale_after_the_timed_region": res.get("loss_scale"),
-                       "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1, "env_knobs": ops.env_knobs(),
+                       "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1, "env_knobs": ops.env_knobs(), "module_overrides": list(a.set),
                        "rccl_env": rccl_env or None,
                        "grad_allreduce": (dict(bytes=int(sum(b for b, _ in t_ar[2])), arena_bytes=res["grad_bytes"],
                                                wire=("bf16" if sum(b for b, _ in t_ar[2]) * 2 <= res["grad_bytes"] + 1024 else "fp32"),

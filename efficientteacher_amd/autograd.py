@@ -22,9 +22,13 @@ FUSE_BN_BWD = True
 # issues the producer's y reads of a whole slab round up front (conv.hip conv_epilogue_act, EPF) instead of one load + wait per store
 # iteration; the register-bound 256x256 tiles cannot afford that prefetch and keep the separate reduce pass.  Measured, alternating,
 # two boxes (profiles/r04_stream_full_and_fuse_ab_current_build.txt, r04_knob_combinations_ab.txt): 1 -> 5 = 52.27 / 52.46 -> 52.15 /
-# 52.29 ms and 51.37 / 51.43 -> 51.24 / 51.31 ms: BatchNorm family -0.7 ms, gather-GEMMs +0.6 ms, -0.1 ms net in every pair.  Hence 5.
+# 52.29 ms and 51.37 / 51.43 -> 51.24 / 51.31 ms: BatchNorm family -0.7 ms, gather-GEMMs +0.6 ms, -0.1 ms net in every pair.  Hence 5 (until r06, below).
 # (An earlier A/B of this round that showed +0.15 ms had run a STALE library without the prefetch: profiles/r04_fuse_bn_bwd_rs_tiles_ab.txt.)
-FUSE_BN_BWD_K = 5
+# r06, re-measured at the final build (buffer-descriptor pieces in the row-shift kernels, weight gradients on their own stream; bench.py --set
+# autograd.FUSE_BN_BWD_K=..., profiles/r06_fuse_bn_bwd_by_kernel_ab.txt): 5 -> 1 = 49.53 -> 49.32 ms over 100 steps, 49.65 -> 49.46 over 20 (three / two
+# alternations), 7 = +0.06, 0 = +0.13.  The row-shift tiles lose more to the fatter epilogue now than the reduce pass costs beside the weight-gradient
+# stream.  Hence 1: only the HBM-bound 1x1 dgrads carry the sums.
+FUSE_BN_BWD_K = 1
 _RS_DGRAD = {}
 
 
