@@ -838,10 +838,12 @@ def main():
         import ast
         import importlib
         name, val = kv.split("=", 1)
-        mod, attr = name.rsplit(".", 1)
-        m = importlib.import_module("efficientteacher_amd." + mod)
-        assert hasattr(m, attr), f"--set: efficientteacher_amd.{mod} has no {attr}"
-        setattr(m, attr, ast.literal_eval(val))
+        parts = name.split(".")
+        m = importlib.import_module("efficientteacher_amd." + parts[0])          # module, then attributes (ops.WGRAD_QUEUE.group)
+        for q in parts[1:-1]:
+            m = getattr(m, q)
+        assert hasattr(m, parts[-1]), f"--set: {name} does not exist"
+        setattr(m, parts[-1], ast.literal_eval(val))
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         _respawn(a)

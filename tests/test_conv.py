@@ -271,6 +271,19 @@ def test_row_shift_flat_address_twins(hip, case, kf, kd, kw, monkeypatch):
     _check_instantiation(hip, case, kf, kd, kw)
 
 
+FLAT_TWIN_CASES = [c for c in STREAM_CASES] + [c for c in SELECT if c[0][5] == 1 and c[0][6] == 1 and c not in STREAM_CASES][:4]
+
+
+@pytest.mark.parametrize("case,kf,kd,kw", FLAT_TWIN_CASES, ids=[str(c[0]) for c in FLAT_TWIN_CASES])
+def test_stream_and_1x1_wgrad_flat_address_twins(hip, case, kf, kd, kw, monkeypatch):
+    """conv1x1_stream_kernel and the 1x1 stride-1 arm of conv_wgrad_tr_kernel stage through buffer descriptors too (r06); under
+    ET_CONV_BUF_DMA=0 (and for tensors of 2^31 bytes or more) conv1x1_stream_flat_kernel / the flat pieces of the weight gradient run:
+    the same element-wise checks on that arm."""
+    assert len(STREAM_CASES) >= 4 and len(FLAT_TWIN_CASES) > len(STREAM_CASES)
+    monkeypatch.setenv("ET_CONV_BUF_DMA", "0")
+    _check_instantiation(hip, case, kf, kd, kw)
+
+
 @pytest.mark.parametrize("case,kf,kd,kw", SELECT, ids=[str(c[0]) for c in SELECT])
 def test_bench_instantiations_elementwise_fp16(hip, case, kf, kd, kw):
     """the same instantiations with T = et_f16 (IEEE half, v_mfma_f32_32x32x16_f16: the reference's AMP arithmetic, r05): the tile

@@ -18,7 +18,7 @@ import codeobj  # noqa: E402
 
 LIB = os.path.join(ROOT, "efficientteacher_amd", "libet_hip.so")
 EXEMPT = ("conv_gemm_pp_kernel", "conv_gemm_pprs_kernel", "conv_gemm_pprs_flat_kernel")
-RINGS = ("conv_gemm_glds_kernel", "conv_gemm_rs_kernel", "conv_gemm_rs_flat_kernel", "conv1x1_stream_kernel")
+RINGS = ("conv_gemm_glds_kernel", "conv_gemm_rs_kernel", "conv_gemm_rs_flat_kernel", "conv1x1_stream_kernel", "conv1x1_stream_flat_kernel")
 
 
 def _violations(ins):
