@@ -839,9 +839,12 @@ def main():
         import importlib
         name, val = kv.split("=", 1)
         parts = name.split(".")
-        m = importlib.import_module("efficientteacher_amd." + parts[0])          # module, then attributes (ops.WGRAD_QUEUE.group)
-        for q in parts[1:-1]:
-            m = getattr(m, q)
+        m = importlib.import_module("efficientteacher_amd." + parts[0])          # module(s), then attributes (ops.WGRAD_QUEUE.group)
+        for i, q in enumerate(parts[1:-1], 1):
+            try:
+                m = importlib.import_module("efficientteacher_amd." + ".".join(parts[:i + 1]))
+            except ImportError:
+                m = getattr(m, q)
         assert hasattr(m, parts[-1]), f"--set: {name} does not exist"
         setattr(m, parts[-1], ast.literal_eval(val))
 
