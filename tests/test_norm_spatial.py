@@ -76,10 +76,11 @@ def test_bn_silu_fwd_bwd(hip, finalize_form, shape, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("shape", [(2, 9, 7, 16), (1, 20, 20, 32), (1, 3, 2, 8)])
+@pytest.mark.parametrize("shape", [(2, 9, 7, 16), (1, 20, 20, 32), (1, 3, 2, 8), (3, 20, 20, 72), (1, 24, 24, 40), (1, 34, 33, 8)])
 def test_sppf_pool_chain(hip, shape, dtype):
     """x -> y1 -> y2 -> y3 written into slices of one concat buffer; backward through the chain (the pooled maps have plateaus:
-    the gradient routing checks the first-maximum tie rule against torch)."""
+    the gradient routing checks the first-maximum tie rule against torch).  Shapes include channel counts that are not a multiple of 64
+    (72, 40) and maps beyond SPPF's 20 x 20."""
     from efficientteacher_amd import ops
     N, H, W, C = shape
     cat = torch.zeros((N, H, W, 4 * C), dtype=dtype, device=hip.device)
