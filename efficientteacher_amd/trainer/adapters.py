@@ -353,6 +353,7 @@ class _SsodHotPath(_HotPath):
 
     overlap_teacher = True
     teacher_after = "p3"
+    join_teacher_late = True
 
 
 def hot_path_trainers(ref_trainer=None, ref_ssod_trainer=None, compute_dtype=torch.bfloat16, deterministic=False):

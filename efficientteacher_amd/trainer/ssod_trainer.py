@@ -97,6 +97,9 @@ class SSODTrainer(Trainer):
         self.domain_loss = DomainLoss()
         self.target_loss = TargetLoss()
 
+    # main stream joins the teacher stream in front of the UNSUPERVISED loss (True) or right behind the student's forward (False: until r06).  Class attribute: an A/B switch
+    join_teacher_late = True
+
     def update_optimizer(self, loss, ni):
         self.scaler.scale(loss).backward()     # ssod_trainer.py:469 (identity unless the compute dtype is fp16)
         if self._capturing:                # graph capture: launches only; the host-side schedule runs before each replay
@@ -248,10 +251,13 @@ class SSODTrainer(Trainer):
             t9, valid, has_targets = teacher(ev)
         else:
             total_pred, total_feature = self.model(total_imgs)
-        if side is not None:
-            cur.wait_stream(side)
-            for t in (t9, valid, has_targets):
-                t.record_stream(cur)
+        def join_teacher():
+            if side is not None:
+                cur.wait_stream(side)
+                for t in (t9, valid, has_targets):
+                    t.record_stream(cur)
+        if not self.join_teacher_late:
+            join_teacher()
         sup_pred, sup_feature, un_sup_pred, un_sup_feature = self.split_predict_and_feature(total_pred, total_feature, n_img)
         # 4 losses (:628-649); the zero-weighted domain losses (:631-636) contribute nothing
         if sup_table is not None:                      # graph capture: the padded device-resident target table
@@ -265,6 +271,8 @@ class SSODTrainer(Trainer):
             sup_loss = sup_loss + d_loss * self.da_loss_weights + t_loss * self.da_loss_weights
         if self.RANK != -1:
             sup_loss = sup_loss * self.WORLD_SIZE
+        if self.join_teacher_late:                     # the supervised loss does not need the pseudo labels: it runs beside the teacher's NMS tail
+            join_teacher()
         un_sup_loss, un_sup_loss_items = self.compute_un_sup_loss(un_sup_pred, t9, valid)
         un_sup_loss = un_sup_loss * has_targets       # reference: zeros(1) when no pseudo label survived (:640-643)
         if self.RANK != -1:
